@@ -1,0 +1,50 @@
+"""In-tree build of the HIP library (gfx950).  `python -m hybrid_rendering_amd.build`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libhybrid_rendering_amd.so")
+SOURCES = ["api.hip", "shadows.hip", "bvh_build.cpp"]
+OPTIONAL = ["ao.hip", "reflections.hip", "ddgi.hip"]
+# -ffp-contract=off: every fp32 op is individually rounded; FMAs are explicit.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, s) for s in OPTIONAL if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hr_api.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + sources() + ["-o", LIB + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

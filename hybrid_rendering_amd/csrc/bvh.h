@@ -1,0 +1,54 @@
+// Compressed 8-wide BVH: the software replacement for VK_KHR_acceleration_structure
+// (reference call sites: main.cpp:74 build_tlas, common.cpp:355-521 initialize_for_ray_tracing).
+//
+// Node = 80 bytes (five 16-byte loads per lane):
+//   [ 0] origin.xyz (f32), exponent bytes ex,ey,ez (biased like an fp32 exponent), pad
+//   [16] child_base (index of first internal child), tri_base (index of first leaf triangle),
+//        meta[8]: 0 = empty slot; internal: 0x10 | slot (node = child_base + slot);
+//                 leaf: (count << 5) | offset  (triangles tri_base+offset .. +count-1), count 1..4
+//   [32] qlo.x[8] qlo.y[8]   [48] qlo.z[8] qhi.x[8]   [64] qhi.y[8] qhi.z[8]   (uint8 grid coords)
+//   child box = origin + q * 2^(e-127), lo floored / hi ceiled => conservative.
+// Triangle = 48 bytes: v0.xyz, prim | v1.xyz, 0 | v2.xyz, 0   (original vertex positions: the
+// watertight test needs them unmodified for bit-reproducible hit decisions).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace hr {
+
+struct alignas(16) Node8
+{
+    float    ox, oy, oz;
+    uint8_t  ex, ey, ez, pad;
+    uint32_t child_base;
+    uint32_t tri_base;
+    uint8_t  meta[8];
+    uint8_t  qlo[3][8];
+    uint8_t  qhi[3][8];
+};
+static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
+
+struct alignas(16) TriGPU
+{
+    float    v0[3];
+    uint32_t prim;
+    float    v1[3];
+    uint32_t pad1;
+    float    v2[3];
+    uint32_t pad2;
+};
+static_assert(sizeof(TriGPU) == 48, "TriGPU must be 48 bytes");
+
+struct BuiltBVH
+{
+    std::vector<Node8>  nodes;
+    std::vector<TriGPU> tris;
+    float               lo[3], hi[3];
+    float               pad;
+    int                 max_depth;
+};
+
+// positions: [n][3][3].  Deterministic (single-threaded, no RNG).
+void build_bvh8(const float* positions, int n_tris, BuiltBVH& out);
+
+} // namespace hr

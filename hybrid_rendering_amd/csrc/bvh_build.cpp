@@ -1,0 +1,296 @@
+// Host-side builder of the compressed 8-wide BVH (see bvh.h).  Replaces the driver's
+// acceleration-structure build behind dw::RayTracedScene (reference: main.cpp:74,
+// common.cpp:355-521).  Steps: binned-SAH binary tree -> greedy surface-area collapse to
+// 8-wide -> breadth-first layout with contiguous children / leaf triangles -> 8-bit
+// conservative quantisation.
+#include "bvh.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace hr {
+namespace {
+
+struct Box
+{
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX };
+    float hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    void  add(const float* p)
+    {
+        for (int a = 0; a < 3; a++)
+        {
+            if (p[a] < lo[a]) lo[a] = p[a];
+            if (p[a] > hi[a]) hi[a] = p[a];
+        }
+    }
+    void add(const Box& b)
+    {
+        for (int a = 0; a < 3; a++)
+        {
+            if (b.lo[a] < lo[a]) lo[a] = b.lo[a];
+            if (b.hi[a] > hi[a]) hi[a] = b.hi[a];
+        }
+    }
+    double half_area() const
+    {
+        double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+        if (x < 0) return 0.0;
+        return x * y + y * z + z * x;
+    }
+};
+
+struct Bin2
+{
+    Box     box;
+    int32_t a = -1, b = -1; // children, or -1 for leaf
+    int32_t first = 0, count = 0;
+};
+
+constexpr int kBins    = 32;
+constexpr int kMaxLeaf = 4;
+
+struct Builder
+{
+    const float*          pos;
+    std::vector<Box>      tbox;
+    std::vector<float>    tcen;
+    std::vector<int32_t>  idx;
+    std::vector<Bin2>     n2;
+
+    int32_t split(int32_t first, int32_t count)
+    {
+        int32_t me = (int32_t)n2.size();
+        n2.emplace_back();
+        Box nb, cb;
+        for (int32_t i = first; i < first + count; i++)
+        {
+            nb.add(tbox[idx[i]]);
+            cb.add(&tcen[(size_t)idx[i] * 3]);
+        }
+        n2[me].box   = nb;
+        n2[me].first = first;
+        n2[me].count = count;
+        if (count <= kMaxLeaf) return me;
+
+        double  best     = DBL_MAX;
+        int     bax      = -1;
+        int     bsplit   = 0;
+        for (int ax = 0; ax < 3; ax++)
+        {
+            float ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0.0f)) continue;
+            Box   bbox[kBins];
+            int   bcnt[kBins] = { 0 };
+            float k           = (float)kBins / ext;
+            for (int32_t i = first; i < first + count; i++)
+            {
+                int t = idx[i];
+                int b = (int)((tcen[(size_t)t * 3 + ax] - cb.lo[ax]) * k);
+                if (b > kBins - 1) b = kBins - 1;
+                bbox[b].add(tbox[t]);
+                bcnt[b]++;
+            }
+            double rarea[kBins];
+            int    rcnt[kBins];
+            Box    acc;
+            int    c = 0;
+            for (int b = kBins - 1; b >= 1; b--)
+            {
+                acc.add(bbox[b]);
+                c += bcnt[b];
+                rarea[b] = acc.half_area();
+                rcnt[b]  = c;
+            }
+            Box lacc;
+            int lc = 0;
+            for (int b = 0; b < kBins - 1; b++)
+            {
+                lacc.add(bbox[b]);
+                lc += bcnt[b];
+                if (lc == 0 || rcnt[b + 1] == 0) continue;
+                double cost = lacc.half_area() * lc + rarea[b + 1] * rcnt[b + 1];
+                if (cost < best) { best = cost; bax = ax; bsplit = b; }
+            }
+        }
+        int32_t mid;
+        if (bax < 0) mid = first + count / 2;
+        else
+        {
+            float ext = cb.hi[bax] - cb.lo[bax];
+            float k   = (float)kBins / ext;
+            float lo  = cb.lo[bax];
+            auto  it  = std::partition(idx.begin() + first, idx.begin() + first + count, [&](int32_t t) {
+                int b = (int)((tcen[(size_t)t * 3 + bax] - lo) * k);
+                if (b > kBins - 1) b = kBins - 1;
+                return b <= bsplit;
+            });
+            mid = (int32_t)(it - idx.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        int32_t l = split(first, mid - first);
+        int32_t r = split(mid, first + count - mid);
+        n2[me].a  = l;
+        n2[me].b  = r;
+        return me;
+    }
+};
+
+inline uint8_t exponent_for(float extent)
+{
+    // smallest e with extent <= 255 * 2^(e-127)
+    if (!(extent > 0.0f)) return 1;
+    int   ex;
+    float m = std::frexp(extent / 255.0f, &ex); // extent/255 = m * 2^ex, m in [0.5,1)
+    (void)m;
+    int e = ex + 127; // 2^ex >= extent/255
+    while (e > 1 && std::ldexp(255.0, e - 1 - 127) >= (double)extent) e--;
+    while (std::ldexp(255.0, e - 127) < (double)extent) e++;
+    if (e < 1) e = 1;
+    if (e > 254) e = 254;
+    return (uint8_t)e;
+}
+
+} // namespace
+
+void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
+{
+    out.nodes.clear();
+    out.tris.clear();
+    out.max_depth = 0;
+    Builder B;
+    B.pos = positions;
+    B.tbox.resize(n_tris);
+    B.tcen.resize((size_t)n_tris * 3);
+    B.idx.resize(n_tris);
+    Box all;
+    for (int i = 0; i < n_tris; i++)
+    {
+        const float* p = positions + (size_t)i * 9;
+        B.tbox[i].add(p);
+        B.tbox[i].add(p + 3);
+        B.tbox[i].add(p + 6);
+        for (int a = 0; a < 3; a++) B.tcen[(size_t)i * 3 + a] = 0.5f * (B.tbox[i].lo[a] + B.tbox[i].hi[a]);
+        all.add(B.tbox[i]);
+        B.idx[i] = i;
+    }
+    if (n_tris == 0)
+    {
+        for (int a = 0; a < 3; a++) { all.lo[a] = 0; all.hi[a] = 0; }
+    }
+    for (int a = 0; a < 3; a++) { out.lo[a] = all.lo[a]; out.hi[a] = all.hi[a]; }
+    {
+        double dx = (double)all.hi[0] - all.lo[0], dy = (double)all.hi[1] - all.lo[1], dz = (double)all.hi[2] - all.lo[2];
+        // Boxes are padded well above the fp32 error of the triangle test so that box culling can
+        // never reject a triangle the test would accept.
+        out.pad = (float)(3e-5 * std::sqrt(dx * dx + dy * dy + dz * dz));
+        if (!(out.pad > 0.0f)) out.pad = 1e-6f;
+    }
+    for (int i = 0; i < n_tris; i++)
+        for (int a = 0; a < 3; a++) { B.tbox[i].lo[a] -= out.pad; B.tbox[i].hi[a] += out.pad; }
+
+    if (n_tris == 0)
+    {
+        Node8 n;
+        std::memset(&n, 0, sizeof(n));
+        n.ex = n.ey = n.ez = 1;
+        out.nodes.push_back(n);
+        return;
+    }
+    B.n2.reserve((size_t)n_tris);
+    int32_t root2 = B.split(0, n_tris);
+
+    // ---- collapse to 8-wide, breadth-first -----------------------------------------------
+    struct Pending { int32_t n2; int32_t n8; int depth; };
+    std::queue<Pending> q;
+    out.nodes.emplace_back();
+    q.push({ root2, 0, 1 });
+    out.tris.reserve(n_tris);
+    while (!q.empty())
+    {
+        Pending pd = q.front();
+        q.pop();
+        if (pd.depth > out.max_depth) out.max_depth = pd.depth;
+        int32_t kids[8];
+        int     nk = 0;
+        if (B.n2[pd.n2].a < 0) kids[nk++] = pd.n2; // root is itself a leaf
+        else { kids[nk++] = B.n2[pd.n2].a; kids[nk++] = B.n2[pd.n2].b; }
+        while (nk < 8)
+        {
+            int    best = -1;
+            double ba   = -1.0;
+            for (int i = 0; i < nk; i++)
+                if (B.n2[kids[i]].a >= 0)
+                {
+                    double ar = B.n2[kids[i]].box.half_area();
+                    if (ar > ba) { ba = ar; best = i; }
+                }
+            if (best < 0) break;
+            int32_t k   = kids[best];
+            kids[best]  = B.n2[k].a;
+            kids[nk++]  = B.n2[k].b;
+        }
+        Box nb;
+        for (int i = 0; i < nk; i++) nb.add(B.n2[kids[i]].box);
+        Node8 n;
+        std::memset(&n, 0, sizeof(n));
+        n.ox = nb.lo[0]; n.oy = nb.lo[1]; n.oz = nb.lo[2];
+        n.ex = exponent_for(nb.hi[0] - nb.lo[0]);
+        n.ey = exponent_for(nb.hi[1] - nb.lo[1]);
+        n.ez = exponent_for(nb.hi[2] - nb.lo[2]);
+        const uint8_t eb[3] = { n.ex, n.ey, n.ez };
+        n.child_base = (uint32_t)out.nodes.size();
+        n.tri_base   = (uint32_t)out.tris.size();
+        int n_internal = 0;
+        uint32_t tri_off = 0;
+        for (int i = 0; i < nk; i++)
+        {
+            const Bin2& c = B.n2[kids[i]];
+            for (int a = 0; a < 3; a++)
+            {
+                double s  = std::ldexp(1.0, (int)eb[a] - 127);
+                double o  = (a == 0 ? n.ox : (a == 1 ? n.oy : n.oz));
+                double ql = std::floor(((double)c.box.lo[a] - o) / s);
+                double qh = std::ceil(((double)c.box.hi[a] - o) / s);
+                if (ql < 0) ql = 0;
+                if (ql > 255) ql = 255;
+                if (qh > 255) qh = 255;
+                if (qh < ql) qh = ql;
+                n.qlo[a][i] = (uint8_t)ql;
+                n.qhi[a][i] = (uint8_t)qh;
+            }
+            if (c.a >= 0)
+            {
+                n.meta[i] = (uint8_t)(0x10 | n_internal);
+                n_internal++;
+            }
+            else
+            {
+                n.meta[i] = (uint8_t)((c.count << 5) | tri_off);
+                for (int t = 0; t < c.count; t++)
+                {
+                    int32_t      prim = B.idx[c.first + t];
+                    const float* p    = positions + (size_t)prim * 9;
+                    TriGPU       tg;
+                    std::memset(&tg, 0, sizeof(tg));
+                    std::memcpy(tg.v0, p, 12);
+                    std::memcpy(tg.v1, p + 3, 12);
+                    std::memcpy(tg.v2, p + 6, 12);
+                    tg.prim = (uint32_t)prim;
+                    out.tris.push_back(tg);
+                }
+                tri_off += (uint32_t)c.count;
+            }
+        }
+        // reserve the internal children contiguously, then enqueue them in slot order
+        size_t base = out.nodes.size();
+        out.nodes.resize(base + n_internal);
+        out.nodes[pd.n8] = n;
+        int slot = 0;
+        for (int i = 0; i < nk; i++)
+            if (B.n2[kids[i]].a >= 0) q.push({ kids[i], (int32_t)(base + slot++), pd.depth + 1 });
+    }
+}
+
+} // namespace hr

@@ -1,0 +1,599 @@
+// RayTracedShadows on MI355X — HIP replacement for src/ray_traced_shadows.{h,cpp} and
+// src/shaders/shadows/*.  Stage map (reference file:line -> kernel):
+//   ray_trace()              ray_traced_shadows.cpp:972-1011, shadows_ray_trace.comp:89-132   -> k_shadows_trace
+//   reset_args()+temporal()  :1015-1090, shadows_denoise_reprojection.comp:196-293            -> k_shadows_temporal
+//   a_trous_filter()         :1094-1215, shadows_denoise_atrous.comp:94-174 +
+//                            shadows_denoise_copy_shadow_tiles.comp:32-36 (fused via tile class) -> k_shadows_atrous
+//   upsample()               :1219-1255, shadows_upsample.comp:62-109                          -> k_upsample (upsample.h)
+#include "hr_internal.h"
+#include "reproject.h"
+#include "traverse.h"
+#include "upsample.h"
+
+using namespace hr;
+
+// ------------------------------------------------------------------------------------------------
+// lighting.glsl:6-111 with SOFT_SHADOWS | SHADOW_RAY_ONLY | RAY_TRACING
+HR_DEV void fetch_light_shadow(const hr_light& L, f3 P, f3 N, float rx, float ry, f3& Wi, float& t_max, float& attenuation)
+{
+    const int type = (int)L.data3[0];
+    const f3  ldir = mk3(L.data0[0], L.data0[1], L.data0[2]);
+    f3        light_dir;
+    float     radius;
+    if (type == 0)
+    {
+        light_dir   = ldir;
+        radius      = L.data1[3];
+        t_max       = 10000.0f;
+        attenuation = 1.0f;
+    }
+    else
+    {
+        f3    to_light = sub3(mk3(L.data1[0], L.data1[1], L.data1[2]), P);
+        light_dir      = normalize3(to_light);
+        float dist     = len3(to_light);
+        radius         = __fdiv_rn(L.data1[3], dist);
+        t_max          = dist;
+        attenuation    = __fdiv_rn(1.0f, dist * dist);
+    }
+    f3    tangent   = normalize3(cross3(light_dir, mk3(0.0f, 1.0f, 0.0f)));
+    f3    bitangent = normalize3(cross3(tangent, light_dir));
+    float pr        = radius * __fsqrt_rn(rx);
+    float pa        = ry * 2.0f * HR_M_PI;
+    float s, c;
+    det_sincos(pa, s, c);
+    float dx = pr * c, dy = pr * s;
+    Wi       = normalize3(add3(add3(light_dir, scale3(tangent, dx)), scale3(bitangent, dy)));
+    if (type == 2)
+    {
+        float aa    = smoothstep1(L.data3[1], L.data3[2], dot3(Wi, ldir));
+        attenuation = __fdiv_rn(aa, t_max * t_max);
+    }
+    attenuation = attenuation * clamp1(dot3(N, Wi), 0.0f, 1.0f);
+}
+
+struct TraceArgs
+{
+    float           vpi[16];
+    hr_light        light;
+    const float*    depth;
+    const uint2*    gb2;
+    const uint8_t*  sobol;
+    const uint8_t*  sr;
+    uint32_t*       mask;
+    unsigned long long* ray_counter;
+    const Node8*    nodes;
+    const TriGPU*   tris;
+    unsigned long long* stats; // nullable: [0] nodes visited, [1] triangles tested
+    int             w, h;      // pass image (full frame)
+    int             y0, y1;    // resident rows
+    int             mw;        // mask words per row
+    int             tiles_x, tiles_y, tile_y0;
+    float           bias;
+    uint32_t        num_frames;
+};
+
+// One wave = one 8x8 pixel tile = two 8x4 mask words; lane l -> pixel (l & 7, l >> 3), so the
+// wave ballot IS the packed mask (bit y*8+x of shadows_ray_trace.comp:126).
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
+{
+    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.tiles_x * a.tiles_y) return;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    bool      lit = false, fired = false;
+    uint32_t  nn = 0, nt = 0;
+    if (x < a.w && y >= a.y0 && y < a.y1)
+    {
+        const float d = a.depth[(size_t)y * a.w + x];
+        if (d != 1.0f)
+        {
+            const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
+            const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
+            const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+            const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+            const f3    ro = add3(P, scale3(N, a.bias));
+            const float r0 = sample_blue_noise(x, y, (int)a.num_frames, 0, a.sobol, a.sr);
+            const float r1 = sample_blue_noise(x, y, (int)a.num_frames, 1, a.sobol, a.sr);
+            f3    Wi;
+            float t_max, att;
+            fetch_light_shadow(a.light, P, N, r0, r1, Wi, t_max, att);
+            if (att > 0.0f)
+            {
+                fired = true;
+                lit   = !trace_any<STATS>(a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt);
+            }
+        }
+    }
+    const unsigned long long bits = __ballot(lit);
+    const unsigned long long fb   = __ballot(fired);
+    if (STATS)
+    {
+        // wave reduction of the counters
+        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); nt += __shfl_down(nt, o); }
+    }
+    if (lane == 0)
+    {
+        const int my = ty * 2;
+        if (my * 4 >= a.y0 && my * 4 < a.y1) a.mask[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
+        if ((my + 1) * 4 >= a.y0 && (my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) a.mask[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
+        if (fb) atomicAdd(a.ray_counter, (unsigned long long)__popcll(fb));
+        if (STATS && a.stats)
+        {
+            atomicAdd(a.stats + 0, (unsigned long long)nn);
+            atomicAdd(a.stats + 1, (unsigned long long)nt);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct TemporalArgs
+{
+    float           vpi[16];
+    const uint32_t* mask;
+    int             mw, mh;         // mask image dims (full frame)
+    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
+    ImgR32F         depth, pdepth;
+    ImgRG16F        hist;           // previous à-trous feedback image (vis, var)
+    ImgRGBA16F      hist_moments;
+    uint32_t*       out;            // RG16F
+    uint2*          out_moments;    // RGBA16F
+    uint8_t*        tile_class;
+    int             w, h, y0, y1;
+    int             tiles_x, tiles_y, tile_y0;
+    float           alpha, moments_alpha;
+};
+
+__global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
+{
+    __shared__ uint32_t s_mask[4][18];
+    __shared__ float    s_vpi[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
+    const int tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    if (threadIdx.x < 16) s_vpi[threadIdx.x] = a.vpi[threadIdx.x];
+    if (tile_ok && lane < 18)
+    {
+        // populate_cache (:114-123): 3x6 masks around the tile; out-of-image masks read 0 (pinned)
+        const int cx = tx - 1 + lane % 3, cy = ty * 2 - 2 + lane / 3;
+        uint32_t  v  = 0u;
+        if (cx >= 0 && cy >= 0 && cx < a.mw && cy < a.mh && cy * 4 >= a.y0 - 8 && cy * 4 < a.y1 + 8) v = a.mask[(size_t)cy * a.mw + cx];
+        s_mask[wave][lane] = v;
+    }
+    __syncthreads();
+    if (!tile_ok) return;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int x = tx * 8 + lx, y = ty * 8 + ly;
+
+    // 17x17 box sum of visibility bits (neighborhood_mean :157-190): integer popcounts are exact.
+    int sum = 0;
+#pragma unroll
+    for (int yy = -8; yy <= 8; yy++)
+    {
+        const int ry   = ly + 8 + yy;          // row inside the 24-row cache
+        const int mrow = ry >> 2, brow = ry & 3;
+        const uint32_t b0 = (s_mask[wave][mrow * 3 + 0] >> (brow * 8)) & 0xffu;
+        const uint32_t b1 = (s_mask[wave][mrow * 3 + 1] >> (brow * 8)) & 0xffu;
+        const uint32_t b2 = (s_mask[wave][mrow * 3 + 2] >> (brow * 8)) & 0xffu;
+        const uint32_t row = b0 | (b1 << 8) | (b2 << 16);
+        sum += __popc((row >> lx) & 0x1ffffu);
+    }
+    const float mean = __fdiv_rn((float)sum, 289.0f);
+
+    const bool in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    float      out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
+    bool       flag = false;
+    if (in_image)
+    {
+        const float d = a.depth.p[(size_t)y * a.w + x];
+        if (d != 1.0f)
+        {
+            const int   cry = ly + 8, crx = lx + 8;
+            const float visibility = (float)((s_mask[wave][(cry >> 2) * 3 + (crx >> 3)] >> ((cry & 3) * 8 + (crx & 7))) & 1u);
+            ReprojIn in;
+            in.x = x; in.y = y; in.depth = d; in.vpi = s_vpi;
+            in.gb2 = a.gb2; in.gb3 = a.gb3; in.pgb2 = a.pgb2; in.pgb3 = a.pgb3; in.pdepth = a.pdepth;
+            in.w = a.w; in.h = a.h;
+            float hv, hm[2];
+            ImgR16F none { nullptr, 0, 0, 0 };
+            const bool success = reproject<true, true, false, ImgRG16F>(in, a.hist, a.hist_moments, none, &hv, hm, hlen);
+            hlen = min2(32.0f, success ? hlen + 1.0f : 1.0f);
+            if (success)
+            {
+                float sv = max2(mean - mean * mean, 0.0f);
+                float sd = __fsqrt_rn(sv);
+                hv       = clamp1(hv, mean - 0.5f * sd, mean + 0.5f * sd);
+            }
+            const float al = success ? max2(a.alpha, __fdiv_rn(1.0f, hlen)) : 1.0f;
+            const float am = success ? max2(a.moments_alpha, __fdiv_rn(1.0f, hlen)) : 1.0f;
+            m0      = visibility;
+            m1      = m0 * m0;
+            m0      = mix1(hm[0], m0, am);
+            m1      = mix1(hm[1], m1, am);
+            out_var = max2(0.0f, m1 - m0 * m0);
+            out_v   = mix1(hv, visibility, al);
+            flag    = out_v > 0.0f;
+        }
+        a.out_moments[(size_t)y * a.w + x] = make_uint2(pack_h2(m0, m1), pack_h2(hlen, 0.0f));
+        a.out[(size_t)y * a.w + x]         = pack_h2(out_v, out_var);
+    }
+    // tile classification (:275-291): any lit pixel => the tile needs the à-trous filter
+    const unsigned long long any = __ballot(flag);
+    if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AtrousArgs
+{
+    ImgRG16F       in;
+    ImgRGBA16F     gb2, gb3;
+    const uint8_t* tile_class;
+    uint32_t*      out;
+    uint32_t*      out2;    // feedback copy (prev_image) or nullptr
+    int            w, h, y0, y1, tiles_x;
+    int            radius, step;
+    float          phi_visibility, phi_normal, sigma_depth, power;
+};
+
+// edge_stopping.glsl:31-62 with NORMAL + LUMA weights
+HR_DEV float edge_weight(float cd, float sd, float phi_z, f3 cn, f3 sn, float phi_n, float cl, float sl, float phi_l)
+{
+    const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), phi_z));
+    const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), phi_n);
+    const float wL = __fdiv_rn(fabsf(cl - sl), phi_l);
+    return det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
+}
+
+__global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const size_t o = (size_t)y * a.w + x;
+    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)])
+    {
+        a.out[o] = 0u; // shadows_denoise_copy_shadow_tiles.comp:35
+        if (a.out2) a.out2[o] = 0u;
+        return;
+    }
+    const uint32_t c  = a.in.p[o];
+    const float    cv = h2f_lo(c);
+    // compute_variance_center (:65-88)
+    float var = 0.0f;
+#pragma unroll
+    for (int yy = -1; yy <= 1; yy++)
+#pragma unroll
+        for (int xx = -1; xx <= 1; xx++)
+        {
+            const float k = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            var += h2f_hi(a.in.raw(x + xx, y + yy)) * k;
+        }
+    const uint2 g2 = a.gb2.p[o], g3 = a.gb3.p[o];
+    const float center_depth = h2f_hi(g3.y);
+    uint32_t    result;
+    if (center_depth < 0.0f) result = c;
+    else
+    {
+        const f3    cn    = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+        const float phi_v = a.phi_visibility * __fsqrt_rn(max2(0.0f, 1e-10f + var));
+        float sum_w = 1.0f, sum_v = cv, sum_var = h2f_hi(c);
+        for (int yy = -a.radius; yy <= a.radius; yy++)
+            for (int xx = -a.radius; xx <= a.radius; xx++)
+            {
+                const int px = x + xx * a.step, py = y + yy * a.step;
+                if (px < 0 || py < 0 || px >= a.w || py >= a.h || (xx == 0 && yy == 0)) continue;
+                const int   axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                const float kx = axx == 0 ? 1.0f : (axx == 1 ? __fdiv_rn(2.0f, 3.0f) : __fdiv_rn(1.0f, 6.0f));
+                const float ky = ayy == 0 ? 1.0f : (ayy == 1 ? __fdiv_rn(2.0f, 3.0f) : __fdiv_rn(1.0f, 6.0f));
+                const uint32_t s  = a.in.raw(px, py);
+                const uint2    s2 = a.gb2.raw(px, py), s3 = a.gb3.raw(px, py);
+                const float    sv = h2f_lo(s);
+                const f3       sn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
+                const float    w  = edge_weight(center_depth, h2f_hi(s3.y), a.sigma_depth, cn, sn, a.phi_normal, cv, sv, phi_v);
+                const float    wv = w * (kx * ky);
+                sum_w += wv;
+                sum_v += wv * sv;
+                sum_var += (wv * wv) * h2f_hi(s);
+            }
+        float ov = __fdiv_rn(sum_v, sum_w), ovar = __fdiv_rn(sum_var, sum_w * sum_w);
+        if (a.power != 0.0f) ov = det_pow_auto(ov, a.power);
+        result = pack_h2(ov, ovar);
+    }
+    a.out[o] = result;
+    if (a.out2) a.out2[o] = result;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct hr_shadows
+{
+    hr_ctx* ctx = nullptr;
+    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0;
+    int     y0 = 0, y1 = 0;           // resident rows (band + halo)
+    int     band_y0 = 0, band_y1 = 0;
+    int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0;
+    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters;
+    bool    first_frame = true;
+    int     read_idx = 0;             // ATrous::read_idx
+    bool    last_denoise = true;
+    int     last_ping_pong = 0;
+    StageProfiler prof;
+    hipStream_t   last_stream = nullptr;
+};
+
+extern "C" {
+
+void hr_shadows_default_params(hr_shadows_params* p)
+{
+    p->denoise = 1; p->bias = 0.5f; p->alpha = 0.01f; p->moments_alpha = 0.2f; p->phi_visibility = 10.0f;
+    p->phi_normal = 32.0f; p->sigma_depth = 1.0f; p->power = 1.2f; p->radius = 1; p->filter_iterations = 4; p->feedback_iteration = 1;
+}
+
+hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_shadows** out)
+{
+    HR_CHECK_ARG(ctx && out && full_width > 0 && full_height > 0 && (int)scale >= 0 && (int)scale <= 2);
+    HR_HIP(hipSetDevice(ctx->device));
+    hr_shadows* p = new hr_shadows();
+    p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    // m_width = extent / 2^scale (ray_traced_shadows.cpp:80-83: float divide then truncation)
+    p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
+    p->y0 = 0; p->y1 = p->h; p->band_y0 = 0; p->band_y1 = p->h;
+    if (band && band->band_y1 > band->band_y0)
+    {
+        if (band->band_y0 < 0 || band->band_y1 > p->h || (band->band_y0 & 7) || ((band->band_y1 & 7) && band->band_y1 != p->h) || band->halo < 0 || (band->halo & 7))
+        {
+            set_last_error("band rows must be multiples of 8 inside the pass image; halo a multiple of 8");
+            delete p;
+            return HR_ERR_INVALID_ARG;
+        }
+        p->band_y0 = band->band_y0; p->band_y1 = band->band_y1;
+        p->y0 = band->band_y0 - band->halo < 0 ? 0 : band->band_y0 - band->halo;
+        p->y1 = band->band_y1 + band->halo > p->h ? p->h : band->band_y1 + band->halo;
+    }
+    p->mw = cdiv(p->w, 8); p->mh = cdiv(p->h, 4);
+    p->tiles_x = cdiv(p->w, 8); p->tiles_y = cdiv(p->h, 8);
+    const size_t px = (size_t)p->w * p->h; // full-frame sized (bands index with absolute rows)
+    hr_status s;
+#define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
+    A(mask, (size_t)p->mw * p->mh * 4)
+    A(temporal_out, px * 4)
+    A(moments[0], px * 8)
+    A(moments[1], px * 8)
+    A(prev_image, px * 4)
+    A(atrous[0], px * 4)
+    A(atrous[1], px * 4)
+    A(upsample, (size_t)full_width * full_height * 2)
+    A(tile_class, (size_t)p->tiles_x * p->tiles_y)
+    A(counters, 64)
+#undef A
+    HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
+    HR_HIP(hipMemset(p->tile_class.p, 0, p->tile_class.bytes));
+    *out = p;
+    return HR_OK;
+}
+
+hr_status hr_shadows_destroy(hr_shadows* p)
+{
+    if (!p) return HR_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipDeviceSynchronize();
+    delete p;
+    return HR_OK;
+}
+
+hr_status hr_shadows_reset_history(hr_shadows* p)
+{
+    HR_CHECK_ARG(p);
+    p->first_frame = true;
+    return HR_OK;
+}
+
+hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable)
+{
+    HR_CHECK_ARG(p);
+    p->prof.enabled = enable != 0;
+    return HR_OK;
+}
+
+hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out)
+{
+    HR_CHECK_ARG(p && out);
+    p->prof.collect(out);
+    return HR_OK;
+}
+
+hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays)
+{
+    HR_CHECK_ARG(p && rays);
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    return HR_OK;
+}
+
+static hr_status check_inputs(const hr_shadows* p, const hr_frame_inputs* in, bool need_prev)
+{
+    HR_CHECK_ARG(in->cur.depth && in->cur.gb2 && in->cur.gb3);
+    HR_CHECK_ARG(in->cur.width == p->w && in->cur.height == p->h);
+    if (need_prev) HR_CHECK_ARG(in->prev.depth && in->prev.gb2 && in->prev.gb3 && in->prev.width == p->w && in->prev.height == p->h);
+    return HR_OK;
+}
+
+hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && scene && in && prm);
+    hr_status s = check_inputs(p, in, false);
+    if (s != HR_OK) return s;
+    HR_CHECK_ARG(in->sobol && in->scrambling_ranking);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    // clear_images() (ray_traced_shadows.cpp:938-968): first frame zeroes the feedback image and the
+    // history moments slot that will be read.
+    if (p->first_frame)
+    {
+        HR_HIP(hipMemsetAsync(p->prev_image.p, 0, p->prev_image.bytes, st));
+        HR_HIP(hipMemsetAsync(p->moments[!in->ping_pong].p, 0, p->moments[0].bytes, st));
+        p->first_frame = false;
+    }
+    HR_HIP(hipMemsetAsync(p->counters.p, 0, 8, st));
+    TraceArgs a;
+    for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
+    a.light = in->ubo.light;
+    a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2;
+    a.sobol = in->sobol; a.sr = in->scrambling_ranking;
+    a.mask = (uint32_t*)p->mask.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
+    a.stats = nullptr;
+    a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw;
+    a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
+    a.bias = prm->bias; a.num_frames = in->num_frames;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
+    hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm);
+    hr_status s = check_inputs(p, in, true);
+    if (s != HR_OK) return s;
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    TemporalArgs a;
+    for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
+    a.mask = (const uint32_t*)p->mask.p; a.mw = p->mw; a.mh = p->mh;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    a.gb2  = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
+    a.gb3  = ImgRGBA16F { (const uint2*)in->cur.gb3, w, y0, y1 };
+    a.pgb2 = ImgRGBA16F { (const uint2*)in->prev.gb2, w, y0, y1 };
+    a.pgb3 = ImgRGBA16F { (const uint2*)in->prev.gb3, w, y0, y1 };
+    a.depth  = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.pdepth = ImgR32F { in->prev.depth, w, y0, y1 };
+    a.hist         = ImgRG16F { (const uint32_t*)p->prev_image.p, w, y0, y1 };
+    a.hist_moments = ImgRGBA16F { (const uint2*)p->moments[!in->ping_pong].p, w, y0, y1 };
+    a.out = (uint32_t*)p->temporal_out.p; a.out_moments = (uint2*)p->moments[in->ping_pong ? 1 : 0].p;
+    a.tile_class = (uint8_t*)p->tile_class.p;
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
+    a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
+    a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
+    p->last_ping_pong = in->ping_pong ? 1 : 0;
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
+    hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, int32_t i, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm && i >= 0 && i < prm->filter_iterations && prm->filter_iterations <= 8 && prm->radius >= 0 && prm->radius <= 2);
+    hr_status s = check_inputs(p, in, false);
+    if (s != HR_OK) return s;
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    // ping-pong as a_trous_filter() (:1101-1107,1175): read = i odd, write = i even ? 1 : 0
+    const int read_idx = i & 1, write_idx = (i & 1) ^ 1;
+    AtrousArgs a;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    a.in  = ImgRG16F { (const uint32_t*)(i == 0 ? p->temporal_out.p : p->atrous[read_idx].p), w, y0, y1 };
+    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
+    a.gb3 = ImgRGBA16F { (const uint2*)in->cur.gb3, w, y0, y1 };
+    a.tile_class = (const uint8_t*)p->tile_class.p;
+    a.out  = (uint32_t*)p->atrous[write_idx].p;
+    a.out2 = (prm->feedback_iteration == i) ? (uint32_t*)p->prev_image.p : nullptr; // vkCmdCopyImage :1177-1207
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x;
+    a.radius = prm->radius; a.step = 1 << i;
+    a.phi_visibility = prm->phi_visibility; a.phi_normal = prm->phi_normal; a.sigma_depth = prm->sigma_depth;
+    a.power = (i == prm->filter_iterations - 1) ? prm->power : 0.0f;
+    p->read_idx = write_idx;
+    static const char* names[8] = { "atrous_0", "atrous_1", "atrous_2", "atrous_3", "atrous_4", "atrous_5", "atrous_6", "atrous_7" };
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    int ev = p->prof.begin(names[i], st, px * 24 + (a.out2 ? px * 4 : 0));
+    hipLaunchKernelGGL(k_shadows_atrous, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm);
+    if (p->scale == 0) return HR_OK; // ray_traced_shadows.cpp:113
+    HR_CHECK_ARG(in->cur_full.gb2 && in->cur_full.gb3 && in->cur_full.width == p->full_w && in->cur_full.height == p->full_h);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    UpsampleArgs a;
+    a.W = p->full_w; a.H = p->full_h; a.w = p->w; a.h = p->h;
+    a.G2 = (const uint2*)in->cur_full.gb2; a.G3 = (const uint2*)in->cur_full.gb3;
+    a.g2 = (const uint2*)in->cur.gb2; a.g3 = (const uint2*)in->cur.gb3;
+    a.in = p->atrous[p->read_idx].p; a.in_channels = 2; a.channels = 1;
+    a.out = p->upsample.p; a.sky_value = 0.0f; a.power = 0.0f;
+    const uint64_t PX = (uint64_t)p->full_w * p->full_h, px = (uint64_t)p->w * p->h;
+    int ev = p->prof.begin("upsample", st, PX * 18 + px * 20);
+    launch_upsample(a, st);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && scene && in && prm);
+    HR_HIP(hipSetDevice(p->ctx->device));
+    p->prof.begin_frame();
+    p->last_denoise = prm->denoise != 0;
+    hr_status s = hr_shadows_ray_trace(p, scene, in, prm, stream);
+    if (s != HR_OK) return s;
+    if (prm->denoise)
+    {
+        if ((s = hr_shadows_temporal(p, in, prm, stream)) != HR_OK) return s;
+        for (int i = 0; i < prm->filter_iterations; i++)
+            if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+        if (p->scale != 0 && (s = hr_shadows_upsample(p, in, prm, stream)) != HR_OK) return s;
+    }
+    return HR_OK;
+}
+
+static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)
+{
+    v->data = data; v->width = w; v->height = h; v->row_pitch_bytes = w * bpp; v->format = f;
+}
+
+hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* v)
+{
+    HR_CHECK_ARG(p && v);
+    switch (which)
+    {
+        case 0: fill_view(v, p->mask.p, p->mw, p->mh, 4, HR_FORMAT_R32_UINT); break;
+        case 1: fill_view(v, p->temporal_out.p, p->w, p->h, 4, HR_FORMAT_RG16F); break;
+        case 2: fill_view(v, p->moments[0].p, p->w, p->h, 8, HR_FORMAT_RGBA16F); break;
+        case 3: fill_view(v, p->moments[1].p, p->w, p->h, 8, HR_FORMAT_RGBA16F); break;
+        case 4: fill_view(v, p->prev_image.p, p->w, p->h, 4, HR_FORMAT_RG16F); break;
+        case 5: fill_view(v, p->atrous[0].p, p->w, p->h, 4, HR_FORMAT_RG16F); break;
+        case 6: fill_view(v, p->atrous[1].p, p->w, p->h, 4, HR_FORMAT_RG16F); break;
+        case 7: fill_view(v, p->upsample.p, p->full_w, p->full_h, 2, HR_FORMAT_R16F); break;
+        case 8: fill_view(v, p->tile_class.p, p->tiles_x, p->tiles_y, 1, (hr_format)0); break;
+        default: set_last_error("hr_shadows_image: unknown image index"); return HR_ERR_INVALID_ARG;
+    }
+    return HR_OK;
+}
+
+// RayTracedShadows::output_ds (ray_traced_shadows.cpp:135-155)
+hr_status hr_shadows_output(hr_shadows* p, hr_output_kind kind, hr_image_view* v)
+{
+    HR_CHECK_ARG(p && v);
+    if (!p->last_denoise || kind == HR_OUTPUT_RAY_TRACE) return hr_shadows_image(p, 0, v);
+    if (kind == HR_OUTPUT_TEMPORAL_ACCUMULATION) return hr_shadows_image(p, 1, v);
+    if (kind == HR_OUTPUT_ATROUS || p->scale == 0) return hr_shadows_image(p, 5 + p->read_idx, v);
+    return hr_shadows_image(p, 7, v);
+}
+
+} // extern "C"

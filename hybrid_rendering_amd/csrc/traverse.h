@@ -1,0 +1,261 @@
+// Software ray traversal of the compressed 8-wide BVH on CDNA4 — replaces rayQueryEXT /
+// traceRayEXT (reference call sites: ray_query.glsl:13-27,42-56; reflections_ray_trace.rgen:150,165;
+// gi_ray_trace.rgen:96).  Semantics kept from the reference's usage: all geometry opaque, no face
+// culling, candidate iff t_min < t < t_max, any-hit = gl_RayFlagsTerminateOnFirstHitEXT.
+//
+// One ray per lane.  Per-lane traversal stack of internal-node indices lives in LDS, laid out
+// [entry][lane] so a wave's pushes/pops hit 64 distinct banks.  Leaf children are not pushed: the
+// hit leaves of a node are merged into a 32-bit triangle mask (their triangles are contiguous from
+// tri_base) and tested right away.
+//
+// Box tests use FMAs and a conservative far-plane scale — they only have to be conservative.
+// The triangle test is the watertight test of Woop/Benthin/Wald (JCGT 2013) in individually
+// rounded fp32 ops (no FMA), so that hit decisions are reproducible bit for bit on a CPU.
+#pragma once
+#include "bvh.h"
+#include "device_math.h"
+
+namespace hr {
+
+#define HR_STACK_ENTRIES 24   // LDS entries per lane; deeper pushes spill to a per-lane scratch array
+#define HR_SPILL_ENTRIES 40
+
+struct RayPre
+{
+    f3    o;
+    int   kx, ky, kz;
+    float Sx, Sy, Sz;
+    // box-test side
+    float idx, idy, idz;     // 1/d with |d| clamped away from 0
+    float ox, oy, oz;        // -o * id
+    uint32_t sel;            // bit a set => d[a] < 0 (near plane is qhi)
+};
+
+HR_DEV float pick(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+HR_DEV RayPre ray_prepare(f3 o, f3 d)
+{
+    RayPre r;
+    r.o = o;
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int   kz = 0;
+    if (ay > ax) kz = 1;
+    if (az > (kz == 0 ? ax : ay)) kz = 2;
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    if (pick(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    float dz = pick(d, kz);
+    r.Sx = __fdiv_rn(pick(d, kx), dz);
+    r.Sy = __fdiv_rn(pick(d, ky), dz);
+    r.Sz = __fdiv_rn(1.0f, dz);
+    const float tiny = 1e-18f;
+    float dx_ = fabsf(d.x) < tiny ? (d.x < 0.0f ? -tiny : tiny) : d.x;
+    float dy_ = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
+    float dz_ = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
+    r.idx = __frcp_rn(dx_); r.idy = __frcp_rn(dy_); r.idz = __frcp_rn(dz_);
+    r.sel = (dx_ < 0.0f ? 1u : 0u) | (dy_ < 0.0f ? 2u : 0u) | (dz_ < 0.0f ? 4u : 0u);
+    return r;
+}
+
+// Watertight ray/triangle test.  true iff t_min < t < t_max.  Optionally returns t,u,v.
+template <bool WANT_TUV>
+HR_DEV bool ray_tri(const RayPre& r, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float& t_out, float& u_out, float& v_out)
+{
+    f3 A = sub3(v0, r.o), B = sub3(v1, r.o), C = sub3(v2, r.o);
+    float Akz = pick(A, r.kz), Bkz = pick(B, r.kz), Ckz = pick(C, r.kz);
+    float Ax = pick(A, r.kx) - r.Sx * Akz, Ay = pick(A, r.ky) - r.Sy * Akz;
+    float Bx = pick(B, r.kx) - r.Sx * Bkz, By = pick(B, r.ky) - r.Sy * Bkz;
+    float Cx = pick(C, r.kx) - r.Sx * Ckz, Cy = pick(C, r.ky) - r.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    float T  = (U * Az + V * Bz) + W * Cz;
+    float sg = det < 0.0f ? -1.0f : 1.0f;
+    float Ts = T * sg, ad = det * sg;
+    if (!(Ts > t_min * ad && Ts < t_max * ad)) return false;
+    if (WANT_TUV)
+    {
+        float inv = __fdiv_rn(1.0f, det);
+        t_out = T * inv;
+        u_out = V * inv;
+        v_out = W * inv;
+    }
+    return true;
+}
+
+HR_DEV float ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+
+struct NodeHits
+{
+    uint32_t child_base, tri_base;
+    uint32_t meta_lo, meta_hi;
+    uint32_t hit8;   // bit i set => child i's box is hit
+};
+
+// Tests the 8 quantised child boxes of node `ni`.  t_far is the current far limit.
+HR_DEV NodeHits test_node(const Node8* __restrict__ nodes, uint32_t ni, const RayPre& r, float t_near, float t_far)
+{
+    const uint4* p  = reinterpret_cast<const uint4*>(nodes + ni);
+    const uint4  q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    const float  nox = __uint_as_float(q0.x), noy = __uint_as_float(q0.y), noz = __uint_as_float(q0.z);
+    const float  sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+    const float  ax = sx * r.idx, ay = sy * r.idy, az = sz * r.idz;
+    const float  bx = (nox - r.o.x) * r.idx, by = (noy - r.o.y) * r.idy, bz = (noz - r.o.z) * r.idz;
+    // per axis: words holding the near / far plane bytes for children 0-3 and 4-7
+    const bool   nx = r.sel & 1u, ny = r.sel & 2u, nz = r.sel & 4u;
+    const uint32_t lox0 = q2.x, lox1 = q2.y, loy0 = q2.z, loy1 = q2.w, loz0 = q3.x, loz1 = q3.y;
+    const uint32_t hix0 = q3.z, hix1 = q3.w, hiy0 = q4.x, hiy1 = q4.y, hiz0 = q4.z, hiz1 = q4.w;
+    const uint32_t nX[2] = { nx ? hix0 : lox0, nx ? hix1 : lox1 }, fX[2] = { nx ? lox0 : hix0, nx ? lox1 : hix1 };
+    const uint32_t nY[2] = { ny ? hiy0 : loy0, ny ? hiy1 : loy1 }, fY[2] = { ny ? loy0 : hiy0, ny ? loy1 : hiy1 };
+    const uint32_t nZ[2] = { nz ? hiz0 : loz0, nz ? hiz1 : loz1 }, fZ[2] = { nz ? loz0 : hiz0, nz ? loz1 : hiz1 };
+    NodeHits h;
+    h.child_base = q1.x; h.tri_base = q1.y; h.meta_lo = q1.z; h.meta_hi = q1.w;
+    uint32_t hits = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        const uint32_t meta = half ? h.meta_hi : h.meta_lo;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            float tnx = hr_fma(ubyte(nX[half], k), ax, bx), tfx = hr_fma(ubyte(fX[half], k), ax, bx);
+            float tny = hr_fma(ubyte(nY[half], k), ay, by), tfy = hr_fma(ubyte(fY[half], k), ay, by);
+            float tnz = hr_fma(ubyte(nZ[half], k), az, bz), tfz = hr_fma(ubyte(fZ[half], k), az, bz);
+            float tn  = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_near));
+            float tf  = fminf(fminf(tfx, tfy), fminf(tfz, t_far)) * 1.0000005f;
+            bool  ok  = (tn <= tf) && (((meta >> (8 * k)) & 0xffu) != 0u);
+            hits |= ok ? (1u << (half * 4 + k)) : 0u;
+        }
+    }
+    h.hit8 = hits;
+    return h;
+}
+
+// Per-lane stack: LDS part [HR_STACK_ENTRIES][64] per wave, spill part in private memory.
+struct LaneStack
+{
+    uint32_t* lds;   // &wave_region[lane]
+    uint32_t  spill[HR_SPILL_ENTRIES];
+    int       sp;
+    HR_DEV void init(uint32_t* wave_region, int lane) { lds = wave_region + lane; sp = 0; }
+    HR_DEV void push(uint32_t v)
+    {
+        if (sp < HR_STACK_ENTRIES) lds[sp * 64] = v;
+        else if (sp - HR_STACK_ENTRIES < HR_SPILL_ENTRIES) spill[sp - HR_STACK_ENTRIES] = v;
+        sp++;
+    }
+    HR_DEV uint32_t pop()
+    {
+        sp--;
+        if (sp < HR_STACK_ENTRIES) return lds[sp * 64];
+        return spill[sp - HR_STACK_ENTRIES];
+    }
+};
+
+HR_DEV void load_tri(const TriGPU* __restrict__ tris, uint32_t i, f3& v0, f3& v1, f3& v2, uint32_t& prim)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(tris + i);
+    uint4 a = p[0], b = p[1], c = p[2];
+    v0 = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    v1 = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+    v2 = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+    prim = a.w;
+}
+
+// push the internal children of a tested node, return the triangle mask of its hit leaves
+HR_DEV uint32_t expand_hits(const NodeHits& h, LaneStack& st)
+{
+    uint32_t trimask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        if (h.hit8 & (1u << i))
+        {
+            uint32_t m = ((i < 4 ? h.meta_lo : h.meta_hi) >> (8 * (i & 3))) & 0xffu;
+            uint32_t cnt = m >> 5;
+            if (cnt) trimask |= ((1u << cnt) - 1u) << (m & 31u);
+            else st.push(h.child_base + (m & 7u));
+        }
+    }
+    return trimask;
+}
+
+// Any-hit query (query_distance / query_visibility).  Returns true if occluded.
+template <bool STATS>
+HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
+                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris)
+{
+    RayPre    r = ray_prepare(o, d);
+    LaneStack st;
+    st.init(wave_stack, lane);
+    st.push(0u);
+    while (st.sp > 0)
+    {
+        uint32_t ni = st.pop();
+        NodeHits h  = test_node(nodes, ni, r, t_min, t_max);
+        if (STATS) n_nodes++;
+        uint32_t trimask = expand_hits(h, st);
+        while (trimask)
+        {
+            uint32_t i = (uint32_t)__builtin_ctz(trimask);
+            trimask &= trimask - 1u;
+            f3       v0, v1, v2;
+            uint32_t prim;
+            load_tri(tris, h.tri_base + i, v0, v1, v2, prim);
+            if (STATS) n_tris++;
+            float t, u, v;
+            if (ray_tri<false>(r, v0, v1, v2, t_min, t_max, t, u, v)) return true;
+        }
+    }
+    return false;
+}
+
+struct HitRec
+{
+    float   t, u, v;
+    int32_t prim; // -1 = miss
+};
+
+// Closest hit: smallest t, ties broken by the smallest original triangle index (so the answer
+// does not depend on traversal order).
+HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
+                            uint32_t* wave_stack, int lane)
+{
+    RayPre    r = ray_prepare(o, d);
+    LaneStack st;
+    st.init(wave_stack, lane);
+    st.push(0u);
+    HitRec best;
+    best.t = t_max; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
+    while (st.sp > 0)
+    {
+        uint32_t ni   = st.pop();
+        float    tfar = best.prim < 0 ? t_max : best.t * 1.0000005f;
+        NodeHits h    = test_node(nodes, ni, r, t_min, tfar);
+        uint32_t trimask = expand_hits(h, st);
+        while (trimask)
+        {
+            uint32_t i = (uint32_t)__builtin_ctz(trimask);
+            trimask &= trimask - 1u;
+            f3       v0, v1, v2;
+            uint32_t prim;
+            load_tri(tris, h.tri_base + i, v0, v1, v2, prim);
+            float t, u, v;
+            if (ray_tri<true>(r, v0, v1, v2, t_min, t_max, t, u, v))
+            {
+                if (best.prim < 0 || t < best.t || (t == best.t && (int32_t)prim < best.prim))
+                {
+                    best.t = t; best.u = u; best.v = v; best.prim = (int32_t)prim;
+                }
+            }
+        }
+    }
+    return best;
+}
+
+} // namespace hr

@@ -1,0 +1,243 @@
+/* hybrid_rendering_amd — C ABI of the MI355X-native ray-trace + denoise back end.
+ *
+ * Drop-in boundary for the four hot-path pass classes of diharaw/hybrid-rendering:
+ *   RayTracedShadows      (src/ray_traced_shadows.h:7-142)
+ *   RayTracedAO           (src/ray_traced_ao.h:7-126)
+ *   RayTracedReflections  (src/ray_traced_reflections.h:8-150)
+ *   DDGI                  (src/ddgi.h:6-135)
+ * Each pass keeps the reference's shape: create(backend, resolution, scale) -> render(cmd_buf[, ddgi])
+ * -> output_ds().  Here the Vulkan command buffer becomes a HIP stream (void* = hipStream_t), a
+ * descriptor set becomes an hr_image_view (device pointer + extent + format), and the per-frame
+ * UBO (src/common.h:161-179) is passed by value inside hr_frame_inputs.
+ *
+ * Conventions
+ *   - plain C types only; every entry point returns hr_status (0 = HR_OK); no exceptions cross the ABI.
+ *   - all image pointers are DEVICE pointers to tightly packed row-major images in the reference's
+ *     formats (RGBA8 / RGBA16F / R32F depth / R32_UINT masks); the caller owns inputs, the pass owns
+ *     intermediates and outputs; output views stay valid until the next render()/destroy().
+ *   - calls on one handle must be externally serialised; work is asynchronous on the given stream.
+ *   - "band" fields describe row tiling across GPUs: a pass instance owns rows [band_y0, band_y1) of
+ *     a full_height-row frame and its images hold rows [alloc_y0, alloc_y1) (band + halo).
+ */
+#ifndef HR_API_H
+#define HR_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int hr_status;
+enum
+{
+    HR_OK                = 0,
+    HR_ERR_INVALID_ARG   = 1,
+    HR_ERR_HIP           = 2, /* a HIP runtime call failed; see hr_last_error() */
+    HR_ERR_NO_DEVICE     = 3,
+    HR_ERR_OUT_OF_MEMORY = 4,
+    HR_ERR_UNSUPPORTED   = 5
+};
+
+const char* hr_status_string(hr_status s);
+const char* hr_last_error(void); /* thread-local detail of the last failure */
+const char* hr_version(void);
+
+/* ---- formats -------------------------------------------------------------------------------- */
+typedef enum
+{
+    HR_FORMAT_R32_UINT = 1, /* packed 8x4 visibility masks (ray_traced_shadows.cpp:165) */
+    HR_FORMAT_R16F     = 2,
+    HR_FORMAT_RG16F    = 3,
+    HR_FORMAT_RGBA16F  = 4,
+    HR_FORMAT_R32F     = 5,
+    HR_FORMAT_RGBA8    = 6
+} hr_format;
+
+typedef struct
+{
+    void*     data; /* device pointer */
+    int32_t   width, height;
+    int32_t   row_pitch_bytes;
+    hr_format format;
+} hr_image_view;
+
+/* ---- per-frame inputs (replaces CommonResources + GBuffer descriptor sets) ------------------ */
+/* src/common.h:106-158 */
+typedef struct
+{
+    float data0[4]; /* xyz direction TO the light (main.cpp:963), w intensity */
+    float data1[4]; /* xyz position, w radius */
+    float data2[4]; /* xyz colour */
+    float data3[4]; /* x type (0 directional, 1 point, 2 spot), y cos(outer), z cos(inner) */
+} hr_light;
+
+/* src/common.h:161-179; column-major mat4, 416 bytes */
+typedef struct
+{
+    float    view_inverse[16];
+    float    proj_inverse[16];
+    float    view_proj_inverse[16];
+    float    prev_view_proj[16];
+    float    view_proj[16];
+    float    cam_pos[4];
+    float    current_prev_jitter[4];
+    hr_light light;
+} hr_ubo;
+
+/* One G-buffer level (g_buffer.frag:96-111): the pass reads the level matching its scale
+ * (g_buffer_mip), the upsample stage additionally reads level 0. */
+typedef struct
+{
+    const void*  gb1;   /* RGBA8   albedo.rgb, metallic            (may be NULL where unused) */
+    const void*  gb2;   /* RGBA16F oct normal.xy, motion.xy                                 */
+    const void*  gb3;   /* RGBA16F roughness, curvature, mesh id, linear z (sky: w = -1)     */
+    const float* depth; /* R32F    ndc depth, sky == 1.0                                    */
+    int32_t      width, height;
+} hr_gbuffer_level;
+
+typedef struct
+{
+    hr_gbuffer_level cur;       /* at the pass resolution (mip = scale)  — GBuffer::output_ds()  */
+    hr_gbuffer_level prev;      /* previous frame, same level            — GBuffer::history_ds() */
+    hr_gbuffer_level cur_full;  /* level 0 (only read by upsample when scale != 0)               */
+    hr_ubo           ubo;
+    uint32_t         num_frames;          /* CommonResources::num_frames                          */
+    int32_t          ping_pong;           /* CommonResources::ping_pong                           */
+    const uint8_t*   sobol;               /* device, [256][4] RGBA8   (blue_noise.cpp:5-19)        */
+    const uint8_t*   scrambling_ranking;  /* device, [128][128][4] RGBA8                          */
+    float            z_buffer_params[4];  /* main.cpp:253-254 (AO blur only)                      */
+} hr_frame_inputs;
+
+/* ---- context & scene ------------------------------------------------------------------------- */
+typedef struct hr_ctx   hr_ctx;
+typedef struct hr_scene hr_scene;
+
+hr_status hr_ctx_create(int device_ordinal, hr_ctx** out);
+hr_status hr_ctx_destroy(hr_ctx* ctx);
+
+/* Replaces dw::RayTracedScene (BLAS/TLAS build, main.cpp:74 build_tlas, common.cpp:355-521
+ * initialize_for_ray_tracing): flattens instances to world space, builds the compressed 8-wide BVH
+ * on the host and uploads it.  All host pointers; data is copied. */
+typedef struct
+{
+    const float*    positions;    /* [n_tris][3][3] world-space vertex positions               */
+    const float*    normals;      /* [n_tris][3][3] vertex normals, or NULL (geometric)         */
+    const uint32_t* tri_material; /* [n_tris] or NULL                                           */
+    const uint32_t* tri_mesh_id;  /* [n_tris] or NULL                                           */
+    int32_t         n_tris;
+    const float*    materials;    /* [n_materials][8]: albedo rgb, metallic, roughness, emissive rgb */
+    int32_t         n_materials;
+} hr_scene_desc;
+
+typedef struct
+{
+    int32_t  n_tris, n_nodes, max_depth;
+    uint64_t node_bytes, tri_bytes;
+    float    bounds_lo[3], bounds_hi[3];
+    float    box_pad;
+} hr_scene_info;
+
+hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* desc, hr_scene** out);
+hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info);
+hr_status hr_scene_destroy(hr_scene* scene);
+
+/* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).
+ * rays: device [n][8] floats = origin xyz, t_max, direction xyz, t_min.
+ * any-hit: out_occluded device [n] uint8.  closest: out_tuv device [n][3] (t,u,v), out_prim device [n] int32 (-1 miss).
+ * stats (nullable, device [2] uint64): accumulates nodes visited, triangles tested. */
+hr_status hr_trace_any_hit(const hr_scene* scene, int64_t n, const float* rays, uint8_t* out_occluded, uint64_t* stats, void* stream);
+hr_status hr_trace_closest_hit(const hr_scene* scene, int64_t n, const float* rays, float* out_tuv, int32_t* out_prim, void* stream);
+
+/* G-buffer synthesis by primary-ray casting (tooling: stands in for the raster GBuffer pass,
+ * src/g_buffer.cpp + shaders/g_buffer.frag:86-112, so bench inputs can be produced on the GPU). */
+hr_status hr_gbuffer_raycast(const hr_scene* scene, const hr_ubo* ubo, int32_t width, int32_t height, void* gb1, void* gb2, void* gb3,
+                             float* depth, void* stream);
+
+/* ---- common pass plumbing ---------------------------------------------------------------------- */
+typedef enum
+{
+    HR_SCALE_FULL_RES    = 0, /* RAY_TRACE_SCALE_FULL_RES    (common.h) */
+    HR_SCALE_HALF_RES    = 1,
+    HR_SCALE_QUARTER_RES = 2
+} hr_scale;
+
+/* RayTracedShadows::OutputType etc. (ray_traced_shadows.h:10-16) */
+typedef enum
+{
+    HR_OUTPUT_RAY_TRACE             = 0,
+    HR_OUTPUT_TEMPORAL_ACCUMULATION = 1,
+    HR_OUTPUT_ATROUS                = 2, /* AO: bilateral blur */
+    HR_OUTPUT_UPSAMPLE              = 3
+} hr_output_kind;
+
+/* Row band owned by this GPU.  Zero-initialised = whole frame. */
+typedef struct
+{
+    int32_t band_y0, band_y1; /* rows owned, in pass-resolution pixels; 0,0 = whole frame */
+    int32_t halo;             /* extra rows held on each side */
+} hr_band;
+
+#define HR_MAX_STAGES 16
+typedef struct
+{
+    int32_t     n_stages;
+    const char* name[HR_MAX_STAGES];
+    float       ms[HR_MAX_STAGES];     /* last profiled render(), hipEvent elapsed */
+    uint64_t    bytes[HR_MAX_STAGES];  /* algorithmic bytes of the stage */
+} hr_stage_times;
+
+/* ---- RayTracedShadows (src/ray_traced_shadows.h) ----------------------------------------------- */
+typedef struct hr_shadows hr_shadows;
+
+/* member defaults: ray_traced_shadows.h:52,69-70,101-107 */
+typedef struct
+{
+    int32_t denoise;            /* m_denoise = true                              */
+    float   bias;               /* RayTrace::bias = 0.5                          */
+    float   alpha;              /* TemporalAccumulation::alpha = 0.01            */
+    float   moments_alpha;      /* TemporalAccumulation::moments_alpha = 0.2     */
+    float   phi_visibility;     /* ATrous::phi_visibility = 10                   */
+    float   phi_normal;         /* ATrous::phi_normal = 32                       */
+    float   sigma_depth;        /* ATrous::sigma_depth = 1                       */
+    float   power;              /* ATrous::power = 1.2                           */
+    int32_t radius;             /* ATrous::radius = 1                            */
+    int32_t filter_iterations;  /* ATrous::filter_iterations = 4  (1..5)         */
+    int32_t feedback_iteration; /* ATrous::feedback_iteration = 1                */
+} hr_shadows_params;
+
+void      hr_shadows_default_params(hr_shadows_params* p);
+hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_shadows** out);
+/* RayTracedShadows::render (ray_traced_shadows.cpp:100-116) */
+hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
+/* RayTracedShadows::output_ds (ray_traced_shadows.cpp:135-155) */
+hr_status hr_shadows_output(hr_shadows* p, hr_output_kind kind, hr_image_view* view);
+/* m_first_frame = true (ray_traced_shadows.cpp:938-968) */
+hr_status hr_shadows_reset_history(hr_shadows* p);
+hr_status hr_shadows_destroy(hr_shadows* p);
+/* Stage-level entry points (the private methods ray_trace / temporal_accumulation / a_trous_filter /
+ * upsample, ray_traced_shadows.cpp:972-1255) so a multi-GPU driver can exchange halos between them. */
+hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
+hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
+hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, int32_t iteration, void* stream);
+hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
+/* Views of intermediates for halo exchange / golden taps: 0 mask, 1 temporal out, 2/3 moments[0/1],
+ * 4 prev (feedback) image, 5/6 à-trous ping/pong, 7 upsample, 8 tile classes (uint8 as R8 in an R32 view is not
+ * representable: width/height are in tiles, format HR_FORMAT_R32_UINT is NOT implied — 1 byte per tile). */
+hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* view);
+hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable);
+hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out); /* synchronises the recorded events */
+/* rays fired by the last ray_trace (lit, non-sky pixels); synchronises the stream it ran on */
+hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
+
+/* ---- self test ------------------------------------------------------------------------------------ */
+/* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
+ * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)
+ * 4 fp32->fp16 bits (as float of the uint16)  5 oct_decode(x,y)->(nx,ny,nz)  6 oct_encode(x,y,z)->(ex,ey).
+ * in: device [n][3] floats, out: device [n][3] floats. */
+hr_status hr_selftest_math(int32_t which, int64_t n, const float* in, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HR_API_H */

@@ -1,0 +1,52 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points of the CPU oracle (loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product).
+// Parity unpinned by the reference (no tests / golden vectors upstream).
+#pragma once
+#include <cstdint>
+
+extern "C" {
+
+// ---- scene -----------------------------------------------------------------------------
+// verts: [n][3][3] world-space positions.  normals (nullable): [n][3][3] vertex normals.
+// tri_material / tri_mesh_id (nullable): per triangle.  materials (nullable): [m][8] =
+// albedo rgb, metallic, roughness, emissive rgb.
+void*    orc_scene_create(const float* verts, int n_tris, const float* normals, const uint32_t* tri_material, const uint32_t* tri_mesh_id, const float* materials, int n_materials);
+void     orc_scene_destroy(void* scene);
+int      orc_scene_num_nodes(const void* scene);
+// rays: [n][8] = origin xyz, t_max, dir xyz, t_min.  out: [n] uint8 (1 = occluded).
+void     orc_any_hit_batch(const void* scene, int n, const float* rays, uint8_t* out, int brute_force, uint64_t* stats /*[2] nodes,tris; nullable*/);
+// out: [n][4] float = t, u, v, prim (as float bits of int32; -1 miss)
+void     orc_closest_hit_batch(const void* scene, int n, const float* rays, float* out_tuv, int32_t* out_prim, int brute_force);
+
+// ---- G-buffer synthesis (test tooling; mirrors g_buffer.frag:86-112 output conventions) --
+void     orc_gbuffer_raycast(const void* scene, const void* ubo, int w, int h, uint8_t* gb1, uint16_t* gb2, uint16_t* gb3, float* depth);
+
+// ---- shadows ----------------------------------------------------------------------------
+void orc_shadows_ray_trace(const void* scene, const void* ubo, int w, int h, const float* depth, const uint16_t* gb2,
+                           const uint8_t* sobol, const uint8_t* scrambling_ranking, float bias, uint32_t num_frames,
+                           uint32_t* mask, uint64_t* rays_out);
+void orc_shadows_gen_rays(const void* ubo, int w, int h, const float* depth, const uint16_t* gb2, const uint8_t* sobol,
+                          const uint8_t* scrambling_ranking, float bias, uint32_t num_frames, float* rays);
+void orc_shadows_temporal(const void* ubo, int w, int h, const uint32_t* mask, const float* depth, const uint16_t* gb2,
+                          const uint16_t* gb3, const float* prev_depth, const uint16_t* prev_gb2, const uint16_t* prev_gb3,
+                          const uint16_t* hist_vis_var, const uint16_t* hist_moments, float alpha, float moments_alpha,
+                          uint16_t* out_vis_var, uint16_t* out_moments, uint8_t* tile_class);
+void orc_shadows_atrous(int w, int h, const uint16_t* in_vis_var, const uint16_t* gb2, const uint16_t* gb3,
+                        const uint8_t* tile_class, int radius, int step_size, float phi_visibility, float phi_normal,
+                        float sigma_depth, float power, uint16_t* out_vis_var);
+void orc_upsample(int W, int H, int w, int h, const uint16_t* gb2_full, const uint16_t* gb3_full, const uint16_t* gb2_mip,
+                  const uint16_t* gb3_mip, const uint16_t* in_lowres, int in_channels, int channels, float sky_value, float power,
+                  uint16_t* out_full);
+
+// ---- scalar helpers exported for known-answer tests ---------------------------------------
+uint16_t orc_f32_to_f16(float f);
+float    orc_f16_to_f32(uint16_t h);
+void     orc_sincos(float x, float* s, float* c);
+float    orc_exp(float x);
+float    orc_log(float x);
+float    orc_pow(float x, float y);
+void     orc_oct_decode(float ex, float ey, float* out3);
+void     orc_oct_encode(const float* n3, float* out2);
+float    orc_sample_blue_noise(int x, int y, int sample_index, int dim, const uint8_t* sobol, const uint8_t* scrambling_ranking);
+void     orc_world_position_from_depth(float u, float v, float depth, const float* view_proj_inverse, float* out3);
+}

@@ -1,0 +1,201 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (hybrid_rendering_amd) never does.  Parity unpinned by the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libhr_oracle.so")
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_uint8)
+c_u16p = C.POINTER(C.c_uint16)
+c_u32p = C.POINTER(C.c_uint32)
+c_i32p = C.POINTER(C.c_int32)
+c_u64p = C.POINTER(C.c_uint64)
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/_build/libhr_oracle.so with the committed Makefile."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE) if f.endswith((".cpp", ".h", "Makefile"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_scene_create.restype = C.c_void_p
+        _lib.orc_scene_num_nodes.restype = C.c_int
+        _lib.orc_f32_to_f16.restype = C.c_uint16
+        _lib.orc_f32_to_f16.argtypes = [C.c_float]
+        _lib.orc_f16_to_f32.restype = C.c_float
+        _lib.orc_f16_to_f32.argtypes = [C.c_uint16]
+        for n in ("orc_exp", "orc_log"):
+            getattr(_lib, n).restype = C.c_float
+            getattr(_lib, n).argtypes = [C.c_float]
+        _lib.orc_pow.restype = C.c_float
+        _lib.orc_pow.argtypes = [C.c_float, C.c_float]
+        _lib.orc_sample_blue_noise.restype = C.c_float
+    return _lib
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(t)
+
+
+def _ubo_ptr(ubo: np.ndarray):
+    assert ubo.nbytes == 416
+    return C.c_void_p(ubo.ctypes.data)
+
+
+class Scene:
+    """Oracle scene handle (BVH2 + per-triangle shading data)."""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self.verts = np.ascontiguousarray(sd.verts, np.float32)
+        self.normals = np.ascontiguousarray(sd.normals, np.float32) if sd.normals is not None else None
+        self.tri_material = np.ascontiguousarray(sd.tri_material, np.uint32)
+        self.tri_mesh_id = np.ascontiguousarray(sd.tri_mesh_id, np.uint32)
+        self.materials = np.ascontiguousarray(sd.materials, np.float32)
+        self.h = C.c_void_p(lib().orc_scene_create(
+            _p(self.verts, c_f32p), C.c_int(sd.n_tris), _p(self.normals, c_f32p), _p(self.tri_material, c_u32p),
+            _p(self.tri_mesh_id, c_u32p), _p(self.materials, c_f32p), C.c_int(len(self.materials))))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def num_nodes(self):
+        return lib().orc_scene_num_nodes(self.h)
+
+    def any_hit(self, rays: np.ndarray, brute_force=False, stats=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.uint8)
+        st = np.zeros(2, np.uint64) if stats else None
+        lib().orc_any_hit_batch(self.h, C.c_int(len(rays)), _p(rays, c_f32p), _p(out, c_u8p), C.c_int(int(brute_force)), _p(st, c_u64p))
+        return (out, st) if stats else out
+
+    def closest_hit(self, rays: np.ndarray, brute_force=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        tuv = np.zeros((len(rays), 3), np.float32)
+        prim = np.zeros(len(rays), np.int32)
+        lib().orc_closest_hit_batch(self.h, C.c_int(len(rays)), _p(rays, c_f32p), _p(tuv, c_f32p), _p(prim, c_i32p), C.c_int(int(brute_force)))
+        return tuv, prim
+
+    def gbuffer(self, ubo, w, h):
+        gb1 = np.zeros((h, w, 4), np.uint8)
+        gb2 = np.zeros((h, w, 4), np.uint16)
+        gb3 = np.zeros((h, w, 4), np.uint16)
+        depth = np.zeros((h, w), np.float32)
+        lib().orc_gbuffer_raycast(self.h, _ubo_ptr(ubo), C.c_int(w), C.c_int(h), _p(gb1, c_u8p), _p(gb2, c_u16p), _p(gb3, c_u16p), _p(depth, c_f32p))
+        return dict(gb1=gb1, gb2=gb2, gb3=gb3, depth=depth)
+
+
+# ---------------------------------------------------------------------------------- shadows
+
+def shadows_ray_trace(scene: Scene, ubo, depth, gb2, sobol, sr, bias=0.5, num_frames=0):
+    h, w = depth.shape
+    mask = np.zeros(((h + 3) // 4, (w + 7) // 8), np.uint32)
+    rays = C.c_uint64(0)
+    lib().orc_shadows_ray_trace(scene.h, _ubo_ptr(ubo), C.c_int(w), C.c_int(h), _p(depth, c_f32p), _p(gb2, c_u16p), _p(sobol, c_u8p),
+                                _p(sr, c_u8p), C.c_float(bias), C.c_uint32(num_frames), _p(mask, c_u32p), C.byref(rays))
+    return mask, rays.value
+
+
+def shadows_gen_rays(ubo, depth, gb2, sobol, sr, bias=0.5, num_frames=0):
+    h, w = depth.shape
+    rays = np.zeros((h * w, 8), np.float32)
+    lib().orc_shadows_gen_rays(_ubo_ptr(ubo), C.c_int(w), C.c_int(h), _p(depth, c_f32p), _p(gb2, c_u16p), _p(sobol, c_u8p), _p(sr, c_u8p),
+                               C.c_float(bias), C.c_uint32(num_frames), _p(rays, c_f32p))
+    return rays
+
+
+def shadows_temporal(ubo, mask, cur, prev, hist_vis_var, hist_moments, alpha=0.01, moments_alpha=0.2):
+    h, w = cur["depth"].shape
+    out = np.zeros((h, w, 2), np.uint16)
+    mom = np.zeros((h, w, 4), np.uint16)
+    tiles = np.zeros(((h + 7) // 8, (w + 7) // 8), np.uint8)
+    lib().orc_shadows_temporal(_ubo_ptr(ubo), C.c_int(w), C.c_int(h), _p(mask, c_u32p), _p(cur["depth"], c_f32p), _p(cur["gb2"], c_u16p),
+                               _p(cur["gb3"], c_u16p), _p(prev["depth"], c_f32p), _p(prev["gb2"], c_u16p), _p(prev["gb3"], c_u16p),
+                               _p(hist_vis_var, c_u16p), _p(hist_moments, c_u16p), C.c_float(alpha), C.c_float(moments_alpha),
+                               _p(out, c_u16p), _p(mom, c_u16p), _p(tiles, c_u8p))
+    return out, mom, tiles
+
+
+def shadows_atrous(inp, gb2, gb3, tiles, step, radius=1, phi_visibility=10.0, phi_normal=32.0, sigma_depth=1.0, power=0.0):
+    h, w = inp.shape[:2]
+    out = np.zeros((h, w, 2), np.uint16)
+    lib().orc_shadows_atrous(C.c_int(w), C.c_int(h), _p(inp, c_u16p), _p(gb2, c_u16p), _p(gb3, c_u16p), _p(tiles, c_u8p), C.c_int(radius),
+                             C.c_int(step), C.c_float(phi_visibility), C.c_float(phi_normal), C.c_float(sigma_depth), C.c_float(power),
+                             _p(out, c_u16p))
+    return out
+
+
+def upsample(full, mip, lowres, channels=1, sky_value=0.0, power=0.0):
+    H, W = full["gb2"].shape[:2]
+    h, w = mip["gb2"].shape[:2]
+    in_ch = lowres.shape[2] if lowres.ndim == 3 else 1
+    out = np.zeros((H, W, channels), np.uint16)
+    lib().orc_upsample(C.c_int(W), C.c_int(H), C.c_int(w), C.c_int(h), _p(full["gb2"], c_u16p), _p(full["gb3"], c_u16p), _p(mip["gb2"], c_u16p),
+                       _p(mip["gb3"], c_u16p), _p(lowres, c_u16p), C.c_int(in_ch), C.c_int(channels), C.c_float(sky_value), C.c_float(power),
+                       _p(out, c_u16p))
+    return out
+
+
+class ShadowsPass:
+    """Host-side sequencing of RayTracedShadows::render (ray_traced_shadows.cpp:100-116) on the oracle."""
+
+    def __init__(self, w, h, bias=0.5, alpha=0.01, moments_alpha=0.2, phi_visibility=10.0, phi_normal=32.0, sigma_depth=1.0,
+                 power=1.2, radius=1, filter_iterations=4, feedback_iteration=1):
+        self.w, self.h = w, h
+        self.p = dict(bias=bias, alpha=alpha, moments_alpha=moments_alpha, phi_visibility=phi_visibility, phi_normal=phi_normal,
+                      sigma_depth=sigma_depth, power=power, radius=radius, filter_iterations=filter_iterations,
+                      feedback_iteration=feedback_iteration)
+        self.prev_image = np.zeros((h, w, 2), np.uint16)      # clear_images(): zero (:938-968)
+        self.moments = np.zeros((h, w, 4), np.uint16)
+        self.stages = {}
+
+    def render(self, scene, ubo, cur, prev, sobol, sr, num_frames):
+        p = self.p
+        mask, nrays = shadows_ray_trace(scene, ubo, cur["depth"], cur["gb2"], sobol, sr, p["bias"], num_frames)
+        tv, mom, tiles = shadows_temporal(ubo, mask, cur, prev, self.prev_image, self.moments, p["alpha"], p["moments_alpha"])
+        self.moments = mom
+        img = tv
+        atrous = []
+        for i in range(p["filter_iterations"]):
+            power = p["power"] if i == p["filter_iterations"] - 1 else 0.0
+            img = shadows_atrous(img, cur["gb2"], cur["gb3"], tiles, 1 << i, p["radius"], p["phi_visibility"], p["phi_normal"],
+                                 p["sigma_depth"], power)
+            atrous.append(img)
+            if i == p["feedback_iteration"]:
+                self.prev_image = img.copy()
+        self.stages = dict(mask=mask, rays=nrays, temporal=tv, moments=mom, tiles=tiles, atrous=atrous, output=img)
+        return img
+
+
+def f16(a):
+    """uint16 fp16 bit patterns -> float32 values."""
+    return np.asarray(a, np.uint16).view(np.float16).astype(np.float32)

@@ -1,0 +1,89 @@
+"""Shared test fixtures: seeded synthetic frames built with the oracle's CPU G-buffer synthesiser."""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from hybrid_rendering_amd import synth
+
+
+@functools.lru_cache(maxsize=8)
+def scene_data(name: str):
+    if name == "cornell":
+        return synth.cornell32()
+    if name == "sponza_small":
+        return synth.sponza_like(0.25)
+    if name == "sponza":
+        return synth.sponza_like(1.0)
+    raise KeyError(name)
+
+
+def cameras(name: str, aspect: float, n_frames: int, dolly: float):
+    if name == "cornell":
+        base = synth.cornell_camera(aspect)
+        cams = []
+        for f in range(n_frames):
+            e = np.array(base.eye) + np.array([0.6, 0.2, -1.0]) * dolly * f
+            cams.append(synth.Camera(tuple(e), base.target, fov=base.fov, aspect=aspect))
+        return cams
+    return [synth.sponza_camera(aspect, frame=f, dolly=dolly) for f in range(n_frames)]
+
+
+def light_for(name: str, kind: str = "default"):
+    if name == "cornell":
+        return synth.cornell_light(hard=(kind != "soft"))
+    if kind == "point":
+        return synth.make_light(synth.LIGHT_POINT, position=(100.0, 300.0, 20.0), radius=4.0, intensity=50000.0)
+    if kind == "spot":
+        return synth.make_light(synth.LIGHT_SPOT, direction_to_light=(0.2, 1.0, 0.1), position=(60.0, 330.0, 30.0), radius=3.0,
+                                intensity=50000.0, cone_inner_deg=25.0, cone_outer_deg=40.0)
+    return synth.sponza_light()
+
+
+def make_frames(oracle, oscene, name, w, h, n_frames=3, dolly=0.0, light_kind="default", scale_mips=0):
+    """List of dicts(ubo, gb (numpy G-buffer at (w,h)), mips...) for consecutive frames."""
+    cams = cameras(name, w / h, n_frames, dolly)
+    light = light_for(name, light_kind)
+    frames = []
+    for f in range(n_frames):
+        ubo = synth.make_ubo(cams[f], cams[f - 1] if f > 0 else None, light)
+        gb = oscene.gbuffer(ubo, w, h)
+        fr = dict(ubo=ubo, gb=gb)
+        if scale_mips:
+            fr["mips"] = [gb] + [nearest_mip(gb, s) for s in range(1, scale_mips + 1)]
+        frames.append(fr)
+    return frames
+
+
+def nearest_mip(gb, level):
+    """Point-sampled mip (g_buffer.cpp:240-243 VK_FILTER_NEAREST): keep texel (x << level, y << level)."""
+    s = 1 << level
+    h, w = gb["depth"].shape
+    hh, ww = h >> level, w >> level
+    return {k: np.ascontiguousarray(v[:hh * s:s, :ww * s:s]) for k, v in gb.items()}
+
+
+def to_cuda(gb):
+    import torch
+    out = {}
+    for k, v in gb.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        if t.dtype == torch.uint16:
+            t = t.view(torch.float16)
+        out[k] = t.cuda()
+    return out
+
+
+def bits16(t):
+    """cuda fp16 tensor -> numpy uint16 bit patterns."""
+    import torch
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def unpack_mask(mask, w, h):
+    bits = np.zeros((((h + 3) // 4) * 4, ((w + 7) // 8) * 8), np.uint8)
+    for ly in range(4):
+        for lx in range(8):
+            bits[ly::4, lx::8] = (mask >> np.uint32(ly * 8 + lx)) & 1
+    return bits[:h, :w]

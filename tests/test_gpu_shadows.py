@@ -1,0 +1,86 @@
+"""GPU parity: RayTracedShadows (HIP, through the C ABI) vs the CPU oracle, stage by stage.
+
+Bar: the packed visibility mask, tile classes and every fp16 stage image are compared BIT FOR BIT
+(the numerical contract of DESIGN.md §3 makes all of them reproducible)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(oracle, hr, ctx, name, w, h, n_frames, dolly, light_kind="default", params=None):
+    import torch
+    sd = helpers.scene_data(name)
+    osc = oracle.Scene(sd)
+    gsc = hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, w, h, n_frames, dolly, light_kind)
+    sob, sr = __import__("hybrid_rendering_amd.synth", fromlist=["x"]).blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    gp = hr.RayTracedShadows(ctx, w, h)
+    kw = dict(params or {})
+    for k, v in kw.items():
+        setattr(gp.params, k, v)
+    op = oracle.ShadowsPass(w, h, **kw)
+    ping = False
+    for f in range(n_frames):
+        cur, prev = frames[f]["gb"], frames[f - 1]["gb"] if f > 0 else frames[f]["gb"]
+        op.render(osc, frames[f]["ubo"], cur, prev, sob, sr, f)
+        cur_d, prev_d = helpers.to_cuda(cur), helpers.to_cuda(prev)
+        fi = hr.frame_inputs(cur_d, prev_d, frames[f]["ubo"], f, ping, sob_d, sr_d)
+        gp.render(gsc, fi)
+        torch.cuda.synchronize()
+        st = op.stages
+        mask = gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32)
+        nbad = int((mask != st["mask"]).sum())
+        assert nbad == 0, f"frame {f}: {nbad} mask words differ"
+        assert gp.ray_count() == st["rays"], f"frame {f}: ray count"
+        tiles = gp.image(gp.IMG_TILES).cpu().numpy()
+        assert np.array_equal(tiles, st["tiles"]), f"frame {f}: tile classes differ"
+        tv = helpers.bits16(gp.image(gp.IMG_TEMPORAL))
+        assert np.array_equal(tv, st["temporal"]), f"frame {f}: temporal output differs in {(tv != st['temporal']).sum()} halfs"
+        mom = helpers.bits16(gp.image(gp.IMG_MOMENTS1 if ping else gp.IMG_MOMENTS0))
+        assert np.array_equal(mom, st["moments"]), f"frame {f}: moments differ"
+        out = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
+        assert np.array_equal(out, st["output"]), f"frame {f}: a-trous output differs in {(out != st['output']).sum()} halfs"
+        prev_img = helpers.bits16(gp.image(gp.IMG_PREV))
+        assert np.array_equal(prev_img, op.prev_image), f"frame {f}: feedback image differs"
+        ping = not ping
+    gp.close()
+    gsc.close()
+    return op
+
+
+def test_cornell_hard_shadows_256(oracle, hr, ctx):
+    """BASELINE.json configs[0]: 256x256 Cornell box, 32 triangles, hard shadows, 1 spp."""
+    op = _run_case(oracle, hr, ctx, "cornell", 256, 256, 3, 0.0)
+    lit = helpers.unpack_mask(op.stages["mask"], 256, 256).mean()
+    assert 0.05 < lit < 0.95
+
+
+def test_cornell_soft_moving(oracle, hr, ctx):
+    _run_case(oracle, hr, ctx, "cornell", 256, 192, 4, 1.5, light_kind="soft")
+
+
+def test_sponza_small_directional(oracle, hr, ctx):
+    _run_case(oracle, hr, ctx, "sponza_small", 320, 184, 3, 0.0)
+
+
+def test_sponza_small_moving_camera(oracle, hr, ctx):
+    _run_case(oracle, hr, ctx, "sponza_small", 256, 144, 4, 2.0)
+
+
+@pytest.mark.parametrize("kind", ["point", "spot"])
+def test_sponza_small_punctual(oracle, hr, ctx, kind):
+    _run_case(oracle, hr, ctx, "sponza_small", 192, 112, 2, 1.0, light_kind=kind)
+
+
+def test_ragged_size(oracle, hr, ctx):
+    """Width/height not multiples of the 8x8 / 8x4 tiles."""
+    _run_case(oracle, hr, ctx, "cornell", 150, 101, 3, 1.0, light_kind="soft")
+
+
+def test_params_variants(oracle, hr, ctx):
+    _run_case(oracle, hr, ctx, "cornell", 128, 128, 3, 1.0, light_kind="soft",
+              params=dict(filter_iterations=5, feedback_iteration=0, phi_normal=7.5, power=2.0, alpha=0.05, radius=2))

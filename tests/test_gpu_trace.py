@@ -1,0 +1,145 @@
+"""GPU parity of the raw ray queries and device arithmetic against the CPU oracle (bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_rays(sd, n, seed, tmax_mode="mixed"):
+    rng = np.random.RandomState(seed)
+    lo, hi = sd.bounds()
+    o = rng.uniform(lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo), size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a few axis-aligned / degenerate directions
+    d[::97] = np.eye(3)[rng.randint(0, 3, size=len(d[::97]))] * rng.choice([-1.0, 1.0], size=(len(d[::97]), 1))
+    tmax = np.full(n, 1.0e4)
+    if tmax_mode == "mixed":
+        tmax[::2] = rng.uniform(1.0, np.linalg.norm(hi - lo), size=len(tmax[::2]))
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, tmax, d, 0.01
+    return rays
+
+
+@pytest.mark.parametrize("name,n", [("cornell", 200_000), ("sponza_small", 400_000), ("sponza", 1_000_000)])
+def test_any_hit_matches_oracle(oracle, hr, ctx, name, n):
+    import torch
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    rays = _random_rays(sd, n, 1)
+    ref = osc.any_hit(rays)
+    got = gsc.any_hit(torch.from_numpy(rays).cuda()).cpu().numpy()
+    assert 0.02 < ref.mean() < 0.999
+    assert int((ref != got).sum()) == 0
+    gsc.close()
+
+
+@pytest.mark.parametrize("name,n", [("cornell", 100_000), ("sponza_small", 300_000)])
+def test_closest_hit_matches_oracle(oracle, hr, ctx, name, n):
+    import torch
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    rays = _random_rays(sd, n, 2, tmax_mode="far")
+    tuv, prim = osc.closest_hit(rays)
+    gt, gp = gsc.closest_hit(torch.from_numpy(rays).cuda())
+    gt, gp = gt.cpu().numpy(), gp.cpu().numpy()
+    assert (prim >= 0).mean() > 0.3
+    assert np.array_equal(prim, gp)
+    hit = prim >= 0
+    assert np.array_equal(tuv[hit].view(np.uint32), gt[hit].view(np.uint32))
+    gsc.close()
+
+
+def test_gbuffer_raycast_matches_oracle(oracle, hr, ctx):
+    from hybrid_rendering_amd import synth
+    sd = helpers.scene_data("sponza_small")
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    w, h = 320, 180
+    cam0, cam1 = synth.sponza_camera(w / h, 0, 2.0), synth.sponza_camera(w / h, 1, 2.0)
+    ubo = synth.make_ubo(cam1, cam0, synth.sponza_light())
+    ref = osc.gbuffer(ubo, w, h)
+    got = gsc.gbuffer(ubo, w, h)
+    assert np.array_equal(ref["depth"].view(np.uint32), got["depth"].cpu().numpy().view(np.uint32))
+    assert np.array_equal(ref["gb1"], got["gb1"].cpu().numpy())
+    assert np.array_equal(ref["gb2"], helpers.bits16(got["gb2"]))
+    assert np.array_equal(ref["gb3"], helpers.bits16(got["gb3"]))
+    gsc.close()
+
+
+def _selftest(hr, which, arr):
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(arr, np.float32)).cuda()
+    out = torch.zeros_like(x)
+    st = hr.lib().hr_selftest_math(C.c_int32(which), C.c_int64(x.shape[0]), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_device_math_bit_exact(oracle, hr, ctx):
+    L = oracle.lib()
+    rng = np.random.RandomState(3)
+    n = 200_000
+    x = np.zeros((n, 3), np.float32)
+    # sincos over [0, 2pi] (+ some outside)
+    x[:, 0] = rng.uniform(-1.0, 7.5, n)
+    got = _selftest(hr, 0, x)
+    s, c = C.c_float(), C.c_float()
+    for i in range(0, n, 37):
+        L.orc_sincos(C.c_float(float(x[i, 0])), C.byref(s), C.byref(c))
+        assert np.float32(s.value).view(np.uint32) == got[i, 0].view(np.uint32)
+        assert np.float32(c.value).view(np.uint32) == got[i, 1].view(np.uint32)
+    # exp / log / pow
+    x[:, 0] = rng.uniform(-20.0, 5.0, n)
+    got = _selftest(hr, 1, x)
+    for i in range(0, n, 41):
+        assert np.float32(L.orc_exp(float(x[i, 0]))).view(np.uint32) == got[i, 0].view(np.uint32)
+    x[:, 0] = np.exp(rng.uniform(-20.0, 10.0, n)).astype(np.float32)
+    got = _selftest(hr, 2, x)
+    for i in range(0, n, 41):
+        assert np.float32(L.orc_log(float(x[i, 0]))).view(np.uint32) == got[i, 0].view(np.uint32)
+    x[:, 0] = rng.uniform(0.0, 1.0, n)
+    x[:, 1] = rng.choice([32.0, 1.2, 2.0, 7.5, 50.0], n)
+    got = _selftest(hr, 3, x)
+    for i in range(0, n, 41):
+        assert np.float32(L.orc_pow(float(x[i, 0]), float(x[i, 1]))).view(np.uint32) == got[i, 0].view(np.uint32)
+
+
+def test_fp16_conversion_bit_exact(oracle, hr, ctx):
+    """v_cvt_f16_f32 (RTNE, denormals kept) == the oracle's software conversion, over boundaries + random."""
+    L = oracle.lib()
+    rng = np.random.RandomState(4)
+    vals = np.concatenate([
+        rng.uniform(-70000, 70000, 50000), rng.uniform(-1e-4, 1e-4, 50000), rng.uniform(-2, 2, 50000),
+        np.float32([0.0, -0.0, 65504.0, 65519.9, 65520.0, 6.1e-5, 5.96e-8, 2.98e-8, 2.9802322e-8, 3.0e-8, 1e-10, np.inf, -np.inf]),
+    ]).astype(np.float32)
+    # exact ties: halfway between consecutive halfs
+    h = rng.randint(0, 0x7bff, 20000).astype(np.uint16)
+    a = h.view(np.float16).astype(np.float32)
+    b = (h + 1).astype(np.uint16).view(np.float16).astype(np.float32)
+    vals = np.concatenate([vals, ((a.astype(np.float64) + b) / 2).astype(np.float32)])
+    x = np.zeros((len(vals), 3), np.float32)
+    x[:, 0] = vals
+    got = _selftest(hr, 4, x)[:, 0].astype(np.uint32)
+    ref = np.array([L.orc_f32_to_f16(float(v)) for v in vals], np.uint32)
+    assert np.array_equal(ref, got)
+    assert np.array_equal(ref.astype(np.uint16), vals.astype(np.float16).view(np.uint16))
+
+
+def test_octahedral_bit_exact(oracle, hr, ctx):
+    L = oracle.lib()
+    rng = np.random.RandomState(5)
+    n = 20000
+    x = np.zeros((n, 3), np.float32)
+    x[:, :2] = rng.uniform(-1, 1, (n, 2))
+    x[:, :2] = x[:, :2].astype(np.float16).astype(np.float32)
+    got = _selftest(hr, 5, x)
+    out = (C.c_float * 3)()
+    for i in range(0, n, 7):
+        L.orc_oct_decode(C.c_float(float(x[i, 0])), C.c_float(float(x[i, 1])), out)
+        assert np.array_equal(np.float32(list(out)).view(np.uint32), got[i].view(np.uint32))
