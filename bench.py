@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native ray-trace + denoise hot path.
+
+One "step" = one frame of RayTracedShadows::render (1 spp soft-shadow trace + SVGF temporal +
+4 x a-trous) on synthetic 1080p G-buffers of the procedural Sponza-like scene (~278k triangles),
+inputs resident in HBM (BASELINE.json configs[1]).  Prints ONE JSON line (see the driver contract).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the frame is row-tiled, one 1080-row band per GPU (a 1920 x 1080*N frame; weak scaling);
+no collective is on the data path of the shadows pass at this band height except the halo rows,
+which each rank re-traces / re-filters locally (zero-communication variant of SURVEY.md §8e).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES = 80, 48
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~278k triangles)")
+    ap.add_argument("--ring", type=int, default=8, help="distinct camera positions cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=10)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+
+    from hybrid_rendering_amd import api as hr
+    from hybrid_rendering_amd import synth
+
+    W, H = args.width, args.height
+    sd = synth.sponza_like(args.detail)
+    ctx = hr.Context(local_rank)
+    scene = hr.Scene(ctx, sd)
+    light = synth.sponza_light()
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+
+    # ring of camera positions (dolly 0.5 units/frame); each rank of a tiled
+    # frame looks at its own band of a taller frame == an independent vertical camera offset here.
+    R = max(2, args.ring)
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(R + 1)]
+    if world > 1:
+        cams = [synth.Camera((c.eye[0], c.eye[1] + 3.0 * rank, c.eye[2]), (c.target[0], c.target[1] + 3.0 * rank, c.target[2]), aspect=c.aspect) for c in cams]
+    # G-buffers: ring position i rendered with prev = i-1 (forward sweep) and with prev = i+1 (backward sweep)
+    gbs = {}
+    ubos = {}
+    for i in range(R):
+        for direction, j in (("f", i - 1 if i > 0 else 0), ("b", i + 1)):
+            ubo = synth.make_ubo(cams[i], cams[j], light)
+            ubos[(i, direction)] = ubo
+            gbs[(i, direction)] = scene.gbuffer(ubo, W, H)
+    torch.cuda.synchronize()
+
+    # sequence of (cur, prev) keys: 0f,1f,...,R-1f, R-2b, ..., 0b, 1f, ...
+    seq = [(i, "f") for i in range(R)] + [(i, "b") for i in range(R - 2, -1, -1)]
+    seq = seq[1:] if len(seq) > 1 else seq
+
+    def inputs_for(k):
+        key = seq[k % len(seq)]
+        pk = seq[(k - 1) % len(seq)]
+        return hr.frame_inputs(gbs[key], gbs[pk], ubos[key], k, k & 1, sob_d, sr_d)
+
+    cycle = [inputs_for(k) for k in range(len(seq) * 2)]  # even length: ping_pong parity preserved when cycling
+    shadows = hr.RayTracedShadows(ctx, W, H)
+
+    def step(k):
+        fi = cycle[k % len(cycle)]
+        fi.num_frames = k
+        shadows.render(scene, fi)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-stage HIP-event timing (same stream, outside the timed region) + ray counts -------------
+    shadows.set_profiling(True)
+    acc, rays_total, n_prof = {}, 0, min(args.steps, 60)
+    k0 = args.warmup + args.steps
+    for k in range(k0, k0 + n_prof):
+        step(k)
+        rays_total += shadows.ray_count()
+        for name, ms, nbytes in shadows.stage_times():
+            a = acc.setdefault(name, [0.0, nbytes])
+            a[0] += ms
+    shadows.set_profiling(False)
+    rays_per_frame = rays_total / n_prof
+    stages = {n: dict(ms=v[0] / n_prof, bytes=v[1]) for n, v in acc.items()}
+    # instrumented trace (node visits / triangle tests) on a few frames of the cycle
+    nn = nt = nr = 0
+    for k in range(4):
+        r, a, b = shadows.trace_stats(scene, cycle[(k0 + k) % len(cycle)])
+        nr, nn, nt = nr + r, nn + a, nt + b
+    nodes_per_ray, tris_per_ray = nn / max(nr, 1), nt / max(nr, 1)
+    px = W * H
+    trace_bytes = px * 12.125 + rays_per_frame * (nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES)
+    if "ray_trace" in stages:
+        stages["ray_trace"]["bytes"] = int(trace_bytes)
+    for s in stages.values():
+        s["GBps"] = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
+        s["frac"] = s["GBps"] / HBM_PEAK_GBS
+
+    total_rays = rays_per_frame * args.steps * world
+    if world > 1:
+        t = torch.tensor([rays_per_frame], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_rays = float(t.item()) * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / elapsed / 1e6
+    dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
+    out = {
+        "metric": "shadow Mrays/s over the fully denoised frame (1 spp trace + SVGF temporal + 4x a-trous)",
+        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise, 1 band per GPU",
+                   "rays_per_frame": int(rays_per_frame), "pixels": px, "bvh_nodes": int(scene.info.n_nodes),
+                   "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
+        "denoised_frames_per_s": round(world * args.steps / elapsed, 2),
+        "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
+        "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(dom[1]["frac"], 4), "traffic": None},
+        "stages": {n: {"ms": round(s["ms"], 4), "GBps": round(s["GBps"], 1), "frac": round(s["frac"], 4), "bytes": s["bytes"]} for n, s in stages.items()},
+    }
+
+    # ---- CPU baseline: the oracle (a port) on the host cores, bounded sample, rank 0 at N=1 only --------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        osc = po.Scene(sd)
+        op = po.ShadowsPass(W, H)
+        host = {k: {n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in gbs[k].items()} for k in seq[:3]}
+        op.render(osc, ubos[seq[0]], host[seq[0]], host[seq[0]], sob, sr, 0)  # warm (page-in, history)
+        nrays, t0c = 0, time.perf_counter()
+        nf = max(1, args.cpu_frames)
+        for f in range(nf):
+            key, pk = seq[(f + 1) % 3], seq[f % 3]
+            op.render(osc, ubos[key], host[key], host[pk], sob, sr, f + 1)
+            nrays += op.stages["rays"]
+        dt = time.perf_counter() - t0c
+        out["cpu_baseline"] = {"value": round(nrays / dt / 1e6, 3), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{nf} full {W}x{H} frames (trace + SVGF denoise) of the same workload through oracle/ (OpenMP, {os.cpu_count()} threads)",
+                               "frames_per_s": round(nf / dt, 3)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

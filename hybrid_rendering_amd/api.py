@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_shadows_ray_count", "hr_selftest_math",
+    "hr_shadows_ray_count", "hr_shadows_trace_stats", "hr_selftest_math",
 ]
 
 _lib = None
@@ -310,3 +310,9 @@ class RayTracedShadows(_Pass):
         n = C.c_uint64(0)
         _check(lib().hr_shadows_ray_count(self.h, C.byref(n)), "hr_shadows_ray_count")
         return n.value
+
+    def trace_stats(self, scene, inputs, stream=None):
+        """(rays, nodes visited, triangles tested) from the instrumented trace kernel."""
+        out = (C.c_uint64 * 3)()
+        _check(lib().hr_shadows_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(self.params), out, _stream_ptr(stream)), "hr_shadows_trace_stats")
+        return int(out[0]), int(out[1]), int(out[2])

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_raycast(GBufArgs a)
         f3    dxv = mk3(0, 0, 0), dyv = mk3(0, 0, 0);
         if (gb_plane_bary(a, hit.prim, cam, gb_pixel_dir(a, (float)x + 1.5f, (float)y + 0.5f), c0, c1, c2)) dxv = sub3(gb_normal_at(a, hit.prim, c0, c1, c2), nI);
         if (gb_plane_bary(a, hit.prim, cam, gb_pixel_dir(a, (float)x + 0.5f, (float)y + 1.5f), c0, c1, c2)) dyv = sub3(gb_normal_at(a, hit.prim, c0, c1, c2), nI);
-        curvature = __fsqrt_rn(max2(dot3(dxv, dxv), dot3(dyv, dyv)));
+        curvature = hr_sqrt(max2(dot3(dxv, dxv), dot3(dyv, dyv)));
     }
     float ox, oy;
     oct_encode(n, ox, oy);

@@ -19,6 +19,9 @@ namespace hr {
 
 struct f3 { float x, y, z; };
 
+// correctly rounded sqrt (llvm.sqrt.f32 under -fhip-fp32-correctly-rounded-divide-sqrt).  NB: HIP's
+// __fsqrt_rn() is the NATIVE (1 ulp) v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined.
+HR_DEV float hr_sqrt(float x) { return __builtin_sqrtf(x); }
 HR_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 HR_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 HR_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -26,10 +29,10 @@ HR_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 HR_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 HR_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 HR_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
-HR_DEV float len3(f3 a) { return __fsqrt_rn(dot3(a, a)); }
+HR_DEV float len3(f3 a) { return hr_sqrt(dot3(a, a)); }
 HR_DEV f3 normalize3(f3 a)
 {
-    float inv = __fdiv_rn(1.0f, __fsqrt_rn(dot3(a, a)));
+    float inv = __fdiv_rn(1.0f, hr_sqrt(dot3(a, a)));
     return scale3(a, inv);
 }
 HR_DEV float min2(float a, float b) { return a < b ? a : b; }

@@ -38,7 +38,7 @@ HR_DEV void fetch_light_shadow(const hr_light& L, f3 P, f3 N, float rx, float ry
     }
     f3    tangent   = normalize3(cross3(light_dir, mk3(0.0f, 1.0f, 0.0f)));
     f3    bitangent = normalize3(cross3(tangent, light_dir));
-    float pr        = radius * __fsqrt_rn(rx);
+    float pr        = radius * hr_sqrt(rx);
     float pa        = ry * 2.0f * HR_M_PI;
     float s, c;
     det_sincos(pa, s, c);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             if (success)
             {
                 float sv = max2(mean - mean * mean, 0.0f);
-                float sd = __fsqrt_rn(sv);
+                float sd = hr_sqrt(sv);
                 hv       = clamp1(hv, mean - 0.5f * sd, mean + 0.5f * sd);
             }
             const float al = success ? max2(a.alpha, __fdiv_rn(1.0f, hlen)) : 1.0f;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
     else
     {
         const f3    cn    = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
-        const float phi_v = a.phi_visibility * __fsqrt_rn(max2(0.0f, 1e-10f + var));
+        const float phi_v = a.phi_visibility * hr_sqrt(max2(0.0f, 1e-10f + var));
         float sum_w = 1.0f, sum_v = cv, sum_var = h2f_hi(c);
         for (int yy = -a.radius; yy <= a.radius; yy++)
             for (int xx = -a.radius; xx <= a.radius; xx++)
@@ -322,6 +322,7 @@ struct hr_shadows
     int     last_ping_pong = 0;
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
+    bool          want_stats = false;
 };
 
 extern "C" {
@@ -452,10 +453,33 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    if (p->want_stats)
+    {
+        // instrumented build of the same kernel: counts node visits / triangle tests
+        HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 16, st));
+        a.stats = (unsigned long long*)((char*)p->counters.p + 16);
+        hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
     hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
+{
+    HR_CHECK_ARG(p && out3);
+    p->want_stats = true;
+    hr_status s = hr_shadows_ray_trace(p, scene, in, prm, stream);
+    p->want_stats = false;
+    if (s != HR_OK) return s;
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t host[4];
+    HR_HIP(hipMemcpy(host, p->counters.p, 32, hipMemcpyDeviceToHost));
+    out3[0] = host[0]; out3[1] = host[2]; out3[2] = host[3];
     return HR_OK;
 }
 

@@ -229,6 +229,10 @@ hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable);
 hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out); /* synchronises the recorded events */
 /* rays fired by the last ray_trace (lit, non-sky pixels); synchronises the stream it ran on */
 hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
+/* Runs the instrumented build of the trace kernel on the same inputs (same masks are produced) and
+ * returns out3 = { rays fired, BVH nodes visited, triangles tested } — the terms of the trace pass's
+ * algorithmic-bytes figure.  Synchronises the stream. */
+hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
 
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
