@@ -73,6 +73,11 @@ class hr_shadows_params(C.Structure):
                 ("filter_iterations", C.c_int32), ("feedback_iteration", C.c_int32)]
 
 
+class hr_ao_params(C.Structure):
+    _fields_ = [("denoise", C.c_int32), ("ray_length", C.c_float), ("bias", C.c_float), ("alpha", C.c_float), ("blur_radius", C.c_int32),
+                ("power", C.c_float), ("spp", C.c_int32)]
+
+
 HR_FORMAT = {1: ("R32_UINT", 4), 2: ("R16F", 2), 3: ("RG16F", 4), 4: ("RGBA16F", 8), 5: ("R32F", 4), 6: ("RGBA8", 4), 0: ("R8", 1)}
 OUTPUT_RAY_TRACE, OUTPUT_TEMPORAL_ACCUMULATION, OUTPUT_ATROUS, OUTPUT_UPSAMPLE = 0, 1, 2, 3
 SCALE_FULL_RES, SCALE_HALF_RES, SCALE_QUARTER_RES = 0, 1, 2
@@ -316,3 +321,49 @@ class RayTracedShadows(_Pass):
         out = (C.c_uint64 * 3)()
         _check(lib().hr_shadows_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(self.params), out, _stream_ptr(stream)), "hr_shadows_trace_stats")
         return int(out[0]), int(out[1]), int(out[2])
+
+
+class RayTracedAO(_Pass):
+    """src/ray_traced_ao.h:7-126.  ``render(scene, frame_inputs)`` = RayTracedAO::render(cmd_buf)."""
+    _prefix = "hr_ao"
+    IMG_MASK, IMG_AO0, IMG_AO1, IMG_LEN0, IMG_LEN1, IMG_BLUR0, IMG_BLUR1, IMG_UPSAMPLE, IMG_TILES = range(9)
+
+    def __init__(self, ctx: Context, width: int, height: int, scale: int = SCALE_HALF_RES, band=None):
+        self.ctx = ctx
+        self.params = hr_ao_params()
+        lib().hr_ao_default_params(C.byref(self.params))
+        self.h = C.c_void_p()
+        b = hr_band(*band) if band else None
+        _check(lib().hr_ao_create(ctx.h, C.c_int32(width), C.c_int32(height), C.c_int(scale), C.byref(b) if b else None, C.byref(self.h)), "hr_ao_create")
+        self.scale = scale
+        self.width, self.height = width >> scale, height >> scale
+
+    def render(self, scene: Scene, inputs: hr_frame_inputs, stream=None):
+        _check(lib().hr_ao_render(self.h, scene.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_render")
+
+    def ray_trace(self, scene, inputs, stream=None):
+        _check(lib().hr_ao_ray_trace(self.h, scene.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_ray_trace")
+
+    def temporal(self, inputs, stream=None):
+        _check(lib().hr_ao_temporal(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_temporal")
+
+    def blur(self, inputs, which, stream=None):
+        _check(lib().hr_ao_blur(self.h, C.byref(inputs), C.byref(self.params), C.c_int32(which), _stream_ptr(stream)), "hr_ao_blur")
+
+    def upsample(self, inputs, stream=None):
+        _check(lib().hr_ao_upsample(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_upsample")
+
+    def ray_count(self) -> int:
+        n = C.c_uint64(0)
+        _check(lib().hr_ao_ray_count(self.h, C.byref(n)), "hr_ao_ray_count")
+        return n.value
+
+    def trace_stats(self, scene, inputs, stream=None):
+        out = (C.c_uint64 * 3)()
+        _check(lib().hr_ao_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(self.params), out, _stream_ptr(stream)), "hr_ao_trace_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
+
+ABI_SYMBOLS += ["hr_ao_default_params", "hr_ao_create", "hr_ao_render", "hr_ao_output", "hr_ao_reset_history", "hr_ao_destroy", "hr_ao_ray_trace",
+                "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
+                "hr_ao_trace_stats"]

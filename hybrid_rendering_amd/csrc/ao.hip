@@ -1,0 +1,501 @@
+// RayTracedAO on MI355X — HIP replacement for src/ray_traced_ao.{h,cpp} and src/shaders/ao/*.
+//   ray_trace()              ray_traced_ao.cpp:863-903,  ao_ray_trace.comp:90-126            -> k_ao_trace
+//   temporal_accumulation()  :983-1028,                  ao_denoise_reprojection.comp:191-260 -> k_ao_temporal
+//   bilateral_blur()         :1032-1137 (dir (1,0) then (0,1)), ao_denoise_bilateral_blur.comp:75-139 -> k_ao_blur
+//   upsample()               :918-955,                   ao_upsample.comp:63-112             -> k_upsample (upsample.h)
+// Extension (BASELINE.json configs[2]): spp samples per pixel (one mask plane per sample,
+// sample index = spp*num_frames + s); spp = 1 is the reference behaviour.
+#include "hr_internal.h"
+#include "reproject.h"
+#include "traverse.h"
+#include "upsample.h"
+
+using namespace hr;
+
+// brdf.glsl:8-32 sample_cosine_lobe + make_rotation_matrix
+HR_DEV f3 sample_cosine_lobe(f3 n, float rx, float ry)
+{
+    rx = max2(0.00001f, rx);
+    ry = max2(0.00001f, ry);
+    const float phi = 2.0f * HR_M_PI * ry;
+    const float ct = hr_sqrt(rx), st = hr_sqrt(1.0f - rx);
+    float s, c;
+    det_sincos(phi, s, c);
+    const f3 t   = mk3(st * c, st * s, ct);
+    const f3 ref = fabsf(dot3(n, mk3(0.0f, 1.0f, 0.0f))) > 0.99f ? mk3(0.0f, 0.0f, 1.0f) : mk3(0.0f, 1.0f, 0.0f);
+    const f3 x   = normalize3(cross3(ref, n));
+    const f3 y   = cross3(n, x);
+    return normalize3(mk3((x.x * t.x + y.x * t.y) + n.x * t.z, (x.y * t.x + y.y * t.y) + n.y * t.z, (x.z * t.x + y.z * t.y) + n.z * t.z));
+}
+
+struct AOTraceArgs
+{
+    float              vpi[16];
+    const float*       depth;
+    const uint2*       gb2;
+    const uint8_t*     sobol;
+    const uint8_t*     sr;
+    uint32_t*          mask;       // [spp][mh][mw]
+    unsigned long long* ray_counter;
+    const Node8*       nodes;
+    const TriGPU*      tris;
+    unsigned long long* stats;
+    int                w, h, y0, y1, mw, mh;
+    int                tiles_x, tiles_y, tile_y0;
+    float              bias, ray_length;
+    uint32_t           num_frames;
+    int                spp;
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_ao_trace(AOTraceArgs a)
+{
+    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.tiles_x * a.tiles_y) return;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    bool  active = false;
+    f3    ro = mk3(0, 0, 0), N = mk3(0, 0, 1);
+    if (x < a.w && y >= a.y0 && y < a.y1)
+    {
+        const float d = a.depth[(size_t)y * a.w + x];
+        if (d != 1.0f)
+        {
+            const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
+            const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
+            const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+            N      = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+            ro     = add3(P, scale3(N, a.bias));
+            active = true;
+        }
+    }
+    uint32_t nn = 0, nt = 0;
+    const unsigned long long fired = __ballot(active);
+    for (int s = 0; s < a.spp; s++)
+    {
+        bool visible = false;
+        if (active)
+        {
+            const int   idx = (int)a.num_frames * a.spp + s;
+            const float r0  = sample_blue_noise(x, y, idx, 0, a.sobol, a.sr), r1 = sample_blue_noise(x, y, idx, 1, a.sobol, a.sr);
+            const f3    dir = sample_cosine_lobe(N, r0, r1);
+            visible         = !trace_any<STATS>(a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, nn, nt);
+        }
+        const unsigned long long bits = __ballot(visible);
+        if (lane == 0)
+        {
+            const int my = ty * 2;
+            uint32_t* m  = a.mask + (size_t)s * a.mh * a.mw;
+            if (my * 4 >= a.y0 && my * 4 < a.y1) m[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
+            if ((my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) m[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
+        }
+    }
+    if (STATS)
+        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); nt += __shfl_down(nt, o); }
+    if (lane == 0)
+    {
+        if (fired) atomicAdd(a.ray_counter, (unsigned long long)__popcll(fired) * (unsigned long long)a.spp);
+        if (STATS && a.stats)
+        {
+            atomicAdd(a.stats + 0, (unsigned long long)nn);
+            atomicAdd(a.stats + 1, (unsigned long long)nt);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AOTemporalArgs
+{
+    float           vpi[16];
+    const uint32_t* mask;
+    int             mw, mh, spp;
+    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
+    ImgR32F         depth, pdepth;
+    ImgR16F         hist, hist_len;
+    uint16_t*       out;
+    uint16_t*       out_len;
+    uint8_t*        tile_class;
+    int             w, h, y0, y1;
+    int             tiles_x, tiles_y, tile_y0;
+    float           alpha;
+};
+
+__global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
+{
+    __shared__ uint32_t s_mask[4][18];
+    __shared__ float    s_vpi[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
+    const int tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int x = tx * 8 + lx, y = ty * 8 + ly;
+    if (threadIdx.x < 16) s_vpi[threadIdx.x] = a.vpi[threadIdx.x];
+    int sum = 0, own = 0;
+    for (int s = 0; s < a.spp; s++)
+    {
+        __syncthreads();
+        if (tile_ok && lane < 18)
+        {
+            // populate_cache (:101-119): masks outside the mask image read all-ones
+            const int cx = tx - 1 + lane % 3, cy = ty * 2 - 2 + lane / 3;
+            uint32_t  v  = 0xFFFFFFFFu;
+            if (cx >= 0 && cy >= 0 && cx < a.mw && cy < a.mh) v = a.mask[((size_t)s * a.mh + cy) * a.mw + cx];
+            s_mask[wave][lane] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int yy = -8; yy <= 8; yy++)
+        {
+            const int ry = ly + 8 + yy, mrow = ry >> 2, brow = ry & 3;
+            const uint32_t b0 = (s_mask[wave][mrow * 3 + 0] >> (brow * 8)) & 0xffu;
+            const uint32_t b1 = (s_mask[wave][mrow * 3 + 1] >> (brow * 8)) & 0xffu;
+            const uint32_t b2 = (s_mask[wave][mrow * 3 + 2] >> (brow * 8)) & 0xffu;
+            sum += __popc(((b0 | (b1 << 8) | (b2 << 16)) >> lx) & 0x1ffffu);
+        }
+        const int cry = ly + 8, crx = lx + 8;
+        own += (int)((s_mask[wave][(cry >> 2) * 3 + (crx >> 3)] >> ((cry & 3) * 8 + (crx & 7))) & 1u);
+    }
+    if (!tile_ok) return;
+    const float mean = __fdiv_rn((float)sum, 289.0f * (float)a.spp);
+    const bool  in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    bool        flag = false;
+    if (in_image)
+    {
+        const float d = a.depth.p[(size_t)y * a.w + x];
+        float out = 1.0f, hlen = 0.0f;
+        if (d != 1.0f)
+        {
+            const float ao = __fdiv_rn((float)own, (float)a.spp);
+            ReprojIn in;
+            in.x = x; in.y = y; in.depth = d; in.vpi = s_vpi;
+            in.gb2 = a.gb2; in.gb3 = a.gb3; in.pgb2 = a.pgb2; in.pgb3 = a.pgb3; in.pdepth = a.pdepth;
+            in.w = a.w; in.h = a.h;
+            float hao, dummy[2];
+            ImgRGBA16F none { nullptr, 0, 0, 0 };
+            const bool success = reproject<true, false, false, ImgR16F>(in, a.hist, none, a.hist_len, &hao, dummy, hlen);
+            hlen = min2(32.0f, success ? hlen + 1.0f : 1.0f);
+            if (success)
+            {
+                float sv = max2(mean - mean * mean, 0.0f);
+                float sd = hr_sqrt(sv);
+                hao      = clamp1(hao, mean - 0.5f * sd, mean + 0.5f * sd);
+            }
+            const float al = success ? max2(a.alpha, __fdiv_rn(1.0f, hlen)) : 1.0f;
+            out = mix1(hao, ao, al);
+        }
+        a.out[(size_t)y * a.w + x]     = f2h(out);
+        a.out_len[(size_t)y * a.w + x] = f2h(hlen);
+        flag = out < 1.0f;
+    }
+    const unsigned long long any = __ballot(flag);
+    if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AOBlurArgs
+{
+    ImgR16F        in;
+    ImgR32F        depth;
+    ImgRGBA16F     gb2;
+    const uint8_t* tile_class;
+    uint16_t*      out;
+    float          zbp[4];
+    int            w, h, y0, y1, tiles_x;
+    int            dx, dy, radius;
+};
+
+HR_DEV float linear_eye_depth(float z, const float* zbp) { return __fdiv_rn(1.0f, zbp[2] * z + zbp[3]); }
+
+// common.glsl:160-165
+HR_DEV float gaussian_weight(float offset, float deviation)
+{
+    float w = __fdiv_rn(1.0f, hr_sqrt(2.0f * HR_M_PI * deviation * deviation));
+    return w * det_exp(__fdiv_rn(-(offset * offset), 2.0f * deviation * deviation));
+}
+
+__global__ __launch_bounds__(256) void k_ao_blur(AOBlurArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const size_t o = (size_t)y * a.w + x;
+    const uint16_t one = f2h(1.0f);
+    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) { a.out[o] = one; return; } // cleared image (:1048-1055)
+    const float d = a.depth.p[o];
+    if (d == 1.0f) { a.out[o] = one; return; }
+    const float deviation = __fdiv_rn((float)a.radius, 1.5f);
+    float total_ao = h2f(a.in.p[o]), total_w = 1.0f;
+    const float cd = linear_eye_depth(d, a.zbp);
+    const uint2 g2 = a.gb2.p[o];
+    const f3    cn = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+    for (int i = -a.radius; i <= a.radius; i++)
+    {
+        if (i == 0) continue;
+        const int   sx = x + a.dx * i, sy = y + a.dy * i;
+        const float sd = linear_eye_depth(a.depth.fetch(sx, sy), a.zbp);
+        const float sa = a.in.fetch(sx, sy);
+        const uint2 s2 = a.gb2.raw(sx, sy);
+        const f3    sn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
+        float w = gaussian_weight((float)i, deviation);
+        const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), 1.0f));
+        const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), 32.0f);
+        w = w * (det_exp((0.0f - 1.0f) - max2(wZ, 0.0f)) * wN);
+        total_ao += w * sa;
+        total_w += w;
+    }
+    a.out[o] = f2h(__fdiv_rn(total_ao, max2(total_w, 0.0001f)));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct hr_ao
+{
+    hr_ctx* ctx = nullptr;
+    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0;
+    int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0, max_spp = 4;
+    DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters;
+    bool    first_frame = true, last_denoise = true, want_stats = false;
+    int     last_pp = 0;
+    StageProfiler prof;
+    hipStream_t   last_stream = nullptr;
+};
+
+extern "C" {
+
+void hr_ao_default_params(hr_ao_params* p)
+{
+    p->denoise = 1; p->ray_length = 7.0f; p->bias = 0.3f; p->alpha = 0.01f; p->blur_radius = 4; p->power = 1.2f; p->spp = 1;
+}
+
+hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_ao** out)
+{
+    HR_CHECK_ARG(ctx && out && full_width > 0 && full_height > 0 && (int)scale >= 0 && (int)scale <= 2);
+    HR_HIP(hipSetDevice(ctx->device));
+    hr_ao* p = new hr_ao();
+    p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
+    p->y0 = 0; p->y1 = p->h;
+    if (band && band->band_y1 > band->band_y0)
+    {
+        p->y0 = band->band_y0 - band->halo < 0 ? 0 : band->band_y0 - band->halo;
+        p->y1 = band->band_y1 + band->halo > p->h ? p->h : band->band_y1 + band->halo;
+        if ((p->y0 & 7) || ((p->y1 & 7) && p->y1 != p->h)) { set_last_error("band rows must be multiples of 8"); delete p; return HR_ERR_INVALID_ARG; }
+    }
+    p->mw = cdiv(p->w, 8); p->mh = cdiv(p->h, 4); p->tiles_x = cdiv(p->w, 8); p->tiles_y = cdiv(p->h, 8);
+    const size_t px = (size_t)p->w * p->h;
+    hr_status s;
+#define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
+    A(mask, (size_t)p->max_spp * p->mw * p->mh * 4)
+    A(color[0], px * 2) A(color[1], px * 2) A(length[0], px * 2) A(length[1], px * 2)
+    A(blur[0], px * 2) A(blur[1], px * 2)
+    A(upsample, (size_t)full_width * full_height * 2)
+    A(tile_class, (size_t)p->tiles_x * p->tiles_y)
+    A(counters, 64)
+#undef A
+    HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
+    *out = p;
+    return HR_OK;
+}
+
+hr_status hr_ao_destroy(hr_ao* p)
+{
+    if (!p) return HR_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipDeviceSynchronize();
+    delete p;
+    return HR_OK;
+}
+hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_ao_set_profiling(hr_ao* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
+hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
+hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays)
+{
+    HR_CHECK_ARG(p && rays);
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    return HR_OK;
+}
+
+hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && scene && in && prm && prm->spp >= 1 && prm->spp <= p->max_spp);
+    HR_CHECK_ARG(in->cur.depth && in->cur.gb2 && in->cur.gb3 && in->cur.width == p->w && in->cur.height == p->h && in->sobol && in->scrambling_ranking);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    if (p->first_frame)
+    {
+        // clear_images() (ray_traced_ao.cpp:828-860): the history slots that will be read start at 0
+        HR_HIP(hipMemsetAsync(p->color[!in->ping_pong].p, 0, p->color[0].bytes, st));
+        HR_HIP(hipMemsetAsync(p->length[!in->ping_pong].p, 0, p->length[0].bytes, st));
+        p->first_frame = false;
+    }
+    HR_HIP(hipMemsetAsync(p->counters.p, 0, 32, st));
+    AOTraceArgs a;
+    for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
+    a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2; a.sobol = in->sobol; a.sr = in->scrambling_ranking;
+    a.mask = (uint32_t*)p->mask.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
+    a.stats = p->want_stats ? (unsigned long long*)((char*)p->counters.p + 16) : nullptr;
+    a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw; a.mh = p->mh;
+    a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
+    a.bias = prm->bias; a.ray_length = prm->ray_length; a.num_frames = in->num_frames; a.spp = prm->spp;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    if (p->want_stats)
+    {
+        hipLaunchKernelGGL(k_ao_trace<true>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
+    int ev = p->prof.begin("ray_trace", st, px * 12 + px * prm->spp / 8);
+    hipLaunchKernelGGL(k_ao_trace<false>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, uint64_t* out3, void* stream)
+{
+    HR_CHECK_ARG(p && out3);
+    p->want_stats = true;
+    hr_status s = hr_ao_ray_trace(p, scene, in, prm, stream);
+    p->want_stats = false;
+    if (s != HR_OK) return s;
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t host[4];
+    HR_HIP(hipMemcpy(host, p->counters.p, 32, hipMemcpyDeviceToHost));
+    out3[0] = host[0]; out3[1] = host[2]; out3[2] = host[3];
+    return HR_OK;
+}
+
+hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm && prm->spp >= 1 && prm->spp <= p->max_spp);
+    HR_CHECK_ARG(in->cur.depth && in->cur.gb2 && in->cur.gb3 && in->prev.depth && in->prev.gb2 && in->prev.gb3 && in->cur.width == p->w && in->prev.width == p->w);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int pp = in->ping_pong ? 1 : 0, w = p->w, y0 = p->y0, y1 = p->y1;
+    AOTemporalArgs a;
+    for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
+    a.mask = (const uint32_t*)p->mask.p; a.mw = p->mw; a.mh = p->mh; a.spp = prm->spp;
+    a.gb2  = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
+    a.gb3  = ImgRGBA16F { (const uint2*)in->cur.gb3, w, y0, y1 };
+    a.pgb2 = ImgRGBA16F { (const uint2*)in->prev.gb2, w, y0, y1 };
+    a.pgb3 = ImgRGBA16F { (const uint2*)in->prev.gb3, w, y0, y1 };
+    a.depth = ImgR32F { in->cur.depth, w, y0, y1 }; a.pdepth = ImgR32F { in->prev.depth, w, y0, y1 };
+    a.hist = ImgR16F { (const uint16_t*)p->color[!pp].p, w, y0, y1 };
+    a.hist_len = ImgR16F { (const uint16_t*)p->length[!pp].p, w, y0, y1 };
+    a.out = (uint16_t*)p->color[pp].p; a.out_len = (uint16_t*)p->length[pp].p; a.tile_class = (uint8_t*)p->tile_class.p;
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
+    a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
+    a.alpha = prm->alpha;
+    p->last_pp = pp;
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);
+    hipLaunchKernelGGL(k_ao_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, int32_t pass, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm && (pass == 0 || pass == 1) && prm->blur_radius >= 1 && prm->blur_radius <= 16);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    AOBlurArgs a;
+    a.in = ImgR16F { (const uint16_t*)(pass == 0 ? p->color[p->last_pp].p : p->blur[0].p), w, y0, y1 };
+    a.depth = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
+    a.tile_class = (const uint8_t*)p->tile_class.p;
+    a.out = (uint16_t*)p->blur[pass].p;
+    for (int i = 0; i < 4; i++) a.zbp[i] = in->z_buffer_params[i];
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x;
+    a.dx = pass == 0 ? 1 : 0; a.dy = pass == 0 ? 0 : 1; a.radius = prm->blur_radius; // X first, then Y (quirk 8)
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    int ev = p->prof.begin(pass == 0 ? "blur_x" : "blur_y", st, px * 16);
+    hipLaunchKernelGGL(k_ao_blur, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm);
+    if (p->scale == 0) return HR_OK;
+    HR_CHECK_ARG(in->cur_full.gb2 && in->cur_full.gb3 && in->cur_full.width == p->full_w && in->cur_full.height == p->full_h);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    UpsampleArgs a;
+    a.W = p->full_w; a.H = p->full_h; a.w = p->w; a.h = p->h;
+    a.G2 = (const uint2*)in->cur_full.gb2; a.G3 = (const uint2*)in->cur_full.gb3;
+    a.g2 = (const uint2*)in->cur.gb2; a.g3 = (const uint2*)in->cur.gb3;
+    a.in = p->blur[1].p; a.in_channels = 1; a.channels = 1; a.out = p->upsample.p; a.sky_value = 1.0f; a.power = prm->power;
+    const uint64_t PX = (uint64_t)p->full_w * p->full_h, px = (uint64_t)p->w * p->h;
+    int ev = p->prof.begin("upsample", st, PX * 18 + px * 18);
+    launch_upsample(a, st);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+// RayTracedAO::render (ray_traced_ao.cpp:98-112)
+hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && scene && in && prm);
+    HR_HIP(hipSetDevice(p->ctx->device));
+    p->prof.begin_frame();
+    p->last_denoise = prm->denoise != 0;
+    hr_status s = hr_ao_ray_trace(p, scene, in, prm, stream);
+    if (s != HR_OK) return s;
+    if (prm->denoise)
+    {
+        if ((s = hr_ao_temporal(p, in, prm, stream)) != HR_OK) return s;
+        if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
+        if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+        if (p->scale != 0 && (s = hr_ao_upsample(p, in, prm, stream)) != HR_OK) return s;
+    }
+    return HR_OK;
+}
+
+static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)
+{
+    v->data = data; v->width = w; v->height = h; v->row_pitch_bytes = w * bpp; v->format = f;
+}
+
+// 0 mask (plane 0..spp-1 stacked vertically), 1/2 AO colour[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes
+hr_status hr_ao_image(hr_ao* p, int32_t which, hr_image_view* v)
+{
+    HR_CHECK_ARG(p && v);
+    switch (which)
+    {
+        case 0: fill_view(v, p->mask.p, p->mw, p->mh * p->max_spp, 4, HR_FORMAT_R32_UINT); break;
+        case 1: fill_view(v, p->color[0].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 2: fill_view(v, p->color[1].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 3: fill_view(v, p->length[0].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 4: fill_view(v, p->length[1].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 5: fill_view(v, p->blur[0].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 6: fill_view(v, p->blur[1].p, p->w, p->h, 2, HR_FORMAT_R16F); break;
+        case 7: fill_view(v, p->upsample.p, p->full_w, p->full_h, 2, HR_FORMAT_R16F); break;
+        case 8: fill_view(v, p->tile_class.p, p->tiles_x, p->tiles_y, 1, (hr_format)0); break;
+        default: set_last_error("hr_ao_image: unknown image index"); return HR_ERR_INVALID_ARG;
+    }
+    return HR_OK;
+}
+
+// RayTracedAO::output_ds (ray_traced_ao.cpp:128-148)
+hr_status hr_ao_output(hr_ao* p, hr_output_kind kind, hr_image_view* v)
+{
+    HR_CHECK_ARG(p && v);
+    if (!p->last_denoise || kind == HR_OUTPUT_RAY_TRACE) return hr_ao_image(p, 0, v);
+    if (kind == HR_OUTPUT_TEMPORAL_ACCUMULATION) return hr_ao_image(p, 1 + p->last_pp, v);
+    if (kind == HR_OUTPUT_ATROUS || p->scale == 0) return hr_ao_image(p, 6, v);
+    return hr_ao_image(p, 7, v);
+}
+
+} // extern "C"

@@ -234,6 +234,42 @@ hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
  * algorithmic-bytes figure.  Synchronises the stream. */
 hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
 
+/* ---- RayTracedAO (src/ray_traced_ao.h) ------------------------------------------------------------ */
+typedef struct hr_ao hr_ao;
+
+/* member defaults: ray_traced_ao.h:53-54,72,92,103 */
+typedef struct
+{
+    int32_t denoise;     /* m_denoise = true                    */
+    float   ray_length;  /* RayTrace::ray_length = 7.0          */
+    float   bias;        /* RayTrace::bias = 0.3                */
+    float   alpha;       /* TemporalAccumulation::alpha = 0.01  */
+    int32_t blur_radius; /* BilateralBlur::blur_radius = 4      */
+    float   power;       /* Upsample::power = 1.2               */
+    int32_t spp;         /* EXTENSION (reference = 1): samples per pixel, 1..4 (BASELINE.json configs[2]) */
+} hr_ao_params;
+
+void      hr_ao_default_params(hr_ao_params* p);
+hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_ao** out);
+/* RayTracedAO::render (ray_traced_ao.cpp:98-112) */
+hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
+/* RayTracedAO::output_ds (ray_traced_ao.cpp:128-148); HR_OUTPUT_ATROUS = OUTPUT_BILATERAL_BLUR */
+hr_status hr_ao_output(hr_ao* p, hr_output_kind kind, hr_image_view* view);
+hr_status hr_ao_reset_history(hr_ao* p);
+hr_status hr_ao_destroy(hr_ao* p);
+/* stage-level entry points: ray_trace (:863-903), temporal_accumulation (:983-1028),
+ * bilateral_blur pass 0 = direction (1,0), pass 1 = (0,1) (:1032-1137), upsample (:918-955) */
+hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
+hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
+hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, int32_t pass, void* stream);
+hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
+/* 0 mask planes, 1/2 AO[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes (1 byte per tile) */
+hr_status hr_ao_image(hr_ao* p, int32_t which, hr_image_view* view);
+hr_status hr_ao_set_profiling(hr_ao* p, int32_t enable);
+hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out);
+hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays);
+hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, uint64_t* out3, void* stream);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

@@ -38,6 +38,15 @@ void orc_upsample(int W, int H, int w, int h, const uint16_t* gb2_full, const ui
                   const uint16_t* gb3_mip, const uint16_t* in_lowres, int in_channels, int channels, float sky_value, float power,
                   uint16_t* out_full);
 
+// ---- ambient occlusion ---------------------------------------------------------------------
+void orc_ao_ray_trace(const void* scene, const void* ubo, int w, int h, const float* depth, const uint16_t* gb2, const uint8_t* sobol,
+                      const uint8_t* scrambling_ranking, float bias, float ray_length, uint32_t num_frames, int spp, uint32_t* mask, uint64_t* rays_out);
+void orc_ao_temporal(const void* ubo, int w, int h, int spp, const uint32_t* mask, const float* depth, const uint16_t* gb2, const uint16_t* gb3,
+                     const float* prev_depth, const uint16_t* prev_gb2, const uint16_t* prev_gb3, const uint16_t* hist_ao,
+                     const uint16_t* hist_len, float alpha, uint16_t* out_ao, uint16_t* out_len, uint8_t* tile_class);
+void orc_ao_blur(int w, int h, const uint16_t* in_ao, const float* depth, const uint16_t* gb2, const uint8_t* tile_class, const float* zbp,
+                 int dir_x, int dir_y, int radius, uint16_t* out_ao);
+
 // ---- scalar helpers exported for known-answer tests ---------------------------------------
 uint16_t orc_f32_to_f16(float f);
 float    orc_f16_to_f32(uint16_t h);

@@ -196,6 +196,62 @@ class ShadowsPass:
         return img
 
 
+# ---------------------------------------------------------------------------------- ambient occlusion
+
+def ao_ray_trace(scene, ubo, depth, gb2, sobol, sr, bias=0.3, ray_length=7.0, num_frames=0, spp=1):
+    h, w = depth.shape
+    mask = np.zeros((spp, (h + 3) // 4, (w + 7) // 8), np.uint32)
+    rays = C.c_uint64(0)
+    lib().orc_ao_ray_trace(scene.h, _ubo_ptr(ubo), C.c_int(w), C.c_int(h), _p(depth, c_f32p), _p(gb2, c_u16p), _p(sobol, c_u8p), _p(sr, c_u8p),
+                           C.c_float(bias), C.c_float(ray_length), C.c_uint32(num_frames), C.c_int(spp), _p(mask, c_u32p), C.byref(rays))
+    return mask, rays.value
+
+
+def ao_temporal(ubo, mask, cur, prev, hist_ao, hist_len, alpha=0.01):
+    h, w = cur["depth"].shape
+    out, ln = np.zeros((h, w), np.uint16), np.zeros((h, w), np.uint16)
+    tiles = np.zeros(((h + 7) // 8, (w + 7) // 8), np.uint8)
+    lib().orc_ao_temporal(_ubo_ptr(ubo), C.c_int(w), C.c_int(h), C.c_int(mask.shape[0]), _p(mask, c_u32p), _p(cur["depth"], c_f32p),
+                          _p(cur["gb2"], c_u16p), _p(cur["gb3"], c_u16p), _p(prev["depth"], c_f32p), _p(prev["gb2"], c_u16p),
+                          _p(prev["gb3"], c_u16p), _p(hist_ao, c_u16p), _p(hist_len, c_u16p), C.c_float(alpha), _p(out, c_u16p),
+                          _p(ln, c_u16p), _p(tiles, c_u8p))
+    return out, ln, tiles
+
+
+def ao_blur(inp, depth, gb2, tiles, zbp, direction, radius=4):
+    h, w = inp.shape
+    out = np.zeros((h, w), np.uint16)
+    zbp = np.ascontiguousarray(zbp, np.float32)
+    lib().orc_ao_blur(C.c_int(w), C.c_int(h), _p(inp, c_u16p), _p(depth, c_f32p), _p(gb2, c_u16p), _p(tiles, c_u8p), _p(zbp, c_f32p),
+                      C.c_int(direction[0]), C.c_int(direction[1]), C.c_int(radius), _p(out, c_u16p))
+    return out
+
+
+class AOPass:
+    """Host-side sequencing of RayTracedAO::render (ray_traced_ao.cpp:98-112) on the oracle."""
+
+    def __init__(self, w, h, bias=0.3, ray_length=7.0, alpha=0.01, blur_radius=4, power=1.2, spp=1, zbp=(-0.999, 1.0, -0.999, 1.0)):
+        self.w, self.h = w, h
+        self.p = dict(bias=bias, ray_length=ray_length, alpha=alpha, blur_radius=blur_radius, power=power, spp=spp)
+        self.zbp = np.asarray(zbp, np.float32)
+        self.hist_ao = np.zeros((h, w), np.uint16)    # clear_images(): zero (:831-857)
+        self.hist_len = np.zeros((h, w), np.uint16)
+        self.stages = {}
+
+    def render(self, scene, ubo, cur, prev, sobol, sr, num_frames, full=None):
+        p = self.p
+        mask, nrays = ao_ray_trace(scene, ubo, cur["depth"], cur["gb2"], sobol, sr, p["bias"], p["ray_length"], num_frames, p["spp"])
+        out, ln, tiles = ao_temporal(ubo, mask, cur, prev, self.hist_ao, self.hist_len, p["alpha"])
+        self.hist_ao, self.hist_len = out, ln
+        b0 = ao_blur(out, cur["depth"], cur["gb2"], tiles, self.zbp, (1, 0), p["blur_radius"])
+        b1 = ao_blur(b0, cur["depth"], cur["gb2"], tiles, self.zbp, (0, 1), p["blur_radius"])
+        up = None
+        if full is not None:
+            up = upsample(full, cur, b1[..., None], channels=1, sky_value=1.0, power=p["power"])
+        self.stages = dict(mask=mask, rays=nrays, temporal=out, length=ln, tiles=tiles, blur0=b0, blur1=b1, upsample=up, output=b1 if up is None else up)
+        return self.stages["output"]
+
+
 def f16(a):
     """uint16 fp16 bit patterns -> float32 values."""
     return np.asarray(a, np.uint16).view(np.float16).astype(np.float32)
