@@ -1,0 +1,444 @@
+// DDGI on MI355X — HIP replacement for src/ddgi.{h,cpp} and src/shaders/gi/*.
+//   ray_trace()         ddgi.cpp:767-825, gi_ray_trace.{rgen:78-100, rchit:95-128, rmiss:24-27} -> k_ddgi_trace
+//   probe_update()      :829-900, gi_probe_update.glsl:136-184 (irradiance + depth variants)     -> k_ddgi_probe_update<DEPTH>
+//   border_update()     :904-939, gi_border_update.glsl:151-175                                  -> k_ddgi_border<DEPTH>
+//   sample_probe_grid() :943-986, gi_sample_probe_grid.comp:75-99                                -> k_ddgi_sample
+#include "hr_internal.h"
+#include "shading.h"
+
+using namespace hr;
+
+// gi_ray_trace.rgen:61-72.  PHI = sqrt(5)*0.5+0.5 evaluated in fp32; PHI - 1 is exact.
+HR_DEV f3 spherical_fibonacci(float i, float n)
+{
+    const float PHI_M1 = 0.61803400516510009765625f;
+    const float a   = i * PHI_M1;
+    const float phi = 2.0f * HR_M_PI * (a - floorf(a));
+    const float ct  = 1.0f - (2.0f * i + 1.0f) * __fdiv_rn(1.0f, n);
+    const float st  = hr_sqrt(clamp1(1.0f - ct * ct, 0.0f, 1.0f));
+    float s, c;
+    det_sincos(phi, s, c);
+    return mk3(c * st, s * st, ct);
+}
+
+struct DDGITraceArgs
+{
+    DDGIU         d;
+    hr_light      light;
+    float         orientation[9];
+    const Node8*  nodes;
+    const TriGPU* tris;
+    SceneShading  sh;
+    CubeMap       sky;
+    AtlasRGBA     prev_irr;
+    AtlasRG       prev_depth;
+    uint2*        radiance;
+    uint2*        dirdist;
+    unsigned long long* ray_counter;
+    uint32_t      num_frames;
+    int           infinite_bounces;
+    float         gi_intensity;
+    int           n_probes;
+};
+
+// one thread per (probe, ray); a wave covers 64 consecutive rays of one probe
+__global__ __launch_bounds__(256) void k_ddgi_trace(DDGITraceArgs a)
+{
+    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = a.d.rays_per_probe;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int probe = (int)(gid / R), ray = (int)(gid % R);
+    uint32_t  rays = 0;
+    if (probe < a.n_probes)
+    {
+        const f3 origin = probe_location(a.d, probe);
+        const f3 f      = spherical_fibonacci((float)ray, (float)R);
+        const float* M  = a.orientation;
+        const f3 dir = normalize3(mk3((M[0] * f.x + M[3] * f.y) + M[6] * f.z, (M[1] * f.x + M[4] * f.y) + M[7] * f.z, (M[2] * f.x + M[5] * f.y) + M[8] * f.z));
+        Rng   rng = rng_init((uint32_t)ray, (uint32_t)probe, a.num_frames);
+        f3    L;
+        float hit_distance = 10000.0f;
+        rays++;
+        const HitRec h = trace_closest(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane);
+        if (h.prim < 0) L = a.sky.fetch(dir);
+        else
+        {
+            const SurfaceHit s = surface_at(a.sh, h);
+            const f3 Wo = neg3(dir);
+            const f3 F0 = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
+            const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
+            const float r2x = next_float(rng), r2y = next_float(rng);
+            TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
+            f3 Lo = direct_lighting(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
+            if (a.infinite_bounces == 1)
+            {
+                const f3 F   = fresnel_schlick_roughness(max2(dot3(s.N, Wo), 0.0f), F0, s.roughness);
+                const f3 kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);
+                const f3 irr = sample_irradiance(a.d, s.P, s.N, Wo, a.prev_irr, a.prev_depth);
+                Lo = add3(Lo, mul3(mul3(scale3(kD, a.gi_intensity), c_diffuse), irr));
+            }
+            L = Lo;
+            hit_distance = 0.001f + h.t;
+        }
+        const size_t o = (size_t)probe * R + ray;
+        a.radiance[o] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, 0.0f));
+        a.dirdist[o]  = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
+    }
+    for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
+    if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DDGIUpdateArgs
+{
+    DDGIU        d;
+    const uint2* radiance;
+    const uint2* dirdist;
+    const void*  prev_atlas;
+    void*        out_atlas;
+    int          first_frame;
+};
+
+// one workgroup per probe (gx = x + y*cx, gy = z), one thread per interior texel; the probe's rays are
+// staged through LDS in batches (gi_probe_update.glsl:73-84) — the accumulation order over rays is the
+// reference's (r = 0..rays_per_probe-1), so the fp32 sums are reproducible.
+template <bool DEPTH>
+__global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
+{
+    constexpr int CACHE = 256;
+    __shared__ float4 s_dd[CACHE];
+    __shared__ float4 s_rad[DEPTH ? 1 : CACHE];
+    const int side = DEPTH ? a.d.depth_probe_side_length : a.d.irradiance_probe_side_length;
+    const int tw   = DEPTH ? a.d.depth_texture_width : a.d.irradiance_texture_width;
+    const int gx = blockIdx.x, gy = blockIdx.y;
+    const int lx = threadIdx.x % side, ly = threadIdx.x / side;
+    const int x = gx * (side + 2) + 2 + lx, y = gy * (side + 2) + 2 + ly;
+    const int probe = gx + (a.d.probe_counts[0] * a.d.probe_counts[1]) * gy; // == probe_id(current_coord, ...)
+    const int R = a.d.rays_per_probe;
+    const float ncx = ((float)lx + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f, ncy = ((float)ly + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f;
+    const f3  texel_dir = gi_oct_decode(ncx, ncy);
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, total_w = 0.0f;
+    for (int offset = 0; offset < R; offset += CACHE)
+    {
+        const int num = (R - offset) < CACHE ? (R - offset) : CACHE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < num; i += blockDim.x)
+        {
+            const uint2 q = a.dirdist[(size_t)probe * R + offset + i];
+            s_dd[i] = make_float4(h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), h2f_hi(q.y));
+            if (!DEPTH)
+            {
+                const uint2 c = a.radiance[(size_t)probe * R + offset + i];
+                s_rad[i] = make_float4(h2f_lo(c.x), h2f_hi(c.x), h2f_lo(c.y), 0.0f);
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < num; r++)
+        {
+            const float4 dd = s_dd[r];
+            const float  dp = max2(0.0f, dot3(texel_dir, mk3(dd.x, dd.y, dd.z)));
+            if (DEPTH)
+            {
+                float dist = min2(a.d.max_distance, dd.w - 0.01f);
+                if (dist == -1.0f) dist = a.d.max_distance;
+                const float w = det_pow_auto(dp, a.d.depth_sharpness);
+                if (w >= 0.00000001f) { r0 += dist * w; r1 += (dist * dist) * w; total_w += w; }
+            }
+            else
+            {
+                if (dp >= 0.00000001f)
+                {
+                    const float4 c = s_rad[r];
+                    r0 += (c.x * 0.95f) * dp; r1 += (c.y * 0.95f) * dp; r2 += (c.z * 0.95f) * dp;
+                    total_w += dp;
+                }
+            }
+        }
+    }
+    if (total_w > 0.00000001f) { r0 = __fdiv_rn(r0, total_w); r1 = __fdiv_rn(r1, total_w); r2 = __fdiv_rn(r2, total_w); }
+    const size_t o = (size_t)y * tw + x;
+    if (DEPTH)
+    {
+        if (a.first_frame == 0)
+        {
+            const uint32_t pv = ((const uint32_t*)a.prev_atlas)[o];
+            r0 = mix1(r0, h2f_lo(pv), a.d.hysteresis); r1 = mix1(r1, h2f_hi(pv), a.d.hysteresis);
+        }
+        ((uint32_t*)a.out_atlas)[o] = pack_h2(r0, r1);
+    }
+    else
+    {
+        if (a.first_frame == 0)
+        {
+            const uint2 pv = ((const uint2*)a.prev_atlas)[o];
+            r0 = mix1(r0, h2f_lo(pv.x), a.d.hysteresis); r1 = mix1(r1, h2f_hi(pv.x), a.d.hysteresis); r2 = mix1(r2, h2f_lo(pv.y), a.d.hysteresis);
+        }
+        ((uint2*)a.out_atlas)[o] = make_uint2(pack_h2(r0, r1), pack_h2(r2, 1.0f));
+    }
+}
+
+// border texels = octahedral wrap copies of interior texels (table of gi_border_update.glsl:35-143 by formula)
+template <bool DEPTH>
+__global__ void k_ddgi_border(DDGIU d, void* atlas)
+{
+    const int S  = DEPTH ? d.depth_probe_side_length : d.irradiance_probe_side_length;
+    const int tw = DEPTH ? d.depth_texture_width : d.irradiance_texture_width;
+    const int cx = blockIdx.x * (S + 2) + 1, cy = blockIdx.y * (S + 2) + 1;
+    const int i = threadIdx.x;
+    if (i >= 4 * S + 4) return;
+    int sx, sy, dx, dy;
+    if (i < S) { sx = S - i; sy = 1; dx = i + 1; dy = 0; }
+    else if (i < 2 * S) { const int k = i - S; sx = S - k; sy = S; dx = k + 1; dy = S + 1; }
+    else if (i < 3 * S) { const int k = i - 2 * S; sx = 1; sy = S - k; dx = 0; dy = k + 1; }
+    else if (i < 4 * S) { const int k = i - 3 * S; sx = S; sy = S - k; dx = S + 1; dy = k + 1; }
+    else
+    {
+        const int k = i - 4 * S;
+        sx = (k == 0 || k == 2) ? S : 1; sy = (k == 0 || k == 1) ? S : 1;
+        dx = (k == 0 || k == 2) ? 0 : S + 1; dy = (k == 0 || k == 1) ? 0 : S + 1;
+    }
+    const size_t so = (size_t)(cy + sy) * tw + cx + sx, dst_o = (size_t)(cy + dy) * tw + cx + dx;
+    if (DEPTH) ((uint32_t*)atlas)[dst_o] = ((const uint32_t*)atlas)[so];
+    else ((uint2*)atlas)[dst_o] = ((const uint2*)atlas)[so];
+}
+
+struct DDGISampleArgs
+{
+    DDGIU        d;
+    float        vpi[16];
+    float        cam[3];
+    const float* depth;
+    const uint2* gb2;
+    AtlasRGBA    irr;
+    AtlasRG      dep;
+    uint2*       out;
+    int          w, h;
+    float        gi_intensity;
+};
+
+__global__ __launch_bounds__(256) void k_ddgi_sample(DDGISampleArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.h) return;
+    const size_t o  = (size_t)y * a.w + x;
+    const float  dp = a.depth[o];
+    if (dp == 1.0f) { a.out[o] = make_uint2(0u, 0u); return; }
+    const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
+    const f3    P  = world_pos_from_depth(tu, tv, dp, a.vpi);
+    const uint2 g2 = a.gb2[o];
+    const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+    const f3    Wo = normalize3(sub3(mk3(a.cam[0], a.cam[1], a.cam[2]), P));
+    const f3    irr = scale3(sample_irradiance(a.d, P, N, Wo, a.irr, a.dep), a.gi_intensity);
+    a.out[o] = make_uint2(pack_h2(irr.x, irr.y), pack_h2(irr.z, 1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct hr_ddgi
+{
+    hr_ctx* ctx = nullptr;
+    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0;
+    DDGIU   d;
+    int     n_probes = 0;
+    DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters;
+    bool    first_frame = true, ping_pong = false;
+    StageProfiler prof;
+    hipStream_t   last_stream = nullptr;
+};
+
+extern "C" {
+
+void hr_ddgi_default_params(hr_ddgi_params* p)
+{
+    p->infinite_bounces = 1; p->infinite_bounce_intensity = 1.7f; p->gi_intensity = 1.0f;
+    for (int i = 0; i < 9; i++) p->random_orientation[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+}
+
+hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_ddgi_uniforms* grid, hr_ddgi** out)
+{
+    HR_CHECK_ARG(ctx && out && grid && full_width > 0 && full_height > 0 && (int)scale >= 0 && (int)scale <= 2);
+    const DDGIU& g = *grid;
+    HR_CHECK_ARG(g.probe_counts[0] > 0 && g.probe_counts[1] > 0 && g.probe_counts[2] > 0 && g.rays_per_probe > 0);
+    HR_CHECK_ARG(g.irradiance_probe_side_length >= 2 && g.irradiance_probe_side_length <= 16 && g.depth_probe_side_length >= 2 && g.depth_probe_side_length <= 16);
+    // atlas sizing of ddgi.cpp:197-201
+    HR_CHECK_ARG(g.irradiance_texture_width == (g.irradiance_probe_side_length + 2) * g.probe_counts[0] * g.probe_counts[1] + 2);
+    HR_CHECK_ARG(g.irradiance_texture_height == (g.irradiance_probe_side_length + 2) * g.probe_counts[2] + 2);
+    HR_CHECK_ARG(g.depth_texture_width == (g.depth_probe_side_length + 2) * g.probe_counts[0] * g.probe_counts[1] + 2);
+    HR_CHECK_ARG(g.depth_texture_height == (g.depth_probe_side_length + 2) * g.probe_counts[2] + 2);
+    HR_HIP(hipSetDevice(ctx->device));
+    hr_ddgi* p = new hr_ddgi();
+    p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
+    p->d = g;
+    p->n_probes = g.probe_counts[0] * g.probe_counts[1] * g.probe_counts[2];
+    hr_status s;
+#define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
+    const size_t nr = (size_t)p->n_probes * g.rays_per_probe;
+    A(radiance, nr * 8) A(dirdist, nr * 8)
+    const size_t ib = (size_t)g.irradiance_texture_width * g.irradiance_texture_height * 8, db = (size_t)g.depth_texture_width * g.depth_texture_height * 4;
+    A(irr[0], ib) A(irr[1], ib) A(dep[0], db) A(dep[1], db)
+    A(sample, (size_t)p->w * p->h * 8)
+    A(counters, 64)
+#undef A
+    for (int i = 0; i < 2; i++) { HR_HIP(hipMemset(p->irr[i].p, 0, ib)); HR_HIP(hipMemset(p->dep[i].p, 0, db)); }
+    HR_HIP(hipMemset(p->counters.p, 0, 64));
+    *out = p;
+    return HR_OK;
+}
+
+hr_status hr_ddgi_destroy(hr_ddgi* p)
+{
+    if (!p) return HR_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipDeviceSynchronize();
+    delete p;
+    return HR_OK;
+}
+hr_status hr_ddgi_restart_accumulation(hr_ddgi* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
+hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
+hr_status hr_ddgi_get_uniforms(hr_ddgi* p, hr_ddgi_uniforms* out) { HR_CHECK_ARG(p && out); *out = p->d; return HR_OK; }
+hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays)
+{
+    HR_CHECK_ARG(p && rays);
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    return HR_OK;
+}
+
+static void scene_shading(const hr_scene* scene, SceneShading& sh)
+{
+    sh.positions    = (const float*)scene->positions.p;
+    sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
+    sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
+    sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
+}
+
+hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && scene && in && env && prm && env->sky && env->sky_size > 0);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    HR_HIP(hipMemsetAsync(p->counters.p, 0, 8, st));
+    const int rd = p->ping_pong ? 0 : 1; // read_idx = !m_ping_pong
+    DDGITraceArgs a;
+    a.d = p->d; a.light = in->ubo.light;
+    for (int i = 0; i < 9; i++) a.orientation[i] = prm->random_orientation[i];
+    a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
+    scene_shading(scene, a.sh);
+    a.sky = CubeMap { (const uint2*)env->sky, env->sky_size };
+    a.prev_irr   = AtlasRGBA { (const uint2*)p->irr[rd].p, p->d.irradiance_texture_width, p->d.irradiance_texture_height };
+    a.prev_depth = AtlasRG { (const uint32_t*)p->dep[rd].p, p->d.depth_texture_width, p->d.depth_texture_height };
+    a.radiance = (uint2*)p->radiance.p; a.dirdist = (uint2*)p->dirdist.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.num_frames = in->num_frames;
+    a.infinite_bounces = (prm->infinite_bounces && !p->first_frame) ? 1 : 0; // ddgi.cpp:790
+    a.gi_intensity = prm->infinite_bounce_intensity;
+    a.n_probes = p->n_probes;
+    const long long n = (long long)p->n_probes * p->d.rays_per_probe;
+    int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
+    hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
+{
+    HR_CHECK_ARG(p);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int rd = p->ping_pong ? 0 : 1, wr = p->ping_pong ? 1 : 0;
+    const dim3 grid(p->d.probe_counts[0] * p->d.probe_counts[1], p->d.probe_counts[2]);
+    const uint64_t nr = (uint64_t)p->n_probes * p->d.rays_per_probe;
+    DDGIUpdateArgs a;
+    a.d = p->d; a.radiance = (const uint2*)p->radiance.p; a.dirdist = (const uint2*)p->dirdist.p; a.first_frame = p->first_frame ? 1 : 0;
+    a.prev_atlas = p->irr[rd].p; a.out_atlas = p->irr[wr].p;
+    int ev = p->prof.begin("irradiance_probe_update", st, nr * 16 + 2 * p->irr[0].bytes);
+    hipLaunchKernelGGL(k_ddgi_probe_update<false>, grid, dim3(p->d.irradiance_probe_side_length * p->d.irradiance_probe_side_length), 0, st, a);
+    p->prof.end(ev, st);
+    a.prev_atlas = p->dep[rd].p; a.out_atlas = p->dep[wr].p;
+    ev = p->prof.begin("depth_probe_update", st, nr * 8 + 2 * p->dep[0].bytes);
+    hipLaunchKernelGGL(k_ddgi_probe_update<true>, grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
+    p->prof.end(ev, st);
+    ev = p->prof.begin("border_update", st, 0);
+    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(64), 0, st, p->d, p->irr[wr].p);
+    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(128), 0, st, p->d, p->dep[wr].p);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const hr_ddgi_params* prm, void* stream_)
+{
+    HR_CHECK_ARG(p && in && prm && in->cur.depth && in->cur.gb2 && in->cur.width == p->w && in->cur.height == p->h);
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int wr = p->ping_pong ? 1 : 0; // read_ds[m_ping_pong] (ddgi.cpp:971): the atlases just written
+    DDGISampleArgs a;
+    a.d = p->d;
+    for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
+    for (int i = 0; i < 3; i++) a.cam[i] = in->ubo.cam_pos[i];
+    a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2;
+    a.irr = AtlasRGBA { (const uint2*)p->irr[wr].p, p->d.irradiance_texture_width, p->d.irradiance_texture_height };
+    a.dep = AtlasRG { (const uint32_t*)p->dep[wr].p, p->d.depth_texture_width, p->d.depth_texture_height };
+    a.out = (uint2*)p->sample.p; a.w = p->w; a.h = p->h; a.gi_intensity = prm->gi_intensity;
+    int ev = p->prof.begin("sample_probe_grid", st, (uint64_t)p->w * p->h * 20);
+    hipLaunchKernelGGL(k_ddgi_sample, dim3(cdiv(p->w, 32), cdiv(p->h, 8)), dim3(256), 0, st, a);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+hr_status hr_ddgi_end_frame(hr_ddgi* p)
+{
+    HR_CHECK_ARG(p);
+    p->first_frame = false;
+    p->ping_pong   = !p->ping_pong;
+    return HR_OK;
+}
+
+hr_status hr_ddgi_render(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && scene && in && env && prm);
+    HR_HIP(hipSetDevice(p->ctx->device));
+    p->prof.begin_frame();
+    hr_status s;
+    if ((s = hr_ddgi_ray_trace(p, scene, in, env, prm, stream)) != HR_OK) return s;
+    if ((s = hr_ddgi_probe_update(p, stream)) != HR_OK) return s;
+    if ((s = hr_ddgi_sample_probe_grid(p, in, prm, stream)) != HR_OK) return s;
+    return hr_ddgi_end_frame(p);
+}
+
+static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)
+{
+    v->data = data; v->width = w; v->height = h; v->row_pitch_bytes = w * bpp; v->format = f;
+}
+
+hr_status hr_ddgi_image(hr_ddgi* p, int32_t which, hr_image_view* v)
+{
+    HR_CHECK_ARG(p && v);
+    const DDGIU& d = p->d;
+    switch (which)
+    {
+        case 0: fill_view(v, p->radiance.p, d.rays_per_probe, p->n_probes, 8, HR_FORMAT_RGBA16F); break;
+        case 1: fill_view(v, p->dirdist.p, d.rays_per_probe, p->n_probes, 8, HR_FORMAT_RGBA16F); break;
+        case 2: case 3: fill_view(v, p->irr[which - 2].p, d.irradiance_texture_width, d.irradiance_texture_height, 8, HR_FORMAT_RGBA16F); break;
+        case 4: case 5: fill_view(v, p->dep[which - 4].p, d.depth_texture_width, d.depth_texture_height, 4, HR_FORMAT_RG16F); break;
+        case 6: fill_view(v, p->sample.p, p->w, p->h, 8, HR_FORMAT_RGBA16F); break;
+        default: set_last_error("hr_ddgi_image: unknown image index"); return HR_ERR_INVALID_ARG;
+    }
+    return HR_OK;
+}
+
+hr_status hr_ddgi_output(hr_ddgi* p, hr_image_view* v) { return hr_ddgi_image(p, 6, v); }
+
+hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth)
+{
+    HR_CHECK_ARG(p && irradiance && depth);
+    const int i = p->ping_pong ? 0 : 1; // read_ds[!m_ping_pong]
+    hr_status s = hr_ddgi_image(p, 2 + i, irradiance);
+    if (s != HR_OK) return s;
+    return hr_ddgi_image(p, 4 + i, depth);
+}
+
+} // extern "C"

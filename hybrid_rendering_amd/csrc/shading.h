@@ -1,0 +1,374 @@
+// Hit shading shared by the reflection and DDGI trace kernels — device restatement of
+//   brdf.glsl:36-142 (GGX / Schlick / evaluate_uber_brdf), lighting.glsl:6-196 (fetch_light_properties
+//   without SOFT_SHADOWS, direct_lighting with RAY_THROUGHPUT / SAMPLE_SKY_LIGHT),
+//   gi_common.glsl:39-320 (probe addressing, oct coding, sample_irradiance), random.glsl:11-56,
+//   scene_descriptor_set.glsl:102-220 (interpolated_vertex / transform_vertex / fetch_* for untextured
+//   materials; instances are flattened at scene build, so the model matrix is the identity).
+// Pinned where the reference defers to samplers / absent assets: environment cubemaps
+// are fetched NEAREST with the Vulkan face-selection rule; DDGI atlases are sampled bilinearly
+// (ddgi.cpp:478,499) with fp32 weights mix(mix(t00,t10,fx), mix(t01,t11,fx), fy), clamp-to-edge.
+#pragma once
+#include "../../include/hr_api.h"
+#include "traverse.h"
+
+namespace hr {
+
+#define HR_EPSILON 0.0001f
+
+// ---- random.glsl ------------------------------------------------------------------------------
+struct Rng { uint32_t x, y; };
+HR_DEV uint32_t rng_rotl(uint32_t x, uint32_t k) { return (x << k) | (x >> (32 - k)); }
+HR_DEV uint32_t rng_next(Rng& r)
+{
+    uint32_t result = r.x * 0x9e3779bbu;
+    r.y ^= r.x;
+    r.x = rng_rotl(r.x, 26) ^ r.y ^ (r.y << 9);
+    r.y = rng_rotl(r.y, 13);
+    return result;
+}
+HR_DEV uint32_t rng_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+HR_DEV Rng rng_init(uint32_t idx, uint32_t idy, uint32_t frame)
+{
+    Rng r;
+    r.x = rng_hash((idx << 16) | idy);
+    r.y = rng_hash(frame);
+    rng_next(r);
+    return r;
+}
+HR_DEV float next_float(Rng& r) { return __uint_as_float(0x3f800000u | (rng_next(r) >> 9)) - 1.0f; }
+
+// ---- environment ------------------------------------------------------------------------------
+struct CubeMap
+{
+    const uint2* p; // [6][S][S] RGBA16F
+    int          S;
+    HR_DEV f3 fetch(f3 d) const
+    {
+        const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+        int   face;
+        float sc, tc, ma;
+        if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+        else if (ay >= az) { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+        else { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+        const float s = 0.5f * (__fdiv_rn(sc, ma) + 1.0f), t = 0.5f * (__fdiv_rn(tc, ma) + 1.0f);
+        int ix = (int)floorf(s * (float)S), iy = (int)floorf(t * (float)S);
+        ix = ix < 0 ? 0 : (ix > S - 1 ? S - 1 : ix);
+        iy = iy < 0 ? 0 : (iy > S - 1 ? S - 1 : iy);
+        const uint2 q = p[((size_t)face * S + iy) * S + ix];
+        return mk3(h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y));
+    }
+};
+
+// ---- brdf.glsl -----------------------------------------------------------------------------------
+HR_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HR_DEV f3 div3s(f3 a, float s) { return mk3(__fdiv_rn(a.x, s), __fdiv_rn(a.y, s), __fdiv_rn(a.z, s)); }
+HR_DEV f3 mix3(f3 a, f3 b, float t) { return add3(scale3(a, 1.0f - t), scale3(b, t)); }
+HR_DEV f3 one3() { return mk3(1.0f, 1.0f, 1.0f); }
+
+HR_DEV float D_ggx(float ndoth, float alpha)
+{
+    const float a2 = alpha * alpha;
+    const float denom = (ndoth * ndoth) * (a2 - 1.0f) + 1.0f;
+    return __fdiv_rn(a2, max2(HR_EPSILON, (HR_M_PI * denom * denom)));
+}
+HR_DEV float G1_schlick_ggx(float roughness, float ndotv)
+{
+    const float k = __fdiv_rn((roughness + 1.0f) * (roughness + 1.0f), 8.0f);
+    return __fdiv_rn(ndotv, max2(HR_EPSILON, (ndotv * (1.0f - k) + k)));
+}
+HR_DEV float G_schlick_ggx(float ndotl, float ndotv, float roughness) { return G1_schlick_ggx(roughness, ndotl) * G1_schlick_ggx(roughness, ndotv); }
+HR_DEV f3 F_schlick(f3 f0, float vdoth)
+{
+    const float p = det_powi(1.0f - vdoth, 5);
+    return add3(f0, scale3(sub3(one3(), f0), p));
+}
+HR_DEV f3 evaluate_specular_brdf(float roughness, f3 F, float ndoth, float ndotl, float ndotv)
+{
+    const float alpha = roughness * roughness;
+    const f3    num   = scale3(scale3(F, D_ggx(ndoth, alpha)), G_schlick_ggx(ndotl, ndotv, roughness));
+    return div3s(num, max2(HR_EPSILON, (4.0f * ndotl * ndotv)));
+}
+HR_DEV f3 evaluate_uber_brdf(f3 diffuse_color, float roughness, f3 N, f3 F0, f3 Wo, f3 Wh, f3 Wi)
+{
+    const float NdotL = max2(dot3(N, Wi), 0.0f), NdotV = max2(dot3(N, Wo), 0.0f), NdotH = max2(dot3(N, Wh), 0.0f), VdotH = max2(dot3(Wi, Wh), 0.0f);
+    const f3 F        = F_schlick(F0, VdotH);
+    const f3 specular = evaluate_specular_brdf(roughness, F, NdotH, NdotL, NdotV);
+    const f3 diffuse  = div3s(diffuse_color, HR_M_PI);
+    return add3(mul3(sub3(one3(), F), diffuse), specular);
+}
+HR_DEV f3 fresnel_schlick_roughness(float cos_theta, f3 F0, float roughness)
+{
+    const float r1 = 1.0f - roughness;
+    const f3    m  = mk3(max2(r1, F0.x), max2(r1, F0.y), max2(r1, F0.z));
+    const float p  = det_powi(max2(1.0f - cos_theta, 0.0f), 5);
+    return add3(F0, scale3(sub3(m, F0), p));
+}
+// brdf.glsl:8-32
+HR_DEV f3 sample_cosine_lobe_n(f3 n, float rx, float ry)
+{
+    rx = max2(0.00001f, rx);
+    ry = max2(0.00001f, ry);
+    const float phi = 2.0f * HR_M_PI * ry;
+    const float ct = hr_sqrt(rx), st = hr_sqrt(1.0f - rx);
+    float s, c;
+    det_sincos(phi, s, c);
+    const f3 t   = mk3(st * c, st * s, ct);
+    const f3 ref = fabsf(dot3(n, mk3(0.0f, 1.0f, 0.0f))) > 0.99f ? mk3(0.0f, 0.0f, 1.0f) : mk3(0.0f, 1.0f, 0.0f);
+    const f3 x   = normalize3(cross3(ref, n));
+    const f3 y   = cross3(n, x);
+    return normalize3(mk3((x.x * t.x + y.x * t.y) + n.x * t.z, (x.y * t.x + y.y * t.y) + n.y * t.z, (x.z * t.x + y.z * t.y) + n.z * t.z));
+}
+
+// ---- gi_common.glsl ----------------------------------------------------------------------------------
+typedef hr_ddgi_uniforms DDGIU;
+
+HR_DEV float sign_not_zero(float k) { return k >= 0.0f ? 1.0f : -1.0f; }
+HR_DEV void gi_oct_encode(f3 v, float& rx, float& ry)
+{
+    const float l1  = (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z);
+    const float inv = __fdiv_rn(1.0f, l1);
+    rx = v.x * inv;
+    ry = v.y * inv;
+    if (v.z < 0.0f)
+    {
+        const float nx = (1.0f - fabsf(ry)) * sign_not_zero(rx);
+        const float ny = (1.0f - fabsf(rx)) * sign_not_zero(ry);
+        rx = nx; ry = ny;
+    }
+}
+HR_DEV f3 gi_oct_decode(float ox, float oy)
+{
+    f3 v = mk3(ox, oy, 1.0f - fabsf(ox) - fabsf(oy));
+    if (v.z < 0.0f)
+    {
+        const float nx = (1.0f - fabsf(v.y)) * sign_not_zero(v.x);
+        const float ny = (1.0f - fabsf(v.x)) * sign_not_zero(v.y);
+        v.x = nx; v.y = ny;
+    }
+    return normalize3(v);
+}
+HR_DEV f3 grid_coord_to_position(const DDGIU& d, int cx, int cy, int cz)
+{
+    return mk3(d.grid_step[0] * (float)cx + d.grid_start_position[0], d.grid_step[1] * (float)cy + d.grid_start_position[1],
+               d.grid_step[2] * (float)cz + d.grid_start_position[2]);
+}
+HR_DEV f3 probe_location(const DDGIU& d, int index)
+{
+    const int cx = index % d.probe_counts[0];
+    const int cy = (index % (d.probe_counts[0] * d.probe_counts[1])) / d.probe_counts[0];
+    const int cz = index / (d.probe_counts[0] * d.probe_counts[1]);
+    return grid_coord_to_position(d, cx, cy, cz);
+}
+HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
+{
+    float ox, oy;
+    gi_oct_encode(normalize3(dir), ox, oy);
+    const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;
+    const float pwb = (float)side + 2.0f;
+    const float cx = __fdiv_rn(zx * (float)side, (float)tw), cy = __fdiv_rn(zy * (float)side, (float)th);
+    const int   per_row = (tw - 2) / (side + 2);
+    const float tlx = (float)(probe_index % per_row) * pwb + 2.0f; // mod() of small integers is exact
+    const float tly = (float)(probe_index / per_row) * pwb + 2.0f;
+    u = __fdiv_rn(tlx, (float)tw) + cx;
+    v = __fdiv_rn(tly, (float)th) + cy;
+}
+HR_DEV int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
+
+struct AtlasRGBA { const uint2* p; int w, h; };
+struct AtlasRG { const uint32_t* p; int w, h; };
+HR_DEV void bilinear_setup(float u, float v, int w, int h, int& x0, int& x1, int& y0, int& y1, float& fx, float& fy)
+{
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    fx = x - fx0; fy = y - fy0;
+    x0 = (int)fx0; y0 = (int)fy0; x1 = x0 + 1; y1 = y0 + 1;
+    x0 = clampi(x0, 0, w - 1); x1 = clampi(x1, 0, w - 1); y0 = clampi(y0, 0, h - 1); y1 = clampi(y1, 0, h - 1);
+}
+HR_DEV f3 atlas_bilinear_rgb(const AtlasRGBA& a, float u, float v)
+{
+    int x0, x1, y0, y1; float fx, fy;
+    bilinear_setup(u, v, a.w, a.h, x0, x1, y0, y1, fx, fy);
+    const uint2 t00 = a.p[(size_t)y0 * a.w + x0], t10 = a.p[(size_t)y0 * a.w + x1], t01 = a.p[(size_t)y1 * a.w + x0], t11 = a.p[(size_t)y1 * a.w + x1];
+    f3 r;
+    r.x = mix1(mix1(h2f_lo(t00.x), h2f_lo(t10.x), fx), mix1(h2f_lo(t01.x), h2f_lo(t11.x), fx), fy);
+    r.y = mix1(mix1(h2f_hi(t00.x), h2f_hi(t10.x), fx), mix1(h2f_hi(t01.x), h2f_hi(t11.x), fx), fy);
+    r.z = mix1(mix1(h2f_lo(t00.y), h2f_lo(t10.y), fx), mix1(h2f_lo(t01.y), h2f_lo(t11.y), fx), fy);
+    return r;
+}
+HR_DEV void atlas_bilinear_rg(const AtlasRG& a, float u, float v, float& r0, float& r1)
+{
+    int x0, x1, y0, y1; float fx, fy;
+    bilinear_setup(u, v, a.w, a.h, x0, x1, y0, y1, fx, fy);
+    const uint32_t t00 = a.p[(size_t)y0 * a.w + x0], t10 = a.p[(size_t)y0 * a.w + x1], t01 = a.p[(size_t)y1 * a.w + x0], t11 = a.p[(size_t)y1 * a.w + x1];
+    r0 = mix1(mix1(h2f_lo(t00), h2f_lo(t10), fx), mix1(h2f_lo(t01), h2f_lo(t11), fx), fy);
+    r1 = mix1(mix1(h2f_hi(t00), h2f_hi(t10), fx), mix1(h2f_hi(t01), h2f_hi(t11), fx), fy);
+}
+
+// gi_common.glsl:188-320
+HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+{
+    const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]);
+    const f3 g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
+    const int bx = clampi((int)__fdiv_rn(P.x - g0.x, gs.x), 0, d.probe_counts[0] - 1);
+    const int by = clampi((int)__fdiv_rn(P.y - g0.y, gs.y), 0, d.probe_counts[1] - 1);
+    const int bz = clampi((int)__fdiv_rn(P.z - g0.z, gs.z), 0, d.probe_counts[2] - 1);
+    const f3  base_pos = grid_coord_to_position(d, bx, by, bz);
+    f3    sum_irr = mk3(0.0f, 0.0f, 0.0f);
+    float sum_w   = 0.0f;
+    const f3 alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
+                         clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
+    for (int i = 0; i < 8; ++i)
+    {
+        const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
+        const int cx = clampi(bx + ox, 0, d.probe_counts[0] - 1), cy = clampi(by + oy, 0, d.probe_counts[1] - 1), cz = clampi(bz + oz, 0, d.probe_counts[2] - 1);
+        const int p  = cx + cy * d.probe_counts[0] + cz * d.probe_counts[0] * d.probe_counts[1];
+        const f3 probe_pos      = grid_coord_to_position(d, cx, cy, cz);
+        const f3 probe_to_point = add3(sub3(P, probe_pos), scale3(add3(N, scale3(Wo, 3.0f)), d.normal_bias));
+        const f3 dir            = normalize3(neg3(probe_to_point));
+        const f3 tri = mk3(mix1(1.0f - alpha.x, alpha.x, (float)ox), mix1(1.0f - alpha.y, alpha.y, (float)oy), mix1(1.0f - alpha.z, alpha.z, (float)oz));
+        float weight = 1.0f;
+        {
+            const f3    tdp = normalize3(sub3(probe_pos, P));
+            const float t   = max2(0.0001f, (dot3(tdp, N) + 1.0f) * 0.5f);
+            weight          = weight * (t * t + 0.2f);
+        }
+        if (d.visibility_test == 1)
+        {
+            float u, v, mean, m2;
+            texture_coord_from_direction(neg3(dir), p, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
+            const float dist = len3(probe_to_point);
+            atlas_bilinear_rg(depth, u, v, mean, m2);
+            const float variance = fabsf(mean * mean - m2);
+            const float dm  = max2(dist - mean, 0.0f);
+            float che = __fdiv_rn(variance, variance + dm * dm);
+            che       = max2(che * che * che, 0.0f);
+            weight    = weight * ((dist <= mean) ? 1.0f : che);
+        }
+        weight = max2(0.000001f, weight);
+        float u, v;
+        texture_coord_from_direction(normalize3(N), p, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
+        f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
+        const float crush = 0.2f;
+        if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
+        weight    = weight * (tri.x * tri.y * tri.z);
+        probe_irr = mk3(hr_sqrt(probe_irr.x), hr_sqrt(probe_irr.y), hr_sqrt(probe_irr.z)); // sqrt-space blending (LINEAR_BLENDING undefined)
+        sum_irr   = add3(sum_irr, scale3(probe_irr, weight));
+        sum_w += weight;
+    }
+    f3 net = div3s(sum_irr, sum_w);
+    net.x = (net.x != net.x) ? 0.5f : net.x;
+    net.y = (net.y != net.y) ? 0.5f : net.y;
+    net.z = (net.z != net.z) ? 0.5f : net.z;
+    net = mul3(net, net);
+    net = scale3(net, d.energy_preservation);
+    return scale3(net, 0.5f * HR_M_PI);
+}
+
+// ---- scene access at a hit -----------------------------------------------------------------------------
+struct SceneShading
+{
+    const float*    positions;   // [n][3][3] by original triangle index
+    const float*    normals;     // [n][3][3] or null
+    const uint32_t* tri_material;
+    const float*    materials;   // [m][8]
+};
+struct SurfaceHit
+{
+    f3    P, N, albedo;
+    float roughness, metallic;
+};
+HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
+{
+    SurfaceHit o;
+    const float* p = s.positions + (size_t)h.prim * 9;
+    const f3 v0 = mk3(p[0], p[1], p[2]), v1 = mk3(p[3], p[4], p[5]), v2 = mk3(p[6], p[7], p[8]);
+    const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+    o.P = add3(add3(scale3(v0, b0), scale3(v1, b1)), scale3(v2, b2));
+    f3 n;
+    if (s.normals)
+    {
+        const float* q = s.normals + (size_t)h.prim * 9;
+        n = add3(add3(scale3(mk3(q[0], q[1], q[2]), b0), scale3(mk3(q[3], q[4], q[5]), b1)), scale3(mk3(q[6], q[7], q[8]), b2));
+    }
+    else
+        n = cross3(sub3(v1, v0), sub3(v2, v0));
+    o.N = normalize3(normalize3(n));
+    const uint32_t mat = s.tri_material ? s.tri_material[h.prim] : 0u;
+    if (s.materials)
+    {
+        const float* m = s.materials + (size_t)mat * 8;
+        o.albedo = mk3(m[0], m[1], m[2]); o.metallic = m[3]; o.roughness = max2(m[4], 0.1f);
+    }
+    else { o.albedo = mk3(0.8f, 0.8f, 0.8f); o.metallic = 0.0f; o.roughness = 0.5f; }
+    return o;
+}
+
+// fetch_light_properties without SOFT_SHADOWS (lighting.glsl:6-111)
+HR_DEV void fetch_light_hard(const hr_light& L, f3 Wo, f3 P, f3 N, f3& Li, f3& Wi, f3& Wh, float& t_max, float& attenuation)
+{
+    const int type = (int)L.data3[0];
+    const f3  ldir = mk3(L.data0[0], L.data0[1], L.data0[2]);
+    Li = scale3(mk3(L.data2[0], L.data2[1], L.data2[2]), L.data0[3]);
+    if (type == 0) { Wi = ldir; t_max = 10000.0f; attenuation = 1.0f; }
+    else
+    {
+        const f3 to_light = sub3(mk3(L.data1[0], L.data1[1], L.data1[2]), P);
+        Wi                = normalize3(to_light);
+        const float dist  = len3(to_light);
+        t_max             = dist;
+        if (type == 1) attenuation = __fdiv_rn(1.0f, dist * dist);
+        else attenuation = __fdiv_rn(smoothstep1(L.data3[1], L.data3[2], dot3(Wi, ldir)), dist * dist);
+    }
+    Wh          = normalize3(add3(Wo, Wi));
+    attenuation = attenuation * clamp1(dot3(N, Wi), 0.0f, 1.0f);
+}
+
+struct TraceCtx
+{
+    const Node8*  nodes;
+    const TriGPU* tris;
+    uint32_t*     wave_stack;
+    int           lane;
+};
+
+// direct_lighting (lighting.glsl:117-196)
+HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N, f3 P, f3 F0, f3 diffuse_color, float roughness, f3 T,
+                          bool sample_sky, float r2x, float r2y, const CubeMap& sky, uint32_t& rays)
+{
+    f3       Lo = mk3(0.0f, 0.0f, 0.0f);
+    const f3 ray_origin = add3(P, scale3(N, 0.1f));
+    uint32_t nn = 0, nt = 0;
+    {
+        f3    Li, Wi, Wh;
+        float t_max, attenuation;
+        fetch_light_hard(light, Wo, P, N, Li, Wi, Wh, t_max, attenuation);
+        if (attenuation > 0.0f)
+        {
+            rays++;
+            attenuation = attenuation * (trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
+        }
+        const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
+        Lo = add3(Lo, mul3(scale3(mul3(T, brdf), attenuation), Li));
+    }
+    if (sample_sky)
+    {
+        const f3 Wi = sample_cosine_lobe_n(N, r2x, r2y);
+        f3       Li = sky.fetch(Wi);
+        const f3 Wh = normalize3(add3(Wo, Wi));
+        rays++;
+        Li = scale3(Li, trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
+        const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
+        Lo = add3(Lo, mul3(mul3(T, brdf), Li));
+    }
+    return Lo;
+}
+
+} // namespace hr

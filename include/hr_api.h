@@ -270,6 +270,72 @@ hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out);
 hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays);
 hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, uint64_t* out3, void* stream);
 
+/* ---- environment inputs (replace CommonResources::current_skybox_ds / IBL images) ------------------- */
+/* Cubemaps are [6][size][size] RGBA16F, faces +X -X +Y -Y +Z -Z, fetched NEAREST.
+ * prefiltered: `prefiltered_levels` mips of the specular-prefiltered environment, level l has size
+ * prefiltered_size >> l and starts right after level l-1.  brdf_lut: [lut_size][lut_size] RG16F. */
+typedef struct
+{
+    const void* sky;
+    int32_t     sky_size;
+    const void* prefiltered;
+    int32_t     prefiltered_size, prefiltered_levels;
+    const void* brdf_lut;
+    int32_t     brdf_lut_size;
+} hr_environment;
+
+/* ---- DDGI (src/ddgi.h) ---------------------------------------------------------------------------- */
+typedef struct hr_ddgi hr_ddgi;
+
+/* DDGIUniforms, scalar layout, 88 bytes (ddgi.cpp:14-32 == shaders/gi/gi_common.glsl:10-28) */
+typedef struct
+{
+    float   grid_start_position[3];
+    float   grid_step[3];
+    int32_t probe_counts[3];
+    float   max_distance, depth_sharpness, hysteresis, normal_bias, energy_preservation;
+    int32_t irradiance_probe_side_length, irradiance_texture_width, irradiance_texture_height;
+    int32_t depth_probe_side_length, depth_texture_width, depth_texture_height;
+    int32_t rays_per_probe, visibility_test;
+} hr_ddgi_uniforms;
+
+/* member defaults: ddgi.h:54-56,102 */
+typedef struct
+{
+    int32_t infinite_bounces;          /* RayTrace::infinite_bounces = true            */
+    float   infinite_bounce_intensity; /* RayTrace::infinite_bounce_intensity = 1.7    */
+    float   gi_intensity;              /* SampleProbeGrid::gi_intensity = 1.0          */
+    float   random_orientation[9];     /* column-major 3x3 probe-ray rotation of this frame: the reference draws
+                                          it from std::mt19937 seeded by std::random_device (ddgi.cpp:73,788);
+                                          here the caller supplies it so frames are reproducible */
+} hr_ddgi_params;
+
+void      hr_ddgi_default_params(hr_ddgi_params* p);
+/* DDGI(backend, common, g_buffer, scale) + initialize_probe_grid/recreate_probe_grid_resources
+ * (ddgi.cpp:61-76,150-237): the grid description is passed in (probe counts, atlas sizes). */
+hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_ddgi_uniforms* grid, hr_ddgi** out);
+/* DDGI::render (ddgi.cpp:89-104): ray_trace -> probe_update (irradiance, depth, borders) -> sample_probe_grid */
+hr_status hr_ddgi_render(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, void* stream);
+/* DDGI::output_ds (ddgi.cpp:128-131): the per-pixel sampled irradiance, RGBA16F */
+hr_status hr_ddgi_output(hr_ddgi* p, hr_image_view* view);
+/* DDGI::current_read_ds (ddgi.cpp:135-138): irradiance + depth atlases written by the last render() */
+hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
+/* DDGI::restart_accumulation (ddgi.h:33) */
+hr_status hr_ddgi_restart_accumulation(hr_ddgi* p);
+hr_status hr_ddgi_destroy(hr_ddgi* p);
+/* stage-level entry points (ddgi.cpp:767-986); probe range [probe0, probe1) lets a multi-GPU driver
+ * split G1-G4 by z-slab and all-gather the atlas rows */
+hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, void* stream);
+hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream);
+hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const hr_ddgi_params* params, void* stream);
+hr_status hr_ddgi_end_frame(hr_ddgi* p); /* m_first_frame = false; m_ping_pong = !m_ping_pong (ddgi.cpp:101-103) */
+/* 0 radiance, 1 direction+distance ([probes][rays] RGBA16F), 2/3 irradiance atlas[0/1], 4/5 depth atlas[0/1], 6 sample image */
+hr_status hr_ddgi_image(hr_ddgi* p, int32_t which, hr_image_view* view);
+hr_status hr_ddgi_get_uniforms(hr_ddgi* p, hr_ddgi_uniforms* out);
+hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t enable);
+hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out);
+hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

@@ -47,6 +47,18 @@ void orc_ao_temporal(const void* ubo, int w, int h, int spp, const uint32_t* mas
 void orc_ao_blur(int w, int h, const uint16_t* in_ao, const float* depth, const uint16_t* gb2, const uint8_t* tile_class, const float* zbp,
                  int dir_x, int dir_y, int radius, uint16_t* out_ao);
 
+// ---- DDGI -----------------------------------------------------------------------------------
+// ddgi: 88-byte DDGIUniforms (ddgi.cpp:14-32).  orientation: column-major 3x3 probe-ray rotation.
+// sky: [6][S][S][4] fp16 cubemap (+X -X +Y -Y +Z -Z).
+void orc_ddgi_ray_trace(const void* scene, const void* ubo, const void* ddgi, const float* orientation, uint32_t num_frames,
+                        int infinite_bounces, float gi_intensity, const uint16_t* sky, int sky_size, const uint16_t* prev_irradiance,
+                        const uint16_t* prev_depth, uint16_t* radiance, uint16_t* direction_distance, uint64_t* rays_out);
+void orc_ddgi_probe_update(const void* ddgi, int depth_probe, int first_frame, const uint16_t* radiance, const uint16_t* direction_distance,
+                           const uint16_t* prev_atlas, uint16_t* out_atlas);
+void orc_ddgi_border_update(const void* ddgi, int depth_probe, uint16_t* atlas);
+void orc_ddgi_sample_probe_grid(const void* ubo, const void* ddgi, int w, int h, const float* depth, const uint16_t* gb2, float gi_intensity,
+                                const uint16_t* irradiance, const uint16_t* depth_atlas, uint16_t* out);
+
 // ---- scalar helpers exported for known-answer tests ---------------------------------------
 uint16_t orc_f32_to_f16(float f);
 float    orc_f16_to_f32(uint16_t h);
