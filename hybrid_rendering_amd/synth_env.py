@@ -83,3 +83,30 @@ def sky_cubemap(size: int = 32, sun_dir=(0.3, 0.9, 0.2), intensity: float = 1.0)
         out[f, ..., :3] = col * intensity
         out[f, ..., 3] = 1.0
     return out.astype(np.float16).view(np.uint16)
+
+
+def prefiltered_chain(sky_u16: np.ndarray, levels: int = 5) -> np.ndarray:
+    """Stand-in for dw::CubemapPrefiler (common.h:94): mip chain by 2x2 box filtering, levels packed back to
+    back ([6][s][s][4] each, s = S >> level) as the hr_environment contract asks."""
+    lvl = sky_u16.view(np.float16).astype(np.float32)
+    out = []
+    for _ in range(levels):
+        out.append(lvl.astype(np.float16).reshape(-1))
+        if lvl.shape[1] > 1:
+            lvl = 0.25 * (lvl[:, 0::2, 0::2] + lvl[:, 1::2, 0::2] + lvl[:, 0::2, 1::2] + lvl[:, 1::2, 1::2])
+    return np.ascontiguousarray(np.concatenate(out)).view(np.uint16)
+
+
+def brdf_lut(size: int = 32) -> np.ndarray:
+    """Stand-in for dw::BRDFIntegrateLUT (common.h:228): [size][size][2] fp16 (scale, bias) over (N.V, roughness),
+    Karis' analytic fit of the split-sum integral."""
+    nv = (np.arange(size, dtype=np.float64) + 0.5) / size
+    r = (np.arange(size, dtype=np.float64) + 0.5) / size
+    NV, R = np.meshgrid(nv, r)  # rows = roughness (v), cols = N.V (u)
+    c0 = np.array([-1.0, -0.0275, -0.572, 0.022])
+    c1 = np.array([1.0, 0.0425, 1.04, -0.04])
+    rr = R[..., None] * c0 + c1
+    a004 = np.minimum(rr[..., 0] * rr[..., 0], 2.0 ** (-9.28 * NV)) * rr[..., 0] + rr[..., 1]
+    A = -1.04 * a004 + rr[..., 2]
+    B = 1.04 * a004 + rr[..., 3]
+    return np.ascontiguousarray(np.stack([A, B], -1).astype(np.float16)).view(np.uint16)

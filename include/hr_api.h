@@ -336,6 +336,54 @@ hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t enable);
 hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out);
 hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays);
 
+/* ---- RayTracedReflections (src/ray_traced_reflections.h) ---------------------------------------------- */
+typedef struct hr_reflections hr_reflections;
+
+/* member defaults: ray_traced_reflections.h:53-59,77-79,110-116 */
+typedef struct
+{
+    int32_t denoise;                         /* m_denoise = true                                  */
+    int32_t sample_gi;                       /* RayTrace::sample_gi = true                        */
+    int32_t approximate_with_ddgi;           /* RayTrace::approximate_with_ddgi = true            */
+    float   gi_intensity;                    /* 0.5                                               */
+    float   rough_ddgi_intensity;            /* 0.5                                               */
+    float   ibl_indirect_specular_intensity; /* 0.05                                              */
+    float   bias;                            /* 0.5                                               */
+    float   trim;                            /* 0.8                                               */
+    float   alpha;                           /* TemporalAccumulation::alpha = 0.01                */
+    float   moments_alpha;                   /* 0.2                                               */
+    int32_t blur_as_input;                   /* false                                             */
+    float   phi_color;                       /* ATrous::phi_color = 10                            */
+    float   phi_normal;                      /* 32                                                */
+    float   sigma_depth;                     /* 1                                                 */
+    int32_t radius;                          /* 1                                                 */
+    int32_t filter_iterations;               /* 4                                                 */
+    int32_t feedback_iteration;              /* 1                                                 */
+    float   camera_delta[3];                 /* CommonResources::camera_delta (main.cpp:1077-1079) */
+    float   frame_time;                      /* CommonResources::frame_time (pushed, unused by the shader) */
+} hr_reflections_params;
+
+void      hr_reflections_default_params(hr_reflections_params* p);
+hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_reflections** out);
+/* RayTracedReflections::render(cmd_buf, ddgi) (ray_traced_reflections.cpp:107-123); reads ddgi->current_read_ds() */
+hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
+                                const hr_reflections_params* params, void* stream);
+/* RayTracedReflections::output_ds (ray_traced_reflections.cpp:149-169) */
+hr_status hr_reflections_output(hr_reflections* p, hr_output_kind kind, hr_image_view* view);
+hr_status hr_reflections_reset_history(hr_reflections* p);
+hr_status hr_reflections_destroy(hr_reflections* p);
+/* stage-level entry points: ray_trace (:997-1057), temporal_accumulation (:1087-1139), a_trous_filter iteration (:1143-1256), upsample (:1260-1296) */
+hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
+                                   const hr_reflections_params* params, void* stream);
+hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
+hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, int32_t iteration, void* stream);
+hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
+/* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes */
+hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* view);
+hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);
+hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out);
+hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

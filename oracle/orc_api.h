@@ -59,6 +59,26 @@ void orc_ddgi_border_update(const void* ddgi, int depth_probe, uint16_t* atlas);
 void orc_ddgi_sample_probe_grid(const void* ubo, const void* ddgi, int w, int h, const float* depth, const uint16_t* gb2, float gi_intensity,
                                 const uint16_t* irradiance, const uint16_t* depth_atlas, uint16_t* out);
 
+// ---- reflections -----------------------------------------------------------------------------
+struct orc_refl_trace_params
+{
+    float    bias, trim;
+    uint32_t num_frames;
+    int      sample_gi, approximate_with_ddgi;
+    float    gi_intensity, rough_ddgi_intensity, ibl_indirect_specular_intensity;
+};
+void orc_reflections_ray_trace(const void* scene, const void* ubo, const void* ddgi, int w, int h, const float* depth, const uint16_t* gb2,
+                               const uint16_t* gb3, const uint8_t* sobol, const uint8_t* scrambling_ranking, const orc_refl_trace_params* prm,
+                               const uint16_t* sky, int sky_size, const uint16_t* prefiltered, int pre_size, int pre_levels, const uint16_t* lut,
+                               int lut_size, const uint16_t* irradiance, const uint16_t* depth_atlas, uint16_t* out, uint64_t* rays_out);
+void orc_reflections_temporal(const void* ubo, int w, int h, const uint16_t* input, const float* depth, const uint16_t* gb2, const uint16_t* gb3,
+                              const float* prev_depth, const uint16_t* prev_gb2, const uint16_t* prev_gb3, const uint16_t* hist_color,
+                              const uint16_t* hist_moments, const float* camera_delta, float alpha, float moments_alpha, int approximate_with_ddgi,
+                              uint16_t* out_color, uint16_t* out_moments, uint8_t* tile_class);
+void orc_reflections_atrous(int w, int h, const uint16_t* in_color, const float* depth, const uint16_t* gb2, const uint16_t* gb3,
+                            const uint8_t* tile_class, int radius, int step_size, float phi_color, float phi_normal, float sigma_depth,
+                            int approximate_with_ddgi, uint16_t* out_color);
+
 // ---- scalar helpers exported for known-answer tests ---------------------------------------
 uint16_t orc_f32_to_f16(float f);
 float    orc_f16_to_f32(uint16_t h);
