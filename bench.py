@@ -9,9 +9,10 @@ inputs resident in HBM (BASELINE.json configs[1]).  Prints ONE JSON line (see th
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: the frame is row-tiled, one 1080-row band per GPU (a 1920 x 1080*N frame; weak scaling);
-no collective is on the data path of the shadows pass at this band height except the halo rows,
-which each rank re-traces / re-filters locally (zero-communication variant of SURVEY.md §8e).
+N > 1: ONE frame of 1920 x (1080*N) pixels is row-tiled, one 1080-row band per GPU (weak scaling).  Every band
+re-traces / re-filters 24 halo rows locally and, once per frame, exchanges the 40 history rows next to each band
+boundary with its neighbours over RCCL (hybrid_rendering_amd/tiling.py); band rows are bit-identical to the
+single-GPU result (tests/test_gpu_tiling.py).  `value` counts only the rays of band rows (halo work is overhead).
 """
 from __future__ import annotations
 
@@ -60,9 +61,9 @@ def main():
         dist.init_process_group("nccl")
 
     from hybrid_rendering_amd import api as hr
-    from hybrid_rendering_amd import synth
+    from hybrid_rendering_amd import synth, tiling
 
-    W, H = args.width, args.height
+    W, H = args.width, args.height * world      # one band of args.height rows per GPU
     sd = synth.sponza_like(args.detail)
     ctx = hr.Context(local_rank)
     scene = hr.Scene(ctx, sd)
@@ -70,12 +71,14 @@ def main():
     sob, sr = synth.blue_noise_tables()
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
 
-    # ring of camera positions (dolly 0.5 units/frame); each rank of a tiled
-    # frame looks at its own band of a taller frame == an independent vertical camera offset here.
+    # ring of camera positions (dolly 0.5 units/frame)
     R = max(2, args.ring)
     cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(R + 1)]
-    if world > 1:
-        cams = [synth.Camera((c.eye[0], c.eye[1] + 3.0 * rank, c.eye[2]), (c.target[0], c.target[1] + 3.0 * rank, c.target[2]), aspect=c.aspect) for c in cams]
+    if world > 1:  # keep the horizontal field of view of the 16:9 frame when the frame gets taller
+        import math
+        hfov = 2 * math.atan(math.tan(math.radians(30.0)) * 16 / 9)
+        vfov = math.degrees(2 * math.atan(math.tan(hfov / 2) * H / W))
+        cams = [synth.Camera(c.eye, c.target, fov=min(vfov, 150.0), aspect=W / H) for c in cams]
     # G-buffers: ring position i rendered with prev = i-1 (forward sweep) and with prev = i+1 (backward sweep)
     gbs = {}
     ubos = {}
@@ -96,12 +99,14 @@ def main():
         return hr.frame_inputs(gbs[key], gbs[pk], ubos[key], k, k & 1, sob_d, sr_d)
 
     cycle = [inputs_for(k) for k in range(len(seq) * 2)]  # even length: ping_pong parity preserved when cycling
-    shadows = hr.RayTracedShadows(ctx, W, H)
+    tiled = tiling.TiledShadows(ctx, W, H, rank, world)
+    shadows = tiled.pass_
+    b0, b1 = tiled.b0, tiled.b1
 
     def step(k):
         fi = cycle[k % len(cycle)]
         fi.num_frames = k
-        shadows.render(scene, fi)
+        tiled.render(scene, fi)
 
     def barrier():
         if world > 1:
@@ -136,6 +141,17 @@ def main():
             a[0] += ms
     shadows.set_profiling(False)
     rays_per_frame = rays_total / n_prof
+    if world > 1:
+        # useful rays = rays of the band rows only: count them with a halo-free pass on the same inputs
+        counter = hr.RayTracedShadows(ctx, W, H, hr.SCALE_FULL_RES, band=(b0, b1, 0, 0))
+        tot = 0
+        for k in range(k0, k0 + 8):
+            fi = cycle[k % len(cycle)]
+            fi.num_frames = k
+            counter.ray_trace(scene, fi)
+            tot += counter.ray_count()
+        traced_per_frame, rays_per_frame = rays_per_frame, tot / 8
+        counter.close()
     stages = {n: dict(ms=v[0] / n_prof, bytes=v[1]) for n, v in acc.items()}
     # instrumented trace (node visits / triangle tests) on a few frames of the cycle
     nn = nt = nr = 0
@@ -143,7 +159,7 @@ def main():
         r, a, b = shadows.trace_stats(scene, cycle[(k0 + k) % len(cycle)])
         nr, nn, nt = nr + r, nn + a, nt + b
     nodes_per_ray, tris_per_ray = nn / max(nr, 1), nt / max(nr, 1)
-    px = W * H
+    px = W * (b1 - b0)
     trace_bytes = px * 12.125 + rays_per_frame * (nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES)
     if "ray_trace" in stages:
         stages["ray_trace"]["bytes"] = int(trace_bytes)
@@ -164,10 +180,11 @@ def main():
         "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise, 1 band per GPU",
-                   "rays_per_frame": int(rays_per_frame), "pixels": px, "bvh_nodes": int(scene.info.n_nodes),
+        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise, row-tiled: one {args.height}-row band per GPU",
+                   "rays_per_frame_per_gpu": int(rays_per_frame), "pixels_per_gpu": px, "bvh_nodes": int(scene.info.n_nodes),
                    "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
-        "denoised_frames_per_s": round(world * args.steps / elapsed, 2),
+        "denoised_frames_per_s": round(args.steps / elapsed, 2),                  # frames of W x H (the whole tiled frame)
+        "denoised_1080p_equiv_per_s": round(world * args.steps / elapsed, 2),   # bands of W x args.height per second
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
         "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(dom[1]["frac"], 4), "traffic": None},

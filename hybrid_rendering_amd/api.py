@@ -57,7 +57,7 @@ class hr_scene_info(C.Structure):
 
 
 class hr_band(C.Structure):
-    _fields_ = [("band_y0", C.c_int32), ("band_y1", C.c_int32), ("halo", C.c_int32)]
+    _fields_ = [("band_y0", C.c_int32), ("band_y1", C.c_int32), ("halo", C.c_int32), ("history_halo", C.c_int32)]
 
 
 HR_MAX_STAGES = 16

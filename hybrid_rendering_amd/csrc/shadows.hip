@@ -314,6 +314,7 @@ struct hr_shadows
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0;
     int     y0 = 0, y1 = 0;           // resident rows (band + halo)
     int     band_y0 = 0, band_y1 = 0;
+    int     ry0 = 0, ry1 = 0;         // rows whose history / G-buffer may be read (band + history halo)
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0;
     DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters;
     bool    first_frame = true;
@@ -341,7 +342,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     // m_width = extent / 2^scale (ray_traced_shadows.cpp:80-83: float divide then truncation)
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
-    p->y0 = 0; p->y1 = p->h; p->band_y0 = 0; p->band_y1 = p->h;
+    p->y0 = 0; p->y1 = p->h; p->band_y0 = 0; p->band_y1 = p->h; p->ry0 = 0; p->ry1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
         if (band->band_y0 < 0 || band->band_y1 > p->h || (band->band_y0 & 7) || ((band->band_y1 & 7) && band->band_y1 != p->h) || band->halo < 0 || (band->halo & 7))
@@ -353,6 +354,9 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
         p->band_y0 = band->band_y0; p->band_y1 = band->band_y1;
         p->y0 = band->band_y0 - band->halo < 0 ? 0 : band->band_y0 - band->halo;
         p->y1 = band->band_y1 + band->halo > p->h ? p->h : band->band_y1 + band->halo;
+        const int hh = band->history_halo > band->halo ? band->history_halo : band->halo;
+        p->ry0 = band->band_y0 - hh < 0 ? 0 : band->band_y0 - hh;
+        p->ry1 = band->band_y1 + hh > p->h ? p->h : band->band_y1 + hh;
     }
     p->mw = cdiv(p->w, 8); p->mh = cdiv(p->h, 4);
     p->tiles_x = cdiv(p->w, 8); p->tiles_y = cdiv(p->h, 8);
@@ -493,15 +497,15 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     TemporalArgs a;
     for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
     a.mask = (const uint32_t*)p->mask.p; a.mw = p->mw; a.mh = p->mh;
-    const int w = p->w, y0 = p->y0, y1 = p->y1;
-    a.gb2  = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
-    a.gb3  = ImgRGBA16F { (const uint2*)in->cur.gb3, w, y0, y1 };
-    a.pgb2 = ImgRGBA16F { (const uint2*)in->prev.gb2, w, y0, y1 };
-    a.pgb3 = ImgRGBA16F { (const uint2*)in->prev.gb3, w, y0, y1 };
-    a.depth  = ImgR32F { in->cur.depth, w, y0, y1 };
-    a.pdepth = ImgR32F { in->prev.depth, w, y0, y1 };
-    a.hist         = ImgRG16F { (const uint32_t*)p->prev_image.p, w, y0, y1 };
-    a.hist_moments = ImgRGBA16F { (const uint2*)p->moments[!in->ping_pong].p, w, y0, y1 };
+    const int w = p->w, y0 = p->y0, y1 = p->y1, ry0 = p->ry0, ry1 = p->ry1;
+    a.gb2  = ImgRGBA16F { (const uint2*)in->cur.gb2, w, ry0, ry1 };
+    a.gb3  = ImgRGBA16F { (const uint2*)in->cur.gb3, w, ry0, ry1 };
+    a.pgb2 = ImgRGBA16F { (const uint2*)in->prev.gb2, w, ry0, ry1 };
+    a.pgb3 = ImgRGBA16F { (const uint2*)in->prev.gb3, w, ry0, ry1 };
+    a.depth  = ImgR32F { in->cur.depth, w, ry0, ry1 };
+    a.pdepth = ImgR32F { in->prev.depth, w, ry0, ry1 };
+    a.hist         = ImgRG16F { (const uint32_t*)p->prev_image.p, w, ry0, ry1 };
+    a.hist_moments = ImgRGBA16F { (const uint2*)p->moments[!in->ping_pong].p, w, ry0, ry1 };
     a.out = (uint32_t*)p->temporal_out.p; a.out_moments = (uint2*)p->moments[in->ping_pong ? 1 : 0].p;
     a.tile_class = (uint8_t*)p->tile_class.p;
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
@@ -528,8 +532,8 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     AtrousArgs a;
     const int w = p->w, y0 = p->y0, y1 = p->y1;
     a.in  = ImgRG16F { (const uint32_t*)(i == 0 ? p->temporal_out.p : p->atrous[read_idx].p), w, y0, y1 };
-    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
-    a.gb3 = ImgRGBA16F { (const uint2*)in->cur.gb3, w, y0, y1 };
+    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, p->ry0, p->ry1 };
+    a.gb3 = ImgRGBA16F { (const uint2*)in->cur.gb3, w, p->ry0, p->ry1 };
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out  = (uint32_t*)p->atrous[write_idx].p;
     a.out2 = (prm->feedback_iteration == i) ? (uint32_t*)p->prev_image.p : nullptr; // vkCmdCopyImage :1177-1207

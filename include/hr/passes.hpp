@@ -1,0 +1,233 @@
+// C++ host shims over the C ABI (hr_api.h) that keep the reference's class / method shapes, so the
+// application code of diharaw/hybrid-rendering (src/main.cpp:80-83, src/deferred_shading.cpp:715-723)
+// can call the MI355X back end with the same call sites:
+//
+//   reference                                                     this header
+//   ------------------------------------------------------------  ---------------------------------------------
+//   RayTracedShadows(backend, common, g_buffer, scale)            hr::RayTracedShadows(ctx, width, height, scale)
+//   void render(dw::vk::CommandBuffer::Ptr cmd_buf)               void render(hr::Stream, const hr::Frame&)
+//   dw::vk::DescriptorSet::Ptr output_ds()                        hr::ImageView output_ds()
+//   width()/height()/scale()/current_output()/set_current_output  same names
+//   DDGI::current_read_ds(), restart_accumulation(), setters      same names
+//
+// dw::vk::CommandBuffer::Ptr -> hr::Stream (a hipStream_t), dw::vk::DescriptorSet::Ptr -> hr::ImageView
+// (device pointer + extent + format), CommonResources/GBuffer -> hr::Frame (hr_frame_inputs + scene + env).
+// render() returns void like the reference; failures throw hr::Error on THIS side of the ABI only.
+#pragma once
+#include "../hr_api.h"
+#include <stdexcept>
+#include <string>
+
+namespace hr {
+
+struct Error : std::runtime_error
+{
+    hr_status status;
+    Error(hr_status s, const char* what) : std::runtime_error(std::string(what) + ": " + hr_status_string(s) + " — " + hr_last_error()), status(s) {}
+};
+inline void check(hr_status s, const char* what)
+{
+    if (s != HR_OK) throw Error(s, what);
+}
+
+using Stream    = void*;         // hipStream_t
+using ImageView = hr_image_view; // replaces dw::vk::DescriptorSet::Ptr of an output
+
+enum RayTraceScale { RAY_TRACE_SCALE_FULL_RES = HR_SCALE_FULL_RES, RAY_TRACE_SCALE_HALF_RES = HR_SCALE_HALF_RES, RAY_TRACE_SCALE_QUARTER_RES = HR_SCALE_QUARTER_RES };
+
+class Context
+{
+public:
+    explicit Context(int device = 0) { check(hr_ctx_create(device, &m_ctx), "hr_ctx_create"); }
+    ~Context() { hr_ctx_destroy(m_ctx); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    hr_ctx* handle() const { return m_ctx; }
+private:
+    hr_ctx* m_ctx = nullptr;
+};
+
+// dw::RayTracedScene
+class Scene
+{
+public:
+    Scene(Context& ctx, const hr_scene_desc& desc) { check(hr_scene_create(ctx.handle(), &desc, &m_scene), "hr_scene_create"); }
+    ~Scene() { hr_scene_destroy(m_scene); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    hr_scene* handle() const { return m_scene; }
+private:
+    hr_scene* m_scene = nullptr;
+};
+
+// What CommonResources + GBuffer hand to every pass each frame.
+struct Frame
+{
+    const Scene*          scene = nullptr;
+    hr_frame_inputs       inputs {};
+    const hr_environment* environment = nullptr; // reflections / DDGI
+};
+
+class RayTracedShadows
+{
+public:
+    enum OutputType { OUTPUT_RAY_TRACE, OUTPUT_TEMPORAL_ACCUMULATION, OUTPUT_ATROUS, OUTPUT_UPSAMPLE }; // ray_traced_shadows.h:10-16
+
+    RayTracedShadows(Context& ctx, uint32_t width, uint32_t height, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES, const hr_band* band = nullptr) :
+        m_scale(scale), m_width(width >> scale), m_height(height >> scale)
+    {
+        hr_shadows_default_params(&params);
+        check(hr_shadows_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_shadows_create");
+    }
+    ~RayTracedShadows() { hr_shadows_destroy(m_pass); }
+    RayTracedShadows(const RayTracedShadows&) = delete;
+    RayTracedShadows& operator=(const RayTracedShadows&) = delete;
+
+    void render(Stream cmd_buf, const Frame& frame) { check(hr_shadows_render(m_pass, frame.scene->handle(), &frame.inputs, &params, cmd_buf), "RayTracedShadows::render"); }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_shadows_output(m_pass, (hr_output_kind)m_current_output, &v), "RayTracedShadows::output_ds");
+        return v;
+    }
+    uint32_t      width() const { return m_width; }
+    uint32_t      height() const { return m_height; }
+    RayTraceScale scale() const { return m_scale; }
+    OutputType    current_output() const { return m_current_output; }
+    void          set_current_output(OutputType o) { m_current_output = o; }
+    void          reset_history() { check(hr_shadows_reset_history(m_pass), "reset_history"); }
+    hr_shadows*   handle() const { return m_pass; }
+
+    hr_shadows_params params; // the members the reference exposes through gui() (ray_traced_shadows.cpp:120-131)
+
+private:
+    hr_shadows*   m_pass = nullptr;
+    RayTraceScale m_scale;
+    OutputType    m_current_output = OUTPUT_UPSAMPLE;
+    uint32_t      m_width, m_height;
+};
+
+class RayTracedAO
+{
+public:
+    enum OutputType { OUTPUT_RAY_TRACE, OUTPUT_TEMPORAL_ACCUMULATION, OUTPUT_BILATERAL_BLUR, OUTPUT_UPSAMPLE }; // ray_traced_ao.h:10-16
+
+    RayTracedAO(Context& ctx, uint32_t width, uint32_t height, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES, const hr_band* band = nullptr) :
+        m_scale(scale), m_width(width >> scale), m_height(height >> scale)
+    {
+        hr_ao_default_params(&params);
+        check(hr_ao_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_ao_create");
+    }
+    ~RayTracedAO() { hr_ao_destroy(m_pass); }
+    RayTracedAO(const RayTracedAO&) = delete;
+    RayTracedAO& operator=(const RayTracedAO&) = delete;
+
+    void render(Stream cmd_buf, const Frame& frame) { check(hr_ao_render(m_pass, frame.scene->handle(), &frame.inputs, &params, cmd_buf), "RayTracedAO::render"); }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_ao_output(m_pass, (hr_output_kind)m_current_output, &v), "RayTracedAO::output_ds");
+        return v;
+    }
+    uint32_t      width() const { return m_width; }
+    uint32_t      height() const { return m_height; }
+    RayTraceScale scale() const { return m_scale; }
+    OutputType    current_output() const { return m_current_output; }
+    void          set_current_output(OutputType o) { m_current_output = o; }
+    hr_ao*        handle() const { return m_pass; }
+
+    hr_ao_params params;
+
+private:
+    hr_ao*        m_pass = nullptr;
+    RayTraceScale m_scale;
+    OutputType    m_current_output = OUTPUT_UPSAMPLE;
+    uint32_t      m_width, m_height;
+};
+
+class DDGI
+{
+public:
+    DDGI(Context& ctx, uint32_t width, uint32_t height, const hr_ddgi_uniforms& grid, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
+        m_scale(scale), m_width(width >> scale), m_height(height >> scale)
+    {
+        hr_ddgi_default_params(&params);
+        check(hr_ddgi_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, &grid, &m_pass), "hr_ddgi_create");
+    }
+    ~DDGI() { hr_ddgi_destroy(m_pass); }
+    DDGI(const DDGI&) = delete;
+    DDGI& operator=(const DDGI&) = delete;
+
+    void render(Stream cmd_buf, const Frame& frame)
+    {
+        check(hr_ddgi_render(m_pass, frame.scene->handle(), &frame.inputs, frame.environment, &params, cmd_buf), "DDGI::render");
+    }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_ddgi_output(m_pass, &v), "DDGI::output_ds");
+        return v;
+    }
+    // DDGI::current_read_ds(): the irradiance + depth atlases written by the last render()
+    void current_read_ds(ImageView& irradiance, ImageView& depth) { check(hr_ddgi_current_read(m_pass, &irradiance, &depth), "DDGI::current_read_ds"); }
+    uint32_t      width() const { return m_width; }
+    uint32_t      height() const { return m_height; }
+    RayTraceScale scale() const { return m_scale; }
+    float         infinite_bounce_intensity() const { return params.infinite_bounce_intensity; }
+    float         gi_intensity() const { return params.gi_intensity; }
+    void          set_infinite_bounce_intensity(float v) { params.infinite_bounce_intensity = v; }
+    void          set_gi_intensity(float v) { params.gi_intensity = v; }
+    void          restart_accumulation() { check(hr_ddgi_restart_accumulation(m_pass), "DDGI::restart_accumulation"); }
+    hr_ddgi*      handle() const { return m_pass; }
+
+    hr_ddgi_params params; // incl. this frame's probe-ray rotation (std::mt19937 in the reference, ddgi.cpp:788)
+
+private:
+    hr_ddgi*      m_pass = nullptr;
+    RayTraceScale m_scale;
+    uint32_t      m_width, m_height;
+};
+
+class RayTracedReflections
+{
+public:
+    enum OutputType { OUTPUT_RAY_TRACE, OUTPUT_TEMPORAL_ACCUMULATION, OUTPUT_ATROUS, OUTPUT_UPSAMPLE }; // ray_traced_reflections.h:11-17
+
+    RayTracedReflections(Context& ctx, uint32_t width, uint32_t height, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES, const hr_band* band = nullptr) :
+        m_scale(scale), m_width(width >> scale), m_height(height >> scale)
+    {
+        hr_reflections_default_params(&params);
+        check(hr_reflections_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_reflections_create");
+    }
+    ~RayTracedReflections() { hr_reflections_destroy(m_pass); }
+    RayTracedReflections(const RayTracedReflections&) = delete;
+    RayTracedReflections& operator=(const RayTracedReflections&) = delete;
+
+    // RayTracedReflections::render(cmd_buf, ddgi) — ray_traced_reflections.h:27
+    void render(Stream cmd_buf, const Frame& frame, DDGI* ddgi)
+    {
+        check(hr_reflections_render(m_pass, frame.scene->handle(), &frame.inputs, frame.environment, ddgi->handle(), &params, cmd_buf), "RayTracedReflections::render");
+    }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_reflections_output(m_pass, (hr_output_kind)m_current_output, &v), "RayTracedReflections::output_ds");
+        return v;
+    }
+    uint32_t        width() const { return m_width; }
+    uint32_t        height() const { return m_height; }
+    RayTraceScale   scale() const { return m_scale; }
+    OutputType      current_output() const { return m_current_output; }
+    void            set_current_output(OutputType o) { m_current_output = o; }
+    hr_reflections* handle() const { return m_pass; }
+
+    hr_reflections_params params;
+
+private:
+    hr_reflections* m_pass = nullptr;
+    RayTraceScale   m_scale;
+    OutputType      m_current_output = OUTPUT_UPSAMPLE;
+    uint32_t        m_width, m_height;
+};
+
+} // namespace hr

@@ -175,7 +175,9 @@ typedef enum
 typedef struct
 {
     int32_t band_y0, band_y1; /* rows owned, in pass-resolution pixels; 0,0 = whole frame */
-    int32_t halo;             /* extra rows held on each side */
+    int32_t halo;             /* rows recomputed redundantly on each side (multiple of 8); the a-trous chain needs 15 */
+    int32_t history_halo;     /* rows on each side whose HISTORY (and G-buffer) is readable: the driver fills them by
+                                 neighbour exchange after every frame (>= halo + the largest motion in rows) */
 } hr_band;
 
 #define HR_MAX_STAGES 16

@@ -62,3 +62,14 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in txt and "orc_" not in txt and "libhr_oracle" not in txt, f
+
+
+def test_cpp_shims_compile():
+    """include/hr/passes.hpp (the C++ mirror of the reference's pass classes) is valid C++14 against hr_api.h."""
+    import subprocess
+    import tempfile
+    src = '#include <hr/passes.hpp>\nint main() { hr_shadows_params p; hr_shadows_default_params(&p); return sizeof(hr::RayTracedShadows) + sizeof(hr::DDGI) > 0 ? 0 : 1; }\n'
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
+        f.write(src)
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])
+    os.unlink(f.name)

