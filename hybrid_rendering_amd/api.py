@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_shadows_ray_count", "hr_shadows_trace_stats", "hr_selftest_math",
+    "hr_shadows_ray_count", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None

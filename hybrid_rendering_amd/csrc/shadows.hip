@@ -68,7 +68,7 @@ struct TraceArgs
     int             w, h;      // pass image (full frame)
     int             y0, y1;    // resident rows
     int             mw;        // mask words per row
-    int             tiles_x, tiles_y, tile_y0;
+    int             tiles_x, tiles_y, tile_y0, tile_stride;
     float           bias;
     uint32_t        num_frames;
 };
@@ -80,12 +80,16 @@ __global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
 {
     __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;
+    const int slot = blockIdx.x * 4 + wave;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    if (slot >= n_tiles) return;
+    // (a stride permutation of the tile order was measured: no gain over row-major — the kernel is bound by the
+    // per-step dependent-load latency, not by a dispatch tail — so tiles keep their L2-friendly row-major order)
+    const int tile = slot;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool      lit = false, fired = false;
-    uint32_t  nn = 0, nt = 0;
+    uint32_t  nn = 0, nt = 0, wave_max = 0;
     if (x < a.w && y >= a.y0 && y < a.y1)
     {
         const float d = a.depth[(size_t)y * a.w + x];
@@ -113,6 +117,9 @@ __global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
     if (STATS)
     {
         // wave reduction of the counters
+        uint32_t mx = nn + nt; // per-lane traversal steps; the wave runs until its slowest lane is done
+        for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(mx, o); mx = t > mx ? t : mx; }
+        wave_max = mx;
         for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); nt += __shfl_down(nt, o); }
     }
     if (lane == 0)
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
         {
             atomicAdd(a.stats + 0, (unsigned long long)nn);
             atomicAdd(a.stats + 1, (unsigned long long)nt);
+            atomicAdd(a.stats + 2, (unsigned long long)wave_max);
         }
     }
 }
@@ -142,6 +150,7 @@ struct TemporalArgs
     uint32_t*       out;            // RG16F
     uint2*          out_moments;    // RGBA16F
     uint8_t*        tile_class;
+    float4*         nd;             // decoded normal.xyz + linear z (GB3.w), written for the a-trous iterations
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha, moments_alpha;
@@ -219,6 +228,12 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             flag    = out_v > 0.0f;
         }
         a.out_moments[(size_t)y * a.w + x] = make_uint2(pack_h2(m0, m1), pack_h2(hlen, 0.0f));
+        {
+            // the a-trous iterations read every pixel's normal 9x4 times: decode it once here
+            const uint2 cg2 = a.gb2.p[(size_t)y * a.w + x], cg3 = a.gb3.p[(size_t)y * a.w + x];
+            const f3    cn  = oct_decode(h2f_lo(cg2.x), h2f_hi(cg2.x));
+            a.nd[(size_t)y * a.w + x] = make_float4(cn.x, cn.y, cn.z, h2f_hi(cg3.y));
+        }
         a.out[(size_t)y * a.w + x]         = pack_h2(out_v, out_var);
     }
     // tile classification (:275-291): any lit pixel => the tile needs the à-trous filter
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
 struct AtrousArgs
 {
     ImgRG16F       in;
-    ImgRGBA16F     gb2, gb3;
+    const float4*  nd;      // decoded normal + linear z of every pixel (k_shadows_temporal)
     const uint8_t* tile_class;
     uint32_t*      out;
     uint32_t*      out2;    // feedback copy (prev_image) or nullptr
@@ -239,15 +254,24 @@ struct AtrousArgs
     float          phi_visibility, phi_normal, sigma_depth, power;
 };
 
-// edge_stopping.glsl:31-62 with NORMAL + LUMA weights
+// edge_stopping.glsl:31-62 with NORMAL + LUMA weights.  FAST = the reference's default parameters
+// (phi_normal == 32, sigma_depth == 1): x / 1.0f == x and pow(x, 32) is five squarings — same bits, fewer ops.
+template <bool FAST>
 HR_DEV float edge_weight(float cd, float sd, float phi_z, f3 cn, f3 sn, float phi_n, float cl, float sl, float phi_l)
 {
-    const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), phi_z));
-    const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), phi_n);
+    const float dz = -fabsf(cd - sd);
+    const float wZ = det_exp(FAST ? dz : __fdiv_rn(dz, phi_z));
+    const float dn = clamp1(dot3(cn, sn), 0.0f, 1.0f);
+    float wN;
+    if (FAST) { float b = dn * dn; b = b * b; b = b * b; b = b * b; wN = b * b; } // det_powi(dn, 32): r = 1 * b^32
+    else wN = det_pow_auto(dn, phi_n);
     const float wL = __fdiv_rn(fabsf(cl - sl), phi_l);
     return det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
 }
 
+// RADIUS >= 0: compile-time filter radius (the reference default is 1: a fully unrolled 3x3 stencil with
+// constant kernel weights); RADIUS < 0: run-time radius.
+template <int RADIUS, bool FAST>
 __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -261,6 +285,24 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
         return;
     }
     const uint32_t c  = a.in.p[o];
+    // RADIUS == 1: issue every load of this pixel (centre, 3x3 variance taps, decoded normals, the 8 stencil taps)
+    // before the first use, so the wave pays ONE memory round trip instead of three dependent ones.
+    uint32_t t_in[8];
+    float4   t_nd[8];
+    bool     t_ok[8];
+    if (RADIUS == 1)
+    {
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+            const int px = x + xx * a.step, py = y + yy * a.step;
+            t_ok[t] = px >= 0 && py >= 0 && px < a.w && py < a.h;
+            const bool res = t_ok[t] && py >= a.y0 && py < a.y1;
+            t_in[t] = res ? a.in.p[(size_t)py * a.w + px] : 0u;
+            t_nd[t] = res ? a.nd[(size_t)py * a.w + px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
     const float    cv = h2f_lo(c);
     // compute_variance_center (:65-88)
     float var = 0.0f;
@@ -272,17 +314,37 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
             const float k = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
             var += h2f_hi(a.in.raw(x + xx, y + yy)) * k;
         }
-    const uint2 g2 = a.gb2.p[o], g3 = a.gb3.p[o];
-    const float center_depth = h2f_hi(g3.y);
+    const float4 cnd = a.nd[o];
+    const float center_depth = cnd.w;
     uint32_t    result;
     if (center_depth < 0.0f) result = c;
     else
     {
-        const f3    cn    = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+        const f3    cn    = mk3(cnd.x, cnd.y, cnd.z);
         const float phi_v = a.phi_visibility * hr_sqrt(max2(0.0f, 1e-10f + var));
         float sum_w = 1.0f, sum_v = cv, sum_var = h2f_hi(c);
-        for (int yy = -a.radius; yy <= a.radius; yy++)
-            for (int xx = -a.radius; xx <= a.radius; xx++)
+        if (RADIUS == 1)
+        {
+            // arithmetic in the reference's accumulation order (yy outer, xx inner); loads were issued above
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+            {
+                if (!t_ok[t]) continue;
+                const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                const float kx = xx == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f), ky = yy == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f);
+                const float sv = h2f_lo(t_in[t]);
+                const float w  = edge_weight<FAST>(center_depth, t_nd[t].w, a.sigma_depth, cn, mk3(t_nd[t].x, t_nd[t].y, t_nd[t].z), a.phi_normal, cv, sv, phi_v);
+                const float wv = w * (kx * ky);
+                sum_w += wv;
+                sum_v += wv * sv;
+                sum_var += (wv * wv) * h2f_hi(t_in[t]);
+            }
+        }
+        else
+        {
+        const int R = RADIUS >= 0 ? RADIUS : a.radius;
+        for (int yy = -R; yy <= R; yy++)
+            for (int xx = -R; xx <= R; xx++)
             {
                 const int px = x + xx * a.step, py = y + yy * a.step;
                 if (px < 0 || py < 0 || px >= a.w || py >= a.h || (xx == 0 && yy == 0)) continue;
@@ -290,15 +352,16 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
                 const float kx = axx == 0 ? 1.0f : (axx == 1 ? __fdiv_rn(2.0f, 3.0f) : __fdiv_rn(1.0f, 6.0f));
                 const float ky = ayy == 0 ? 1.0f : (ayy == 1 ? __fdiv_rn(2.0f, 3.0f) : __fdiv_rn(1.0f, 6.0f));
                 const uint32_t s  = a.in.raw(px, py);
-                const uint2    s2 = a.gb2.raw(px, py), s3 = a.gb3.raw(px, py);
+                const float4   snd = (py >= a.y0 && py < a.y1) ? a.nd[(size_t)py * a.w + px] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 const float    sv = h2f_lo(s);
-                const f3       sn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
-                const float    w  = edge_weight(center_depth, h2f_hi(s3.y), a.sigma_depth, cn, sn, a.phi_normal, cv, sv, phi_v);
+                const f3       sn = mk3(snd.x, snd.y, snd.z);
+                const float    w  = edge_weight<FAST>(center_depth, snd.w, a.sigma_depth, cn, sn, a.phi_normal, cv, sv, phi_v);
                 const float    wv = w * (kx * ky);
                 sum_w += wv;
                 sum_v += wv * sv;
                 sum_var += (wv * wv) * h2f_hi(s);
             }
+        }
         float ov = __fdiv_rn(sum_v, sum_w), ovar = __fdiv_rn(sum_var, sum_w * sum_w);
         if (a.power != 0.0f) ov = det_pow_auto(ov, a.power);
         result = pack_h2(ov, ovar);
@@ -316,7 +379,7 @@ struct hr_shadows
     int     band_y0 = 0, band_y1 = 0;
     int     ry0 = 0, ry1 = 0;         // rows whose history / G-buffer may be read (band + history halo)
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0;
-    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters;
+    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters, nd;
     bool    first_frame = true;
     int     read_idx = 0;             // ATrous::read_idx
     bool    last_denoise = true;
@@ -324,6 +387,7 @@ struct hr_shadows
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
+    uint64_t      last_wave_max_steps = 0; // sum over waves of the slowest lane's (node + triangle) steps
 };
 
 extern "C" {
@@ -372,6 +436,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     A(atrous[1], px * 4)
     A(upsample, (size_t)full_width * full_height * 2)
     A(tile_class, (size_t)p->tiles_x * p->tiles_y)
+    A(nd, px * 16)
     A(counters, 64)
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -456,11 +521,12 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
+    a.tile_stride = 1;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
     {
         // instrumented build of the same kernel: counts node visits / triangle tests
-        HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 16, st));
+        HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
         hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
         HR_HIP(hipGetLastError());
@@ -473,6 +539,13 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     return HR_OK;
 }
 
+hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps)
+{
+    HR_CHECK_ARG(p && wave_max_steps);
+    *wave_max_steps = p->last_wave_max_steps;
+    return HR_OK;
+}
+
 hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
 {
     HR_CHECK_ARG(p && out3);
@@ -481,9 +554,10 @@ hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_
     p->want_stats = false;
     if (s != HR_OK) return s;
     HR_HIP(hipStreamSynchronize((hipStream_t)stream));
-    uint64_t host[4];
-    HR_HIP(hipMemcpy(host, p->counters.p, 32, hipMemcpyDeviceToHost));
+    uint64_t host[5];
+    HR_HIP(hipMemcpy(host, p->counters.p, 40, hipMemcpyDeviceToHost));
     out3[0] = host[0]; out3[1] = host[2]; out3[2] = host[3];
+    p->last_wave_max_steps = host[4];
     return HR_OK;
 }
 
@@ -508,6 +582,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.hist_moments = ImgRGBA16F { (const uint2*)p->moments[!in->ping_pong].p, w, ry0, ry1 };
     a.out = (uint32_t*)p->temporal_out.p; a.out_moments = (uint2*)p->moments[in->ping_pong ? 1 : 0].p;
     a.tile_class = (uint8_t*)p->tile_class.p;
+    a.nd = (float4*)p->nd.p;
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
@@ -532,8 +607,7 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     AtrousArgs a;
     const int w = p->w, y0 = p->y0, y1 = p->y1;
     a.in  = ImgRG16F { (const uint32_t*)(i == 0 ? p->temporal_out.p : p->atrous[read_idx].p), w, y0, y1 };
-    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, p->ry0, p->ry1 };
-    a.gb3 = ImgRGBA16F { (const uint2*)in->cur.gb3, w, p->ry0, p->ry1 };
+    a.nd = (const float4*)p->nd.p;
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out  = (uint32_t*)p->atrous[write_idx].p;
     a.out2 = (prm->feedback_iteration == i) ? (uint32_t*)p->prev_image.p : nullptr; // vkCmdCopyImage :1177-1207
@@ -545,7 +619,11 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     static const char* names[8] = { "atrous_0", "atrous_1", "atrous_2", "atrous_3", "atrous_4", "atrous_5", "atrous_6", "atrous_7" };
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin(names[i], st, px * 24 + (a.out2 ? px * 4 : 0));
-    hipLaunchKernelGGL(k_shadows_atrous, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    const dim3 grid(cdiv(w, 32), cdiv(y1 - y0, 8));
+    const bool fast = (prm->phi_normal == 32.0f && prm->sigma_depth == 1.0f);
+    if (prm->radius == 1 && fast) hipLaunchKernelGGL((k_shadows_atrous<1, true>), grid, dim3(256), 0, st, a);
+    else if (prm->radius == 1) hipLaunchKernelGGL((k_shadows_atrous<1, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_shadows_atrous<-1, false>), grid, dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -17,8 +17,8 @@
 
 namespace hr {
 
-#define HR_STACK_ENTRIES 24   // LDS entries per lane; deeper pushes spill to a per-lane scratch array
-#define HR_SPILL_ENTRIES 40
+#define HR_STACK_ENTRIES 16   // LDS entries per lane (16 KB per 4-wave block => 8 waves/SIMD); deeper pushes spill to scratch
+#define HR_SPILL_ENTRIES 48
 
 struct RayPre
 {

@@ -235,6 +235,9 @@ hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
  * returns out3 = { rays fired, BVH nodes visited, triangles tested } — the terms of the trace pass's
  * algorithmic-bytes figure.  Synchronises the stream. */
 hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
+/* After hr_shadows_trace_stats: sum over waves of the slowest lane's (node + triangle) steps.  SIMD lane utilisation of
+ * the traversal loop = (nodes + triangles) / (64 * wave_max_steps). */
+hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps);
 
 /* ---- RayTracedAO (src/ray_traced_ao.h) ------------------------------------------------------------ */
 typedef struct hr_ao hr_ao;
