@@ -36,7 +36,7 @@ struct AOTraceArgs
     const uint8_t*     sobol;
     const uint8_t*     sr;
     uint32_t*          mask;       // [spp][mh][mw]
-    unsigned long long* ray_counter;
+    uint32_t*          ray_slots;  // rays per 8x8 tile (a single shared atomic counter serialises the waves)
     const Node8*       nodes;
     const TriGPU*      tris;
     unsigned long long* stats;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_ao_trace(AOTraceArgs a)
         for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); nt += __shfl_down(nt, o); }
     if (lane == 0)
     {
-        if (fired) atomicAdd(a.ray_counter, (unsigned long long)__popcll(fired) * (unsigned long long)a.spp);
+        a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint32_t)__popcll(fired) * (uint32_t)a.spp;
         if (STATS && a.stats)
         {
             atomicAdd(a.stats + 0, (unsigned long long)nn);
@@ -255,7 +255,7 @@ struct hr_ao
     hr_ctx* ctx = nullptr;
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0;
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0, max_spp = 4;
-    DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters;
+    DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true, want_stats = false;
     int     last_pp = 0;
     StageProfiler prof;
@@ -293,8 +293,10 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     A(upsample, (size_t)full_width * full_height * 2)
     A(tile_class, (size_t)p->tiles_x * p->tiles_y)
     A(counters, 64)
+    A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
     *out = p;
     return HR_OK;
@@ -315,7 +317,11 @@ hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays)
 {
     HR_CHECK_ARG(p && rays);
     HR_HIP(hipStreamSynchronize(p->last_stream));
-    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slots((size_t)p->tiles_x * p->tiles_y);
+    HR_HIP(hipMemcpy(slots.data(), p->ray_slots.p, slots.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t v : slots) total += v;
+    *rays = total;
     return HR_OK;
 }
 
@@ -336,7 +342,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     AOTraceArgs a;
     for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
     a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2; a.sobol = in->sobol; a.sr = in->scrambling_ranking;
-    a.mask = (uint32_t*)p->mask.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.mask = (uint32_t*)p->mask.p; a.ray_slots = (uint32_t*)p->ray_slots.p;
     a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
     a.stats = p->want_stats ? (unsigned long long*)((char*)p->counters.p + 16) : nullptr;
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw; a.mh = p->mh;
@@ -367,7 +373,9 @@ hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inpu
     HR_HIP(hipStreamSynchronize((hipStream_t)stream));
     uint64_t host[4];
     HR_HIP(hipMemcpy(host, p->counters.p, 32, hipMemcpyDeviceToHost));
-    out3[0] = host[0]; out3[1] = host[2]; out3[2] = host[3];
+    hr_status rs = hr_ao_ray_count(p, &out3[0]);
+    if (rs != HR_OK) return rs;
+    out3[1] = host[2]; out3[2] = host[3];
     return HR_OK;
 }
 

@@ -34,7 +34,7 @@ struct DDGITraceArgs
     AtlasRG       prev_depth;
     uint2*        radiance;
     uint2*        dirdist;
-    unsigned long long* ray_counter;
+    uint32_t*     ray_slots;  // rays per wave
     uint32_t      num_frames;
     int           infinite_bounces;
     float         gi_intensity;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_ddgi_trace(DDGITraceArgs a)
         a.dirdist[o]  = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
     }
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
-    if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
+    if (lane == 0) a.ray_slots[blockIdx.x * 4 + wave] = rays;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +240,7 @@ struct hr_ddgi
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0;
     DDGIU   d;
     int     n_probes = 0;
-    DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters;
+    DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters, ray_slots;
     bool    first_frame = true, ping_pong = false;
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
@@ -279,9 +279,11 @@ hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, h
     A(irr[0], ib) A(irr[1], ib) A(dep[0], db) A(dep[1], db)
     A(sample, (size_t)p->w * p->h * 8)
     A(counters, 64)
+    A(ray_slots, ((nr + 255) / 256) * 4 * 4)
 #undef A
     for (int i = 0; i < 2; i++) { HR_HIP(hipMemset(p->irr[i].p, 0, ib)); HR_HIP(hipMemset(p->dep[i].p, 0, db)); }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     *out = p;
     return HR_OK;
 }
@@ -302,7 +304,11 @@ hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays)
 {
     HR_CHECK_ARG(p && rays);
     HR_HIP(hipStreamSynchronize(p->last_stream));
-    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slots(p->ray_slots.bytes / 4);
+    HR_HIP(hipMemcpy(slots.data(), p->ray_slots.p, slots.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t v : slots) total += v;
+    *rays = total;
     return HR_OK;
 }
 
@@ -329,7 +335,7 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     a.sky = CubeMap { (const uint2*)env->sky, env->sky_size };
     a.prev_irr   = AtlasRGBA { (const uint2*)p->irr[rd].p, p->d.irradiance_texture_width, p->d.irradiance_texture_height };
     a.prev_depth = AtlasRG { (const uint32_t*)p->dep[rd].p, p->d.depth_texture_width, p->d.depth_texture_height };
-    a.radiance = (uint2*)p->radiance.p; a.dirdist = (uint2*)p->dirdist.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.radiance = (uint2*)p->radiance.p; a.dirdist = (uint2*)p->dirdist.p; a.ray_slots = (uint32_t*)p->ray_slots.p;
     a.num_frames = in->num_frames;
     a.infinite_bounces = (prm->infinite_bounces && !p->first_frame) ? 1 : 0; // ddgi.cpp:790
     a.gi_intensity = prm->infinite_bounce_intensity;

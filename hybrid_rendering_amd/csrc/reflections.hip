@@ -75,7 +75,7 @@ struct ReflTraceArgs
     AtlasRGBA      irr;
     AtlasRG        dep;
     uint2*         out;
-    unsigned long long* ray_counter;
+    uint32_t*      ray_slots;  // rays per 8x8 tile
     int            w, h, y0, y1, tiles_x, tiles_y, tile_y0;
     float          bias, trim;
     uint32_t       num_frames;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_refl_trace(ReflTraceArgs a)
         }
     }
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
-    if (lane == 0 && rays) atomicAdd(a.ray_counter, (unsigned long long)rays);
+    if (lane == 0) a.ray_slots[tile] = rays;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,7 +341,7 @@ struct hr_reflections
 {
     hr_ctx* ctx = nullptr;
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, tiles_x = 0, tiles_y = 0;
-    DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters;
+    DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true;
     int     read_idx = 0, last_pp = 0;
     StageProfiler prof;
@@ -376,9 +376,10 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     hr_status s;
 #define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
     A(trace, px * 8) A(color[0], px * 8) A(color[1], px * 8) A(moments[0], px * 8) A(moments[1], px * 8) A(prev_image, px * 8)
-    A(atrous[0], px * 8) A(atrous[1], px * 8) A(upsample, (size_t)full_width * full_height * 8) A(tile_class, (size_t)p->tiles_x * p->tiles_y) A(counters, 64)
+    A(atrous[0], px * 8) A(atrous[1], px * 8) A(upsample, (size_t)full_width * full_height * 8) A(tile_class, (size_t)p->tiles_x * p->tiles_y) A(counters, 64) A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     *out = p;
     return HR_OK;
 }
@@ -398,7 +399,11 @@ hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays)
 {
     HR_CHECK_ARG(p && rays);
     HR_HIP(hipStreamSynchronize(p->last_stream));
-    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slots((size_t)p->tiles_x * p->tiles_y);
+    HR_HIP(hipMemcpy(slots.data(), p->ray_slots.p, slots.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t v : slots) total += v;
+    *rays = total;
     return HR_OK;
 }
 
@@ -440,7 +445,7 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     a.env.sky = CubeMap { (const uint2*)env->sky, env->sky_size };
     a.env.prefiltered = (const uint2*)env->prefiltered; a.env.pre_size = env->prefiltered_size; a.env.pre_levels = env->prefiltered_levels;
     a.env.lut = (const uint32_t*)env->brdf_lut; a.env.lut_size = env->brdf_lut_size;
-    a.out = (uint2*)p->trace.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.out = (uint2*)p->trace.p; a.ray_slots = (uint32_t*)p->ray_slots.p + (size_t)(p->y0 / 8) * p->tiles_x;
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1;
     a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     a.bias = prm->bias; a.trim = prm->trim; a.num_frames = in->num_frames;

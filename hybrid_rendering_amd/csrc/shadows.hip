@@ -61,26 +61,28 @@ struct TraceArgs
     const uint8_t*  sobol;
     const uint8_t*  sr;
     uint32_t*       mask;
-    unsigned long long* ray_counter;
+    uint16_t*       ray_slots;  // rays fired per 8x8 tile (no shared atomic counter: one contended address serialised ~13 ns per wave)
     const Node8*    nodes;
     const TriGPU*   tris;
     unsigned long long* stats; // nullable: [0] nodes visited, [1] triangles tested
     int             w, h;      // pass image (full frame)
     int             y0, y1;    // resident rows
     int             mw;        // mask words per row
-    int             tiles_x, tiles_y, tile_y0, tile_stride;
+    int             tiles_x, tiles_y, tile_y0, tile_stride, debug_skip_traversal;
     float           bias;
     uint32_t        num_frames;
 };
 
 // One wave = one 8x8 pixel tile = two 8x4 mask words; lane l -> pixel (l & 7, l >> 3), so the
 // wave ballot IS the packed mask (bit y*8+x of shadows_ray_trace.comp:126).
+#define TRACE_WAVES 1 // waves (8x8 tiles) per workgroup: 1 lets the dispatcher back-fill a CU wave by wave — tile
+                      // costs differ by >10x, and with 4-wave groups the finished waves' slots idle until the slowest ends
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
+__global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
 {
-    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ uint32_t s_stack[TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wave;
+    const int slot = blockIdx.x * TRACE_WAVES + wave;
     const int n_tiles = a.tiles_x * a.tiles_y;
     if (slot >= n_tiles) return;
     // (a stride permutation of the tile order was measured: no gain over row-major — the kernel is bound by the
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
             if (att > 0.0f)
             {
                 fired = true;
-                lit   = !trace_any<STATS>(a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt);
+                lit   = a.debug_skip_traversal ? (ro.x + Wi.y > -1e30f) : !trace_any<STATS>(a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt);
             }
         }
     }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k_shadows_trace(TraceArgs a)
         const int my = ty * 2;
         if (my * 4 >= a.y0 && my * 4 < a.y1) a.mask[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
         if ((my + 1) * 4 >= a.y0 && (my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) a.mask[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
-        if (fb) atomicAdd(a.ray_counter, (unsigned long long)__popcll(fb));
+        a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint16_t)__popcll(fb);
         if (STATS && a.stats)
         {
             atomicAdd(a.stats + 0, (unsigned long long)nn);
@@ -379,7 +381,7 @@ struct hr_shadows
     int     band_y0 = 0, band_y1 = 0;
     int     ry0 = 0, ry1 = 0;         // rows whose history / G-buffer may be read (band + history halo)
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0;
-    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters, nd;
+    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters, nd, ray_slots;
     bool    first_frame = true;
     int     read_idx = 0;             // ATrous::read_idx
     bool    last_denoise = true;
@@ -438,8 +440,10 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     A(tile_class, (size_t)p->tiles_x * p->tiles_y)
     A(nd, px * 16)
     A(counters, 64)
+    A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 2)
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
+    HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
     HR_HIP(hipMemset(p->tile_class.p, 0, p->tile_class.bytes));
     *out = p;
@@ -480,7 +484,11 @@ hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays)
 {
     HR_CHECK_ARG(p && rays);
     HR_HIP(hipStreamSynchronize(p->last_stream));
-    HR_HIP(hipMemcpy(rays, p->counters.p, 8, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> slots((size_t)p->tiles_x * p->tiles_y);
+    HR_HIP(hipMemcpy(slots.data(), p->ray_slots.p, slots.size() * 2, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint16_t v : slots) total += v;
+    *rays = total;
     return HR_OK;
 }
 
@@ -508,13 +516,12 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         HR_HIP(hipMemsetAsync(p->moments[!in->ping_pong].p, 0, p->moments[0].bytes, st));
         p->first_frame = false;
     }
-    HR_HIP(hipMemsetAsync(p->counters.p, 0, 8, st));
     TraceArgs a;
     for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
     a.light = in->ubo.light;
     a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2;
     a.sobol = in->sobol; a.sr = in->scrambling_ranking;
-    a.mask = (uint32_t*)p->mask.p; a.ray_counter = (unsigned long long*)p->counters.p;
+    a.mask = (uint32_t*)p->mask.p; a.ray_slots = (uint16_t*)p->ray_slots.p;
     a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
     a.stats = nullptr;
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw;
@@ -522,18 +529,19 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
     a.tile_stride = 1;
+    a.debug_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") ? 1 : 0; // developer ablation switch (tools/)
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
     {
         // instrumented build of the same kernel: counts node visits / triangle tests
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
-        hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
-    hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -556,7 +564,9 @@ hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_
     HR_HIP(hipStreamSynchronize((hipStream_t)stream));
     uint64_t host[5];
     HR_HIP(hipMemcpy(host, p->counters.p, 40, hipMemcpyDeviceToHost));
-    out3[0] = host[0]; out3[1] = host[2]; out3[2] = host[3];
+    hr_status rs = hr_shadows_ray_count(p, &out3[0]);
+    if (rs != HR_OK) return rs;
+    out3[1] = host[2]; out3[2] = host[3];
     p->last_wave_max_steps = host[4];
     return HR_OK;
 }

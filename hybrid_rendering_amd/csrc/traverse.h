@@ -136,13 +136,16 @@ HR_DEV NodeHits test_node(const Node8* __restrict__ nodes, uint32_t ni, const Ra
     return h;
 }
 
-// Per-lane stack: LDS part [HR_STACK_ENTRIES][64] per wave, spill part in private memory.
+// Per-lane stack: LDS part [HR_STACK_ENTRIES][64] per wave; deeper pushes go to a per-lane private array.
+// The private array is a SEPARATE object (only its address is kept here): dynamic indexing pins an object to
+// scratch memory, and when `sp` lived in the same struct every push/pop of the hot loop became a scratch
+// round trip (found in the ISA: scratch_load/store of sp around each of the 8 child pushes).
 struct LaneStack
 {
     uint32_t* lds;   // &wave_region[lane]
-    uint32_t  spill[HR_SPILL_ENTRIES];
+    uint32_t* spill; // private overflow array, HR_SPILL_ENTRIES entries
     int       sp;
-    HR_DEV void init(uint32_t* wave_region, int lane) { lds = wave_region + lane; sp = 0; }
+    HR_DEV void init(uint32_t* wave_region, int lane, uint32_t* spill_array) { lds = wave_region + lane; spill = spill_array; sp = 0; }
     HR_DEV void push(uint32_t v)
     {
         if (sp < HR_STACK_ENTRIES) lds[sp * 64] = v;
@@ -191,8 +194,9 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
                       uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris)
 {
     RayPre    r = ray_prepare(o, d);
+    uint32_t  spill_array[HR_SPILL_ENTRIES];
     LaneStack st;
-    st.init(wave_stack, lane);
+    st.init(wave_stack, lane, spill_array);
     st.push(0u);
     while (st.sp > 0)
     {
@@ -227,8 +231,9 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
                             uint32_t* wave_stack, int lane)
 {
     RayPre    r = ray_prepare(o, d);
+    uint32_t  spill_array[HR_SPILL_ENTRIES];
     LaneStack st;
-    st.init(wave_stack, lane);
+    st.init(wave_stack, lane, spill_array);
     st.push(0u);
     HitRec best;
     best.t = t_max; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
