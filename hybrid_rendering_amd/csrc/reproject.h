@@ -130,18 +130,43 @@ HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& h
     if (MOMENTS) { hmom[0] = 0.0f; hmom[1] = 0.0f; }
 
     const int bx = (int)hfx, by = (int)hfy;
-    bool      v[4];
-    bool      valid = false;
+    // Issue EVERY load of the 2x2 bilinear footprint (previous G-buffer, history colour, history moments) and the
+    // history-length texel before the first use: one memory round trip instead of three dependent ones
+    // (validity -> history -> length).  Texels of invalid taps are fetched but never used.
+    uint2 t2[4], t3[4], tm[4];
+    float td[4], tcol[4][NC];
 #pragma unroll
     for (int s = 0; s < 4; s++)
     {
-        int   lx = bx + (s & 1), ly = by + (s >> 1);
-        uint2 s2 = in.pgb2.raw(lx, ly), s3 = in.pgb3.raw(lx, ly);
-        float sd = in.pdepth.fetch(lx, ly);
-        f3    hn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
-        f3    hp = world_pos_from_depth(htu, htv, sd, in.vpi);
-        v[s]     = reprojection_valid(hcx, hcy, cur_pos, hp, cur_n, hn, cur_id, h2f_lo(s3.y), w, h);
-        valid    = valid || v[s];
+        const int lx = bx + (s & 1), ly = by + (s >> 1);
+        t2[s] = in.pgb2.raw(lx, ly);
+        t3[s] = in.pgb3.raw(lx, ly);
+        td[s] = in.pdepth.fetch(lx, ly);
+        if constexpr (SINGLE)
+        {
+            if constexpr (sizeof(hist.p[0]) == 4) tcol[s][0] = h2f_lo(hist.raw(lx, ly));
+            else tcol[s][0] = hist.fetch(lx, ly);
+        }
+        else
+        {
+            const uint2 t = hist.raw(lx, ly);
+            tcol[s][0] = h2f_lo(t.x); tcol[s][1] = h2f_hi(t.x); tcol[s][2] = h2f_lo(t.y);
+        }
+        if (MOMENTS) tm[s] = hist_moments.raw(lx, ly);
+    }
+    float len_prefetch;
+    if (MOMENTS) len_prefetch = h2f_lo(hist_moments.raw(hcx, hcy).y);
+    else len_prefetch = hist_length.fetch(hcx, hcy);
+
+    bool v[4];
+    bool valid = false;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+    {
+        f3 hn = oct_decode(h2f_lo(t2[s].x), h2f_hi(t2[s].x));
+        f3 hp = world_pos_from_depth(htu, htv, td[s], in.vpi);
+        v[s]  = reprojection_valid(hcx, hcy, cur_pos, hp, cur_n, hn, cur_id, h2f_lo(t3[s].y), w, h);
+        valid = valid || v[s];
     }
     auto fetch_hist = [&](int px, int py, float* col) {
         if constexpr (SINGLE)
@@ -165,16 +190,12 @@ HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& h
         {
             if (v[s])
             {
-                int   lx = bx + (s & 1), ly = by + (s >> 1);
-                float col[3];
-                fetch_hist(lx, ly, col);
 #pragma unroll
-                for (int c = 0; c < NC; c++) hcol[c] += wgt[s] * col[c];
+                for (int c = 0; c < NC; c++) hcol[c] += wgt[s] * tcol[s][c];
                 if (MOMENTS)
                 {
-                    uint2 m = hist_moments.raw(lx, ly);
-                    hmom[0] += wgt[s] * h2f_lo(m.x);
-                    hmom[1] += wgt[s] * h2f_hi(m.x);
+                    hmom[0] += wgt[s] * h2f_lo(tm[s].x);
+                    hmom[1] += wgt[s] * h2f_hi(tm[s].x);
                 }
                 sumw += wgt[s];
             }
@@ -228,8 +249,7 @@ HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& h
     }
     if (valid)
     {
-        if (MOMENTS) history_length = h2f_lo(hist_moments.raw(hcx, hcy).y);
-        else history_length = hist_length.fetch(hcx, hcy);
+        history_length = len_prefetch;
     }
     else
     {

@@ -156,11 +156,13 @@ struct TemporalArgs
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha, moments_alpha;
+    int             debug_skip_reproject; // developer ablation switch (HR_DEBUG_SKIP_REPROJECT)
 };
 
 __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
 {
     __shared__ uint32_t s_mask[4][18];
+    __shared__ uint32_t s_rows[4][24];
     __shared__ float    s_vpi[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
@@ -176,23 +178,23 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
         s_mask[wave][lane] = v;
     }
     __syncthreads();
-    if (!tile_ok) return;
     const int lx = lane & 7, ly = lane >> 3;
     const int x = tx * 8 + lx, y = ty * 8 + ly;
 
     // 17x17 box sum of visibility bits (neighborhood_mean :157-190): integer popcounts are exact.
+    // The 24-bit row patterns of the 24 cached pixel rows are the same for every lane of the wave: lanes 0..23 build
+    // one each (3 byte extracts) into LDS, then every lane popcounts its 17-row x 17-bit window.
+    if (lane < 24)
+    {
+        const int m = lane >> 2, br = lane & 3;
+        const uint32_t w0 = s_mask[wave][m * 3 + 0], w1 = s_mask[wave][m * 3 + 1], w2 = s_mask[wave][m * 3 + 2];
+        s_rows[wave][lane] = ((w0 >> (br * 8)) & 0xffu) | (((w1 >> (br * 8)) & 0xffu) << 8) | (((w2 >> (br * 8)) & 0xffu) << 16);
+    }
+    __syncthreads();
     int sum = 0;
 #pragma unroll
-    for (int yy = -8; yy <= 8; yy++)
-    {
-        const int ry   = ly + 8 + yy;          // row inside the 24-row cache
-        const int mrow = ry >> 2, brow = ry & 3;
-        const uint32_t b0 = (s_mask[wave][mrow * 3 + 0] >> (brow * 8)) & 0xffu;
-        const uint32_t b1 = (s_mask[wave][mrow * 3 + 1] >> (brow * 8)) & 0xffu;
-        const uint32_t b2 = (s_mask[wave][mrow * 3 + 2] >> (brow * 8)) & 0xffu;
-        const uint32_t row = b0 | (b1 << 8) | (b2 << 16);
-        sum += __popc((row >> lx) & 0x1ffffu);
-    }
+    for (int yy = 0; yy <= 16; yy++) sum += __popc((s_rows[wave][ly + yy] >> lx) & 0x1ffffu);
+    if (!tile_ok) return;
     const float mean = __fdiv_rn((float)sum, 289.0f);
 
     const bool in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
@@ -206,12 +208,14 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             const int   cry = ly + 8, crx = lx + 8;
             const float visibility = (float)((s_mask[wave][(cry >> 2) * 3 + (crx >> 3)] >> ((cry & 3) * 8 + (crx & 7))) & 1u);
             ReprojIn in;
-            in.x = x; in.y = y; in.depth = d; in.vpi = s_vpi;
+            in.x = x; in.y = y; in.depth = d; in.vpi = a.vpi; // kernel argument => scalar registers
             in.gb2 = a.gb2; in.gb3 = a.gb3; in.pgb2 = a.pgb2; in.pgb3 = a.pgb3; in.pdepth = a.pdepth;
             in.w = a.w; in.h = a.h;
             float hv, hm[2];
             ImgR16F none { nullptr, 0, 0, 0 };
-            const bool success = reproject<true, true, false, ImgRG16F>(in, a.hist, a.hist_moments, none, &hv, hm, hlen);
+            bool success = false;
+            if (!a.debug_skip_reproject) success = reproject<true, true, false, ImgRG16F>(in, a.hist, a.hist_moments, none, &hv, hm, hlen);
+            else { hv = 0.0f; hm[0] = hm[1] = 0.0f; hlen = 0.0f; }
             hlen = min2(32.0f, success ? hlen + 1.0f : 1.0f);
             if (success)
             {
@@ -596,6 +600,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
+    a.debug_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") ? 1 : 0;
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
