@@ -55,10 +55,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("HR_FORCE_DEVICE") is not None:  # developer switch: several ranks on ONE GPU (functional test of the N>1 path)
+        local_rank = int(os.environ["HR_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("HR_DIST_BACKEND", "nccl"))  # "nccl" is RCCL on ROCm
 
     from hybrid_rendering_amd import api as hr
     from hybrid_rendering_amd import synth, tiling
