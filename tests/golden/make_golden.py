@@ -1,0 +1,77 @@
+"""Generates the committed golden fixtures from the CPU oracle (run from the repo root):
+
+    python tests/golden/make_golden.py
+
+The reference cannot be built or run here (no Vulkan SDK / framework / assets — SURVEY.md §8c), so these vectors
+pin the ORACLE (they catch unintended changes to it) rather than the reference; both the oracle and the HIP path
+are checked against them.  One small multi-frame case per pass; everything is stored as exact bit patterns.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def build_cases():
+    """Returns {name: {array_name: np.ndarray}} — shared by the generator and tests/test_golden.py."""
+    import helpers
+    from hybrid_rendering_amd import synth, synth_env
+    from oracle import pyoracle as po, pyoracle_ddgi as od, pyoracle_reflections as orf
+    out = {}
+    sob, sr = synth.blue_noise_tables()
+    # ---- shadows: Cornell-32, 64x64, soft light, 3 frames with a moving camera ------------------------------
+    sd = helpers.scene_data("cornell")
+    sc = po.Scene(sd)
+    w = h = 64
+    frames = helpers.make_frames(po, sc, "cornell", w, h, 3, 1.5, "soft")
+    sp = po.ShadowsPass(w, h)
+    for f in range(3):
+        sp.render(sc, frames[f]["ubo"], frames[f]["gb"], frames[f - 1]["gb"] if f else frames[f]["gb"], sob, sr, f)
+    out["shadows_cornell64"] = dict(gb2=frames[2]["gb"]["gb2"], depth=frames[2]["gb"]["depth"], mask=sp.stages["mask"], temporal=sp.stages["temporal"],
+                                    moments=sp.stages["moments"], tiles=sp.stages["tiles"], output=sp.stages["output"])
+    # ---- AO: same frames, half resolution + upsample ------------------------------------------------------------
+    ap = po.AOPass(w // 2, h // 2, zbp=synth.z_buffer_params())
+    for f in range(3):
+        cur, prev = helpers.nearest_mip(frames[f]["gb"], 1), helpers.nearest_mip(frames[f - 1]["gb"] if f else frames[f]["gb"], 1)
+        ap.render(sc, frames[f]["ubo"], cur, prev, sob, sr, f, full=frames[f]["gb"])
+    out["ao_cornell64_half"] = dict(mask=ap.stages["mask"], temporal=ap.stages["temporal"], blur1=ap.stages["blur1"], output=ap.stages["output"])
+    # ---- DDGI + reflections: small Sponza, 48x32, 2 frames ------------------------------------------------------
+    sd2 = helpers.scene_data("sponza_small")
+    sc2 = po.Scene(sd2)
+    w2, h2 = 48, 32
+    fr2 = helpers.make_frames(po, sc2, "sponza_small", w2, h2, 2, 1.0)
+    lo, hi = sd2.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    dp, rp = od.DDGIPass(ddgi), orf.ReflectionsPass(w2, h2)
+    rng = np.random.RandomState(3)
+    for f in range(2):
+        dp.render(sc2, fr2[f]["ubo"], fr2[f]["gb"], sky, synth_env.random_orientation(rng), f)
+        irr, dep = dp.current_read()
+        rp.render(sc2, fr2[f]["ubo"], ddgi, fr2[f]["gb"], fr2[f - 1]["gb"] if f else fr2[f]["gb"], sob, sr, f, env, irr, dep, camera_delta=(-1.0, 0, 0) if f else (0, 0, 0))
+    out["ddgi_sponza"] = dict(radiance=dp.stages["radiance"], direction_distance=dp.stages["direction_distance"], irradiance=dp.stages["irradiance"],
+                              depth=dp.stages["depth"], output=dp.stages["output"])
+    out["reflections_sponza"] = dict(trace=rp.stages["trace"], temporal=rp.stages["temporal"], tiles=rp.stages["tiles"], output=rp.stages["output"])
+    return out
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = build_cases()
+    index = {}
+    for name, arrs in cases.items():
+        np.savez_compressed(os.path.join(here, name + ".npz"), **arrs)
+        index[name] = {k: sha(v) for k, v in arrs.items()}
+        print(name, {k: (v.shape, str(v.dtype)) for k, v in arrs.items()})
+    import json
+    json.dump(index, open(os.path.join(here, "index.json"), "w"), indent=1, sort_keys=True)
