@@ -177,6 +177,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
     dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this build (separate --pmc runs;
+    # FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md §HBM) — PMC cannot be sampled from inside this process.
+    traffic, traffic_src = None, None
+    try:
+        pdirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
+        if pdirs and world == 1 and (W, args.height) == (1920, 1080):
+            pm = json.load(open(os.path.join(ROOT, "profiles", pdirs[-1], "pmc_summary.json")))
+            kname = {"ray_trace": "k_shadows_trace<false>", "temporal_accumulation": "k_shadows_temporal"}.get(dom[0], "k_shadows_atrous")
+            for k, v in pm.items():
+                if kname in k:
+                    traffic = int((2 * v["FETCH_SIZE_KB_avg_per_launch"] + v["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+                    traffic_src = f"profiles/{pdirs[-1]}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE)"
+    except Exception:
+        pass
     out = {
         "metric": "shadow Mrays/s over the fully denoised frame (1 spp trace + SVGF temporal + 4x a-trous)",
         "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,7 +203,7 @@ def main():
         "denoised_1080p_equiv_per_s": round(world * args.steps / elapsed, 2),   # bands of W x args.height per second
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
         "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom[1]["frac"], 4), "traffic": None},
+                     "frac": round(dom[1]["frac"], 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(dom[1]["bytes"])},
         "stages": {n: {"ms": round(s["ms"], 4), "GBps": round(s["GBps"], 1), "frac": round(s["frac"], 4), "bytes": s["bytes"]} for n, s in stages.items()},
     }
 
