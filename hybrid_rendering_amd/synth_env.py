@@ -110,3 +110,29 @@ def brdf_lut(size: int = 32) -> np.ndarray:
     A = -1.04 * a004 + rr[..., 2]
     B = 1.04 * a004 + rr[..., 3]
     return np.ascontiguousarray(np.stack([A, B], -1).astype(np.float16)).view(np.uint16)
+
+
+def sh9_from_cubemap(sky_u16: np.ndarray) -> np.ndarray:
+    """Stand-in for dw::CubemapSHProjection (common.h:93): projects the sky cubemap onto 9 SH coefficients
+    ([9][4] float32, rgb used) with the basis of deferred.frag:96-113."""
+    sky = sky_u16.view(np.float16).astype(np.float64)[..., :3]
+    S = sky.shape[1]
+    t = (np.arange(S) + 0.5) / S * 2 - 1
+    sc, tc = np.meshgrid(t, t)
+    one = np.ones_like(sc)
+    dirs = [np.stack([one, -tc, -sc], -1), np.stack([-one, -tc, sc], -1), np.stack([sc, one, tc], -1),
+            np.stack([sc, -one, -tc], -1), np.stack([sc, -tc, one], -1), np.stack([-sc, -tc, -one], -1)]
+    out = np.zeros((9, 4))
+    wsum = 0.0
+    for f, d in enumerate(dirs):
+        r2 = (d ** 2).sum(-1)
+        w = 4.0 / (r2 ** 1.5) / (S * S)                      # texel solid angle
+        d = d / np.sqrt(r2)[..., None]
+        x, y, z = d[..., 0], d[..., 1], d[..., 2]
+        basis = [0.282095 * one, -0.488603 * y, 0.488603 * z, -0.488603 * x, 1.092548 * x * y, -1.092548 * y * z,
+                 0.315392 * (3 * z * z - 1), -1.092548 * x * z, 0.546274 * (x * x - y * y)]
+        for k, b in enumerate(basis):
+            out[k, :3] += (sky[f] * (b * w)[..., None]).sum((0, 1))
+        wsum += w.sum()
+    out[:, :3] *= 4 * math.pi / wsum
+    return out.astype(np.float32)

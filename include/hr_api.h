@@ -389,6 +389,32 @@ hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);
 hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out);
 hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);
 
+/* ---- DeferredShading composite (src/deferred_shading.h; SURVEY.md §8f "next" row 1) ------------------- */
+/* The consumer of the four passes: shaders/deferred.frag:177-205 as a per-pixel kernel.  Inputs are full-resolution views
+ * (the passes' OUTPUT_UPSAMPLE outputs).  No sky test — like the reference, every pixel is shaded (the skybox is drawn later). */
+typedef struct hr_deferred hr_deferred;
+
+typedef struct
+{
+    int32_t use_ray_traced_shadows;     /* Shading::use_ray_traced_shadows = true     */
+    int32_t use_ray_traced_ao;          /* true                                        */
+    int32_t use_ray_traced_reflections; /* true                                        */
+    int32_t use_ddgi;                   /* true                                        */
+    float   irradiance_sh9[9][4];       /* s_IrradianceSH (9x1 texels, rgb used) — dw::CubemapSHProjection output */
+} hr_deferred_params;
+
+void      hr_deferred_default_params(hr_deferred_params* p);
+hr_status hr_deferred_create(hr_ctx* ctx, int32_t width, int32_t height, hr_deferred** out);
+/* DeferredShading::render(cmd_buf, ao, shadows, reflections, ddgi) -> render_shading (deferred_shading.cpp:715-723):
+ * shadow / ao: R16F or RG16F view (channel 0 is read); reflections / gi: RGBA16F; any of them may be NULL when its flag is 0.
+ * in->cur_full supplies GB1/GB2/GB3/depth; env supplies the prefiltered cubemap + BRDF LUT. */
+hr_status hr_deferred_render(hr_deferred* p, const hr_frame_inputs* in, const hr_environment* env, const hr_image_view* shadow,
+                             const hr_image_view* ao, const hr_image_view* reflections, const hr_image_view* gi,
+                             const hr_deferred_params* params, void* stream);
+/* DeferredShading::output_ds: RGBA16F HDR colour */
+hr_status hr_deferred_output(hr_deferred* p, hr_image_view* view);
+hr_status hr_deferred_destroy(hr_deferred* p);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

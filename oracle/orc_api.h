@@ -79,6 +79,12 @@ void orc_reflections_atrous(int w, int h, const uint16_t* in_color, const float*
                             const uint8_t* tile_class, int radius, int step_size, float phi_color, float phi_normal, float sigma_depth,
                             int approximate_with_ddgi, uint16_t* out_color);
 
+// ---- deferred composite ---------------------------------------------------
+void orc_deferred_shade(const void* ubo, int w, int h, const uint8_t* gb1, const uint16_t* gb2, const uint16_t* gb3, const float* depth,
+                        const uint16_t* shadow, int shadow_channels, const uint16_t* ao, int ao_channels, const uint16_t* reflections,
+                        const uint16_t* gi, int flags, const float* sh9, const uint16_t* prefiltered, int pre_size, int pre_levels,
+                        const uint16_t* lut, int lut_size, uint16_t* out);
+
 // ---- scalar helpers exported for known-answer tests ---------------------------------------
 uint16_t orc_f32_to_f16(float f);
 float    orc_f16_to_f32(uint16_t h);
