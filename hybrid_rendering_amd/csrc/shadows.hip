@@ -85,9 +85,10 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
     const int slot = blockIdx.x * TRACE_WAVES + wave;
     const int n_tiles = a.tiles_x * a.tiles_y;
     if (slot >= n_tiles) return;
-    // (a stride permutation of the tile order was measured: no gain over row-major — the kernel is bound by the
-    // per-step dependent-load latency, not by a dispatch tail — so tiles keep their L2-friendly row-major order)
-    const int tile = slot;
+    // Load balance: ray cost is strongly screen-space correlated (sky / back-facing tiles fire no ray, the lit floor
+    // traverses deepest) and workgroups are dispatched in index order, so a row-major order ends in a long tail of
+    // expensive tiles.  tile_stride > 1 visits tiles in a stride permutation (stride coprime to the tile count).
+    const int tile = a.tile_stride > 1 ? (int)(((long long)slot * a.tile_stride) % n_tiles) : slot;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool      lit = false, fired = false;
@@ -135,6 +136,146 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
             atomicAdd(a.stats + 0, (unsigned long long)nn);
             atomicAdd(a.stats + 1, (unsigned long long)nt);
             atomicAdd(a.stats + 2, (unsigned long long)wave_max);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent-wave variant (HR_TRACE_KERNEL=queue; NOT the default — measured 13% slower on the bench scene although it
+// raises the SIMD lane utilisation of the traversal loop from 0.50 to 0.83-0.89: mixing rays of several tiles and
+// traversal stages in one wave multiplies the distinct BVH nodes a wave fetches per step, and the loop is bound by
+// those vector-memory requests, not by idle lanes).  A workgroup owns PW_TILES consecutive 8x8 tiles.
+//   phase 1  every wave generates the shadow rays of its tiles and appends the FIRED ones to a ray queue in LDS
+//            (wave ballot + popcount prefix, one LDS atomic per wave);
+//   phase 2  the waves drain the queue: a lane whose ray has terminated fetches the next ray as soon as
+//            PW_REFILL lanes of its wave are idle (ballot / popcount prefix compaction), so the SIMD lanes stay
+//            busy although only ~1/3 of the pixels fire a ray and traversal lengths differ by >10x;
+//   phase 3  visibility bits collected in LDS (atomicOr) are written out as packed 8x4 mask words.
+// The any-hit answer of a ray does not depend on which lane traces it, so the masks are bit-identical.
+#define PW_TILES 4
+#define PW_REFILL 12
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shadows_trace_pw(TraceArgs a)
+{
+    __shared__ float4   s_qa[PW_TILES * 64];   // origin.xyz, t_max
+    __shared__ float4   s_qb[PW_TILES * 64];   // direction.xyz, pixel code (tile_local << 6 | bit)
+    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ uint32_t s_bits[PW_TILES][2];
+    __shared__ int      s_head, s_tail;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    if (threadIdx.x < PW_TILES * 2) s_bits[threadIdx.x >> 1][threadIdx.x & 1] = 0u;
+    if (threadIdx.x == 0) { s_head = 0; s_tail = 0; }
+    __syncthreads();
+    // ---- phase 1: ray generation -------------------------------------------------------------------------
+    for (int r = 0; r < PW_TILES / 4; r++)
+    {
+        const int tl   = r * 4 + wave;
+        const int tile = blockIdx.x * PW_TILES + tl;
+        bool      fired = false;
+        f3        ro = mk3(0, 0, 0), Wi = mk3(0, 0, 1);
+        float     t_max = 0.0f;
+        int       tx = 0, ty = 0;
+        if (tile < n_tiles)
+        {
+            tx = tile % a.tiles_x; ty = tile / a.tiles_x + a.tile_y0;
+            const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+            if (x < a.w && y >= a.y0 && y < a.y1)
+            {
+                const float d = a.depth[(size_t)y * a.w + x];
+                if (d != 1.0f)
+                {
+                    const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
+                    const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
+                    const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+                    const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+                    ro = add3(P, scale3(N, a.bias));
+                    const float r0 = sample_blue_noise(x, y, (int)a.num_frames, 0, a.sobol, a.sr);
+                    const float r1 = sample_blue_noise(x, y, (int)a.num_frames, 1, a.sobol, a.sr);
+                    float att;
+                    fetch_light_shadow(a.light, P, N, r0, r1, Wi, t_max, att);
+                    fired = att > 0.0f;
+                }
+            }
+        }
+        const unsigned long long fb = __ballot(fired);
+        if (fb)
+        {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_tail, __popcll(fb));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (fired)
+            {
+                const int q = base + __popcll(fb & ((1ull << lane) - 1ull));
+                s_qa[q] = make_float4(ro.x, ro.y, ro.z, t_max);
+                s_qb[q] = make_float4(Wi.x, Wi.y, Wi.z, __uint_as_float((uint32_t)(tl << 6 | lane)));
+            }
+        }
+        if (lane == 0 && tile < n_tiles) a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint16_t)__popcll(fb);
+    }
+    __syncthreads();
+    // ---- phase 2: drain the queue with refilling lanes ----------------------------------------------------------
+    const int  tail = s_tail;
+    uint32_t   spill_array[HR_SPILL_ENTRIES];
+    AnyHitLane st;
+    bool       has = false;
+    uint32_t   code = 0, nn = 0, nt = 0, steps = 0;
+    while (true)
+    {
+        const unsigned long long idle = __ballot(!has);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= PW_REFILL || n_idle == 64)
+        {
+            int head = 0;
+            if (lane == 0) head = (s_head < tail) ? atomicAdd(&s_head, n_idle) : tail;
+            head = __builtin_amdgcn_readfirstlane(head);
+            if (head >= tail && n_idle == 64) break;     // queue empty and nothing in flight
+            if (!has)
+            {
+                const int q = head + __popcll(idle & ((1ull << lane) - 1ull));
+                if (q < tail)
+                {
+                    const float4 qa = s_qa[q], qb = s_qb[q];
+                    code = __float_as_uint(qb.w);
+                    if (a.debug_skip_traversal) atomicOr(&s_bits[code >> 6][(code >> 5) & 1u], 1u << (code & 31u));
+                    else
+                    {
+                        anyhit_begin(st, mk3(qa.x, qa.y, qa.z), mk3(qb.x, qb.y, qb.z), 0.01f, qa.w, s_stack[wave], lane, spill_array);
+                        has = true;
+                    }
+                }
+            }
+            if (!__ballot(has)) { if (head >= tail) break; else continue; }
+        }
+        if (has)
+        {
+            const int res = anyhit_step<STATS>(st, a.nodes, a.tris, nn, nt);
+            if (res == 2) atomicOr(&s_bits[code >> 6][(code >> 5) & 1u], 1u << (code & 31u));
+            if (res != 0) has = false;
+        }
+        if (STATS) steps++;
+    }
+    __syncthreads();
+    // ---- phase 3: packed mask words -----------------------------------------------------------------------------
+    if (threadIdx.x < PW_TILES * 2)
+    {
+        const int tl = threadIdx.x >> 1, half = threadIdx.x & 1, tile = blockIdx.x * PW_TILES + tl;
+        if (tile < n_tiles)
+        {
+            const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0, my = ty * 2 + half;
+            if (my * 4 >= a.y0 && my * 4 < a.y1 && my * 4 < a.h) a.mask[(size_t)my * a.mw + tx] = s_bits[tl][half];
+        }
+    }
+    if (STATS && a.stats)
+    {
+        uint32_t mx = steps;
+        for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(mx, o); mx = t > mx ? t : mx; }
+        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_down(nn, o); nt += __shfl_down(nt, o); }
+        if (lane == 0)
+        {
+            atomicAdd(a.stats + 0, (unsigned long long)nn);
+            atomicAdd(a.stats + 1, (unsigned long long)nt);
+            atomicAdd(a.stats + 2, (unsigned long long)mx);
         }
     }
 }
@@ -393,6 +534,7 @@ struct hr_shadows
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
+    bool          persistent_waves = false; // HR_TRACE_KERNEL=queue selects the persistent-wave ray-queue kernel (A/B measurements)
     uint64_t      last_wave_max_steps = 0; // sum over waves of the slowest lane's (node + triangle) steps
 };
 
@@ -410,6 +552,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     HR_HIP(hipSetDevice(ctx->device));
     hr_shadows* p = new hr_shadows();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    { const char* e = getenv("HR_TRACE_KERNEL"); p->persistent_waves = (e && std::string(e) == "queue"); }
     // m_width = extent / 2^scale (ray_traced_shadows.cpp:80-83: float divide then truncation)
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h; p->band_y0 = 0; p->band_y1 = p->h; p->ry0 = 0; p->ry1 = p->h;
@@ -532,7 +675,13 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
-    a.tile_stride = 1;
+    {
+        const char* e = getenv("HR_TILE_STRIDE"); // developer switch; default: golden-ratio stride
+        int st_ = e ? atoi(e) : 1; // row-major measured best (L2 locality of the BVH)
+        auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
+        while (st_ > 1 && gcd(st_, n_tiles) != 1) st_ -= 2;
+        a.tile_stride = st_ < 1 ? 1 : st_;
+    }
     a.debug_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") ? 1 : 0; // developer ablation switch (tools/)
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
@@ -540,12 +689,14 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         // instrumented build of the same kernel: counts node visits / triangle tests
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
-        hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<true>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
-    hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+    if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<false>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -219,6 +219,47 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     return false;
 }
 
+
+// ---- step-wise any-hit traversal (for persistent waves that refill idle lanes from a ray queue) ------------------
+struct AnyHitLane
+{
+    RayPre    r;
+    float     t_min, t_max;
+    LaneStack st;
+};
+
+HR_DEV void anyhit_begin(AnyHitLane& s, f3 o, f3 d, float t_min, float t_max, uint32_t* wave_stack, int lane, uint32_t* spill_array)
+{
+    s.r = ray_prepare(o, d);
+    s.t_min = t_min;
+    s.t_max = t_max;
+    s.st.init(wave_stack, lane, spill_array);
+    s.st.push(0u);
+}
+
+// One node (box tests + the triangles of its hit leaves).  Returns 0 = keep going, 1 = occluded, 2 = done, no hit.
+template <bool STATS>
+HR_DEV int anyhit_step(AnyHitLane& s, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, uint32_t& n_nodes, uint32_t& n_tris)
+{
+    if (s.st.sp <= 0) return 2;
+    const uint32_t ni = s.st.pop();
+    const NodeHits h  = test_node(nodes, ni, s.r, s.t_min, s.t_max);
+    if (STATS) n_nodes++;
+    uint32_t trimask = expand_hits(h, s.st);
+    while (trimask)
+    {
+        const uint32_t i = (uint32_t)__builtin_ctz(trimask);
+        trimask &= trimask - 1u;
+        f3       v0, v1, v2;
+        uint32_t prim;
+        load_tri(tris, h.tri_base + i, v0, v1, v2, prim);
+        if (STATS) n_tris++;
+        float t, u, v;
+        if (ray_tri<false>(s.r, v0, v1, v2, s.t_min, s.t_max, t, u, v)) return 1;
+    }
+    return s.st.sp > 0 ? 0 : 2;
+}
+
 struct HitRec
 {
     float   t, u, v;
