@@ -2,9 +2,11 @@
 // (reference call sites: main.cpp:74 build_tlas, common.cpp:355-521 initialize_for_ray_tracing).
 //
 // Node = 80 bytes (five 16-byte loads per lane):
-//   [ 0] origin.xyz (f32), exponent bytes ex,ey,ez (biased like an fp32 exponent), pad
+//   [ 0] origin.xyz (f32), exponent bytes ex,ey,ez (biased like an fp32 exponent),
+//        counts = n_internal | n_children << 4.  Slots 0..n_internal-1 are the internal children (slot i is node
+//        child_base + i), slots n_internal..n_children-1 the leaves, the rest empty.
 //   [16] child_base (index of first internal child), tri_base (index of first leaf triangle),
-//        meta[8]: 0 = empty slot; internal: 0x10 | slot (node = child_base + slot);
+//        meta[8]: 0 = empty slot; internal: 0x10 | slot;
 //                 leaf: (count << 5) | offset  (triangles tri_base+offset .. +count-1), count 1..4
 //   [32] qlo.x[8] qlo.y[8]   [48] qlo.z[8] qhi.x[8]   [64] qhi.y[8] qhi.z[8]   (uint8 grid coords)
 //   child box = origin + q * 2^(e-127), lo floored / hi ceiled => conservative.
@@ -19,7 +21,7 @@ namespace hr {
 struct alignas(16) Node8
 {
     float    ox, oy, oz;
-    uint8_t  ex, ey, ez, pad;
+    uint8_t  ex, ey, ez, counts;
     uint32_t child_base;
     uint32_t tri_base;
     uint8_t  meta[8];

@@ -231,6 +231,9 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
             kids[best]  = B.n2[k].a;
             kids[nk++]  = B.n2[k].b;
         }
+        // slots: internal children first (slot i <-> node child_base + i), then the leaves — the traversal keeps
+        // one (child_base, hit mask) stack entry per node instead of one entry per child
+        std::stable_partition(kids, kids + nk, [&](int32_t k) { return B.n2[k].a >= 0; });
         Box nb;
         for (int i = 0; i < nk; i++) nb.add(B.n2[kids[i]].box);
         Node8 n;
@@ -283,6 +286,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
                 tri_off += (uint32_t)c.count;
             }
         }
+        n.counts = (uint8_t)(n_internal | (nk << 4));
         // reserve the internal children contiguously, then enqueue them in slot order
         size_t base = out.nodes.size();
         out.nodes.resize(base + n_internal);

@@ -65,10 +65,11 @@ struct TraceArgs
     const Node8*    nodes;
     const TriGPU*   tris;
     unsigned long long* stats; // nullable: [0] nodes visited, [1] triangles tested
+    unsigned long long* timeline; // nullable (HR_DEBUG_TIMELINE): per tile {start, end} in 100 MHz ticks + hw id
     int             w, h;      // pass image (full frame)
     int             y0, y1;    // resident rows
     int             mw;        // mask words per row
-    int             tiles_x, tiles_y, tile_y0, tile_stride, debug_skip_traversal;
+    int             tiles_x, tiles_y, tile_y0, debug_skip_traversal, debug_only_tx, debug_only_ty;
     float           bias;
     uint32_t        num_frames;
 };
@@ -83,13 +84,14 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
     __shared__ uint32_t s_stack[TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.x * TRACE_WAVES + wave;
-    const int n_tiles = a.tiles_x * a.tiles_y;
-    if (slot >= n_tiles) return;
-    // Load balance: ray cost is strongly screen-space correlated (sky / back-facing tiles fire no ray, the lit floor
-    // traverses deepest) and workgroups are dispatched in index order, so a row-major order ends in a long tail of
-    // expensive tiles.  tile_stride > 1 visits tiles in a stride permutation (stride coprime to the tile count).
-    const int tile = a.tile_stride > 1 ? (int)(((long long)slot * a.tile_stride) % n_tiles) : slot;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
+    // Row-major tile order.  Measured alternatives (tools/timeline.py): stride permutations lose BVH
+    // locality in L2; heaviest-first order from the previous frame's per-tile wave lifetimes shortens the launch by
+    // ~1 us but needs a 13 us sort — the launch is bounded by its slowest single wave (~72 us with the GPU to itself).
+    if (slot >= a.tiles_x * a.tiles_y) return;
+    const int tx = slot % a.tiles_x, ty_local = slot / a.tiles_x, ty = ty_local + a.tile_y0;
+    if (a.debug_only_tx >= 0 && (tx != a.debug_only_tx || ty != a.debug_only_ty)) return;
+    unsigned long long t_begin = 0;
+    if (a.timeline) t_begin = wall_clock64();
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool      lit = false, fired = false;
     uint32_t  nn = 0, nt = 0, wave_max = 0;
@@ -131,6 +133,18 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
         if (my * 4 >= a.y0 && my * 4 < a.y1) a.mask[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
         if ((my + 1) * 4 >= a.y0 && (my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) a.mask[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
         a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint16_t)__popcll(fb);
+        if (a.timeline)
+        {
+            const unsigned long long t_end = wall_clock64();
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            a.timeline[(size_t)slot * 4 + 0] = t_begin;
+            a.timeline[(size_t)slot * 4 + 1] = t_end;
+            a.timeline[(size_t)slot * 4 + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            a.timeline[(size_t)slot * 4 + 3] = (unsigned long long)wave_max | ((unsigned long long)(nn + nt) << 32); // STATS build only
+        }
         if (STATS && a.stats)
         {
             atomicAdd(a.stats + 0, (unsigned long long)nn);
@@ -671,17 +685,14 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.mask = (uint32_t*)p->mask.p; a.ray_slots = (uint16_t*)p->ray_slots.p;
     a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
     a.stats = nullptr;
+    a.timeline = nullptr;
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw;
     a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
-    {
-        const char* e = getenv("HR_TILE_STRIDE"); // developer switch; default: golden-ratio stride
-        int st_ = e ? atoi(e) : 1; // row-major measured best (L2 locality of the BVH)
-        auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
-        while (st_ > 1 && gcd(st_, n_tiles) != 1) st_ -= 2;
-        a.tile_stride = st_ < 1 ? 1 : st_;
-    }
+    const int n_slots = n_tiles;
+    a.debug_only_tx = a.debug_only_ty = -1;
+    if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &a.debug_only_tx, &a.debug_only_ty); // developer switch (tools/timeline.py)
     a.debug_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") ? 1 : 0; // developer ablation switch (tools/)
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
@@ -690,13 +701,28 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
         if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<true>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        else hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
+    if (const char* tl = getenv("HR_DEBUG_TIMELINE"))
+    {
+        // developer switch (tools/timeline.py): per-wave start/end ticks of ONE launch of the tile kernel, written to the file
+        DevBuf buf;
+        hr_status bs = buf.alloc((size_t)n_tiles * 32);
+        if (bs != HR_OK) return bs;
+        a.timeline = (unsigned long long*)buf.p;
+        if (getenv("HR_DEBUG_TIMELINE_STATS")) hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        HR_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> host((size_t)n_tiles * 4);
+        HR_HIP(hipMemcpy(host.data(), buf.p, host.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(tl, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        a.timeline = nullptr;
+    }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
     if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<false>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_tiles, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
