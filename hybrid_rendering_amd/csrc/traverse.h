@@ -243,6 +243,7 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     LaneStack st;
     st.init(wave_stack, lane, spill_array);
     uint32_t cur = 1u, ni;   // root = "child 0 of child_base 0"
+    bool     hit = false;
     while (walk_next(cur, st, ni))
     {
         const NodeHits h = test_node(load_node(nodes, ni), r, t_min, t_max);
@@ -255,10 +256,11 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
             const TriRaw tri = load_tri_raw(tris, h.tri_base + i);
             if (STATS) n_tris++;
             float t, u, v;
-            if (ray_tri_raw<false>(r, tri, t_min, t_max, t, u, v)) return true;
+            if (ray_tri_raw<false>(r, tri, t_min, t_max, t, u, v)) { hit = true; break; }
         }
+        if (hit) break;
     }
-    return false;
+    return hit;
 }
 
 

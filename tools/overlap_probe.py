@@ -30,4 +30,31 @@ def run(frames, overlap):
 
 for mode in (False, True, False, True):
     run(20, mode)
-    print('overlap=%s  %.4f ms/frame' % (mode, run(200, mode)))
+    print('cross-frame overlap=%s  %.4f ms/frame' % (mode, run(200, mode)))
+
+
+def run_intra(frames, overlap, prio):
+    # trace || temporal inside one frame (fork/join), a-trous after the join: upper bound for splitting the
+    # mask-independent reprojection out of the temporal kernel
+    s = torch.cuda.Stream(priority=prio)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        fi = hr.frame_inputs(gb, gb, ubo, i, i & 1, sob_d, sr_d)
+        if overlap:
+            s.wait_stream(main)
+            p.temporal(fi, stream=s)
+            p.ray_trace(sc, fi, stream=main)
+            main.wait_stream(s)
+        else:
+            p.ray_trace(sc, fi, stream=main)
+            p.temporal(fi, stream=main)
+        for k in range(4):
+            p.atrous_iteration(fi, k, stream=main)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / frames * 1e3
+
+
+for overlap, prio in ((False, 0), (True, 0), (True, -1), (False, 0), (True, 0)):
+    run_intra(20, overlap, prio)
+    print('intra-frame overlap=%s side-priority=%d  %.4f ms/frame' % (overlap, prio, run_intra(200, overlap, prio)))
