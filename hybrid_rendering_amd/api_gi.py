@@ -75,6 +75,27 @@ class DDGI(_Pass):
         _check(lib().hr_ddgi_output(self.h, C.byref(v)), "hr_ddgi_output")
         return view_to_tensor(v)
 
+    # ---- stage-by-stage (ddgi.cpp:89-104) and multi-GPU sharding
+    def ray_trace(self, scene, inputs, env, stream=None):
+        _check(lib().hr_ddgi_ray_trace(self.h, scene.h, C.byref(inputs), C.byref(env), C.byref(self.params), _stream_ptr(stream)), "hr_ddgi_ray_trace")
+
+    def probe_update(self, stream=None):
+        _check(lib().hr_ddgi_probe_update(self.h, _stream_ptr(stream)), "hr_ddgi_probe_update")
+
+    def sample_probe_grid(self, inputs, stream=None):
+        _check(lib().hr_ddgi_sample_probe_grid(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ddgi_sample_probe_grid")
+
+    def end_frame(self):
+        _check(lib().hr_ddgi_end_frame(self.h), "hr_ddgi_end_frame")
+
+    def set_shard(self, probe_z0, probe_z1, row_y0, row_y1):
+        _check(lib().hr_ddgi_set_shard(self.h, C.c_int32(probe_z0), C.c_int32(probe_z1), C.c_int32(row_y0), C.c_int32(row_y1)), "hr_ddgi_set_shard")
+
+    def current_write(self):
+        a, b = hr_image_view(), hr_image_view()
+        _check(lib().hr_ddgi_current_write(self.h, C.byref(a), C.byref(b)), "hr_ddgi_current_write")
+        return view_to_tensor(a), view_to_tensor(b)
+
     def current_read(self):
         a, b = hr_image_view(), hr_image_view()
         _check(lib().hr_ddgi_current_read(self.h, C.byref(a), C.byref(b)), "hr_ddgi_current_read")
@@ -91,4 +112,4 @@ class DDGI(_Pass):
 
 api.ABI_SYMBOLS += ["hr_ddgi_default_params", "hr_ddgi_create", "hr_ddgi_render", "hr_ddgi_output", "hr_ddgi_current_read",
                     "hr_ddgi_restart_accumulation", "hr_ddgi_destroy", "hr_ddgi_ray_trace", "hr_ddgi_probe_update", "hr_ddgi_sample_probe_grid",
-                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count"]
+                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count", "hr_ddgi_set_shard", "hr_ddgi_current_write"]

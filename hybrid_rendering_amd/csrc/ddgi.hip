@@ -38,7 +38,8 @@ struct DDGITraceArgs
     uint32_t      num_frames;
     int           infinite_bounces;
     float         gi_intensity;
-    int           n_probes;
+    int           n_probes;      // one past the last probe traced
+    int           probe_begin;   // first probe traced (probe shard: z-slabs of the grid)
 };
 
 // one thread per (probe, ray); a wave covers 64 consecutive rays of one probe
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_ddgi_trace(DDGITraceArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = a.d.rays_per_probe;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int probe = (int)(gid / R), ray = (int)(gid % R);
+    const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
     uint32_t  rays = 0;
     if (probe < a.n_probes)
     {
@@ -98,6 +99,7 @@ struct DDGIUpdateArgs
     const void*  prev_atlas;
     void*        out_atlas;
     int          first_frame;
+    int          gy0;   // first probe z-slab of this launch
 };
 
 // one workgroup per probe (gx = x + y*cx, gy = z), one thread per interior texel; the probe's rays are
@@ -111,7 +113,7 @@ __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
     __shared__ float4 s_rad[DEPTH ? 1 : CACHE];
     const int side = DEPTH ? a.d.depth_probe_side_length : a.d.irradiance_probe_side_length;
     const int tw   = DEPTH ? a.d.depth_texture_width : a.d.irradiance_texture_width;
-    const int gx = blockIdx.x, gy = blockIdx.y;
+    const int gx = blockIdx.x, gy = blockIdx.y + a.gy0;
     const int lx = threadIdx.x % side, ly = threadIdx.x / side;
     const int x = gx * (side + 2) + 2 + lx, y = gy * (side + 2) + 2 + ly;
     const int probe = gx + (a.d.probe_counts[0] * a.d.probe_counts[1]) * gy; // == probe_id(current_coord, ...)
@@ -180,11 +182,11 @@ __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
 
 // border texels = octahedral wrap copies of interior texels (table of gi_border_update.glsl:35-143 by formula)
 template <bool DEPTH>
-__global__ void k_ddgi_border(DDGIU d, void* atlas)
+__global__ void k_ddgi_border(DDGIU d, void* atlas, int gy0)
 {
     const int S  = DEPTH ? d.depth_probe_side_length : d.irradiance_probe_side_length;
     const int tw = DEPTH ? d.depth_texture_width : d.irradiance_texture_width;
-    const int cx = blockIdx.x * (S + 2) + 1, cy = blockIdx.y * (S + 2) + 1;
+    const int cx = blockIdx.x * (S + 2) + 1, cy = (blockIdx.y + gy0) * (S + 2) + 1;
     const int i = threadIdx.x;
     if (i >= 4 * S + 4) return;
     int sx, sy, dx, dy;
@@ -213,14 +215,14 @@ struct DDGISampleArgs
     AtlasRGBA    irr;
     AtlasRG      dep;
     uint2*       out;
-    int          w, h;
+    int          w, h, y0, y1;   // rows [y0, y1) of the image are produced (row band)
     float        gi_intensity;
 };
 
 __global__ __launch_bounds__(256) void k_ddgi_sample(DDGISampleArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= a.w || y >= a.h) return;
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
     const size_t o  = (size_t)y * a.w + x;
     const float  dp = a.depth[o];
     if (dp == 1.0f) { a.out[o] = make_uint2(0u, 0u); return; }
@@ -242,6 +244,8 @@ struct hr_ddgi
     int     n_probes = 0;
     DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters, ray_slots;
     bool    first_frame = true, ping_pong = false;
+    int     z0 = 0, z1 = 0;     // probe z-slabs this instance traces and updates
+    int     sy0 = 0, sy1 = 0;   // image rows this instance samples
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
 };
@@ -271,6 +275,7 @@ hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, h
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->d = g;
     p->n_probes = g.probe_counts[0] * g.probe_counts[1] * g.probe_counts[2];
+    p->z0 = 0; p->z1 = g.probe_counts[2]; p->sy0 = 0; p->sy1 = p->h;
     hr_status s;
 #define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
     const size_t nr = (size_t)p->n_probes * g.rays_per_probe;
@@ -296,6 +301,16 @@ hr_status hr_ddgi_destroy(hr_ddgi* p)
     delete p;
     return HR_OK;
 }
+hr_status hr_ddgi_set_shard(hr_ddgi* p, int32_t probe_z0, int32_t probe_z1, int32_t row_y0, int32_t row_y1)
+{
+    HR_CHECK_ARG(p && probe_z0 >= 0 && probe_z1 > probe_z0 && probe_z1 <= p->d.probe_counts[2]);
+    HR_CHECK_ARG(row_y0 >= 0 && row_y1 > row_y0 && row_y1 <= p->h && (row_y0 & 7) == 0);
+    p->z0 = probe_z0; p->z1 = probe_z1; p->sy0 = row_y0; p->sy1 = row_y1;
+    HR_HIP(hipSetDevice(p->ctx->device));
+    HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
+    return HR_OK;
+}
+
 hr_status hr_ddgi_restart_accumulation(hr_ddgi* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
 hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
 hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
@@ -339,8 +354,9 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     a.num_frames = in->num_frames;
     a.infinite_bounces = (prm->infinite_bounces && !p->first_frame) ? 1 : 0; // ddgi.cpp:790
     a.gi_intensity = prm->infinite_bounce_intensity;
-    a.n_probes = p->n_probes;
-    const long long n = (long long)p->n_probes * p->d.rays_per_probe;
+    const int slab = p->d.probe_counts[0] * p->d.probe_counts[1];
+    a.probe_begin = p->z0 * slab; a.n_probes = p->z1 * slab;
+    const long long n = (long long)(a.n_probes - a.probe_begin) * p->d.rays_per_probe;
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
     hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
@@ -354,10 +370,10 @@ hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
     const int rd = p->ping_pong ? 0 : 1, wr = p->ping_pong ? 1 : 0;
-    const dim3 grid(p->d.probe_counts[0] * p->d.probe_counts[1], p->d.probe_counts[2]);
-    const uint64_t nr = (uint64_t)p->n_probes * p->d.rays_per_probe;
+    const dim3 grid(p->d.probe_counts[0] * p->d.probe_counts[1], p->z1 - p->z0);
+    const uint64_t nr = (uint64_t)grid.x * grid.y * p->d.rays_per_probe;
     DDGIUpdateArgs a;
-    a.d = p->d; a.radiance = (const uint2*)p->radiance.p; a.dirdist = (const uint2*)p->dirdist.p; a.first_frame = p->first_frame ? 1 : 0;
+    a.d = p->d; a.radiance = (const uint2*)p->radiance.p; a.dirdist = (const uint2*)p->dirdist.p; a.first_frame = p->first_frame ? 1 : 0; a.gy0 = p->z0;
     a.prev_atlas = p->irr[rd].p; a.out_atlas = p->irr[wr].p;
     int ev = p->prof.begin("irradiance_probe_update", st, nr * 16 + 2 * p->irr[0].bytes);
     hipLaunchKernelGGL(k_ddgi_probe_update<false>, grid, dim3(p->d.irradiance_probe_side_length * p->d.irradiance_probe_side_length), 0, st, a);
@@ -367,8 +383,8 @@ hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
     hipLaunchKernelGGL(k_ddgi_probe_update<true>, grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
     p->prof.end(ev, st);
     ev = p->prof.begin("border_update", st, 0);
-    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(64), 0, st, p->d, p->irr[wr].p);
-    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(128), 0, st, p->d, p->dep[wr].p);
+    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(64), 0, st, p->d, p->irr[wr].p, p->z0);
+    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(128), 0, st, p->d, p->dep[wr].p, p->z0);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -387,9 +403,9 @@ hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const
     a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2;
     a.irr = AtlasRGBA { (const uint2*)p->irr[wr].p, p->d.irradiance_texture_width, p->d.irradiance_texture_height };
     a.dep = AtlasRG { (const uint32_t*)p->dep[wr].p, p->d.depth_texture_width, p->d.depth_texture_height };
-    a.out = (uint2*)p->sample.p; a.w = p->w; a.h = p->h; a.gi_intensity = prm->gi_intensity;
-    int ev = p->prof.begin("sample_probe_grid", st, (uint64_t)p->w * p->h * 20);
-    hipLaunchKernelGGL(k_ddgi_sample, dim3(cdiv(p->w, 32), cdiv(p->h, 8)), dim3(256), 0, st, a);
+    a.out = (uint2*)p->sample.p; a.w = p->w; a.h = p->h; a.y0 = p->sy0; a.y1 = p->sy1; a.gi_intensity = prm->gi_intensity;
+    int ev = p->prof.begin("sample_probe_grid", st, (uint64_t)p->w * (p->sy1 - p->sy0) * 20);
+    hipLaunchKernelGGL(k_ddgi_sample, dim3(cdiv(p->w, 32), cdiv(p->sy1 - p->sy0, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -437,6 +453,15 @@ hr_status hr_ddgi_image(hr_ddgi* p, int32_t which, hr_image_view* v)
 }
 
 hr_status hr_ddgi_output(hr_ddgi* p, hr_image_view* v) { return hr_ddgi_image(p, 6, v); }
+
+hr_status hr_ddgi_current_write(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth)
+{
+    HR_CHECK_ARG(p && irradiance && depth);
+    const int i = p->ping_pong ? 1 : 0; // write_ds[m_ping_pong]: what probe_update fills and sample_probe_grid reads
+    hr_status s = hr_ddgi_image(p, 2 + i, irradiance);
+    if (s != HR_OK) return s;
+    return hr_ddgi_image(p, 4 + i, depth);
+}
 
 hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth)
 {

@@ -64,14 +64,35 @@ def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: in
         req.wait()
 
 
-class TiledShadows:
-    """RayTracedShadows on one band of a row-tiled frame.  ``render()`` = the reference's render() for this
-    band + the per-frame history halo exchange."""
+class _TiledPass:
+    """A denoised pass on one band of a row-tiled frame: ``render()`` = the reference's render() for this band + the
+    per-frame exchange of the history rows next to the band boundaries."""
+
+    def __init__(self, rank: int, world: int, height: int, history_rows: int, group=None):
+        self.rank, self.world, self.height, self.group = rank, world, height, group
+        self.b0, self.b1 = band_rows(height, world, rank)
+        self.history_rows = history_rows
+
+    def history_images(self, ping_pong: int) -> List:
+        raise NotImplementedError
+
+    def _render(self, scene, inputs, stream, *extra):
+        self.pass_.render(scene, inputs, *extra, stream=stream)
+
+    def render(self, scene, inputs, *extra, stream=None):
+        self._render(scene, inputs, stream, *extra)
+        if self.world > 1:
+            # torch.distributed orders the NCCL/RCCL ops after the kernels already enqueued on the current stream
+            # and req.wait() makes the current stream wait for them: no host synchronisation.
+            exchange_halo(self.history_images(int(inputs.ping_pong)), self.height, self.world, self.rank, self.history_rows, self.group)
+
+
+class TiledShadows(_TiledPass):
+    """RayTracedShadows on one band (halo 24 = 8 mask rows + 15 a-trous rows; 40 history rows)."""
 
     def __init__(self, ctx, width: int, height: int, rank: int, world: int, halo: int = HALO, history_halo: int = HISTORY_HALO, group=None):
         from . import api
-        self.rank, self.world, self.height, self.group = rank, world, height, group
-        self.b0, self.b1 = band_rows(height, world, rank)
+        super().__init__(rank, world, height, history_halo, group)
         self.history_halo = history_halo
         band = (self.b0, self.b1, halo, history_halo) if world > 1 else None
         self.pass_ = api.RayTracedShadows(ctx, width, height, api.SCALE_FULL_RES, band=band)
@@ -81,14 +102,113 @@ class TiledShadows:
         p = self.pass_
         return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
 
-    def render(self, scene, inputs, stream=None):
+    def _render(self, scene, inputs, stream):
         self.pass_.render(scene, inputs, stream)
-        if self.world > 1:
-            # torch.distributed orders the NCCL/RCCL ops after the kernels already enqueued on the current stream
-            # and req.wait() makes the current stream wait for them: no host synchronisation.
-            exchange_halo(self.history_images(int(inputs.ping_pong)), self.height, self.world, self.rank, self.history_halo, self.group)
 
     def band_output(self, kind=None):
         from . import api
         out = self.pass_.output(api.OUTPUT_ATROUS if kind is None else kind)
         return out[self.b0:self.b1]
+
+
+class TiledAO(_TiledPass):
+    """RayTracedAO on one band of the pass image (``height`` etc. are in PASS resolution: full >> scale).  The halo
+    (24 rows >= 8 mask rows + 4 blur rows + motion) is also the history apron: the temporal output and the history
+    length of the ``halo`` rows next to each boundary are refreshed from their owner every frame; history taps
+    further out read as disoccluded (exact while per-frame motion stays below halo - 12 rows)."""
+
+    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None):
+        from . import api
+        super().__init__(rank, world, full_height >> scale, halo, group)
+        band = (self.b0, self.b1, halo, halo) if world > 1 else None
+        self.pass_ = api.RayTracedAO(ctx, full_width, full_height, scale, band=band)
+        self.params = self.pass_.params
+
+    def history_images(self, ping_pong: int) -> List:
+        p = self.pass_
+        return [p.image(p.IMG_AO1 if ping_pong else p.IMG_AO0), p.image(p.IMG_LEN1 if ping_pong else p.IMG_LEN0)]
+
+    def _render(self, scene, inputs, stream):
+        self.pass_.render(scene, inputs, stream)
+
+
+class TiledReflections(_TiledPass):
+    """RayTracedReflections on one band of the pass image (8-row colour apron of the temporal pass + 15 a-trous rows
+    fit in halo = 24; history = feedback image + moments)."""
+
+    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None):
+        from . import api, api_reflections
+        super().__init__(rank, world, full_height >> scale, halo, group)
+        band = (self.b0, self.b1, halo, halo) if world > 1 else None
+        self.pass_ = api_reflections.RayTracedReflections(ctx, full_width, full_height, scale, band=band)
+        self.params = self.pass_.params
+
+    def history_images(self, ping_pong: int) -> List:
+        p = self.pass_
+        return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
+
+    def _render(self, scene, inputs, stream, env, ddgi=None):
+        self.pass_.render(scene, inputs, env, ddgi, stream=stream)
+
+
+# ---------------------------------------------------------------------------------------------- DDGI
+def probe_slabs(cz: int, world: int, rank: int) -> Tuple[int, int]:
+    """z-slabs [z0, z1) of the probe grid owned by ``rank`` (every rank gets at least one when cz >= world)."""
+    return (cz * rank) // world, (cz * (rank + 1)) // world
+
+
+def slab_rows(side: int, z0: int, z1: int) -> Tuple[int, int]:
+    """Atlas rows of probe z-slabs [z0, z1): probes are laid out x + y*cx along the atlas x axis and z along y, each
+    probe (side + 2) texels wide, inside a 1-texel frame (ddgi.cpp:197-201) -> one contiguous row range."""
+    return 1 + z0 * (side + 2), 1 + z1 * (side + 2)
+
+
+def allgather_slabs(atlas, side: int, cz: int, world: int, rank: int, group=None):
+    """Every rank has written the atlas rows of its own probe slabs; afterwards every rank holds all rows.
+    Equal slabs -> one all_gather of row blocks; ragged slabs -> one broadcast per owner."""
+    import torch.distributed as dist
+    if world == 1:
+        return
+    rows = [slab_rows(side, *probe_slabs(cz, world, r)) for r in range(world)]
+    if len({b - a for a, b in rows}) == 1:
+        outs = [atlas[a:b] for a, b in rows]
+        dist.all_gather(outs, atlas[rows[rank][0]:rows[rank][1]].clone(), group=group)
+    else:
+        for r, (a, b) in enumerate(rows):
+            if b > a:
+                dist.broadcast(atlas[a:b], src=r, group=group)
+
+
+class ShardedDDGI:
+    """DDGI across the GPUs of a node: probes are partitioned by z-slab for the ray trace and the
+    probe updates, the freshly written atlas rows are all-gathered (irradiance 1.7 MB + depth 2.7 MB in total for a
+    16x8x16 grid), then every rank samples the full atlases for its own row band of the image."""
+
+    def __init__(self, ctx, width: int, height: int, np_ddgi, rank: int, world: int, scale: int = 0, group=None):
+        from . import api_gi
+        self.rank, self.world, self.group = rank, world, group
+        self.pass_ = api_gi.DDGI(ctx, width, height, np_ddgi, scale)
+        self.params = self.pass_.params
+        self.cz = int(np_ddgi["probe_counts"][2])
+        self.irr_side, self.dep_side = int(np_ddgi["irradiance_probe_side_length"]), int(np_ddgi["depth_probe_side_length"])
+        if self.cz < world:
+            raise ValueError("ShardedDDGI needs at least one probe z-slab per rank")
+        self.z0, self.z1 = probe_slabs(self.cz, world, rank)
+        self.b0, self.b1 = band_rows(height >> scale, world, rank)
+        if world > 1:
+            self.pass_.set_shard(self.z0, self.z1, self.b0, self.b1)
+
+    def render(self, scene, inputs, env, orientation=None, stream=None):
+        p = self.pass_
+        if orientation is not None:
+            p.set_orientation(orientation)
+        p.ray_trace(scene, inputs, env, stream)
+        p.probe_update(stream)
+        irr, dep = p.current_write()
+        allgather_slabs(irr, self.irr_side, self.cz, self.world, self.rank, self.group)
+        allgather_slabs(dep, self.dep_side, self.cz, self.world, self.rank, self.group)
+        p.sample_probe_grid(inputs, stream)
+        p.end_frame()
+
+    def band_output(self):
+        return self.pass_.output()[self.b0:self.b1]

@@ -325,6 +325,12 @@ hr_status hr_ddgi_render(hr_ddgi* p, const hr_scene* scene, const hr_frame_input
 hr_status hr_ddgi_output(hr_ddgi* p, hr_image_view* view);
 /* DDGI::current_read_ds (ddgi.cpp:135-138): irradiance + depth atlases written by the last render() */
 hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
+/* Multi-GPU sharding (the reference is single-GPU): this instance traces and updates only the probes
+ * of grid z-slabs [probe_z0, probe_z1) — their atlas rows [1 + z0*(side+2), 1 + z1*(side+2)) are contiguous
+ * (ddgi.cpp:197-201) — and samples image rows [row_y0, row_y1) (row_y0 a multiple of 8).  The caller all-gathers the
+ * slab rows of hr_ddgi_current_write() between hr_ddgi_probe_update and hr_ddgi_sample_probe_grid. */
+hr_status hr_ddgi_set_shard(hr_ddgi* p, int32_t probe_z0, int32_t probe_z1, int32_t row_y0, int32_t row_y1);
+hr_status hr_ddgi_current_write(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
 /* DDGI::restart_accumulation (ddgi.h:33) */
 hr_status hr_ddgi_restart_accumulation(hr_ddgi* p);
 hr_status hr_ddgi_destroy(hr_ddgi* p);

@@ -65,3 +65,42 @@ def test_halo_exchange_gloo(world):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def test_probe_slabs_cover_grid():
+    for cz, world in ((16, 8), (16, 2), (5, 3), (4, 4), (7, 2)):
+        sl = [tiling.probe_slabs(cz, world, r) for r in range(world)]
+        assert sl[0][0] == 0 and sl[-1][1] == cz and all(a[1] == b[0] and a[1] > a[0] for a, b in zip(sl, sl[1:]))
+    assert tiling.slab_rows(8, 0, 16) == (1, 161) and tiling.slab_rows(16, 2, 4) == (37, 73)
+
+
+def _slab_worker(rank, world, port, cz, side, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h, w = (side + 2) * cz + 2, 12
+    atlas = torch.full((h, w, 2), -1.0)
+    z0, z1 = tiling.probe_slabs(cz, world, rank)
+    a, b = tiling.slab_rows(side, z0, z1)
+    atlas[a:b] = (100.0 * rank + torch.arange(a, b, dtype=torch.float32))[:, None, None].expand(-1, w, 2)
+    tiling.allgather_slabs(atlas, side, cz, world, rank)
+    ok = float(atlas[0, 0, 0]) == -1.0 and float(atlas[-1, 0, 0]) == -1.0
+    for r in range(world):
+        ra, rb = tiling.slab_rows(side, *tiling.probe_slabs(cz, world, r))
+        ok &= bool(torch.equal(atlas[ra:rb, 0, 0], 100.0 * r + torch.arange(ra, rb, dtype=torch.float32)))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cz", [(2, 4), (3, 5)])
+def test_ddgi_slab_allgather_gloo(world, cz):
+    """even slabs -> all_gather, ragged slabs -> per-owner broadcast"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_worker, args=(r, world, port, cz, 8, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
