@@ -8,50 +8,12 @@
 #include "hr_internal.h"
 #include "reproject.h"
 #include "traverse.h"
+#include "shading.h"
 #include "upsample.h"
 
 using namespace hr;
 
 // ------------------------------------------------------------------------------------------------
-// lighting.glsl:6-111 with SOFT_SHADOWS | SHADOW_RAY_ONLY | RAY_TRACING
-HR_DEV void fetch_light_shadow(const hr_light& L, f3 P, f3 N, float rx, float ry, f3& Wi, float& t_max, float& attenuation)
-{
-    const int type = (int)L.data3[0];
-    const f3  ldir = mk3(L.data0[0], L.data0[1], L.data0[2]);
-    f3        light_dir;
-    float     radius;
-    if (type == 0)
-    {
-        light_dir   = ldir;
-        radius      = L.data1[3];
-        t_max       = 10000.0f;
-        attenuation = 1.0f;
-    }
-    else
-    {
-        f3    to_light = sub3(mk3(L.data1[0], L.data1[1], L.data1[2]), P);
-        light_dir      = normalize3(to_light);
-        float dist     = len3(to_light);
-        radius         = __fdiv_rn(L.data1[3], dist);
-        t_max          = dist;
-        attenuation    = __fdiv_rn(1.0f, dist * dist);
-    }
-    f3    tangent   = normalize3(cross3(light_dir, mk3(0.0f, 1.0f, 0.0f)));
-    f3    bitangent = normalize3(cross3(tangent, light_dir));
-    float pr        = radius * hr_sqrt(rx);
-    float pa        = ry * 2.0f * HR_M_PI;
-    float s, c;
-    det_sincos(pa, s, c);
-    float dx = pr * c, dy = pr * s;
-    Wi       = normalize3(add3(add3(light_dir, scale3(tangent, dx)), scale3(bitangent, dy)));
-    if (type == 2)
-    {
-        float aa    = smoothstep1(L.data3[1], L.data3[2], dot3(Wi, ldir));
-        attenuation = __fdiv_rn(aa, t_max * t_max);
-    }
-    attenuation = attenuation * clamp1(dot3(N, Wi), 0.0f, 1.0f);
-}
-
 struct TraceArgs
 {
     float           vpi[16];

@@ -230,4 +230,80 @@ private:
     uint32_t        m_width, m_height;
 };
 
+// src/ground_truth_path_tracer.h:7-44
+class GroundTruthPathTracer
+{
+public:
+    GroundTruthPathTracer(Context& ctx, uint32_t width, uint32_t height) : m_width(width), m_height(height)
+    {
+        hr_ground_truth_default_params(&params);
+        check(hr_ground_truth_create(ctx.handle(), (int32_t)width, (int32_t)height, nullptr, &m_pass), "hr_ground_truth_create");
+    }
+    ~GroundTruthPathTracer() { hr_ground_truth_destroy(m_pass); }
+    GroundTruthPathTracer(const GroundTruthPathTracer&) = delete;
+    GroundTruthPathTracer& operator=(const GroundTruthPathTracer&) = delete;
+
+    // the reference reads the camera / light UBO and the sky cubemap from CommonResources
+    void render(Stream cmd_buf, const Frame& frame)
+    {
+        check(hr_ground_truth_render(m_pass, frame.scene->handle(), &frame.inputs.ubo, frame.environment, &params, cmd_buf), "GroundTruthPathTracer::render");
+    }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_ground_truth_output(m_pass, &v), "GroundTruthPathTracer::output_ds");
+        return v;
+    }
+    void             restart_accumulation() { check(hr_ground_truth_restart_accumulation(m_pass), "GroundTruthPathTracer::restart_accumulation"); }
+    uint32_t         width() const { return m_width; }
+    uint32_t         height() const { return m_height; }
+    hr_ground_truth* handle() const { return m_pass; }
+
+    hr_ground_truth_params params;
+
+private:
+    hr_ground_truth* m_pass = nullptr;
+    uint32_t         m_width, m_height;
+};
+
+// src/temporal_aa.h:17-62
+class TemporalAA
+{
+public:
+    TemporalAA(Context& ctx, uint32_t width, uint32_t height)
+    {
+        hr_taa_default_params(&params);
+        check(hr_taa_create(ctx.handle(), (int32_t)width, (int32_t)height, &m_pass), "hr_taa_create");
+    }
+    ~TemporalAA() { hr_taa_destroy(m_pass); }
+    TemporalAA(const TemporalAA&) = delete;
+    TemporalAA& operator=(const TemporalAA&) = delete;
+
+    // TemporalAA::update(): CommonResources::num_frames selects the Halton sample
+    void update(uint32_t num_frames) { check(hr_taa_update(m_pass, num_frames, &params, m_jitter), "TemporalAA::update"); }
+    // colour = DeferredShading::output_ds() (or any pass output being visualised); g_buffer = GBuffer::output_ds() level 0
+    void render(Stream cmd_buf, const ImageView& color, const hr_gbuffer_level& g_buffer, bool ping_pong)
+    {
+        m_ping_pong = ping_pong;
+        check(hr_taa_render(m_pass, &color, &g_buffer, ping_pong ? 1 : 0, &params, cmd_buf), "TemporalAA::render");
+    }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_taa_output(m_pass, m_ping_pong ? 1 : 0, &v), "TemporalAA::output_ds");
+        return v;
+    }
+    bool         enabled() const { return params.enabled != 0; }
+    const float* current_jitter() const { return m_jitter; }     // vec2
+    const float* prev_jitter() const { return m_jitter + 2; }    // vec2
+    hr_taa*      handle() const { return m_pass; }
+
+    hr_taa_params params;
+
+private:
+    hr_taa* m_pass = nullptr;
+    float   m_jitter[4] = { 0, 0, 0, 0 };
+    bool    m_ping_pong = false;
+};
+
 } // namespace hr

@@ -421,6 +421,54 @@ hr_status hr_deferred_render(hr_deferred* p, const hr_frame_inputs* in, const hr
 hr_status hr_deferred_output(hr_deferred* p, hr_image_view* view);
 hr_status hr_deferred_destroy(hr_deferred* p);
 
+/* ---- GroundTruthPathTracer (src/ground_truth_path_tracer.h:7-44) — SURVEY.md §8f row 3 ---------------------- */
+typedef struct hr_ground_truth hr_ground_truth;
+typedef struct
+{
+    int32_t max_ray_bounces;      /* PathTrace::max_ray_bounces = 2 (ground_truth_path_tracer.h:30); carried, unused: the bounce is commented out upstream (rchit:95-105) */
+    float   roughness_multiplier; /* CommonResources::roughness_multiplier */
+} hr_ground_truth_params;
+
+void      hr_ground_truth_default_params(hr_ground_truth_params* p);
+/* band: optional rows [band_y0, band_y1) of the image (pixels are independent: no halo, no exchange) */
+hr_status hr_ground_truth_create(hr_ctx* ctx, int32_t width, int32_t height, const hr_band* band, hr_ground_truth** out);
+/* GroundTruthPathTracer::render (ground_truth_path_tracer.cpp:44-111): one jittered primary sample per pixel, direct
+ * light + sky light at the first hit, running mean over the frames since restart_accumulation(). */
+hr_status hr_ground_truth_render(hr_ground_truth* p, const hr_scene* scene, const hr_ubo* ubo, const hr_environment* env,
+                                 const hr_ground_truth_params* params, void* stream);
+/* GroundTruthPathTracer::output_ds (:122-125): RGBA16F running mean */
+hr_status hr_ground_truth_output(hr_ground_truth* p, hr_image_view* view);
+hr_status hr_ground_truth_restart_accumulation(hr_ground_truth* p); /* ground_truth_path_tracer.h:18 */
+hr_status hr_ground_truth_ray_count(hr_ground_truth* p, uint64_t* rays);
+hr_status hr_ground_truth_set_profiling(hr_ground_truth* p, int32_t enable);
+hr_status hr_ground_truth_get_stage_times(hr_ground_truth* p, hr_stage_times* out);
+hr_status hr_ground_truth_destroy(hr_ground_truth* p);
+
+/* ---- TemporalAA (src/temporal_aa.h:17-62) — SURVEY.md §8f row 4 ------------------------------------------------ */
+typedef struct hr_taa hr_taa;
+typedef struct
+{
+    int32_t enabled;      /* m_enabled = true */
+    int32_t sharpen;      /* m_sharpen = true */
+    int32_t reset;        /* m_reset = true and never cleared upstream (temporal_aa.cpp:112,184): history re-seeded every frame; 0 = keep history */
+    float   feedback_min; /* 0.88 */
+    float   feedback_max; /* 0.97 */
+} hr_taa_params;
+
+void      hr_taa_default_params(hr_taa_params* p);
+hr_status hr_taa_create(hr_ctx* ctx, int32_t width, int32_t height, hr_taa** out);
+/* TemporalAA::update (temporal_aa.cpp:64-81): advances the Halton(2,3) jitter; writes (current.xy, prev.xy) — the value
+ * the application puts into hr_ubo.current_prev_jitter and into its projection matrix (main.cpp:941-957).  Nullable out. */
+hr_status hr_taa_update(hr_taa* p, uint32_t num_frames, const hr_taa_params* params, float* current_prev_jitter);
+/* TemporalAA::render (:84-172): colour = the image being anti-aliased (DeferredShading::output_ds), g = full-resolution
+ * G-buffer level (GB2.zw motion vectors, depth), ping_pong = CommonResources::ping_pong. */
+hr_status hr_taa_render(hr_taa* p, const hr_image_view* color, const hr_gbuffer_level* g, int32_t ping_pong, const hr_taa_params* params, void* stream);
+/* TemporalAA::output_ds (:196-199) */
+hr_status hr_taa_output(hr_taa* p, int32_t ping_pong, hr_image_view* view);
+hr_status hr_taa_set_profiling(hr_taa* p, int32_t enable);
+hr_status hr_taa_get_stage_times(hr_taa* p, hr_stage_times* out);
+hr_status hr_taa_destroy(hr_taa* p);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

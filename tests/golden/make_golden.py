@@ -62,7 +62,27 @@ def build_cases():
     out["ddgi_sponza"] = dict(radiance=dp.stages["radiance"], direction_distance=dp.stages["direction_distance"], irradiance=dp.stages["irradiance"],
                               depth=dp.stages["depth"], output=dp.stages["output"])
     out["reflections_sponza"] = dict(trace=rp.stages["trace"], temporal=rp.stages["temporal"], tiles=rp.stages["tiles"], output=rp.stages["output"])
+    # ---- ground-truth accumulator (3 frames) + TAA (2 frames, real history) on the small Sponza frames --------------
+    from oracle import pyoracle_post as opost
+    gt = opost.GroundTruthPass(w2, h2)
+    for f in range(3):
+        gt_out = gt.render(sc2, fr2[0]["ubo"], sky).copy()
+    out["ground_truth_sponza"] = dict(output=gt_out, rays=np.array([gt.rays], np.uint64))
+    taa = opost.TAAPass(w2, h2, reset=False)
+    for f in range(2):
+        jit = taa.update(f).copy()
+        taa.render(hdr_color(fr2[f]["gb"]), fr2[f]["gb"], f & 1)
+    out["taa_sponza"] = dict(jitter=jit, output=taa.output(1).copy())
     return out
+
+
+def hdr_color(gb):
+    """A deterministic HDR stand-in for the deferred composite: albedo x 1.7 where geometry, 0.25 on the sky."""
+    c = np.zeros(gb["gb1"].shape[:2] + (4,), np.float32)
+    c[..., :3] = gb["gb1"][..., :3].astype(np.float32) / 255.0 * 1.7
+    c[gb["depth"] == 1.0, :3] = 0.25
+    c[..., 3] = 1.0
+    return np.ascontiguousarray(c.astype(np.float16)).view(np.uint16)
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 def test_oracle_matches_committed_golden(oracle):
     import make_golden
     cases = make_golden.build_cases()
-    assert set(cases) == {"shadows_cornell64", "ao_cornell64_half", "ddgi_sponza", "reflections_sponza"}
+    assert set(cases) == {"shadows_cornell64", "ao_cornell64_half", "ddgi_sponza", "reflections_sponza", "ground_truth_sponza", "taa_sponza"}
     for name, arrs in cases.items():
         gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
         assert set(gold.files) == set(arrs)
