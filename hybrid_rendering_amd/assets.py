@@ -1,0 +1,195 @@
+"""Asset ingestion: Wavefront OBJ/MTL -> the triangle / normal / material arrays hr_scene_desc takes
+(the layout of scene_descriptor_set.glsl:5-34 after instance flattening), and PNG -> the Heitz-2019 blue-noise tables
+(blue_noise.cpp:5-19: ``sobol_256_4d.png`` row 0 and a 128x128 ``scrambling_ranking_128x128_2d_*spp.png``).
+
+The reference loads meshes through assimp and images through stb_image (external/dwSampleFramework, absent here); these
+are self-contained readers for the subset those assets use: triangulated or polygonal ``f`` records with v / v/vt / v//vn /
+v/vt/vn indices (negative indices allowed), ``usemtl`` + ``mtllib`` (Kd, Pr / Ns, Pm, Ke), ``o`` / ``g`` groups -> mesh ids;
+8-bit non-interlaced PNG of colour type 0, 2, 4 or 6 with all five scanline filters.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import zlib
+
+import numpy as np
+
+from .synth import SceneData
+
+
+# ------------------------------------------------------------------------------------------------ OBJ / MTL
+def load_mtl(path: str) -> dict:
+    """name -> [albedo rgb, metallic, roughness, emissive rgb] (float32[8]).  Pr/Pm are the PBR extension; without Pr the
+    Phong exponent maps to roughness = sqrt(2 / (Ns + 2)) (the usual Blinn-Phong -> GGX conversion)."""
+    mats, cur, has_pr = {}, None, set()
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            k = t[0].lower()
+            if k == "newmtl":
+                name = " ".join(t[1:])
+                cur = np.array([0.8, 0.8, 0.8, 0.0, 0.5, 0.0, 0.0, 0.0], np.float32)
+                mats[name] = cur
+            elif cur is None:
+                continue
+            elif k == "kd":
+                cur[0:3] = [float(x) for x in t[1:4]]
+            elif k == "pr":
+                cur[4] = float(t[1])
+                has_pr.add(name)
+            elif k == "pm":
+                cur[3] = float(t[1])
+            elif k == "ns" and name not in has_pr:
+                cur[4] = float(np.sqrt(2.0 / (float(t[1]) + 2.0)))
+            elif k == "ke":
+                cur[5:8] = [float(x) for x in t[1:4]]
+    return mats
+
+
+def load_obj(path: str, scale: float = 1.0, default_material=(0.8, 0.8, 0.8, 0.0, 0.5, 0.0, 0.0, 0.0)) -> SceneData:
+    """Triangles in file order; polygons are fanned; missing normals become the geometric face normal (what assimp's
+    aiProcess_GenNormals yields for flat faces)."""
+    pos, nrm = [], []
+    tri_v, tri_n, tri_mat, tri_mesh = [], [], [], []
+    mat_names, mat_index, mtl = [], {}, {}
+    cur_mat, cur_mesh, n_mesh = None, 1, 1
+    base = os.path.dirname(os.path.abspath(path))
+
+    def mat_id(name):
+        if name not in mat_index:
+            mat_index[name] = len(mat_names)
+            mat_names.append(name)
+        return mat_index[name]
+
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            k = t[0]
+            if k == "v":
+                pos.append([float(t[1]) * scale, float(t[2]) * scale, float(t[3]) * scale])
+            elif k == "vn":
+                nrm.append([float(t[1]), float(t[2]), float(t[3])])
+            elif k == "f":
+                idx = []
+                for c in t[1:]:
+                    p = c.split("/")
+                    vi = int(p[0])
+                    ni = int(p[2]) if len(p) > 2 and p[2] else 0
+                    idx.append((vi - 1 if vi > 0 else len(pos) + vi, (ni - 1 if ni > 0 else len(nrm) + ni) if ni else -1))
+                for i in range(1, len(idx) - 1):
+                    tri = (idx[0], idx[i], idx[i + 1])
+                    tri_v.append([t_[0] for t_ in tri])
+                    tri_n.append([t_[1] for t_ in tri])
+                    tri_mat.append(mat_id(cur_mat))
+                    tri_mesh.append(cur_mesh)
+            elif k == "usemtl":
+                cur_mat = " ".join(t[1:])
+            elif k == "mtllib":
+                mp = os.path.join(base, " ".join(t[1:]))
+                if os.path.exists(mp):
+                    mtl.update(load_mtl(mp))
+            elif k in ("o", "g"):
+                n_mesh += 1
+                cur_mesh = n_mesh
+    if not tri_v:
+        raise ValueError(f"{path}: no faces")
+    P = np.asarray(pos, np.float32)
+    verts = P[np.asarray(tri_v, np.int64)]                                  # [n,3,3]
+    fn = np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0])
+    fn = fn / np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    normals = np.repeat(fn[:, None, :], 3, axis=1).astype(np.float32)
+    ni = np.asarray(tri_n, np.int64)
+    if len(nrm):
+        N = np.asarray(nrm, np.float32)
+        has = ni >= 0
+        normals[has] = N[ni[has]]
+    materials = np.stack([np.asarray(mtl.get(n, default_material), np.float32) for n in mat_names]) if mat_names else np.asarray([default_material], np.float32)
+    return SceneData(verts=np.ascontiguousarray(verts), normals=np.ascontiguousarray(normals), tri_material=np.asarray(tri_mat, np.uint32),
+                     tri_mesh_id=np.asarray(tri_mesh, np.uint32), materials=np.ascontiguousarray(materials), name=os.path.basename(path),
+                     meta=dict(materials=mat_names))
+
+
+# ------------------------------------------------------------------------------------------------ PNG
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def load_png(path: str) -> np.ndarray:
+    """[H, W, C] uint8 (C = 1, 2, 3 or 4).  8-bit, non-interlaced."""
+    data = open(path, "rb").read()
+    if data[:8] != _PNG_SIG:
+        raise ValueError(f"{path}: not a PNG")
+    o, idat, ihdr = 8, [], None
+    while o < len(data):
+        n, typ = struct.unpack(">I4s", data[o:o + 8])
+        body = data[o + 8:o + 8 + n]
+        if zlib.crc32(typ + body) & 0xffffffff != struct.unpack(">I", data[o + 8 + n:o + 12 + n])[0]:
+            raise ValueError(f"{path}: CRC mismatch in {typ!r}")
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+        o += 12 + n
+    w, h, depth, ctype, _, _, interlace = ihdr
+    if depth != 8 or interlace != 0 or ctype not in (0, 2, 4, 6):
+        raise ValueError(f"{path}: only 8-bit non-interlaced grey / RGB / grey+alpha / RGBA PNGs are supported")
+    c = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    stride = w * c
+    rows = raw.reshape(h, stride + 1)
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        ft, line = int(rows[y, 0]), rows[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft in (1, 3, 4):
+            cur = np.zeros(stride, np.int32)
+            for i in range(stride):                     # left-dependent filters: sequential along the scanline
+                a = cur[i - c] if i >= c else 0
+                b = prev[i]
+                if ft == 1:
+                    p = a
+                elif ft == 3:
+                    p = (a + b) >> 1
+                else:
+                    cc = prev[i - c] if i >= c else 0
+                    pa, pb, pc = abs(b - cc), abs(a - cc), abs(a + b - 2 * cc)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                cur[i] = (line[i] + p) & 255
+        else:
+            raise ValueError(f"{path}: bad filter type {ft}")
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, c)
+
+
+def _rgba(img: np.ndarray) -> np.ndarray:
+    h, w, c = img.shape
+    if c == 4:
+        return img
+    out = np.full((h, w, 4), 255, np.uint8)
+    if c == 1:
+        out[..., :3] = img
+    elif c == 2:
+        out[..., :3] = img[..., :1]; out[..., 3] = img[..., 1]
+    else:
+        out[..., :3] = img
+    return out
+
+
+def load_blue_noise(sobol_png: str, scrambling_ranking_png: str):
+    """(sobol [256,4] uint8, scrambling_ranking [128,128,4] uint8) as hr_frame_inputs takes them: texelFetch(sobol,
+    ivec2(i, 0)) reads row 0 only (bnd_sampler.glsl:16), the scrambling/ranking tile is 128x128 RGBA."""
+    s, r = _rgba(load_png(sobol_png)), _rgba(load_png(scrambling_ranking_png))
+    if s.shape[1] < 256 or r.shape[0] < 128 or r.shape[1] < 128:
+        raise ValueError("blue-noise tables must be at least 256 wide (sobol) and 128x128 (scrambling/ranking)")
+    return np.ascontiguousarray(s[0, :256]), np.ascontiguousarray(r[:128, :128])

@@ -1,0 +1,142 @@
+"""Asset ingestion: OBJ/MTL and PNG readers against files written by the test itself."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from hybrid_rendering_amd import assets
+
+
+def _write_png(path, img, filters):
+    """8-bit PNG encoder with a chosen scanline filter per row (cycled), to exercise every unfilter branch."""
+    h, w, c = img.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    raw = bytearray()
+    prev = np.zeros(w * c, np.int32)
+    for y in range(h):
+        line = img[y].reshape(-1).astype(np.int32)
+        ft = filters[y % len(filters)]
+        a = np.concatenate([np.zeros(c, np.int32), line[:-c]])
+        b = prev
+        cc = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+        if ft == 0: pred = np.zeros_like(line)
+        elif ft == 1: pred = a
+        elif ft == 2: pred = b
+        elif ft == 3: pred = (a + b) >> 1
+        else:
+            pa, pb, pc = np.abs(b - cc), np.abs(a - cc), np.abs(a + b - 2 * cc)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, cc))
+        raw.append(ft)
+        raw += bytes(((line - pred) & 255).astype(np.uint8))
+        prev = line
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    z = zlib.compress(bytes(raw))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_png_roundtrip_all_filters(tmp_path, c):
+    rng = np.random.RandomState(c)
+    img = rng.randint(0, 256, (37, 53, c)).astype(np.uint8)
+    img[5:9] = 7                                               # flat rows (long zero runs after filtering)
+    p = str(tmp_path / "t.png")
+    _write_png(p, img, [0, 1, 2, 3, 4])
+    assert np.array_equal(assets.load_png(p), img)
+
+
+def test_png_rejects_corruption(tmp_path):
+    p = str(tmp_path / "t.png")
+    _write_png(p, np.zeros((4, 4, 3), np.uint8), [0])
+    d = bytearray(open(p, "rb").read())
+    d[40] ^= 0xff
+    open(p, "wb").write(bytes(d))
+    with pytest.raises(ValueError):
+        assets.load_png(p)
+    open(p, "wb").write(b"not a png at all")
+    with pytest.raises(ValueError):
+        assets.load_png(p)
+
+
+def test_blue_noise_tables_from_png_drive_the_sampler(tmp_path, oracle):
+    """tables written as PNGs and read back feed sample_blue_noise exactly like the in-memory ones"""
+    from hybrid_rendering_amd import synth
+    sob, sr = synth.blue_noise_tables()
+    sob_img = np.zeros((1, 256, 4), np.uint8); sob_img[0] = sob
+    _write_png(str(tmp_path / "sobol_256_4d.png"), sob_img, [1])
+    _write_png(str(tmp_path / "scrambling_ranking_128x128_2d_1spp.png"), sr, [4, 2, 3])
+    s2, r2 = assets.load_blue_noise(str(tmp_path / "sobol_256_4d.png"), str(tmp_path / "scrambling_ranking_128x128_2d_1spp.png"))
+    assert np.array_equal(s2, sob) and np.array_equal(r2, sr) and s2.flags.c_contiguous and r2.flags.c_contiguous
+    _write_png(str(tmp_path / "small.png"), np.zeros((8, 8, 4), np.uint8), [0])
+    with pytest.raises(ValueError):
+        assets.load_blue_noise(str(tmp_path / "small.png"), str(tmp_path / "small.png"))
+
+
+OBJ = """# two quads and a triangle
+mtllib scene.mtl
+o floor
+v 0 0 0
+v 1 0 0
+v 1 0 1
+v 0 0 1
+vn 0 1 0
+usemtl red
+f 1//1 2//1 3//1 4//1
+o wall
+v 0 0 0
+v 0 1 0
+v 1 1 0
+usemtl shiny
+f -3 -2 -1
+g lid
+v 0 2 0
+v 1 2 0
+v 1 2 1
+v 0 2 1
+vt 0 0
+f 8/1 9/1 10/1 11/1
+"""
+MTL = """newmtl red
+Kd 0.9 0.1 0.2
+Ns 98
+newmtl shiny
+Kd 0.5 0.5 0.5
+Pr 0.05
+Pm 1.0
+Ns 10
+Ke 1 2 3
+"""
+
+
+def test_obj_mtl_loader(tmp_path):
+    (tmp_path / "scene.obj").write_text(OBJ)
+    (tmp_path / "scene.mtl").write_text(MTL)
+    sd = assets.load_obj(str(tmp_path / "scene.obj"), scale=2.0)
+    assert sd.n_tris == 5 and sd.verts.dtype == np.float32 and sd.verts.shape == (5, 3, 3)
+    assert np.array_equal(sd.verts[0], np.array([[0, 0, 0], [2, 0, 0], [2, 0, 2]], np.float32))      # fan of the first quad, scaled
+    assert np.array_equal(sd.verts[1], np.array([[0, 0, 0], [2, 0, 2], [0, 0, 2]], np.float32))
+    assert np.array_equal(sd.verts[2], np.array([[0, 0, 0], [0, 2, 0], [2, 2, 0]], np.float32))      # negative indices
+    assert np.all(sd.normals[:2] == np.array([0, 1, 0], np.float32))                                  # vn from the file
+    assert np.allclose(sd.normals[2], [0, 0, -1])                                                     # generated face normal
+    assert np.allclose(sd.normals[3], [0, -1, 0]) or np.allclose(sd.normals[3], [0, 1, 0])
+    assert list(sd.tri_material) == [0, 0, 1, 1, 1] and sd.meta["materials"] == ["red", "shiny"]
+    assert list(sd.tri_mesh_id) == [2, 2, 3, 4, 4]                                                    # o / g start new meshes
+    red, shiny = sd.materials
+    assert np.allclose(red[:3], [0.9, 0.1, 0.2]) and abs(red[4] - np.sqrt(2 / 100)) < 1e-6 and red[3] == 0
+    assert shiny[4] == np.float32(0.05) and shiny[3] == 1.0 and np.allclose(shiny[5:], [1, 2, 3])      # Pr wins over Ns
+    lo, hi = sd.bounds()
+    assert np.array_equal(lo, [0, 0, 0]) and np.array_equal(hi, [2, 4, 2])
+
+
+def test_obj_scene_builds_and_traces(tmp_path, oracle):
+    """the loaded arrays go straight into the (oracle) scene: a ray down onto the floor quad hits it"""
+    (tmp_path / "scene.obj").write_text(OBJ)
+    (tmp_path / "scene.mtl").write_text(MTL)
+    sd = assets.load_obj(str(tmp_path / "scene.obj"))
+    sc = oracle.Scene(sd)
+    rays = np.array([[0.5, 0.5, 0.5, 10.0, 0, -1, 0, 0.001], [0.5, 0.5, 0.5, 1.0, 0, 1, 0, 0.001]], np.float32)   # origin, t_max, direction, t_min
+    hit = sc.any_hit(rays)
+    assert list(np.asarray(hit).astype(int)) == [1, 0]
