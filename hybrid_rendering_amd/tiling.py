@@ -44,12 +44,14 @@ def exchange_plan(height: int, world: int, rank: int, rows: int):
     return plan
 
 
-def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None):
+def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None, wait: bool = True):
     """Grouped neighbour exchange of ``rows`` halo rows for every [H, W, ...] tensor in ``images`` (all ranks
-    pass the same list in the same order).  Works on any backend (nccl on GPUs, gloo in the CPU tests)."""
+    pass the same list in the same order).  Works on any backend (nccl on GPUs, gloo in the CPU tests).
+    ``wait=False`` returns the pending requests (+ the tensors they pin) instead of waiting: the caller waits right
+    before the first kernel that reads the received rows, so the transfer overlaps with whatever is enqueued earlier."""
     import torch.distributed as dist
     if world == 1:
-        return
+        return []
     ops, recvs = [], []
     for peer, (s0, s1), (r0, r1) in exchange_plan(height, world, rank, rows):
         for img in images:
@@ -60,8 +62,12 @@ def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: in
             ops.append(dist.P2POp(dist.isend, send, peer, group))
             ops.append(dist.P2POp(dist.irecv, recv, peer, group))
             recvs.append(send)  # keep alive until the batch completes
-    for req in dist.batch_isend_irecv(ops):
+    reqs = dist.batch_isend_irecv(ops)
+    if not wait:
+        return [(reqs, recvs)]
+    for req in reqs:
         req.wait()
+    return []
 
 
 class _TiledPass:
@@ -76,15 +82,29 @@ class _TiledPass:
     def history_images(self, ping_pong: int) -> List:
         raise NotImplementedError
 
+    _pending: list = []
+
     def _render(self, scene, inputs, stream, *extra):
+        self.wait_exchange()
         self.pass_.render(scene, inputs, *extra, stream=stream)
+
+    def wait_exchange(self):
+        """Orders everything enqueued afterwards behind the previous frame's halo exchange.  With RCCL req.wait() only
+        makes the current stream wait for the communication stream (no host synchronisation); with gloo it blocks."""
+        for reqs, _keep in self._pending:
+            for req in reqs:
+                req.wait()
+        self._pending = []
 
     def render(self, scene, inputs, *extra, stream=None):
         self._render(scene, inputs, stream, *extra)
         if self.world > 1:
-            # torch.distributed orders the NCCL/RCCL ops after the kernels already enqueued on the current stream
-            # and req.wait() makes the current stream wait for them: no host synchronisation.
-            exchange_halo(self.history_images(int(inputs.ping_pong)), self.height, self.world, self.rank, self.history_rows, self.group)
+            # torch.distributed orders the NCCL/RCCL ops after the kernels already enqueued on the current stream.  The
+            # received rows are history for the NEXT frame's temporal pass only, so nobody waits here: the next frame's
+            # ray-trace kernel (which reads no history) runs while the rows are in flight; _render() waits before the
+            # first reader.
+            self._pending = exchange_halo(self.history_images(int(inputs.ping_pong)), self.height, self.world, self.rank, self.history_rows,
+                                          self.group, wait=False)
 
 
 class TiledShadows(_TiledPass):
@@ -103,10 +123,19 @@ class TiledShadows(_TiledPass):
         return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
 
     def _render(self, scene, inputs, stream):
-        self.pass_.render(scene, inputs, stream)
+        # RayTracedShadows::render stage by stage (ray_traced_shadows.cpp:100-116): the trace needs no history, so it is
+        # enqueued BEFORE waiting for the halo rows of the previous frame
+        p = self.pass_
+        p.ray_trace(scene, inputs, stream)
+        self.wait_exchange()
+        if p.params.denoise:
+            p.temporal(inputs, stream)
+            for i in range(int(p.params.filter_iterations)):
+                p.atrous_iteration(inputs, i, stream)
 
     def band_output(self, kind=None):
         from . import api
+        self.wait_exchange()
         out = self.pass_.output(api.OUTPUT_ATROUS if kind is None else kind)
         return out[self.b0:self.b1]
 
@@ -129,6 +158,7 @@ class TiledAO(_TiledPass):
         return [p.image(p.IMG_AO1 if ping_pong else p.IMG_AO0), p.image(p.IMG_LEN1 if ping_pong else p.IMG_LEN0)]
 
     def _render(self, scene, inputs, stream):
+        self.wait_exchange()
         self.pass_.render(scene, inputs, stream)
 
 
@@ -148,6 +178,7 @@ class TiledReflections(_TiledPass):
         return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
 
     def _render(self, scene, inputs, stream, env, ddgi=None):
+        self.wait_exchange()
         self.pass_.render(scene, inputs, env, ddgi, stream=stream)
 
 

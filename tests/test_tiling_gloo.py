@@ -31,7 +31,7 @@ def test_exchange_plan_is_symmetric():
             assert back[1] == recv and back[2] == send
 
 
-def _worker(rank, world, port, h, w, rows, q):
+def _worker(rank, world, port, h, w, rows, q, defer=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     b0, b1 = tiling.band_rows(h, world, rank)
@@ -40,7 +40,13 @@ def _worker(rank, world, port, h, w, rows, q):
     for k, img in enumerate(imgs):
         ys = torch.arange(h, dtype=torch.float32)[:, None, None]
         img[b0:b1] = (1000.0 * rank + ys[b0:b1] + 0.25 * k).expand(-1, w, img.shape[2])
-    tiling.exchange_halo(imgs, h, world, rank, rows)
+    if defer:   # the overlapped form TiledShadows uses: wait right before the first reader
+        pending = tiling.exchange_halo(imgs, h, world, rank, rows, wait=False)
+        for reqs, _keep in pending:
+            for r_ in reqs:
+                r_.wait()
+    else:
+        tiling.exchange_halo(imgs, h, world, rank, rows)
     ok = True
     for k, img in enumerate(imgs):
         for y in range(h):
@@ -53,12 +59,12 @@ def _worker(rank, world, port, h, w, rows, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_halo_exchange_gloo(world):
+@pytest.mark.parametrize("world,defer", [(2, False), (3, False), (2, True)])
+def test_halo_exchange_gloo(world, defer):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 264, 16, 40, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 264, 16, 40, q, defer)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
