@@ -48,6 +48,7 @@ struct BuiltBVH
     float               lo[3], hi[3];
     float               pad;
     int                 max_depth;
+    int                 n_refs = 0;   // triangle references after splitting (== tris.size())
 };
 
 // positions: [n][3][3].  Deterministic (single-threaded, no RNG).

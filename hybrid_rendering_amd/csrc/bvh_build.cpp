@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 
@@ -57,6 +58,7 @@ struct Builder
     std::vector<Box>      tbox;
     std::vector<float>    tcen;
     std::vector<int32_t>  idx;
+    std::vector<int32_t>  prim;   // reference -> original triangle
     std::vector<Bin2>     n2;
 
     int32_t split(int32_t first, int32_t count)
@@ -137,6 +139,93 @@ struct Builder
     }
 };
 
+// ---- triangle reference splitting ("early split clipping") -----------------------------------------------------------
+// Large triangles (walls, floors) drag their whole bounding box into every node above them, and a ray that travels along
+// such a surface visits all of those nodes.  Before the SAH build each triangle whose box is longer than `limit` is cut by
+// axis-aligned planes into pieces with tight boxes; the BVH is built over the pieces ("references"), every piece points at
+// the ORIGINAL triangle, so the ray/triangle test and its results are untouched — only the boxes get tighter.
+struct Ref
+{
+    Box     box;
+    int32_t prim;
+};
+
+struct Poly
+{
+    double v[10][3];
+    int    n = 0;
+};
+
+inline void clip_poly(const Poly& in, int ax, double plane, bool keep_below, Poly& out)
+{
+    out.n = 0;
+    for (int i = 0; i < in.n; i++)
+    {
+        const double* a = in.v[i];
+        const double* b = in.v[(i + 1) % in.n];
+        const bool ina = keep_below ? a[ax] <= plane : a[ax] >= plane;
+        const bool inb = keep_below ? b[ax] <= plane : b[ax] >= plane;
+        if (ina && out.n < 10) { std::memcpy(out.v[out.n++], a, 24); }
+        if (ina != inb && out.n < 10)
+        {
+            const double t = (plane - a[ax]) / (b[ax] - a[ax]);
+            double*      q = out.v[out.n++];
+            for (int k = 0; k < 3; k++) q[k] = a[k] + t * (b[k] - a[k]);
+            q[ax] = plane;
+        }
+    }
+}
+
+inline Box poly_box(const Poly& p, const Box& parent)
+{
+    Box b;
+    for (int i = 0; i < p.n; i++)
+    {
+        float f[3];
+        for (int k = 0; k < 3; k++)
+        {
+            // outward-rounded float bounds of the double coordinate, clamped to the parent piece
+            float lo = (float)p.v[i][k], hi = lo;
+            if ((double)lo > p.v[i][k]) lo = std::nextafter(lo, -FLT_MAX);
+            if ((double)hi < p.v[i][k]) hi = std::nextafter(hi, FLT_MAX);
+            if (lo < b.lo[k]) b.lo[k] = lo;
+            if (hi > b.hi[k]) b.hi[k] = hi;
+            f[k] = lo;
+        }
+        (void)f;
+    }
+    for (int k = 0; k < 3; k++)
+    {
+        if (b.lo[k] < parent.lo[k]) b.lo[k] = parent.lo[k];
+        if (b.hi[k] > parent.hi[k]) b.hi[k] = parent.hi[k];
+    }
+    return b;
+}
+
+void split_refs(const Poly& poly, const Box& box, int32_t prim, float limit, int depth, std::vector<Ref>& out)
+{
+    int ax = 0;
+    for (int k = 1; k < 3; k++)
+        if (box.hi[k] - box.lo[k] > box.hi[ax] - box.lo[ax]) ax = k;
+    const float ext = box.hi[ax] - box.lo[ax];
+    if (!(ext > limit) || depth >= 6 || poly.n < 3)
+    {
+        out.push_back(Ref { box, prim });
+        return;
+    }
+    const double plane = 0.5 * ((double)box.lo[ax] + (double)box.hi[ax]);
+    Poly l, r;
+    clip_poly(poly, ax, plane, true, l);
+    clip_poly(poly, ax, plane, false, r);
+    if (l.n < 3 || r.n < 3)
+    {
+        out.push_back(Ref { box, prim });
+        return;
+    }
+    split_refs(l, poly_box(l, box), prim, limit, depth + 1, out);
+    split_refs(r, poly_box(r, box), prim, limit, depth + 1, out);
+}
+
 inline uint8_t exponent_for(float extent)
 {
     // smallest e with extent <= 255 * 2^(e-127)
@@ -161,34 +250,63 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     out.max_depth = 0;
     Builder B;
     B.pos = positions;
-    B.tbox.resize(n_tris);
-    B.tcen.resize((size_t)n_tris * 3);
-    B.idx.resize(n_tris);
     Box all;
     for (int i = 0; i < n_tris; i++)
     {
         const float* p = positions + (size_t)i * 9;
-        B.tbox[i].add(p);
-        B.tbox[i].add(p + 3);
-        B.tbox[i].add(p + 6);
-        for (int a = 0; a < 3; a++) B.tcen[(size_t)i * 3 + a] = 0.5f * (B.tbox[i].lo[a] + B.tbox[i].hi[a]);
-        all.add(B.tbox[i]);
-        B.idx[i] = i;
+        all.add(p); all.add(p + 3); all.add(p + 6);
     }
     if (n_tris == 0)
     {
         for (int a = 0; a < 3; a++) { all.lo[a] = 0; all.hi[a] = 0; }
     }
     for (int a = 0; a < 3; a++) { out.lo[a] = all.lo[a]; out.hi[a] = all.hi[a]; }
+    double diag;
     {
         double dx = (double)all.hi[0] - all.lo[0], dy = (double)all.hi[1] - all.lo[1], dz = (double)all.hi[2] - all.lo[2];
+        diag = std::sqrt(dx * dx + dy * dy + dz * dz);
         // Boxes are padded well above the fp32 error of the triangle test so that box culling can
         // never reject a triangle the test would accept.
-        out.pad = (float)(3e-5 * std::sqrt(dx * dx + dy * dy + dz * dz));
+        out.pad = (float)(3e-5 * diag);
         if (!(out.pad > 0.0f)) out.pad = 1e-6f;
     }
+    // references: one per triangle, or several tight pieces for triangles longer than diag * split_fraction
+    // Off by default: the bench scene is finely tessellated and splitting at diag/16 .. diag/100 changed nodes/ray by
+    // < 2% and the trace time by < 1.5% (tools/stagebench.py).  HR_BVH_SPLIT=<fraction of the scene diagonal> enables it
+    // for scenes with wall-sized triangles (original Sponza: two triangles per wall).
+    double split_fraction = 0.0;
+    if (const char* e = getenv("HR_BVH_SPLIT")) split_fraction = atof(e);
+    const float limit = split_fraction > 0.0 ? (float)(diag * split_fraction) : FLT_MAX;
+    std::vector<Ref> refs;
+    refs.reserve((size_t)n_tris + n_tris / 4);
     for (int i = 0; i < n_tris; i++)
-        for (int a = 0; a < 3; a++) { B.tbox[i].lo[a] -= out.pad; B.tbox[i].hi[a] += out.pad; }
+    {
+        const float* p = positions + (size_t)i * 9;
+        Box tb;
+        tb.add(p); tb.add(p + 3); tb.add(p + 6);
+        Poly poly;
+        poly.n = 3;
+        for (int v = 0; v < 3; v++)
+            for (int k = 0; k < 3; k++) poly.v[v][k] = p[v * 3 + k];
+        split_refs(poly, tb, i, limit, 0, refs);
+    }
+    const int n_refs = (int)refs.size();
+    out.n_refs = n_refs;
+    B.tbox.resize(n_refs);
+    B.tcen.resize((size_t)n_refs * 3);
+    B.idx.resize(n_refs);
+    B.prim.resize(n_refs);
+    for (int i = 0; i < n_refs; i++)
+    {
+        B.tbox[i] = refs[i].box;
+        B.prim[i] = refs[i].prim;
+        for (int a = 0; a < 3; a++)
+        {
+            B.tcen[(size_t)i * 3 + a] = 0.5f * (B.tbox[i].lo[a] + B.tbox[i].hi[a]);
+            B.tbox[i].lo[a] -= out.pad; B.tbox[i].hi[a] += out.pad;
+        }
+        B.idx[i] = i;
+    }
 
     if (n_tris == 0)
     {
@@ -198,15 +316,15 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         out.nodes.push_back(n);
         return;
     }
-    B.n2.reserve((size_t)n_tris);
-    int32_t root2 = B.split(0, n_tris);
+    B.n2.reserve((size_t)n_refs);
+    int32_t root2 = B.split(0, n_refs);
 
     // ---- collapse to 8-wide, breadth-first -----------------------------------------------
     struct Pending { int32_t n2; int32_t n8; int depth; };
     std::queue<Pending> q;
     out.nodes.emplace_back();
     q.push({ root2, 0, 1 });
-    out.tris.reserve(n_tris);
+    out.tris.reserve(n_refs);
     while (!q.empty())
     {
         Pending pd = q.front();
@@ -273,7 +391,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
                 n.meta[i] = (uint8_t)((c.count << 5) | tri_off);
                 for (int t = 0; t < c.count; t++)
                 {
-                    int32_t      prim = B.idx[c.first + t];
+                    int32_t      prim = B.prim[B.idx[c.first + t]];
                     const float* p    = positions + (size_t)prim * 9;
                     TriGPU       tg;
                     std::memset(&tg, 0, sizeof(tg));
