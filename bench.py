@@ -9,15 +9,20 @@ inputs resident in HBM (BASELINE.json configs[1]).  Prints ONE JSON line (see th
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: ONE frame of 1920 x (1080*N) pixels is row-tiled, one 1080-row band per GPU (weak scaling).  Every band
-re-traces / re-filters 24 halo rows locally and, once per frame, exchanges the 40 history rows next to each band
-boundary with its neighbours over RCCL (hybrid_rendering_amd/tiling.py); band rows are bit-identical to the
+N > 1 (weak scaling): the SAME view is rendered with N times the pixels — 1920*sqrt(N) x 1080*sqrt(N), rounded to
+multiples of 8 — so rays and pixels per frame grow with N while the content statistics stay those of the N = 1 frame.
+The frame is row-tiled, one band per GPU; band boundaries are chosen from a calibration frame so that every band
+carries the same share of the cost model  pixels + 1.25 * rays  (tiling.balanced_bounds: sky rows fire no ray, the
+floor fires one per pixel — equal-height bands would leave most GPUs idle).  Every band re-traces / re-filters 24 halo
+rows locally and, once per frame, exchanges the 40 history rows next to each band boundary with its neighbours over
+RCCL (hybrid_rendering_amd/tiling.py), overlapped with the next frame's trace; band rows are bit-identical to the
 single-GPU result (tests/test_gpu_tiling.py).  `value` counts only the rays of band rows (halo work is overhead).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -65,7 +70,9 @@ def main():
     from hybrid_rendering_amd import api as hr
     from hybrid_rendering_amd import synth, tiling
 
-    W, H = args.width, args.height * world      # one band of args.height rows per GPU
+    # N x the pixels of the N = 1 frame, same aspect and view (multiples of 8: tile / band alignment)
+    sc = math.sqrt(world)
+    W, H = (int(round(args.width * sc / 8)) * 8, int(round(args.height * sc / 8)) * 8) if world > 1 else (args.width, args.height)
     sd = synth.sponza_like(args.detail)
     ctx = hr.Context(local_rank)
     scene = hr.Scene(ctx, sd)
@@ -76,11 +83,6 @@ def main():
     # ring of camera positions (dolly 0.5 units/frame)
     R = max(2, args.ring)
     cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(R + 1)]
-    if world > 1:  # keep the horizontal field of view of the 16:9 frame when the frame gets taller
-        import math
-        hfov = 2 * math.atan(math.tan(math.radians(30.0)) * 16 / 9)
-        vfov = math.degrees(2 * math.atan(math.tan(hfov / 2) * H / W))
-        cams = [synth.Camera(c.eye, c.target, fov=min(vfov, 150.0), aspect=W / H) for c in cams]
     # G-buffers: ring position i rendered with prev = i-1 (forward sweep) and with prev = i+1 (backward sweep)
     gbs = {}
     ubos = {}
@@ -101,7 +103,20 @@ def main():
         return hr.frame_inputs(gbs[key], gbs[pk], ubos[key], k, k & 1, sob_d, sr_d)
 
     cycle = [inputs_for(k) for k in range(len(seq) * 2)]  # even length: ping_pong parity preserved when cycling
-    tiled = tiling.TiledShadows(ctx, W, H, rank, world)
+    bounds = None
+    if world > 1:
+        # calibration (outside the timed region, identical on every rank): rays per tile row of the whole frame + geometry
+        # pixels per tile row -> band boundaries of equal modelled cost (tiling.shadow_cost_per_tile_row)
+        cal = hr.RayTracedShadows(ctx, W, H)
+        cal.ray_trace(scene, cycle[0])
+        cost = tiling.shadow_cost_per_tile_row(gbs[seq[0]]["depth"], cal.tile_ray_counts())
+        cal.close()
+        bounds = tiling.balanced_bounds(cost, world, H)
+        if world > 1:
+            tb = torch.tensor(bounds, dtype=torch.int64, device="cuda")
+            dist.broadcast(tb, src=0)      # belt and braces: every rank uses rank 0's partition
+            bounds = [int(v) for v in tb.cpu()]
+    tiled = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds)
     shadows = tiled.pass_
     b0, b1 = tiled.b0, tiled.b1
 
@@ -196,11 +211,12 @@ def main():
         "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise, row-tiled: one {args.height}-row band per GPU",
+        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise"
+                               + (f", same view as 1920x1080 with {world}x the pixels, row-tiled into {world} cost-balanced bands (rows {bounds})" if world > 1 else ""),
                    "rays_per_frame_per_gpu": int(rays_per_frame), "pixels_per_gpu": px, "bvh_nodes": int(scene.info.n_nodes),
                    "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
         "denoised_frames_per_s": round(args.steps / elapsed, 2),                  # frames of W x H (the whole tiled frame)
-        "denoised_1080p_equiv_per_s": round(world * args.steps / elapsed, 2),   # bands of W x args.height per second
+        "denoised_1080p_equiv_per_s": round(W * H / (args.width * args.height) * args.steps / elapsed, 2),
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
         "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(dom[1]["frac"], 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(dom[1]["bytes"])},

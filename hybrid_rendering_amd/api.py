@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_shadows_ray_count", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -315,6 +315,14 @@ class RayTracedShadows(_Pass):
         n = C.c_uint64(0)
         _check(lib().hr_shadows_ray_count(self.h, C.byref(n)), "hr_shadows_ray_count")
         return n.value
+
+    def tile_ray_counts(self) -> np.ndarray:
+        """[tiles_y, tiles_x] uint16: rays fired per 8x8 tile by the last ray_trace"""
+        tx, ty = C.c_int32(0), C.c_int32(0)
+        _check(lib().hr_shadows_tile_ray_counts(self.h, None, C.byref(tx), C.byref(ty)), "hr_shadows_tile_ray_counts")
+        out = np.zeros((ty.value, tx.value), np.uint16)
+        _check(lib().hr_shadows_tile_ray_counts(self.h, out.ctypes.data_as(C.POINTER(C.c_uint16)), None, None), "hr_shadows_tile_ray_counts")
+        return out
 
     def trace_stats(self, scene, inputs, stream=None):
         """(rays, nodes visited, triangles tested) from the instrumented trace kernel."""

@@ -615,6 +615,17 @@ hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays)
     return HR_OK;
 }
 
+hr_status hr_shadows_tile_ray_counts(hr_shadows* p, uint16_t* out, int32_t* tiles_x, int32_t* tiles_y)
+{
+    HR_CHECK_ARG(p);
+    if (tiles_x) *tiles_x = p->tiles_x;
+    if (tiles_y) *tiles_y = p->tiles_y;
+    if (!out) return HR_OK;
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(out, p->ray_slots.p, (size_t)p->tiles_x * p->tiles_y * 2, hipMemcpyDeviceToHost));
+    return HR_OK;
+}
+
 static hr_status check_inputs(const hr_shadows* p, const hr_frame_inputs* in, bool need_prev)
 {
     HR_CHECK_ARG(in->cur.depth && in->cur.gb2 && in->cur.gb3);

@@ -22,29 +22,85 @@ HALO = 24          # multiple of 8 >= 8 (mask footprint) + 15 (a-trous chain)
 HISTORY_HALO = 40  # HALO + 16 rows of motion
 
 
-def band_rows(height: int, world: int, rank: int, align: int = 8) -> Tuple[int, int]:
-    """Contiguous row band of ``rank``; boundaries are multiples of ``align`` (8-row tiles, 4-row masks)."""
+def band_rows(height: int, world: int, rank: int, align: int = 8, bounds: Sequence[int] = None) -> Tuple[int, int]:
+    """Contiguous row band of ``rank``; boundaries are multiples of ``align`` (8-row tiles, 4-row masks).
+    ``bounds`` (world + 1 ascending row boundaries, e.g. from balanced_bounds) replaces the uniform partition."""
+    if bounds is not None:
+        if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != height or any(b % align for b in bounds[:-1]) \
+                or any(b1 <= b0 for b0, b1 in zip(bounds, bounds[1:])):
+            raise ValueError(f"bad band boundaries {list(bounds)} for height {height}, world {world}")
+        return int(bounds[rank]), int(bounds[rank + 1])
     tiles = (height + align - 1) // align
     t0 = (tiles * rank) // world
     t1 = (tiles * (rank + 1)) // world
     return t0 * align, min(t1 * align, height)
 
 
-def exchange_plan(height: int, world: int, rank: int, rows: int):
+def balanced_bounds(cost_per_tile_row: Sequence[float], world: int, height: int, min_tiles: int = 8, align: int = 8) -> List[int]:
+    """Row boundaries that give every band (about) the same share of ``cost_per_tile_row`` (one entry per ``align`` rows,
+    e.g. a * pixels + b * rays of a calibration frame): screen-space cost is far from uniform — sky rows fire no ray, the
+    floor fires one per pixel — and the slowest band sets the frame rate.  Every band keeps at least ``min_tiles`` tile
+    rows so that the halo exchange only ever involves direct neighbours."""
+    c = [max(float(x), 0.0) for x in cost_per_tile_row]
+    n = len(c)
+    if n < world * min_tiles:
+        raise ValueError("image too small for that many bands")
+    total = sum(c) or 1.0
+    cuts, acc, k = [0], 0.0, 1
+    for i in range(n):
+        acc += c[i]
+        # cut after tile row i when the running cost reaches the k-th share, leaving room for the remaining bands
+        while k < world and acc >= total * k / world and (i + 1) - cuts[-1] >= min_tiles:
+            if n - (i + 1) < (world - k) * min_tiles:
+                break
+            cuts.append(i + 1)
+            k += 1
+    while len(cuts) < world:  # not enough cost left: give the remaining bands the minimum height from the bottom
+        cuts.append(0)
+    cuts = sorted(cuts[:world])
+    for j in range(1, world):  # enforce min height going down, then going up
+        cuts[j] = max(cuts[j], cuts[j - 1] + min_tiles)
+    limit = n
+    for j in range(world - 1, 0, -1):
+        cuts[j] = min(cuts[j], limit - min_tiles)
+        limit = cuts[j]
+    return [c_ * align for c_ in cuts] + [height]
+
+
+RAY_WEIGHT = 1.8    # cost of one shadow ray in units of one geometry pixel of denoising.  The 1080p stage times give 1.25 (trace
+                    # 0.131 ns/ray, temporal + a-trous 0.105 ns/pixel); 1.8 balances the measured band times of the 4- and 8-band
+                    # frames best (tools/band_balance.py: slowest/mean band 1.04 instead of 1.10) — ray-dense rows are also the deep ones
+SKY_WEIGHT = 0.3    # sky pixels leave the denoise kernels early
+
+
+def shadow_cost_per_tile_row(depth, tile_rays, ray_weight: float = None, sky_weight: float = SKY_WEIGHT):
+    """Cost model of the shadows pass per 8-row tile row, from a calibration frame: ``depth`` = [H, W] torch depth image
+    (sky == 1.0), ``tile_rays`` = [tiles_y, tiles_x] rays per tile (RayTracedShadows.tile_ray_counts)."""
+    import numpy as np
+    import os
+    rw = float(os.environ.get("HR_RAY_WEIGHT", RAY_WEIGHT)) if ray_weight is None else ray_weight
+    H, W = depth.shape
+    geom = (depth != 1.0).sum(dim=1).double().cpu().numpy()
+    geom_rows = np.add.reduceat(geom, np.arange(0, H, 8))
+    px_rows = np.add.reduceat(np.full(H, float(W)), np.arange(0, H, 8))
+    return geom_rows + sky_weight * (px_rows - geom_rows) + rw * np.asarray(tile_rays, np.float64).sum(axis=1)
+
+
+def exchange_plan(height: int, world: int, rank: int, rows: int, bounds: Sequence[int] = None):
     """Row ranges for one neighbour exchange.  Returns a list of (peer, send_rows, recv_rows) with absolute
     half-open row ranges: I send rows of MY band adjacent to the peer and receive the peer's adjacent rows."""
-    b0, b1 = band_rows(height, world, rank)
+    b0, b1 = band_rows(height, world, rank, bounds=bounds)
     plan = []
     if rank > 0:
-        p0, p1 = band_rows(height, world, rank - 1)
+        p0, p1 = band_rows(height, world, rank - 1, bounds=bounds)
         plan.append((rank - 1, (b0, min(b0 + rows, b1)), (max(p1 - rows, p0), p1)))
     if rank < world - 1:
-        p0, p1 = band_rows(height, world, rank + 1)
+        p0, p1 = band_rows(height, world, rank + 1, bounds=bounds)
         plan.append((rank + 1, (max(b1 - rows, b0), b1), (p0, min(p0 + rows, p1))))
     return plan
 
 
-def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None, wait: bool = True):
+def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None, wait: bool = True, bounds: Sequence[int] = None):
     """Grouped neighbour exchange of ``rows`` halo rows for every [H, W, ...] tensor in ``images`` (all ranks
     pass the same list in the same order).  Works on any backend (nccl on GPUs, gloo in the CPU tests).
     ``wait=False`` returns the pending requests (+ the tensors they pin) instead of waiting: the caller waits right
@@ -53,7 +109,7 @@ def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: in
     if world == 1:
         return []
     ops, recvs = [], []
-    for peer, (s0, s1), (r0, r1) in exchange_plan(height, world, rank, rows):
+    for peer, (s0, s1), (r0, r1) in exchange_plan(height, world, rank, rows, bounds):
         for img in images:
             send = img[s0:s1].contiguous()
             recv = img[r0:r1]
@@ -74,9 +130,10 @@ class _TiledPass:
     """A denoised pass on one band of a row-tiled frame: ``render()`` = the reference's render() for this band + the
     per-frame exchange of the history rows next to the band boundaries."""
 
-    def __init__(self, rank: int, world: int, height: int, history_rows: int, group=None):
+    def __init__(self, rank: int, world: int, height: int, history_rows: int, group=None, bounds: Sequence[int] = None):
         self.rank, self.world, self.height, self.group = rank, world, height, group
-        self.b0, self.b1 = band_rows(height, world, rank)
+        self.bounds = list(bounds) if bounds is not None else None
+        self.b0, self.b1 = band_rows(height, world, rank, bounds=self.bounds)
         self.history_rows = history_rows
 
     def history_images(self, ping_pong: int) -> List:
@@ -104,15 +161,16 @@ class _TiledPass:
             # ray-trace kernel (which reads no history) runs while the rows are in flight; _render() waits before the
             # first reader.
             self._pending = exchange_halo(self.history_images(int(inputs.ping_pong)), self.height, self.world, self.rank, self.history_rows,
-                                          self.group, wait=False)
+                                          self.group, wait=False, bounds=self.bounds)
 
 
 class TiledShadows(_TiledPass):
     """RayTracedShadows on one band (halo 24 = 8 mask rows + 15 a-trous rows; 40 history rows)."""
 
-    def __init__(self, ctx, width: int, height: int, rank: int, world: int, halo: int = HALO, history_halo: int = HISTORY_HALO, group=None):
+    def __init__(self, ctx, width: int, height: int, rank: int, world: int, halo: int = HALO, history_halo: int = HISTORY_HALO, group=None,
+                 bounds: Sequence[int] = None):
         from . import api
-        super().__init__(rank, world, height, history_halo, group)
+        super().__init__(rank, world, height, history_halo, group, bounds)
         self.history_halo = history_halo
         band = (self.b0, self.b1, halo, history_halo) if world > 1 else None
         self.pass_ = api.RayTracedShadows(ctx, width, height, api.SCALE_FULL_RES, band=band)
@@ -146,9 +204,10 @@ class TiledAO(_TiledPass):
     length of the ``halo`` rows next to each boundary are refreshed from their owner every frame; history taps
     further out read as disoccluded (exact while per-frame motion stays below halo - 12 rows)."""
 
-    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None):
+    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None,
+                 bounds: Sequence[int] = None):
         from . import api
-        super().__init__(rank, world, full_height >> scale, halo, group)
+        super().__init__(rank, world, full_height >> scale, halo, group, bounds)
         band = (self.b0, self.b1, halo, halo) if world > 1 else None
         self.pass_ = api.RayTracedAO(ctx, full_width, full_height, scale, band=band)
         self.params = self.pass_.params
@@ -166,9 +225,10 @@ class TiledReflections(_TiledPass):
     """RayTracedReflections on one band of the pass image (8-row colour apron of the temporal pass + 15 a-trous rows
     fit in halo = 24; history = feedback image + moments)."""
 
-    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None):
+    def __init__(self, ctx, full_width: int, full_height: int, rank: int, world: int, scale: int = 0, halo: int = HALO, group=None,
+                 bounds: Sequence[int] = None):
         from . import api, api_reflections
-        super().__init__(rank, world, full_height >> scale, halo, group)
+        super().__init__(rank, world, full_height >> scale, halo, group, bounds)
         band = (self.b0, self.b1, halo, halo) if world > 1 else None
         self.pass_ = api_reflections.RayTracedReflections(ctx, full_width, full_height, scale, band=band)
         self.params = self.pass_.params

@@ -231,6 +231,9 @@ hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable);
 hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out); /* synchronises the recorded events */
 /* rays fired by the last ray_trace (lit, non-sky pixels); synchronises the stream it ran on */
 hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
+/* the same per 8x8 tile: out = host array [tiles_y][tiles_x] (nullable: only the extent is returned) — the cost signal
+ * the multi-GPU driver balances its row bands with (tiling.balanced_bounds) */
+hr_status hr_shadows_tile_ray_counts(hr_shadows* p, uint16_t* out, int32_t* tiles_x, int32_t* tiles_y);
 /* Runs the instrumented build of the trace kernel on the same inputs (same masks are produced) and
  * returns out3 = { rays fired, BVH nodes visited, triangles tested } — the terms of the trace pass's
  * algorithmic-bytes figure.  Synchronises the stream. */

@@ -10,8 +10,8 @@ from hybrid_rendering_amd import synth, tiling
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bands_match_single_pass(oracle, hr, ctx, world):
+@pytest.mark.parametrize("world,bounds", [(2, None), (3, None), (3, [0, 64, 176, 264])])
+def test_bands_match_single_pass(oracle, hr, ctx, world, bounds):
     import torch
     name, W, H, n_frames = "sponza_small", 192, 264, 5
     sd = helpers.scene_data(name)
@@ -20,7 +20,7 @@ def test_bands_match_single_pass(oracle, hr, ctx, world):
     sob, sr = synth.blue_noise_tables()
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
     whole = hr.RayTracedShadows(ctx, W, H)
-    bands = [tiling.TiledShadows(ctx, W, H, r, world) for r in range(world)]
+    bands = [tiling.TiledShadows(ctx, W, H, r, world, bounds=bounds) for r in range(world)]   # uniform or cost-balanced heights
     for b in bands:
         b.world = 1  # exchange is emulated below with device copies
     ping = False
@@ -33,7 +33,7 @@ def test_bands_match_single_pass(oracle, hr, ctx, world):
             b.render(gsc, fi)
         # emulated neighbour exchange (what exchange_halo does over RCCL)
         for r, b in enumerate(bands):
-            for peer, (s0, s1), (r0, r1) in tiling.exchange_plan(H, world, r, tiling.HISTORY_HALO):
+            for peer, (s0, s1), (r0, r1) in tiling.exchange_plan(H, world, r, tiling.HISTORY_HALO, bounds):
                 for mine, theirs in zip(b.history_images(int(ping)), bands[peer].history_images(int(ping))):
                     mine[r0:r1].copy_(theirs[r0:r1])
         torch.cuda.synchronize()

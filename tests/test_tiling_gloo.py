@@ -23,34 +23,55 @@ def test_band_rows_partition():
            [tiling.band_rows(2160, 8, r)[1] - tiling.band_rows(2160, 8, r)[0] for r in range(8)].count(264) == 8
 
 
+def test_balanced_bounds():
+    import numpy as np
+    # cost concentrated in the lower rows (sky on top, floor below): bands get narrower downwards, every band >= 8 tile rows
+    cost = np.concatenate([np.zeros(100), np.ones(100), 3 * np.ones(182)])
+    b = tiling.balanced_bounds(cost, 8, 382 * 8)
+    assert b[0] == 0 and b[-1] == 382 * 8 and all(x % 8 == 0 for x in b) and all(b1 - b0 >= 64 for b0, b1 in zip(b, b[1:]))
+    share = [cost[b0 // 8:b1 // 8].sum() for b0, b1 in zip(b, b[1:])]
+    assert max(share) <= 1.08 * cost.sum() / 8 and min(share) >= 0.9 * cost.sum() / 8
+    assert tiling.balanced_bounds(np.ones(135), 2, 1080) == [0, 544, 1080]
+    for world in (2, 3, 8):   # degenerate inputs still give a valid partition
+        for c in (np.zeros(135), np.r_[np.zeros(120), 5 * np.ones(15)], np.r_[9 * np.ones(3), np.zeros(132)]):
+            bb = tiling.balanced_bounds(c, world, 1080)
+            assert len(bb) == world + 1 and bb[0] == 0 and bb[-1] == 1080 and all(y - x >= 64 for x, y in zip(bb, bb[1:]))
+            assert [tiling.band_rows(1080, world, r, bounds=bb) for r in range(world)] == list(zip(bb, bb[1:]))
+    with pytest.raises(ValueError):
+        tiling.balanced_bounds(np.ones(10), 4, 80)
+    with pytest.raises(ValueError):
+        tiling.band_rows(1080, 2, 0, bounds=[0, 500, 1080])   # 500 is not a multiple of 8
+
+
 def test_exchange_plan_is_symmetric():
     h, world, rows = 264, 3, 40
-    for r in range(world):
-        for peer, send, recv in tiling.exchange_plan(h, world, r, rows):
-            back = [p for p in tiling.exchange_plan(h, world, peer, rows) if p[0] == r][0]
-            assert back[1] == recv and back[2] == send
+    for bounds in (None, [0, 48, 200, 264]):
+        for r in range(world):
+            for peer, send, recv in tiling.exchange_plan(h, world, r, rows, bounds):
+                back = [p for p in tiling.exchange_plan(h, world, peer, rows, bounds) if p[0] == r][0]
+                assert back[1] == recv and back[2] == send
 
 
-def _worker(rank, world, port, h, w, rows, q, defer=False):
+def _worker(rank, world, port, h, w, rows, q, defer=False, bounds=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    b0, b1 = tiling.band_rows(h, world, rank)
+    b0, b1 = tiling.band_rows(h, world, rank, bounds=bounds)
     # every rank owns its band rows of two images (different channel counts, like prev_image / moments)
     imgs = [torch.full((h, w, 2), -1.0), torch.full((h, w, 4), -1.0)]
     for k, img in enumerate(imgs):
         ys = torch.arange(h, dtype=torch.float32)[:, None, None]
         img[b0:b1] = (1000.0 * rank + ys[b0:b1] + 0.25 * k).expand(-1, w, img.shape[2])
     if defer:   # the overlapped form TiledShadows uses: wait right before the first reader
-        pending = tiling.exchange_halo(imgs, h, world, rank, rows, wait=False)
+        pending = tiling.exchange_halo(imgs, h, world, rank, rows, wait=False, bounds=bounds)
         for reqs, _keep in pending:
             for r_ in reqs:
                 r_.wait()
     else:
-        tiling.exchange_halo(imgs, h, world, rank, rows)
+        tiling.exchange_halo(imgs, h, world, rank, rows, bounds=bounds)
     ok = True
     for k, img in enumerate(imgs):
         for y in range(h):
-            owner = [r for r in range(world) if tiling.band_rows(h, world, r)[0] <= y < tiling.band_rows(h, world, r)[1]][0]
+            owner = [r for r in range(world) if tiling.band_rows(h, world, r, bounds=bounds)[0] <= y < tiling.band_rows(h, world, r, bounds=bounds)[1]][0]
             expect = 1000.0 * owner + y + 0.25 * k
             reachable = (b0 - rows <= y < b1 + rows) and abs(owner - rank) <= 1
             val = float(img[y, 0, 0])
@@ -59,12 +80,12 @@ def _worker(rank, world, port, h, w, rows, q, defer=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,defer", [(2, False), (3, False), (2, True)])
-def test_halo_exchange_gloo(world, defer):
+@pytest.mark.parametrize("world,defer,bounds", [(2, False, None), (3, False, None), (2, True, None), (3, True, [0, 48, 200, 264])])
+def test_halo_exchange_gloo(world, defer, bounds):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 264, 16, 40, q, defer)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 264, 16, 40, q, defer, bounds)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
