@@ -216,8 +216,20 @@ HR_DEV float gaussian_weight(float offset, float deviation)
     return w * det_exp(__fdiv_rn(-(offset * offset), 2.0f * deviation * deviation));
 }
 
+#define AO_MAX_BLUR_RADIUS 32
+// RADIUS == 4 (the reference default, ray_traced_ao.h): unrolled, loads up front, weights computed back to back;
+// RADIUS < 0: run-time radius.
+template <int RADIUS>
 __global__ __launch_bounds__(256) void k_ao_blur(AOBlurArgs a)
 {
+    // gaussian_weight(i, radius / 1.5) depends on the tap index only: one lane per tap evaluates it once per workgroup
+    // (two divisions, a square root and an exp) instead of every pixel re-deriving all of them
+    __shared__ float s_gauss[2 * AO_MAX_BLUR_RADIUS + 1];
+    {
+        const int i = (int)threadIdx.x - a.radius;
+        if ((int)threadIdx.x <= 2 * a.radius) s_gauss[threadIdx.x] = gaussian_weight((float)i, __fdiv_rn((float)a.radius, 1.5f));
+    }
+    __syncthreads();
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= a.w || y >= a.y1) return;
@@ -226,25 +238,57 @@ __global__ __launch_bounds__(256) void k_ao_blur(AOBlurArgs a)
     if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) { a.out[o] = one; return; } // cleared image (:1048-1055)
     const float d = a.depth.p[o];
     if (d == 1.0f) { a.out[o] = one; return; }
-    const float deviation = __fdiv_rn((float)a.radius, 1.5f);
     float total_ao = h2f(a.in.p[o]), total_w = 1.0f;
     const float cd = linear_eye_depth(d, a.zbp);
     const uint2 g2 = a.gb2.p[o];
     const f3    cn = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
-    for (int i = -a.radius; i <= a.radius; i++)
+    if constexpr (RADIUS > 0)
     {
-        if (i == 0) continue;
-        const int   sx = x + a.dx * i, sy = y + a.dy * i;
-        const float sd = linear_eye_depth(a.depth.fetch(sx, sy), a.zbp);
-        const float sa = a.in.fetch(sx, sy);
-        const uint2 s2 = a.gb2.raw(sx, sy);
-        const f3    sn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
-        float w = gaussian_weight((float)i, deviation);
-        const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), 1.0f));
-        const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), 32.0f);
-        w = w * (det_exp((0.0f - 1.0f) - max2(wZ, 0.0f)) * wN);
-        total_ao += w * sa;
-        total_w += w;
+        constexpr int N = 2 * RADIUS;
+        float t_d[N], t_a[N];
+        uint2 t_g[N];
+#pragma unroll
+        for (int t = 0; t < N; t++)
+        {
+            const int i = t < RADIUS ? t - RADIUS : t - RADIUS + 1;
+            const int sx = x + a.dx * i, sy = y + a.dy * i;
+            t_d[t] = a.depth.fetch(sx, sy); t_a[t] = a.in.fetch(sx, sy); t_g[t] = a.gb2.raw(sx, sy);
+        }
+        float w8[N];
+#pragma unroll
+        for (int t = 0; t < N; t++)
+        {
+            const int   i  = t < RADIUS ? t - RADIUS : t - RADIUS + 1;
+            const float sd = linear_eye_depth(t_d[t], a.zbp);
+            const f3    sn = oct_decode(h2f_lo(t_g[t].x), h2f_hi(t_g[t].x));
+            const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), 1.0f));
+            const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), 32.0f);
+            w8[t] = s_gauss[i + RADIUS] * (det_exp((0.0f - 1.0f) - max2(wZ, 0.0f)) * wN);
+        }
+#pragma unroll
+        for (int t = 0; t < N; t++)
+        {
+            total_ao += w8[t] * t_a[t];
+            total_w += w8[t];
+        }
+    }
+    else
+    {
+        for (int i = -a.radius; i <= a.radius; i++)
+        {
+            if (i == 0) continue;
+            const int   sx = x + a.dx * i, sy = y + a.dy * i;
+            const float sd = linear_eye_depth(a.depth.fetch(sx, sy), a.zbp);
+            const float sa = a.in.fetch(sx, sy);
+            const uint2 s2 = a.gb2.raw(sx, sy);
+            const f3    sn = oct_decode(h2f_lo(s2.x), h2f_hi(s2.x));
+            float w = s_gauss[i + a.radius];
+            const float wZ = det_exp(__fdiv_rn(-fabsf(cd - sd), 1.0f));
+            const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), 32.0f);
+            w = w * (det_exp((0.0f - 1.0f) - max2(wZ, 0.0f)) * wN);
+            total_ao += w * sa;
+            total_w += w;
+        }
     }
     a.out[o] = f2h(__fdiv_rn(total_ao, max2(total_w, 0.0001f)));
 }
@@ -426,7 +470,8 @@ hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* pr
     a.dx = pass == 0 ? 1 : 0; a.dy = pass == 0 ? 0 : 1; a.radius = prm->blur_radius; // X first, then Y (quirk 8)
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin(pass == 0 ? "blur_x" : "blur_y", st, px * 16);
-    hipLaunchKernelGGL(k_ao_blur, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    if (a.radius == 4) hipLaunchKernelGGL(k_ao_blur<4>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_ao_blur<-1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -279,6 +279,9 @@ struct ReflAtrousArgs
     int            approximate_with_ddgi;
 };
 
+// RADIUS == 1 (the reference default): fully unrolled 3x3 stencil, every load issued up front and the eight tap weights
+// computed unconditionally before the ordered accumulation (see k_shadows_atrous); RADIUS < 0: run-time radius.
+template <int RADIUS>
 __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
@@ -306,8 +309,48 @@ __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
         {
             const f3    cn = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
             const float center_depth = h2f_hi(g3.y);
-            const float phi_c = a.phi_color * hr_sqrt(max2(0.0f, 1e-10f + var));
+            // one denominator, many numerators: share the denominator half of the correctly rounded divisions (device_math.h)
+            const DivBy phi_c = div_prepare(a.phi_color * hr_sqrt(max2(0.0f, 1e-10f + var))), by_sigma = div_prepare(a.sigma_depth);
             float sum_w = 1.0f, s0 = cc.x, s1 = cc.y, s2 = cc.z, s3 = h2f_hi(c.y);
+            if (RADIUS == 1)
+            {
+                uint2 t_in[8], t_g2[8], t_g3[8];
+                bool  t_ok[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                    const int px = x + xx * a.step, py = y + yy * a.step;
+                    t_ok[t] = px >= 0 && py >= 0 && px < a.w && py < a.h;
+                    t_in[t] = a.in.raw(px, py); t_g2[t] = a.gb2.raw(px, py); t_g3[t] = a.gb3.raw(px, py);
+                }
+                float w8[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const f3    sc = mk3(h2f_lo(t_in[t].x), h2f_hi(t_in[t].x), h2f_lo(t_in[t].y));
+                    const float sl = luminance(sc);
+                    const f3    sn = oct_decode(h2f_lo(t_g2[t].x), h2f_hi(t_g2[t].x));
+                    const float wZ = det_exp(div_by(-fabsf(center_depth - h2f_hi(t_g3[t].y)), by_sigma));
+                    const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
+                    const float wL = div_by(fabsf(center_luma - sl), phi_c);
+                    w8[t] = det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    if (!t_ok[t]) continue;
+                    const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                    const float kx = xx == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f), ky = yy == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f);
+                    const f3    sc = mk3(h2f_lo(t_in[t].x), h2f_hi(t_in[t].x), h2f_lo(t_in[t].y));
+                    const float wc = w8[t] * (kx * ky);
+                    sum_w += wc;
+                    s0 += wc * sc.x; s1 += wc * sc.y; s2 += wc * sc.z;
+                    s3 += (wc * wc) * h2f_hi(t_in[t].y);
+                }
+            }
+            else
+            {
             for (int yy = -a.radius; yy <= a.radius; yy++)
                 for (int xx = -a.radius; xx <= a.radius; xx++)
                 {
@@ -320,15 +363,16 @@ __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
                     const f3    sc = mk3(h2f_lo(s.x), h2f_hi(s.x), h2f_lo(s.y));
                     const float sl = luminance(sc);
                     const f3    sn = oct_decode(h2f_lo(q2.x), h2f_hi(q2.x));
-                    const float wZ = det_exp(__fdiv_rn(-fabsf(center_depth - h2f_hi(q3.y)), a.sigma_depth));
+                    const float wZ = det_exp(div_by(-fabsf(center_depth - h2f_hi(q3.y)), by_sigma));
                     const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
-                    const float wL = __fdiv_rn(fabsf(center_luma - sl), phi_c);
+                    const float wL = div_by(fabsf(center_luma - sl), phi_c);
                     const float w  = det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
                     const float wc = w * (kx * ky);
                     sum_w += wc;
                     s0 += wc * sc.x; s1 += wc * sc.y; s2 += wc * sc.z;
                     s3 += (wc * wc) * h2f_hi(s.y);
                 }
+            }
             result = make_uint2(pack_h2(__fdiv_rn(s0, sum_w), __fdiv_rn(s1, sum_w)), pack_h2(__fdiv_rn(s2, sum_w), __fdiv_rn(s3, sum_w * sum_w)));
         }
     }
@@ -508,7 +552,8 @@ hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inpu
     static const char* names[8] = { "atrous_0", "atrous_1", "atrous_2", "atrous_3", "atrous_4", "atrous_5", "atrous_6", "atrous_7" };
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin(names[i], st, px * 36);
-    hipLaunchKernelGGL(k_refl_atrous, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    if (a.radius == 1) hipLaunchKernelGGL(k_refl_atrous<1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_refl_atrous<-1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -380,7 +380,7 @@ struct AtrousArgs
 // edge_stopping.glsl:31-62 with NORMAL + LUMA weights.  FAST = the reference's default parameters
 // (phi_normal == 32, sigma_depth == 1): x / 1.0f == x and pow(x, 32) is five squarings — same bits, fewer ops.
 template <bool FAST>
-HR_DEV float edge_weight(float cd, float sd, float phi_z, f3 cn, f3 sn, float phi_n, float cl, float sl, float phi_l)
+HR_DEV float edge_weight(float cd, float sd, float phi_z, f3 cn, f3 sn, float phi_n, float cl, float sl, const DivBy& phi_l)
 {
     const float dz = -fabsf(cd - sd);
     const float wZ = det_exp(FAST ? dz : __fdiv_rn(dz, phi_z));
@@ -388,7 +388,7 @@ HR_DEV float edge_weight(float cd, float sd, float phi_z, f3 cn, f3 sn, float ph
     float wN;
     if (FAST) { float b = dn * dn; b = b * b; b = b * b; b = b * b; wN = b * b; } // det_powi(dn, 32): r = 1 * b^32
     else wN = det_pow_auto(dn, phi_n);
-    const float wL = __fdiv_rn(fabsf(cl - sl), phi_l);
+    const float wL = div_by(fabsf(cl - sl), phi_l);   // correctly rounded, denominator work shared by the taps of a pixel
     return det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
 }
 
@@ -444,11 +444,18 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
     else
     {
         const f3    cn    = mk3(cnd.x, cnd.y, cnd.z);
-        const float phi_v = a.phi_visibility * hr_sqrt(max2(0.0f, 1e-10f + var));
+        const DivBy phi_v = div_prepare(a.phi_visibility * hr_sqrt(max2(0.0f, 1e-10f + var)));
         float sum_w = 1.0f, sum_v = cv, sum_var = h2f_hi(c);
         if (RADIUS == 1)
         {
-            // arithmetic in the reference's accumulation order (yy outer, xx inner); loads were issued above
+            // Weights of all eight taps first, UNCONDITIONALLY (a tap outside the image was loaded as zeros: finite math,
+            // weight unused) — the eight dependent exp -> divide -> exp chains then interleave instead of running one
+            // after the other behind per-tap branches; measured 25.3 -> 22.8 us per iteration.  The accumulation below
+            // keeps the reference's order (yy outer, xx inner) and skips the outside taps.
+            float w8[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                w8[t] = edge_weight<FAST>(center_depth, t_nd[t].w, a.sigma_depth, cn, mk3(t_nd[t].x, t_nd[t].y, t_nd[t].z), a.phi_normal, cv, h2f_lo(t_in[t]), phi_v);
 #pragma unroll
             for (int t = 0; t < 8; t++)
             {
@@ -456,8 +463,7 @@ __global__ __launch_bounds__(256) void k_shadows_atrous(AtrousArgs a)
                 const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                 const float kx = xx == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f), ky = yy == 0 ? 1.0f : __fdiv_rn(2.0f, 3.0f);
                 const float sv = h2f_lo(t_in[t]);
-                const float w  = edge_weight<FAST>(center_depth, t_nd[t].w, a.sigma_depth, cn, mk3(t_nd[t].x, t_nd[t].y, t_nd[t].z), a.phi_normal, cv, sv, phi_v);
-                const float wv = w * (kx * ky);
+                const float wv = w8[t] * (kx * ky);
                 sum_w += wv;
                 sum_v += wv * sv;
                 sum_var += (wv * wv) * h2f_hi(t_in[t]);
