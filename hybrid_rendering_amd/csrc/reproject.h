@@ -77,6 +77,10 @@ struct ReprojIn
     ImgRGBA16F   gb2, gb3, pgb2, pgb3;
     ImgR32F      pdepth;
     int          w, h;
+    // optional: the caller has already fetched / decoded the centre pixel (shadows: it also stores the decoded normal)
+    bool         has_center = false;
+    uint2        c2, c3;
+    f3           cur_n;
 };
 
 // HistT: ImgRG16F (shadows: r = visibility), ImgR16F (AO), ImgRGBA16F (reflections rgb)
@@ -86,9 +90,9 @@ HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& h
     const int   w = in.w, h = in.h;
     const float fw = (float)w, fh = (float)h;
     const float tu = __fdiv_rn((float)in.x + 0.5f, fw), tv = __fdiv_rn((float)in.y + 0.5f, fh);
-    const uint2 c2 = in.gb2.raw(in.x, in.y), c3 = in.gb3.raw(in.x, in.y);
+    const uint2 c2 = in.has_center ? in.c2 : in.gb2.raw(in.x, in.y), c3 = in.has_center ? in.c3 : in.gb3.raw(in.x, in.y);
     const float mvx = h2f_lo(c2.y), mvy = h2f_hi(c2.y);
-    const f3    cur_n   = oct_decode(h2f_lo(c2.x), h2f_hi(c2.x));
+    const f3    cur_n   = in.has_center ? in.cur_n : oct_decode(h2f_lo(c2.x), h2f_hi(c2.x));
     const float cur_id  = h2f_lo(c3.y);
     const f3    cur_pos = world_pos_from_depth(tu, tv, in.depth, in.vpi);
 

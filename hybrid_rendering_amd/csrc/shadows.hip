@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
     if (in_image)
     {
         const float d = a.depth.p[(size_t)y * a.w + x];
+        // centre G-buffer texel: fetched and decoded ONCE, for the reprojection and for the a-trous iterations (nd)
+        const uint2 cg2 = a.gb2.p[(size_t)y * a.w + x], cg3 = a.gb3.p[(size_t)y * a.w + x];
+        const f3    cn  = oct_decode(h2f_lo(cg2.x), h2f_hi(cg2.x));
         if (d != 1.0f)
         {
             const int   cry = ly + 8, crx = lx + 8;
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             in.x = x; in.y = y; in.depth = d; in.vpi = a.vpi; // kernel argument => scalar registers
             in.gb2 = a.gb2; in.gb3 = a.gb3; in.pgb2 = a.pgb2; in.pgb3 = a.pgb3; in.pdepth = a.pdepth;
             in.w = a.w; in.h = a.h;
+            in.has_center = true; in.c2 = cg2; in.c3 = cg3; in.cur_n = cn;
             float hv, hm[2];
             ImgR16F none { nullptr, 0, 0, 0 };
             bool success = false;
@@ -351,12 +355,8 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             flag    = out_v > 0.0f;
         }
         a.out_moments[(size_t)y * a.w + x] = make_uint2(pack_h2(m0, m1), pack_h2(hlen, 0.0f));
-        {
-            // the a-trous iterations read every pixel's normal 9x4 times: decode it once here
-            const uint2 cg2 = a.gb2.p[(size_t)y * a.w + x], cg3 = a.gb3.p[(size_t)y * a.w + x];
-            const f3    cn  = oct_decode(h2f_lo(cg2.x), h2f_hi(cg2.x));
-            a.nd[(size_t)y * a.w + x] = make_float4(cn.x, cn.y, cn.z, h2f_hi(cg3.y));
-        }
+        // the a-trous iterations read every pixel's normal 9x4 times: store the decoded one
+        a.nd[(size_t)y * a.w + x] = make_float4(cn.x, cn.y, cn.z, h2f_hi(cg3.y));
         a.out[(size_t)y * a.w + x]         = pack_h2(out_v, out_var);
     }
     // tile classification (:275-291): any lit pixel => the tile needs the à-trous filter
