@@ -251,12 +251,18 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
         {
-            const uint32_t i = (uint32_t)__builtin_ctz(trimask);
+            // two triangles per iteration: both fetches in flight together, both tests back to back (AO trace -2.5%)
+            const uint32_t i0 = (uint32_t)__builtin_ctz(trimask);
             trimask &= trimask - 1u;
-            const TriRaw tri = load_tri_raw(tris, h.tri_base + i);
-            if (STATS) n_tris++;
+            const bool     two = trimask != 0u;
+            const uint32_t i1  = two ? (uint32_t)__builtin_ctz(trimask) : i0;
+            trimask &= trimask - 1u;   // no-op on 0
+            const TriRaw ta = load_tri_raw(tris, h.tri_base + i0), tb = load_tri_raw(tris, h.tri_base + i1);
+            if (STATS) n_tris += two ? 2u : 1u;
             float t, u, v;
-            if (ray_tri_raw<false>(r, tri, t_min, t_max, t, u, v)) { hit = true; break; }
+            const bool ha = ray_tri_raw<false>(r, ta, t_min, t_max, t, u, v);
+            const bool hb = ray_tri_raw<false>(r, tb, t_min, t_max, t, u, v);
+            if (ha || hb) { hit = true; break; }
         }
         if (hit) break;
     }
