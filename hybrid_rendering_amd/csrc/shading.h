@@ -225,6 +225,8 @@ HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& 
     float sum_w   = 0.0f;
     const f3 alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
                          clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
+    // deliberately NOT unrolled: fully unrolled the eight probes' fetches overlap, but the kernels that inline this need
+    // 168-178 VGPRs (2-3 waves per SIMD) — DDGI trace 0.43 -> 0.69 ms, reflections trace 0.31 -> 0.47 ms, sample pass unchanged
     for (int i = 0; i < 8; ++i)
     {
         const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
