@@ -121,6 +121,7 @@ __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
     const float ncx = ((float)lx + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f, ncy = ((float)ly + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f;
     const f3  texel_dir = gi_oct_decode(ncx, ncy);
     float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, total_w = 0.0f;
+    const bool sharp50 = a.d.depth_sharpness == 50.0f;
     for (int offset = 0; offset < R; offset += CACHE)
     {
         const int num = (R - offset) < CACHE ? (R - offset) : CACHE;
@@ -144,7 +145,10 @@ __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
             {
                 float dist = min2(a.d.max_distance, dd.w - 0.01f);
                 if (dist == -1.0f) dist = a.d.max_distance;
-                const float w = det_pow_auto(dp, a.d.depth_sharpness);
+                // depth_sharpness = 50 (ddgi.h default): the multiplications det_powi performs for n = 50, written out
+                float w;
+                if (sharp50) { const float b2 = dp * dp, b4 = b2 * b2, b8 = b4 * b4, b16 = b8 * b8, b32 = b16 * b16; w = ((1.0f * b2) * b16) * b32; }
+                else w = det_pow_auto(dp, a.d.depth_sharpness);
                 if (w >= 0.00000001f) { r0 += dist * w; r1 += (dist * dist) * w; total_w += w; }
             }
             else

@@ -267,6 +267,13 @@ __global__ __launch_bounds__(256) void k_refl_temporal(ReflTemporalArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// pow(x, phi_normal): phi_normal = 32 (the reference default) is five squarings — the multiplications det_powi does for n = 32
+HR_DEV float pow_phi_normal(float x, float p)
+{
+    if (p == 32.0f) { float b = x * x; b = b * b; b = b * b; b = b * b; return 1.0f * (b * b); }
+    return det_pow_auto(x, p);
+}
+
 struct ReflAtrousArgs
 {
     ImgRGBA16F     in, gb2, gb3;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
                     const float sl = luminance(sc);
                     const f3    sn = oct_decode(h2f_lo(t_g2[t].x), h2f_hi(t_g2[t].x));
                     const float wZ = det_exp(div_by(-fabsf(center_depth - h2f_hi(t_g3[t].y)), by_sigma));
-                    const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
+                    const float wN = pow_phi_normal(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
                     const float wL = div_by(fabsf(center_luma - sl), phi_c);
                     w8[t] = det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
                 }
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
                     const float sl = luminance(sc);
                     const f3    sn = oct_decode(h2f_lo(q2.x), h2f_hi(q2.x));
                     const float wZ = det_exp(div_by(-fabsf(center_depth - h2f_hi(q3.y)), by_sigma));
-                    const float wN = det_pow_auto(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
+                    const float wN = pow_phi_normal(clamp1(dot3(cn, sn), 0.0f, 1.0f), a.phi_normal);
                     const float wL = div_by(fabsf(center_luma - sl), phi_c);
                     const float w  = det_exp((0.0f - max2(wL, 0.0f)) - max2(wZ, 0.0f)) * wN;
                     const float wc = w * (kx * ky);
