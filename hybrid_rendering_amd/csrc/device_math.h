@@ -231,7 +231,7 @@ HR_DEV float sample_blue_noise(int cx, int cy, int sample_index, int dim, const 
     int      ranked = sample_index ^ (int)((t >> 16) & 0xffu);
     int      value  = (int)sobol[ranked * 4 + dim];
     value ^= (int)((t >> ((dim & 1) * 8)) & 0xffu);
-    return __fdiv_rn(0.5f + (float)value, 256.0f);
+    return (0.5f + (float)value) * 0.00390625f;   // / 256: a power of two, so the product is the correctly rounded quotient
 }
 
 } // namespace hr

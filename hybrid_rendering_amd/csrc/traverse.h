@@ -53,7 +53,8 @@ HR_DEV RayPre ray_prepare(f3 o, f3 d)
     float dx_ = fabsf(d.x) < tiny ? (d.x < 0.0f ? -tiny : tiny) : d.x;
     float dy_ = fabsf(d.y) < tiny ? (d.y < 0.0f ? -tiny : tiny) : d.y;
     float dz_ = fabsf(d.z) < tiny ? (d.z < 0.0f ? -tiny : tiny) : d.z;
-    r.idx = __frcp_rn(dx_); r.idy = __frcp_rn(dy_); r.idz = __frcp_rn(dz_);
+    // box-test side: only has to be conservative (padded boxes, scaled far plane), so the 1-ulp hardware reciprocal will do
+    r.idx = __builtin_amdgcn_rcpf(dx_); r.idy = __builtin_amdgcn_rcpf(dy_); r.idz = __builtin_amdgcn_rcpf(dz_);
     r.sel = (dx_ < 0.0f ? 1u : 0u) | (dy_ < 0.0f ? 2u : 0u) | (dz_ < 0.0f ? 4u : 0u);
     return r;
 }
