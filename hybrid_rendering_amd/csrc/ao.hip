@@ -47,12 +47,15 @@ struct AOTraceArgs
     int                spp;
 };
 
+#ifndef AO_TRACE_WAVES
+#define AO_TRACE_WAVES 1   // waves (8x8 tiles) per workgroup, see k_shadows_trace: finished waves' slots back-fill at once
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_ao_trace(AOTraceArgs a)
+__global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
 {
-    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ uint32_t s_stack[AO_TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * AO_TRACE_WAVES + wave;
     if (tile >= a.tiles_x * a.tiles_y) return;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
@@ -396,12 +399,12 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
     {
-        hipLaunchKernelGGL(k_ao_trace<true>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_ao_trace<true>, dim3(cdiv(n_tiles, AO_TRACE_WAVES)), dim3(64 * AO_TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px * prm->spp / 8);
-    hipLaunchKernelGGL(k_ao_trace<false>, dim3(cdiv(n_tiles, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_ao_trace<false>, dim3(cdiv(n_tiles, AO_TRACE_WAVES)), dim3(64 * AO_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -43,12 +43,15 @@ struct DDGITraceArgs
 };
 
 // one thread per (probe, ray); a wave covers 64 consecutive rays of one probe
-__global__ __launch_bounds__(256) void k_ddgi_trace(DDGITraceArgs a)
+#ifndef DDGI_TRACE_WAVES
+#define DDGI_TRACE_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceArgs a)
 {
-    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ uint32_t s_stack[DDGI_TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = a.d.rays_per_probe;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gid = (long long)blockIdx.x * (64 * DDGI_TRACE_WAVES) + threadIdx.x;
     const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
     uint32_t  rays = 0;
     if (probe < a.n_probes)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k_ddgi_trace(DDGITraceArgs a)
         a.dirdist[o]  = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
     }
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
-    if (lane == 0) a.ray_slots[blockIdx.x * 4 + wave] = rays;
+    if (lane == 0) a.ray_slots[blockIdx.x * DDGI_TRACE_WAVES + wave] = rays;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,7 +365,8 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     a.probe_begin = p->z0 * slab; a.n_probes = p->z1 * slab;
     const long long n = (long long)(a.n_probes - a.probe_begin) * p->d.rays_per_probe;
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
-    hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    const int tb = 64 * DDGI_TRACE_WAVES;
+    hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

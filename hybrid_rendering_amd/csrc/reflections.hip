@@ -83,11 +83,14 @@ struct ReflTraceArgs
     float          gi_intensity, rough_ddgi_intensity, ibl_intensity;
 };
 
-__global__ __launch_bounds__(256) void k_refl_trace(ReflTraceArgs a)
+#ifndef REFL_TRACE_WAVES
+#define REFL_TRACE_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * REFL_TRACE_WAVES) void k_refl_trace(ReflTraceArgs a)
 {
-    __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * REFL_TRACE_WAVES + wave;
     if (tile >= a.tiles_x * a.tiles_y) return;
     const int x = (tile % a.tiles_x) * 8 + (lane & 7), y = (tile / a.tiles_x + a.tile_y0) * 8 + (lane >> 3);
     uint32_t  rays = 0;
@@ -504,7 +507,7 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     a.gi_intensity = prm->gi_intensity; a.rough_ddgi_intensity = prm->rough_ddgi_intensity; a.ibl_intensity = prm->ibl_indirect_specular_intensity;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     int ev = p->prof.begin("ray_trace", st, px * 28);
-    hipLaunchKernelGGL(k_refl_trace, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_refl_trace, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
