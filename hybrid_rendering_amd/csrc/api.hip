@@ -249,7 +249,7 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
     HR_HIP(hipSetDevice(ctx->device));
     BuiltBVH b;
     build_bvh8(d->positions, d->n_tris, b);
-    if (b.nodes.size() >= (1u << 24)) return HR_ERR_UNSUPPORTED;   // traversal stack entries hold child_base in 24 bits
+    if (b.nodes.size() >= (1u << 23)) return HR_ERR_UNSUPPORTED;   // traversal stack entries hold child_base in 23 bits
     hr_scene* s = new hr_scene();
     s->ctx      = ctx;
     hr_status st;

@@ -351,7 +351,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         }
         // slots: internal children first (slot i <-> node child_base + i), then the leaves — the traversal keeps
         // one (child_base, hit mask) stack entry per node instead of one entry per child
-        std::stable_partition(kids, kids + nk, [&](int32_t k) { return B.n2[k].a >= 0; });
+        int32_t* kids_mid = std::stable_partition(kids, kids + nk, [&](int32_t k) { return B.n2[k].a >= 0; });
         Box nb;
         for (int i = 0; i < nk; i++) nb.add(B.n2[kids[i]].box);
         Node8 n;
@@ -361,6 +361,18 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         n.ey = exponent_for(nb.hi[1] - nb.lo[1]);
         n.ez = exponent_for(nb.hi[2] - nb.lo[2]);
         const uint8_t eb[3] = { n.ex, n.ey, n.ez };
+        {
+            // Internal children are ordered along the node's longest axis — the axis with the largest scale exponent, first
+            // one on ties, which the traversal re-derives from the exponent bytes — so that a ray can walk them near to far
+            // (ascending slots for a positive direction component, descending for a negative one).
+            int ax = 0;
+            if (eb[1] > eb[0]) ax = 1;
+            if (eb[2] > eb[ax]) ax = 2;
+            std::stable_sort(kids, kids_mid, [&](int32_t x, int32_t y) {
+                const Box& bx = B.n2[x].box; const Box& by = B.n2[y].box;
+                return (double)bx.lo[ax] + bx.hi[ax] < (double)by.lo[ax] + by.hi[ax];
+            });
+        }
         n.child_base = (uint32_t)out.nodes.size();
         n.tri_base   = (uint32_t)out.tris.size();
         int n_internal = 0;

@@ -97,6 +97,7 @@ struct NodeHits
     uint32_t meta_lo, meta_hi;
     uint32_t hit8;        // bit i set => child i's box is hit
     uint32_t n_internal;  // slots 0..n_internal-1 are internal nodes child_base + i
+    uint32_t rev;         // 1: the ray runs against the axis the internal children are sorted along -> visit high slots first
 };
 
 // Tests the 8 quantised child boxes of a node.  t_far is the current far limit.  (Packed v_pk_fma_f32 for the
@@ -111,6 +112,7 @@ HR_DEV NodeRaw load_node(const Node8* __restrict__ nodes, uint32_t ni)
     return n;
 }
 
+template <bool ORDERED>
 HR_DEV NodeHits test_node(const NodeRaw& n, const RayPre& r, float t_near, float t_far)
 {
     const uint4 q0 = n.q0, q1 = n.q1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
@@ -128,6 +130,15 @@ HR_DEV NodeHits test_node(const NodeRaw& n, const RayPre& r, float t_near, float
     NodeHits h;
     h.child_base = q1.x; h.tri_base = q1.y; h.meta_lo = q1.z; h.meta_hi = q1.w;
     h.n_internal = (q0.w >> 24) & 15u;
+    h.rev = 0u;
+    if (ORDERED)
+    {
+        // axis of the largest scale exponent (first on ties) = the builder's sort axis for the internal children
+        const uint32_t ex = q0.w & 0xffu, ey = (q0.w >> 8) & 0xffu, ez = (q0.w >> 16) & 0xffu;
+        uint32_t ax = ey > ex ? 1u : 0u;
+        if (ez > (ax ? ey : ex)) ax = 2u;
+        h.rev = (r.sel >> ax) & 1u;
+    }
     uint32_t hits = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++)
@@ -197,9 +208,13 @@ HR_DEV bool ray_tri_raw(const RayPre& r, const TriRaw& q, float t_min, float t_m
                              mk3(__uint_as_float(q.c.x), __uint_as_float(q.c.y), __uint_as_float(q.c.z)), t_min, t_max, t, u, v);
 }
 
-// Depth-first walk with one stack entry per NODE: entry = child_base << 8 | mask of its hit internal children that
-// are still to be visited.  The entry being consumed stays in a register (`cur`); it goes to the stack only when a
+// Depth-first walk with one stack entry per NODE: entry = child_base << 9 | rev << 8 | mask of its hit internal children
+// that are still to be visited (rev: take the highest slot first — the children are sorted along the node's longest axis
+// and the ray runs against it).  The entry being consumed stays in a register (`cur`); it goes to the stack only when a
 // newly tested node has internal hits of its own while `cur` still has siblings left.
+// ORDERED (closest hit): near-to-far order pays — reflections trace 0.28 -> 0.26 ms; any-hit queries skip it (their answer
+// does not improve with order, and the extra instructions cost 5-7% there).
+template <bool ORDERED>
 HR_DEV bool walk_next(uint32_t& cur, LaneStack& st, uint32_t& ni)
 {
     if ((cur & 0xffu) == 0u)
@@ -207,9 +222,10 @@ HR_DEV bool walk_next(uint32_t& cur, LaneStack& st, uint32_t& ni)
         if (st.sp == 0) return false;
         cur = st.pop();
     }
-    const uint32_t i = (uint32_t)__builtin_ctz(cur);
-    cur &= cur - 1u;
-    ni = (cur >> 8) + i;
+    const uint32_t m = cur & 0xffu;
+    const uint32_t i = (ORDERED && (cur & 0x100u)) ? 31u - (uint32_t)__builtin_clz(m) : (uint32_t)__builtin_ctz(m);
+    cur &= ~(1u << i);
+    ni = (cur >> 9) + i;
     return true;
 }
 
@@ -221,7 +237,7 @@ HR_DEV uint32_t walk_expand(const NodeHits& h, uint32_t& cur, LaneStack& st)
     if (ih)
     {
         if (cur & 0xffu) st.push(cur);
-        cur = (h.child_base << 8) | ih;
+        cur = (h.child_base << 9) | (h.rev << 8) | ih;
     }
     uint32_t lh = h.hit8 & ~imask, trimask = 0;
     while (lh)
@@ -245,9 +261,9 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     st.init(wave_stack, lane, spill_array);
     uint32_t cur = 1u, ni;   // root = "child 0 of child_base 0"
     bool     hit = false;
-    while (walk_next(cur, st, ni))
+    while (walk_next<false>(cur, st, ni))
     {
-        const NodeHits h = test_node(load_node(nodes, ni), r, t_min, t_max);
+        const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
         if (STATS) n_nodes++;
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
@@ -294,8 +310,8 @@ template <bool STATS>
 HR_DEV int anyhit_step(AnyHitLane& s, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, uint32_t& n_nodes, uint32_t& n_tris)
 {
     uint32_t ni;
-    if (!walk_next(s.cur, s.st, ni)) return 2;
-    const NodeHits h  = test_node(load_node(nodes, ni), s.r, s.t_min, s.t_max);
+    if (!walk_next<false>(s.cur, s.st, ni)) return 2;
+    const NodeHits h  = test_node<false>(load_node(nodes, ni), s.r, s.t_min, s.t_max);
     if (STATS) n_nodes++;
     uint32_t trimask = walk_expand(h, s.cur, s.st);
     while (trimask)
@@ -330,10 +346,10 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
     uint32_t cur = 1u, ni;
     HitRec best;
     best.t = t_max; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
-    while (walk_next(cur, st, ni))
+    while (walk_next<true>(cur, st, ni))
     {
         const float    tfar = best.prim < 0 ? t_max : best.t * 1.0000005f;
-        const NodeHits h    = test_node(load_node(nodes, ni), r, t_min, tfar);
+        const NodeHits h    = test_node<true>(load_node(nodes, ni), r, t_min, tfar);
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
         {
