@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import helpers
+from hybrid_rendering_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -84,3 +85,31 @@ def test_ragged_size(oracle, hr, ctx):
 def test_params_variants(oracle, hr, ctx):
     _run_case(oracle, hr, ctx, "cornell", 128, 128, 3, 1.0, light_kind="soft",
               params=dict(filter_iterations=5, feedback_iteration=0, phi_normal=7.5, power=2.0, alpha=0.05, radius=2))
+
+
+def test_render_is_hipgraph_capturable(oracle, hr, ctx):
+    """render() only enqueues work on the caller's stream (no allocation, no synchronisation), so an integrator can capture
+    the frame into a hipGraph and replay it: three replays equal three eager calls from the same state."""
+    import torch
+    name, W, H = "sponza_small", 256, 144
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, W, H, 2, 1.0)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    gb = [helpers.to_cuda(f["gb"]) for f in frames]
+    eager, graphed = hr.RayTracedShadows(ctx, W, H), hr.RayTracedShadows(ctx, W, H)
+    fi0 = hr.frame_inputs(gb[0], gb[0], frames[0]["ubo"], 0, 0, sob_d, sr_d)
+    fi1 = hr.frame_inputs(gb[1], gb[0], frames[1]["ubo"], 1, 1, sob_d, sr_d)
+    for p in (eager, graphed):
+        p.render(gsc, fi0)                      # first frame (history reset) outside the graph
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.render(gsc, fi1)                # captured on torch's capture stream, not executed
+    for _ in range(3):
+        eager.render(gsc, fi1)
+        g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(helpers.bits16(eager.output(hr.OUTPUT_ATROUS)), helpers.bits16(graphed.output(hr.OUTPUT_ATROUS)))
+    assert np.array_equal(helpers.bits16(eager.image(eager.IMG_MOMENTS1)), helpers.bits16(graphed.image(graphed.IMG_MOMENTS1)))
