@@ -13,14 +13,17 @@ namespace hr {
 // image accessors: tightly packed row-major.  `p` is the address of the (possibly virtual) row 0 of
 // the full-frame image; rows [y0, y1) are resident (whole frame: y0 = 0, y1 = height; a row band on
 // one GPU of a tiled frame: band + halo).  Texels outside [0,w) x [y0,y1) read as 0.
+// Branch-free: an outside tap loads the first resident texel and the result is replaced by 0 — a guarded load costs a
+// saveexec / branch pair per tap and keeps the taps of a stencil from being issued together.
 struct ImgRGBA16F
 {
     const uint2* p;
     int          w, y0, y1;
     HR_DEV uint2 raw(int x, int y) const
     {
-        if (x < 0 || y < y0 || x >= w || y >= y1) return make_uint2(0u, 0u);
-        return p[(size_t)y * w + x];
+        const bool  ok = !(x < 0 || y < y0 || x >= w || y >= y1);
+        const uint2 v  = p[ok ? (size_t)y * w + x : (size_t)y0 * w];
+        return ok ? v : make_uint2(0u, 0u);
     }
 };
 struct ImgRG16F
@@ -29,8 +32,9 @@ struct ImgRG16F
     int             w, y0, y1;
     HR_DEV uint32_t raw(int x, int y) const
     {
-        if (x < 0 || y < y0 || x >= w || y >= y1) return 0u;
-        return p[(size_t)y * w + x];
+        const bool     ok = !(x < 0 || y < y0 || x >= w || y >= y1);
+        const uint32_t v  = p[ok ? (size_t)y * w + x : (size_t)y0 * w];
+        return ok ? v : 0u;
     }
 };
 struct ImgR16F
@@ -39,8 +43,9 @@ struct ImgR16F
     int             w, y0, y1;
     HR_DEV float fetch(int x, int y) const
     {
-        if (x < 0 || y < y0 || x >= w || y >= y1) return 0.0f;
-        return h2f(p[(size_t)y * w + x]);
+        const bool     ok = !(x < 0 || y < y0 || x >= w || y >= y1);
+        const uint16_t v  = p[ok ? (size_t)y * w + x : (size_t)y0 * w];
+        return ok ? h2f(v) : 0.0f;
     }
 };
 struct ImgR32F
@@ -49,8 +54,9 @@ struct ImgR32F
     int          w, y0, y1;
     HR_DEV float fetch(int x, int y) const
     {
-        if (x < 0 || y < y0 || x >= w || y >= y1) return 0.0f;
-        return p[(size_t)y * w + x];
+        const bool  ok = !(x < 0 || y < y0 || x >= w || y >= y1);
+        const float v  = p[ok ? (size_t)y * w + x : (size_t)y0 * w];
+        return ok ? v : 0.0f;
     }
 };
 
