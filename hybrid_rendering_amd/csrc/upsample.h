@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256) void k_upsample(UpsampleArgs a)
 #pragma unroll
     for (int c = 0; c < CH; c++) up[c] = 0.0f;
     float total_w = 0.0f;
+    // all twelve texels of the four low-resolution taps first (clamped addresses: always valid), then the weights
+    uint2    t3[4], t2[4];
+    uint16_t tin[4][CH];
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
@@ -55,17 +58,23 @@ __global__ __launch_bounds__(256) void k_upsample(UpsampleArgs a)
         sx = sx < 0 ? 0 : (sx > a.w - 1 ? a.w - 1 : sx);
         sy = sy < 0 ? 0 : (sy > a.h - 1 ? a.h - 1 : sy);
         const size_t so = (size_t)sy * a.w + sx;
-        const float  cd = h2f_hi(a.g3[so].y);
+        t3[i] = a.g3[so]; t2[i] = a.g2[so];
+        const uint16_t* ip = (const uint16_t*)a.in + so * a.in_channels;
+#pragma unroll
+        for (int c = 0; c < CH; c++) tin[i][c] = ip[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const float cd = h2f_hi(t3[i].y);
         if (cd == -1.0f) continue;
-        const uint2 c2 = a.g2[so];
-        const f3    cn = oct_decode(h2f_lo(c2.x), h2f_hi(c2.x));
+        const f3    cn = oct_decode(h2f_lo(t2[i].x), h2f_hi(t2[i].x));
         // compute_edge_stopping_weight, NORMAL weight only: wL = 1.0 (edge_stopping.glsl:53-59)
         const float wZ = det_exp(__fdiv_rn(-fabsf(hi_depth - cd), 1.0f));
         const float wN = det_pow_auto(clamp1(dot3(hn, cn), 0.0f, 1.0f), 32.0f);
         const float wt = det_exp((0.0f - 1.0f) - max2(wZ, 0.0f)) * wN;
-        const uint16_t* ip = (const uint16_t*)a.in + so * a.in_channels;
 #pragma unroll
-        for (int c = 0; c < CH; c++) up[c] += h2f(ip[c]) * wt;
+        for (int c = 0; c < CH; c++) up[c] += h2f(tin[i][c]) * wt;
         total_w += wt;
     }
 #pragma unroll
