@@ -222,17 +222,20 @@ HR_DEV float luminance(f3 rgb) { return max2(dot3(rgb, mk3(0.299f, 0.587f, 0.114
 
 // bnd_sampler.glsl:4-24.  int(clamp(unorm8 * 256, 0, 255)) is the identity on 0..255
 // (tests/test_oracle_kat.py::test_unorm8_identity), so the byte is used directly.
-HR_DEV float sample_blue_noise(int cx, int cy, int sample_index, int dim, const uint8_t* __restrict__ sobol, const uint8_t* __restrict__ sr)
+// the scrambling / ranking texel of a pixel depends on (x, y) only: kernels fetch it up front, next to the G-buffer texels
+HR_DEV uint32_t blue_noise_texel(int cx, int cy, const uint8_t* __restrict__ sr) { return *(const uint32_t*)(sr + (((cy & 127) * 128 + (cx & 127)) << 2)); }
+HR_DEV float sample_blue_noise_t(uint32_t t, int sample_index, int dim, const uint8_t* __restrict__ sobol)
 {
-    cx &= 127;
-    cy &= 127;
     sample_index &= 255;
     dim &= 3;
-    uint32_t t      = *(const uint32_t*)(sr + ((cy * 128 + cx) << 2));
-    int      ranked = sample_index ^ (int)((t >> 16) & 0xffu);
-    int      value  = (int)sobol[ranked * 4 + dim];
+    int ranked = sample_index ^ (int)((t >> 16) & 0xffu);
+    int value  = (int)sobol[ranked * 4 + dim];
     value ^= (int)((t >> ((dim & 1) * 8)) & 0xffu);
     return (0.5f + (float)value) * 0.00390625f;   // / 256: a power of two, so the product is the correctly rounded quotient
+}
+HR_DEV float sample_blue_noise(int cx, int cy, int sample_index, int dim, const uint8_t* __restrict__ sobol, const uint8_t* __restrict__ sr)
+{
+    return sample_blue_noise_t(blue_noise_texel(cx, cy, sr), sample_index, dim, sobol);
 }
 
 } // namespace hr

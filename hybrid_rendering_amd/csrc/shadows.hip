@@ -57,18 +57,25 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool      lit = false, fired = false;
     uint32_t  nn = 0, nt = 0, wave_max = 0;
-    if (x < a.w && y >= a.y0 && y < a.y1)
+    // depth, normal and blue-noise texel of the pixel in ONE round trip (a lane outside the image reads a valid address and
+    // ignores the values) instead of depth -> normal -> noise one after the other
+    const bool   in_img = x < a.w && y >= a.y0 && y < a.y1;
+    const size_t pix    = in_img ? (size_t)y * a.w + x : (size_t)a.y0 * a.w;
+    const float    d_pre  = a.depth[pix];
+    const uint2    g2_pre = a.gb2[pix];
+    const uint32_t bn_pre = blue_noise_texel(x, y, a.sr);
+    if (in_img)
     {
-        const float d = a.depth[(size_t)y * a.w + x];
+        const float d = d_pre;
         if (d != 1.0f)
         {
             const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
             const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
-            const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+            const uint2 g2 = g2_pre;
             const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
             const f3    ro = add3(P, scale3(N, a.bias));
-            const float r0 = sample_blue_noise(x, y, (int)a.num_frames, 0, a.sobol, a.sr);
-            const float r1 = sample_blue_noise(x, y, (int)a.num_frames, 1, a.sobol, a.sr);
+            const float r0 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 0, a.sobol);
+            const float r1 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 1, a.sobol);
             f3    Wi;
             float t_max, att;
             fetch_light_shadow(a.light, P, N, r0, r1, Wi, t_max, att);
