@@ -1,0 +1,251 @@
+// C++ host example: one hybrid frame loop through include/hr/passes.hpp in the order of the reference's render loop
+// (src/main.cpp:74-99): shadows, AO, DDGI, reflections, deferred composite, TAA — plus the ground-truth accumulator —
+// on a Cornell-style box, three frames with a moving camera.  No Python, no torch: hipMalloc + the C ABI.
+//
+//   hipcc -std=c++17 -I include examples/hybrid_frame.cpp -L hybrid_rendering_amd -lhybrid_rendering_amd \
+//         -Wl,-rpath,$PWD/hybrid_rendering_amd -o /tmp/hybrid_frame && /tmp/hybrid_frame
+#include <hr/passes.hpp>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+void quad(std::vector<float>& v, std::vector<uint32_t>& mat, uint32_t m, V3 a, V3 b, V3 c, V3 d)
+{
+    const V3 t[6] = { a, b, c, a, c, d };
+    for (const V3& p : t) { v.push_back(p.x); v.push_back(p.y); v.push_back(p.z); }
+    mat.push_back(m); mat.push_back(m);
+}
+
+void mul(const float* A, const float* B, float* C)
+{
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+        {
+            float s = 0;
+            for (int k = 0; k < 4; k++) s += A[k * 4 + r] * B[c * 4 + k];
+            C[c * 4 + r] = s;
+        }
+}
+bool invert(const float* m, float* inv)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][4 + c] = r == c; }
+    for (int i = 0; i < 4; i++)
+    {
+        int p = i;
+        for (int r = i + 1; r < 4; r++) if (std::fabs(a[r][i]) > std::fabs(a[p][i])) p = r;
+        if (std::fabs(a[p][i]) < 1e-12) return false;
+        for (int c = 0; c < 8; c++) std::swap(a[i][c], a[p][c]);
+        const double d = a[i][i];
+        for (int c = 0; c < 8; c++) a[i][c] /= d;
+        for (int r = 0; r < 4; r++)
+            if (r != i) { const double f = a[r][i]; for (int c = 0; c < 8; c++) a[r][c] -= f * a[i][c]; }
+    }
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) inv[c * 4 + r] = (float)a[r][4 + c];
+    return true;
+}
+
+uint16_t f2h(float f) // round to nearest even, finite inputs of moderate size only
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    int32_t  e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t m = u & 0x7fffffu;
+    if (e <= 0) return (uint16_t)sign;
+    if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+    uint32_t h = (uint32_t)(e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+float h2f(uint16_t h)
+{
+    const uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m | 0x400u), (int)e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); return 2; } } while (0)
+
+template <typename T>
+T* upload(const std::vector<T>& v)
+{
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return (T*)d;
+}
+
+// mean of channel `c` (of `nch` half channels) over an image view
+double mean_of(const hr::ImageView& v, int nch, int c)
+{
+    std::vector<uint16_t> h((size_t)v.width * v.height * nch);
+    (void)hipMemcpy(h.data(), v.data, h.size() * 2, hipMemcpyDeviceToHost);
+    double s = 0;
+    for (size_t i = 0; i < (size_t)v.width * v.height; i++) s += h2f(h[i * nch + c]);
+    return s / ((double)v.width * v.height);
+}
+
+} // namespace
+
+int main()
+{
+    const int W = 320, H = 192;
+    // ---- scene: Cornell-style room with two boxes; materials: white, red, green, polished grey ----------------------
+    std::vector<float>    v;
+    std::vector<uint32_t> mat;
+    const float S = 100.0f;
+    quad(v, mat, 0, { 0, 0, 0 }, { 0, 0, S }, { S, 0, S }, { S, 0, 0 });
+    quad(v, mat, 0, { 0, S, 0 }, { S, S, 0 }, { S, S, S }, { 0, S, S });
+    quad(v, mat, 0, { 0, 0, 0 }, { S, 0, 0 }, { S, S, 0 }, { 0, S, 0 });
+    quad(v, mat, 1, { 0, 0, 0 }, { 0, S, 0 }, { 0, S, S }, { 0, 0, S });
+    quad(v, mat, 2, { S, 0, 0 }, { S, 0, S }, { S, S, S }, { S, S, 0 });
+    auto box = [&](uint32_t m, V3 lo, V3 hi) {
+        quad(v, mat, m, { lo.x, lo.y, lo.z }, { lo.x, lo.y, hi.z }, { lo.x, hi.y, hi.z }, { lo.x, hi.y, lo.z });
+        quad(v, mat, m, { hi.x, lo.y, lo.z }, { hi.x, hi.y, lo.z }, { hi.x, hi.y, hi.z }, { hi.x, lo.y, hi.z });
+        quad(v, mat, m, { lo.x, hi.y, lo.z }, { lo.x, hi.y, hi.z }, { hi.x, hi.y, hi.z }, { hi.x, hi.y, lo.z });
+        quad(v, mat, m, { lo.x, lo.y, lo.z }, { lo.x, hi.y, lo.z }, { hi.x, hi.y, lo.z }, { hi.x, lo.y, lo.z });
+        quad(v, mat, m, { lo.x, lo.y, hi.z }, { hi.x, lo.y, hi.z }, { hi.x, hi.y, hi.z }, { lo.x, hi.y, hi.z });
+    };
+    box(0, { 15, 0, 15 }, { 45, 60, 45 });
+    box(3, { 55, 0, 50 }, { 85, 30, 80 });
+    const float materials[4][8] = { { 0.75f, 0.75f, 0.75f, 0, 0.6f, 0, 0, 0 }, { 0.7f, 0.1f, 0.1f, 0, 0.6f, 0, 0, 0 },
+                                    { 0.1f, 0.7f, 0.1f, 0, 0.6f, 0, 0, 0 }, { 0.6f, 0.6f, 0.65f, 1.0f, 0.15f, 0, 0, 0 } };
+    const int n_tris = (int)v.size() / 9;
+
+    try
+    {
+        hr::Context ctx(0);
+        hr_scene_desc desc {};
+        desc.positions = v.data(); desc.n_tris = n_tris; desc.tri_material = mat.data();
+        desc.materials = &materials[0][0]; desc.n_materials = 4;
+        hr::Scene scene(ctx, desc);
+
+        // ---- environment: a 16^2 sky cubemap (blue above, dark below), its mip chain, a flat BRDF LUT -------------
+        const int SK = 16, LV = 4;
+        std::vector<uint16_t> sky((size_t)6 * SK * SK * 4), pre, lut((size_t)16 * 16 * 2);
+        for (int f = 0; f < 6; f++)
+            for (int i = 0; i < SK * SK; i++)
+            {
+                const bool up = f == 2 || (f != 3 && (i / SK) < SK / 2); // +Y face and the upper half of the side faces
+                const float c[3] = { up ? 0.35f : 0.08f, up ? 0.55f : 0.07f, up ? 0.9f : 0.06f };
+                for (int k = 0; k < 3; k++) sky[((size_t)f * SK * SK + i) * 4 + k] = f2h(c[k]);
+                sky[((size_t)f * SK * SK + i) * 4 + 3] = f2h(1.0f);
+            }
+        for (int l = 0, s = SK; l < LV; l++, s >>= 1)   // nearest-decimated chain is enough for the example
+            for (int f = 0; f < 6; f++)
+                for (int y = 0; y < s; y++)
+                    for (int x = 0; x < s; x++)
+                        for (int k = 0; k < 4; k++) pre.push_back(sky[(((size_t)f * SK + (y << l)) * SK + (x << l)) * 4 + k]);
+        for (size_t i = 0; i < lut.size(); i += 2) { lut[i] = f2h(0.9f); lut[i + 1] = f2h(0.05f); }
+        hr_environment env {};
+        env.sky = upload(sky); env.sky_size = SK;
+        env.prefiltered = upload(pre); env.prefiltered_size = SK; env.prefiltered_levels = LV;
+        env.brdf_lut = upload(lut); env.brdf_lut_size = 16;
+
+        // ---- DDGI grid 5 x 5 x 5 over the room (ddgi.cpp:150-169, :197-201) -----------------------------------------
+        hr_ddgi_uniforms g {};
+        for (int a = 0; a < 3; a++) { g.grid_start_position[a] = 0.0f; g.grid_step[a] = S / 3.0f; g.probe_counts[a] = 5; }
+        g.max_distance = g.grid_step[0] * 1.5f; g.depth_sharpness = 50.0f; g.hysteresis = 0.98f; g.normal_bias = 1.0f; g.energy_preservation = 0.85f;
+        g.irradiance_probe_side_length = 8; g.depth_probe_side_length = 16; g.rays_per_probe = 64; g.visibility_test = 1;
+        g.irradiance_texture_width = 10 * 25 + 2; g.irradiance_texture_height = 10 * 5 + 2;
+        g.depth_texture_width = 18 * 25 + 2; g.depth_texture_height = 18 * 5 + 2;
+
+        // ---- passes, created like main.cpp:1150-1159 ---------------------------------------------------------------------
+        hr::RayTracedShadows      shadows(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::RayTracedAO           ao(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DDGI                  ddgi(ctx, W, H, g);
+        hr::RayTracedReflections  reflections(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DeferredShading       deferred(ctx, W, H);
+        hr::TemporalAA            taa(ctx, W, H);
+        hr::GroundTruthPathTracer ground_truth(ctx, W, H);
+
+        // ---- G-buffers (two, ping-pong) + blue-noise tables ---------------------------------------------------------------
+        void *gb1[2], *gb2[2], *gb3[2], *depth[2];
+        for (int i = 0; i < 2; i++)
+        {
+            HIP_OK(hipMalloc(&gb1[i], (size_t)W * H * 4)); HIP_OK(hipMalloc(&gb2[i], (size_t)W * H * 8));
+            HIP_OK(hipMalloc(&gb3[i], (size_t)W * H * 8)); HIP_OK(hipMalloc(&depth[i], (size_t)W * H * 4));
+        }
+        std::vector<uint8_t> sob(256 * 4), sr(128 * 128 * 4);
+        uint32_t lcg = 12345u;
+        for (auto& b : sob) { lcg = lcg * 1664525u + 1013904223u; b = (uint8_t)(lcg >> 24); }
+        for (auto& b : sr) { lcg = lcg * 1664525u + 1013904223u; b = (uint8_t)(lcg >> 24); }
+        const uint8_t *sob_d = upload(sob), *sr_d = upload(sr);
+
+        const float fy = 1.0f / std::tan(40.0f * 3.14159265f / 360.0f), fx = fy * (float)H / (float)W, n = 1.0f, fa = 1000.0f;
+        float prev_vp[16] = { 0 };
+        double m_shadow = 0, m_ao = 0, m_gi = 0, m_refl = 0, m_final = 0, m_taa = 0, m_gt = 0;
+        for (uint32_t f = 0; f < 3; f++)
+        {
+            const int pp = (int)(f & 1);
+            hr::Frame frame;
+            std::memset(&frame.inputs, 0, sizeof(frame.inputs));
+            frame.scene = &scene; frame.environment = &env;
+            hr_ubo& u = frame.inputs.ubo;
+            // TemporalAA::update() first: the jitter goes into the projection and the UBO (main.cpp:941-957, :1025)
+            taa.update(f);
+            const float eye[3] = { 50.0f + 1.5f * f, 50.0f, 235.0f - 2.0f * f };
+            float view[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -eye[0], -eye[1], -eye[2], 1 };
+            float proj[16] = { fx, 0, 0, 0, 0, -fy, 0, 0, 0, 0, fa / (n - fa), -1, 0, 0, -(fa * n) / (fa - n), 0 };
+            float jit[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, taa.current_jitter()[0], taa.current_jitter()[1], 0, 1 }, jproj[16];
+            mul(jit, proj, jproj);
+            mul(jproj, view, u.view_proj);
+            std::memcpy(u.prev_view_proj, f ? prev_vp : u.view_proj, sizeof(prev_vp));
+            std::memcpy(prev_vp, u.view_proj, sizeof(prev_vp));
+            if (!invert(u.view_proj, u.view_proj_inverse) || !invert(view, u.view_inverse) || !invert(jproj, u.proj_inverse)) return 3;
+            u.cam_pos[0] = eye[0]; u.cam_pos[1] = eye[1]; u.cam_pos[2] = eye[2]; u.cam_pos[3] = 1.0f;
+            std::memcpy(u.current_prev_jitter, taa.current_jitter(), 8);
+            std::memcpy(u.current_prev_jitter + 2, taa.prev_jitter(), 8);
+            u.light.data0[1] = -1.0f; u.light.data0[3] = 9000.0f;
+            u.light.data1[0] = 50; u.light.data1[1] = 92; u.light.data1[2] = 50; u.light.data1[3] = 3.0f;   // soft point light under the ceiling
+            u.light.data2[0] = u.light.data2[1] = u.light.data2[2] = 1.0f;
+            u.light.data3[0] = 1.0f;
+
+            hr::check(hr_gbuffer_raycast(scene.handle(), &u, W, H, gb1[pp], gb2[pp], gb3[pp], (float*)depth[pp], nullptr), "hr_gbuffer_raycast");
+            hr_gbuffer_level cur { gb1[pp], gb2[pp], gb3[pp], (const float*)depth[pp], W, H };
+            hr_gbuffer_level prv = f ? hr_gbuffer_level { gb1[!pp], gb2[!pp], gb3[!pp], (const float*)depth[!pp], W, H } : cur;
+            frame.inputs.cur = cur; frame.inputs.prev = prv; frame.inputs.cur_full = cur;
+            frame.inputs.num_frames = f; frame.inputs.ping_pong = pp;
+            frame.inputs.sobol = sob_d; frame.inputs.scrambling_ranking = sr_d;
+            frame.inputs.z_buffer_params[0] = 1.0f - fa / n; frame.inputs.z_buffer_params[1] = fa / n;
+            frame.inputs.z_buffer_params[2] = frame.inputs.z_buffer_params[0] / fa; frame.inputs.z_buffer_params[3] = frame.inputs.z_buffer_params[1] / fa;
+
+            // main.cpp:80-99
+            shadows.render(nullptr, frame);
+            ao.render(nullptr, frame);
+            ddgi.render(nullptr, frame);
+            reflections.render(nullptr, frame, &ddgi);
+            hr::ImageView s_v = shadows.output_ds(), a_v = ao.output_ds(), r_v = reflections.output_ds(), g_v = ddgi.output_ds();
+            deferred.render(nullptr, frame, &a_v, &s_v, &r_v, &g_v);
+            hr::ImageView color = deferred.output_ds();
+            taa.render(nullptr, color, cur, pp != 0);
+            ground_truth.render(nullptr, frame);
+            HIP_OK(hipDeviceSynchronize());
+            m_shadow = mean_of(s_v, s_v.format == HR_FORMAT_R16F ? 1 : 2, 0);
+            m_ao = mean_of(a_v, 1, 0); m_gi = mean_of(g_v, 4, 1); m_refl = mean_of(r_v, 4, 1);
+            m_final = mean_of(color, 4, 1); m_taa = mean_of(taa.output_ds(), 4, 1); m_gt = mean_of(ground_truth.output_ds(), 4, 1);
+            std::printf("frame %u: shadow %.4f  ao %.4f  gi %.4f  reflections %.4f  composite %.4f  taa %.4f  ground truth %.4f\n", f, m_shadow, m_ao,
+                        m_gi, m_refl, m_final, m_taa, m_gt);
+        }
+        std::printf("hybrid_frame: %d triangles, %dx%d, all passes ran\n", n_tris, W, H);
+        const bool ok = m_shadow > 0.05 && m_shadow < 1.0 && m_ao > 0.2 && m_ao <= 1.0 && m_gi > 0.0 && m_final > 0.0 && m_taa > 0.0 && m_gt > 0.0 &&
+                        std::isfinite(m_refl) && std::isfinite(m_final);
+        return ok ? 0 : 1;
+    }
+    catch (const hr::Error& e)
+    {
+        std::fprintf(stderr, "hr error: %s\n", e.what());
+        return 4;
+    }
+}

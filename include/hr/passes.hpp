@@ -230,6 +230,39 @@ private:
     uint32_t        m_width, m_height;
 };
 
+// src/deferred_shading.h:15-60 — the shading (composite) part
+class DeferredShading
+{
+public:
+    DeferredShading(Context& ctx, uint32_t width, uint32_t height)
+    {
+        hr_deferred_default_params(&params);
+        check(hr_deferred_create(ctx.handle(), (int32_t)width, (int32_t)height, &m_pass), "hr_deferred_create");
+    }
+    ~DeferredShading() { hr_deferred_destroy(m_pass); }
+    DeferredShading(const DeferredShading&) = delete;
+    DeferredShading& operator=(const DeferredShading&) = delete;
+
+    // DeferredShading::render(cmd_buf, ao, shadows, reflections, ddgi) (deferred_shading.cpp:715-723): the pass outputs
+    // are the views returned by their output_ds()
+    void render(Stream cmd_buf, const Frame& frame, const ImageView* ao, const ImageView* shadows, const ImageView* reflections, const ImageView* gi)
+    {
+        check(hr_deferred_render(m_pass, &frame.inputs, frame.environment, shadows, ao, reflections, gi, &params, cmd_buf), "DeferredShading::render");
+    }
+    ImageView output_ds()
+    {
+        ImageView v;
+        check(hr_deferred_output(m_pass, &v), "DeferredShading::output_ds");
+        return v;
+    }
+    hr_deferred* handle() const { return m_pass; }
+
+    hr_deferred_params params;
+
+private:
+    hr_deferred* m_pass = nullptr;
+};
+
 // src/ground_truth_path_tracer.h:7-44
 class GroundTruthPathTracer
 {

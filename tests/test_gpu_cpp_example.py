@@ -18,3 +18,20 @@ def test_cpp_cornell_example_runs(hr):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "32 triangles" in out.stdout
+
+
+def _run_example(name):
+    exe = os.path.join(ROOT, "examples", "_build", name)
+    if not os.path.exists(exe):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
+                               "-L", os.path.join(ROOT, "hybrid_rendering_amd"), "-lhybrid_rendering_amd", "-Wl,-rpath," + os.path.join(ROOT, "hybrid_rendering_amd"), "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "hybrid_rendering_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    return subprocess.run([exe], capture_output=True, text=True, env=env, timeout=180)
+
+
+def test_cpp_hybrid_frame_example_runs(hr):
+    """every pass of the reference's frame loop (main.cpp:80-99) + composite + TAA + ground truth, driven from C++ only"""
+    out = _run_example("hybrid_frame")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all passes ran" in out.stdout and out.stdout.count("frame ") == 3
