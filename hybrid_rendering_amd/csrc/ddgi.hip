@@ -42,7 +42,8 @@ struct DDGITraceArgs
     int           probe_begin;   // first probe traced (probe shard: z-slabs of the grid)
 };
 
-// one thread per (probe, ray); a wave covers 64 consecutive rays of one probe
+// one thread per (probe, ray); a wave covers 64 consecutive rays of one probe (same origin: the rays share the nodes around
+// it — the transposed mapping, one direction from 64 probes per wave, measured 0.40 -> 0.45 ms)
 #ifndef DDGI_TRACE_WAVES
 #define DDGI_TRACE_WAVES 1
 #endif
