@@ -76,6 +76,14 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
     }
     uint32_t nn = 0, nt = 0;
     const unsigned long long fired = __ballot(active);
+    // every sample ray of the pixel stays within ray_length of its origin: find, once, the deepest BVH node that holds all
+    // the geometry of that ball and start the traversals there instead of at the root (traverse.h: entry_node_for_box)
+    uint32_t entry = 0u;
+    if (active)
+    {
+        const float r = a.ray_length * 1.0001f + 1e-4f;
+        entry = entry_node_for_box(a.nodes, mk3(ro.x - r, ro.y - r, ro.z - r), mk3(ro.x + r, ro.y + r, ro.z + r));
+    }
     for (int s = 0; s < a.spp; s++)
     {
         bool visible = false;
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
             const int   idx = (int)a.num_frames * a.spp + s;
             const float r0  = sample_blue_noise(x, y, idx, 0, a.sobol, a.sr), r1 = sample_blue_noise(x, y, idx, 1, a.sobol, a.sr);
             const f3    dir = sample_cosine_lobe(N, r0, r1);
-            visible         = !trace_any<STATS>(a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, nn, nt);
+            visible         = !trace_any<STATS>(a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, nn, nt, entry);
         }
         const unsigned long long bits = __ballot(visible);
         if (lane == 0)

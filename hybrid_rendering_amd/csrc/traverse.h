@@ -251,15 +251,51 @@ HR_DEV uint32_t walk_expand(const NodeHits& h, uint32_t& cur, LaneStack& st)
 }
 
 // Any-hit query (query_distance / query_visibility).  Returns true if occluded.
+// Deepest node whose subtree holds every triangle that can touch the box [lo, hi]: walk down from the root while exactly
+// one child box overlaps the query box and that child is internal.  Rays that live inside the box (short AO rays around a
+// pixel: all spp share it) can start their traversal there instead of at the root — the hit set is unchanged, because a
+// child whose (conservative) box misses the query box cannot hold a triangle the rays reach.  HR_NO_ENTRY: nothing overlaps.
+#define HR_NO_ENTRY 0xffffffffu
+HR_DEV uint32_t entry_node_for_box(const Node8* __restrict__ nodes, f3 lo, f3 hi)
+{
+    uint32_t ni = 0;
+    for (int depth = 0; depth < 24; depth++)
+    {
+        const NodeRaw n = load_node(nodes, ni);
+        const float nox = __uint_as_float(n.q0.x), noy = __uint_as_float(n.q0.y), noz = __uint_as_float(n.q0.z);
+        const float sx = __uint_as_float((n.q0.w & 0xffu) << 23), sy = __uint_as_float(((n.q0.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((n.q0.w >> 16) & 0xffu) << 23);
+        const uint32_t wlo[6] = { n.q2.x, n.q2.y, n.q2.z, n.q2.w, n.q3.x, n.q3.y };   // lo x0 x1 y0 y1 z0 z1
+        const uint32_t whi[6] = { n.q3.z, n.q3.w, n.q4.x, n.q4.y, n.q4.z, n.q4.w };
+        uint32_t ov = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const bool o = hr_fma(ubyte(wlo[0 + half], k), sx, nox) <= hi.x && hr_fma(ubyte(whi[0 + half], k), sx, nox) >= lo.x &&
+                               hr_fma(ubyte(wlo[2 + half], k), sy, noy) <= hi.y && hr_fma(ubyte(whi[2 + half], k), sy, noy) >= lo.y &&
+                               hr_fma(ubyte(wlo[4 + half], k), sz, noz) <= hi.z && hr_fma(ubyte(whi[4 + half], k), sz, noz) >= lo.z;
+                ov |= o ? (1u << (half * 4 + k)) : 0u;
+            }
+        ov &= (1u << (n.q0.w >> 28)) - 1u;
+        if (ov == 0u) return HR_NO_ENTRY;
+        const uint32_t imask = (1u << ((n.q0.w >> 24) & 15u)) - 1u;
+        if ((ov & (ov - 1u)) != 0u || (ov & ~imask) != 0u) break;   // several children, or a leaf: start here
+        ni = n.q1.x + (uint32_t)__builtin_ctz(ov);
+    }
+    return ni;
+}
+
 template <bool STATS>
 HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris)
+                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u)
 {
+    if (entry == HR_NO_ENTRY) return false;
     RayPre    r = ray_prepare(o, d);
     uint32_t  spill_array[HR_SPILL_ENTRIES];
     LaneStack st;
     st.init(wave_stack, lane, spill_array);
-    uint32_t cur = 1u, ni;   // root = "child 0 of child_base 0"
+    uint32_t cur = (entry << 9) | 1u, ni;   // the entry node (root = 0) = "child 0 of child_base entry"
     bool     hit = false;
     while (walk_next<false>(cur, st, ni))
     {
