@@ -1,6 +1,6 @@
 """Per-stage timings of every pass at a given resolution (developer tool; prints a JSON line per pass).
 
-    python tools/passbench.py [--width 1920 --height 1080 --frames 40] [--passes shadows,ao,reflections,ddgi]
+    python tools/passbench.py [--width 1920 --height 1080 --frames 40] [--passes shadows,ao,reflections,ddgi,post]
 """
 import argparse
 import json
@@ -95,6 +95,29 @@ def main():
         run("ddgi", lambda: ddgi, rd, 0)
     if "reflections" in want:
         run("reflections", lambda: api_reflections.RayTracedReflections(ctx, W, H, args.refl_scale), lambda p, fi, k: p.render(scene, fi, env, ddgi), args.refl_scale)
+    if "post" in want:
+        # the SURVEY 8f rows: deferred composite, TAA, ground-truth accumulator (wall clock per call; one kernel each)
+        from hybrid_rendering_amd import api_deferred, api_post
+        sh = hr.RayTracedShadows(ctx, W, H); ao = hr.RayTracedAO(ctx, W, H, 0); refl = api_reflections.RayTracedReflections(ctx, W, H, 0)
+        fi = hr.frame_inputs(gbs[1], gbs[0], ubos[1], 1, 1, sob_d, sr_d, cur_full=gbs[1], z_buffer_params=zbp)
+        sh.render(scene, fi); ao.render(scene, fi); ddgi.render(scene, fi, env, synth_env.random_orientation(rng)); refl.render(scene, fi, env, ddgi)
+        de, taa, gt = api_deferred.DeferredShading(ctx, W, H), api_post.TemporalAA(ctx, W, H), api_post.GroundTruthPathTracer(ctx, W, H)
+        s_o, a_o, r_o, g_o = sh.output(hr.OUTPUT_ATROUS), ao.output(hr.OUTPUT_UPSAMPLE), refl.output(hr.OUTPUT_UPSAMPLE), ddgi.output()
+
+        def timed(fn, n=args.frames):
+            for _ in range(5): fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n): fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / n * 1e3, 4)
+        out = dict(pass_="post", res=f"{W}x{H}")
+        out["deferred_ms"] = timed(lambda: de.render(fi, env, s_o, a_o, r_o, g_o))
+        color = de.output()
+        taa.update(3)
+        out["taa_ms"] = timed(lambda: taa.render(color, gbs[1], 1))
+        out["ground_truth_ms"] = timed(lambda: gt.render(scene, ubos[1], env))
+        out["ground_truth_Mrays_per_s"] = round(gt.ray_count() / (out["ground_truth_ms"] * 1e-3) / 1e6, 1)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":
