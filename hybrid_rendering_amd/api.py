@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_gbuffer_mip_nearest", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -201,6 +201,20 @@ class Scene:
         _check(lib().hr_gbuffer_raycast(self.h, C.byref(u), C.c_int32(w), C.c_int32(h), _ptr(gb1), _ptr(gb2), _ptr(gb3), _ptr(depth), _stream_ptr(stream)),
                "hr_gbuffer_raycast")
         return dict(gb1=gb1, gb2=gb2, gb3=gb3, depth=depth)
+
+
+def gbuffer_mip(g, level, stream=None):
+    """Nearest mip `level` of a G-buffer dict of cuda tensors (g_buffer.cpp:240-243) -> new dict at (H >> level, W >> level)."""
+    import torch
+    h, w = g["depth"].shape
+    hh, ww = h >> level, w >> level
+    out = dict(gb2=torch.empty((hh, ww, 4), dtype=torch.float16, device="cuda"), gb3=torch.empty((hh, ww, 4), dtype=torch.float16, device="cuda"),
+               depth=torch.empty((hh, ww), dtype=torch.float32, device="cuda"))
+    if g.get("gb1") is not None:
+        out["gb1"] = torch.empty((hh, ww, 4), dtype=torch.uint8, device="cuda")
+    src, dst = gbuffer_level(g), gbuffer_level(out)
+    _check(lib().hr_gbuffer_mip_nearest(C.byref(src), C.byref(dst), C.c_int32(level), _stream_ptr(stream)), "hr_gbuffer_mip_nearest")
+    return out
 
 
 # ------------------------------------------------------------------------------ frame inputs

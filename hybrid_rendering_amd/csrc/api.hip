@@ -279,6 +279,28 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
     return HR_OK;
 }
 
+// nearest-filtered mip level of the four G-buffer images (g_buffer.cpp:240-243: vkCmdBlitImage, VK_FILTER_NEAREST):
+// destination texel (x, y) = source texel (x << level, y << level)
+__global__ __launch_bounds__(256) void k_gbuffer_mip(hr_gbuffer_level src, hr_gbuffer_level dst, int level)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= dst.width || y >= dst.height) return;
+    const size_t so = (size_t)(y << level) * src.width + (x << level), o = (size_t)y * dst.width + x;
+    if (src.gb1 && dst.gb1) ((uint32_t*)dst.gb1)[o] = ((const uint32_t*)src.gb1)[so];
+    ((uint2*)dst.gb2)[o] = ((const uint2*)src.gb2)[so];
+    ((uint2*)dst.gb3)[o] = ((const uint2*)src.gb3)[so];
+    ((float*)dst.depth)[o] = src.depth[so];
+}
+
+extern "C" hr_status hr_gbuffer_mip_nearest(const hr_gbuffer_level* src, const hr_gbuffer_level* dst, int32_t level, void* stream)
+{
+    HR_CHECK_ARG(src && dst && level >= 1 && level <= 8 && src->gb2 && src->gb3 && src->depth && dst->gb2 && dst->gb3 && dst->depth);
+    HR_CHECK_ARG(dst->width == (src->width >> level) && dst->height == (src->height >> level) && dst->width > 0 && dst->height > 0);
+    hipLaunchKernelGGL(k_gbuffer_mip, dim3(cdiv(dst->width, 32), cdiv(dst->height, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, (int)level);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info)
 {
     HR_CHECK_ARG(scene && info);

@@ -153,6 +153,10 @@ hr_status hr_trace_closest_hit(const hr_scene* scene, int64_t n, const float* ra
  * src/g_buffer.cpp + shaders/g_buffer.frag:86-112, so bench inputs can be produced on the GPU). */
 hr_status hr_gbuffer_raycast(const hr_scene* scene, const hr_ubo* ubo, int32_t width, int32_t height, void* gb1, void* gb2, void* gb3,
                              float* depth, void* stream);
+/* Nearest-filtered mip `level` (1..8) of a G-buffer level: dst (width >> level, height >> level) texel (x, y) = src texel
+ * (x << level, y << level) — g_buffer.cpp:240-243 (vkCmdBlitImage with VK_FILTER_NEAREST).  gb1 is optional.  The
+ * half- and quarter-resolution passes read these through hr_frame_inputs.cur / .prev. */
+hr_status hr_gbuffer_mip_nearest(const hr_gbuffer_level* src, const hr_gbuffer_level* dst, int32_t level, void* stream);
 
 /* ---- common pass plumbing ---------------------------------------------------------------------- */
 typedef enum

@@ -106,6 +106,23 @@ def _selftest(hr, which, arr):
     return out.cpu().numpy()
 
 
+def test_gbuffer_nearest_mips(oracle, hr, ctx):
+    """hr_gbuffer_mip_nearest == the point-sampled mip the half / quarter resolution passes are tested with"""
+    import torch
+    sd = helpers.scene_data("sponza_small")
+    osc = oracle.Scene(sd)
+    fr = helpers.make_frames(oracle, osc, "sponza_small", 250, 142, 1, 0.0)[0]      # odd sizes: 125x71, 62x35
+    g = helpers.to_cuda(fr["gb"])
+    for level in (1, 2):
+        ref = helpers.nearest_mip(fr["gb"], level)
+        got = hr.gbuffer_mip(g, level)
+        torch.cuda.synchronize()
+        for k, v in ref.items():
+            t = got[k]
+            a = t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()
+            assert a.shape == v.shape and np.array_equal(a, v), (level, k)
+
+
 def test_device_math_bit_exact(oracle, hr, ctx):
     L = oracle.lib()
     rng = np.random.RandomState(3)
