@@ -65,65 +65,108 @@ struct DevBuf
 };
 
 // Stage profiler: one event pair per named stage, recorded on the pass stream.
+// Per-stage HIP-event timing on the launch stream.  Every stage keeps a RING of event pairs, one pair per profiled frame,
+// so that a caller can leave profiling on over a whole timed region and read the per-kernel AVERAGE afterwards
+// (bench.py: roofline.achieved) without synchronising inside it.  A new frame starts when begin_frame() is called or when a
+// stage is begun for the second time in the current frame (stage-level callers).  collect() averages every frame recorded
+// since the previous collect() and starts over.
 struct StageProfiler
 {
-    bool                     enabled = false;
-    std::vector<std::string> names;
-    std::vector<hipEvent_t>  ev0, ev1;
-    std::vector<uint64_t>    bytes;
-    std::vector<char>        used;
-    int                      find_or_add(const char* name)
+    static constexpr int kRing = 512;
+    struct Stage
     {
-        for (size_t i = 0; i < names.size(); i++)
-            if (names[i] == name) return (int)i;
-        if (names.size() >= HR_MAX_STAGES) return -1;
-        names.push_back(name);
-        hipEvent_t a, b;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        ev0.push_back(a);
-        ev1.push_back(b);
-        bytes.push_back(0);
-        used.push_back(0);
-        return (int)names.size() - 1;
+        std::string             name;
+        std::vector<hipEvent_t> ev0, ev1;   // created lazily, up to kRing pairs
+        std::vector<long long>  stamp;      // epoch * 2^32 + frame of the recording in each slot
+        uint64_t                bytes = 0;
+        int                     last_frame = -1;   // last frame index this stage was recorded in
+    };
+    bool               enabled = false;
+    std::vector<Stage> stages;
+    int                frame = 0;        // frames started since the last collect()
+    long long          epoch = 0;        // collect() calls so far
+    bool               frame_open = false;
+
+    int find_or_add(const char* name)
+    {
+        for (size_t i = 0; i < stages.size(); i++)
+            if (stages[i].name == name) return (int)i;
+        if (stages.size() >= HR_MAX_STAGES) return -1;
+        stages.emplace_back();
+        stages.back().name = name;
+        return (int)stages.size() - 1;
     }
     void begin_frame()
     {
-        for (auto& u : used) u = 0;
+        if (frame_open) frame++;
+        frame_open = false;
     }
     int begin(const char* name, hipStream_t s, uint64_t algorithmic_bytes)
     {
         if (!enabled) return -1;
         int i = find_or_add(name);
         if (i < 0) return -1;
-        bytes[i] = algorithmic_bytes;
-        used[i]  = 1;
-        (void)hipEventRecord(ev0[i], s);
+        Stage& st = stages[i];
+        if (frame_open && st.last_frame == frame) frame++;   // the stage repeats: a new frame has begun
+        frame_open = true;
+        const int slot = frame % kRing;
+        while ((int)st.ev0.size() <= slot)
+        {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            st.ev0.push_back(a);
+            st.ev1.push_back(b);
+            st.stamp.push_back(-1);
+        }
+        st.stamp[slot] = (epoch << 32) + frame;
+        st.bytes      = algorithmic_bytes;
+        st.last_frame = frame;
+        (void)hipEventRecord(st.ev0[slot], s);
         return i;
     }
     void end(int i, hipStream_t s)
     {
-        if (i >= 0) (void)hipEventRecord(ev1[i], s);
+        if (i >= 0) (void)hipEventRecord(stages[i].ev1[stages[i].last_frame % kRing], s);
     }
     void collect(hr_stage_times* out)
     {
         out->n_stages = 0;
-        for (size_t i = 0; i < names.size(); i++)
+        const int n_frames = frame + (frame_open ? 1 : 0);
+        const int first    = n_frames > kRing ? n_frames - kRing : 0;   // older slots were overwritten
+        for (Stage& st : stages)
         {
-            if (!used[i]) continue;
-            float ms = 0.0f;
-            (void)hipEventSynchronize(ev1[i]);
-            (void)hipEventElapsedTime(&ms, ev0[i], ev1[i]);
-            int k        = out->n_stages++;
-            out->name[k] = names[i].c_str();
-            out->ms[k]   = ms;
-            out->bytes[k] = bytes[i];
+            double sum = 0.0;
+            int    cnt = 0;
+            for (int f = first; f < n_frames; f++)
+            {
+                const int slot = f % kRing;
+                if (slot >= (int)st.ev0.size()) continue;
+                if (st.stamp[slot] != (epoch << 32) + f) continue;   // this stage did not run in frame f
+                float ms = 0.0f;
+                if (hipEventSynchronize(st.ev1[slot]) != hipSuccess) continue;
+                if (hipEventElapsedTime(&ms, st.ev0[slot], st.ev1[slot]) != hipSuccess) continue;
+                sum += ms;
+                cnt++;
+            }
+            if (st.last_frame < 0 || cnt == 0) continue;
+            const int k     = out->n_stages++;
+            out->name[k]    = st.name.c_str();
+            out->ms[k]      = (float)(sum / cnt);
+            out->bytes[k]   = st.bytes;
+            st.last_frame   = -1;
         }
+        frame = 0;
+        frame_open = false;
+        epoch++;
     }
     ~StageProfiler()
     {
-        for (auto e : ev0) (void)hipEventDestroy(e);
-        for (auto e : ev1) (void)hipEventDestroy(e);
+        for (Stage& st : stages)
+        {
+            for (auto e : st.ev0) (void)hipEventDestroy(e);
+            for (auto e : st.ev1) (void)hipEventDestroy(e);
+        }
     }
 };
 

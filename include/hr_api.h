@@ -189,7 +189,7 @@ typedef struct
 {
     int32_t     n_stages;
     const char* name[HR_MAX_STAGES];
-    float       ms[HR_MAX_STAGES];     /* last profiled render(), hipEvent elapsed */
+    float       ms[HR_MAX_STAGES];     /* hipEvent elapsed, averaged over the frames profiled since the previous call (up to 512) */
     uint64_t    bytes[HR_MAX_STAGES];  /* algorithmic bytes of the stage */
 } hr_stage_times;
 
