@@ -393,7 +393,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
         HR_HIP(hipMemsetAsync(p->length[!in->ping_pong].p, 0, p->length[0].bytes, st));
         p->first_frame = false;
     }
-    HR_HIP(hipMemsetAsync(p->counters.p, 0, 32, st));
+    if (p->want_stats) HR_HIP(hipMemsetAsync(p->counters.p, 0, 32, st));   // only the instrumented build accumulates into it
     AOTraceArgs a;
     for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
     a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2; a.sobol = in->sobol; a.sr = in->scrambling_ranking;

@@ -348,7 +348,6 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     HR_CHECK_ARG(p && scene && in && env && prm && env->sky && env->sky_size > 0);
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
-    HR_HIP(hipMemsetAsync(p->counters.p, 0, 8, st));
     const int rd = p->ping_pong ? 0 : 1; // read_idx = !m_ping_pong
     DDGITraceArgs a;
     a.d = p->d; a.light = in->ubo.light;

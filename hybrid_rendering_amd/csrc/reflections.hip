@@ -478,7 +478,6 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
         HR_HIP(hipMemsetAsync(p->moments[!pp].p, 0, p->moments[0].bytes, st));
         p->first_frame = false;
     }
-    HR_HIP(hipMemsetAsync(p->counters.p, 0, 8, st));
     ReflTraceArgs a;
     hr_status s = hr_ddgi_get_uniforms(ddgi, &a.d);
     if (s != HR_OK) return s;
