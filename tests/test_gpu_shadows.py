@@ -113,3 +113,66 @@ def test_render_is_hipgraph_capturable(oracle, hr, ctx):
     torch.cuda.synchronize()
     assert np.array_equal(helpers.bits16(eager.output(hr.OUTPUT_ATROUS)), helpers.bits16(graphed.output(hr.OUTPUT_ATROUS)))
     assert np.array_equal(helpers.bits16(eager.image(eager.IMG_MOMENTS1)), helpers.bits16(graphed.image(graphed.IMG_MOMENTS1)))
+
+
+def test_soft_shadow_mean_converges_to_the_light_disk_visibility(oracle, hr, ctx):
+    """the per-pixel mean of the 1-spp masks over many frames is a Monte-Carlo estimate of the fraction of
+    the light disk that is visible.  An independent estimate — the disk sampled with numpy's RNG in float64 and the rays
+    answered by the oracle's any-hit — must agree: the sampler (blue-noise decode, disk mapping, tangent frame), the ray
+    set-up and the traversal are all inside this loop."""
+    import torch
+    name, W, H, n_frames, n_ref = "cornell", 96, 96, 128, 192
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    light = synth.make_light(synth.LIGHT_POINT, position=(50.0, 95.0, 50.0), radius=9.0, intensity=5000.0)   # wide penumbrae
+    cam = synth.cornell_camera(W / H)
+    ubo = synth.make_ubo(cam, None, light)
+    gb = osc.gbuffer(ubo, W, H)
+    gb_d = helpers.to_cuda(gb)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    p = hr.RayTracedShadows(ctx, W, H)
+    acc = np.zeros((H, W), np.float64)
+    for f in range(n_frames):
+        p.ray_trace(gsc, hr.frame_inputs(gb_d, gb_d, ubo, f, f & 1, sob_d, sr_d))
+        acc += helpers.unpack_mask(p.image(p.IMG_MASK).cpu().numpy().view(np.uint32), W, H)
+    mean_gpu = acc / n_frames
+    # independent reference: world positions / normals from the G-buffer in float64, uniform samples on the light disk
+    depth = gb["depth"].astype(np.float64)
+    geo = depth != 1.0
+    ys, xs = np.nonzero(geo)
+    vpi = np.asarray(ubo["view_proj_inverse"], np.float64).reshape(4, 4).T     # column-major -> row-major
+    ndc = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, depth[ys, xs], np.ones(len(xs))], 0)
+    wp = vpi @ ndc
+    P = (wp[:3] / wp[3]).T
+    g2 = gb["gb2"].view(np.float16).astype(np.float64)[ys, xs]
+    ex, ey = g2[:, 0], g2[:, 1]
+    N = np.stack([ex, ey, 1 - np.abs(ex) - np.abs(ey)], 1)
+    neg = N[:, 2] < 0
+    nx = (1 - np.abs(N[:, 1])) * np.where(N[:, 0] >= 0, 1, -1); ny = (1 - np.abs(N[:, 0])) * np.where(N[:, 1] >= 0, 1, -1)
+    N[neg, 0], N[neg, 1] = nx[neg], ny[neg]
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    lpos, lrad = np.array([50.0, 95.0, 50.0]), 9.0
+    to_l = lpos - P
+    dist = np.linalg.norm(to_l, axis=1)
+    ldir = to_l / dist[:, None]
+    T = np.cross(ldir, [0.0, 1.0, 0.0]); T /= np.linalg.norm(T, axis=1, keepdims=True)
+    B = np.cross(T, ldir); B /= np.linalg.norm(B, axis=1, keepdims=True)
+    rng = np.random.RandomState(5)
+    vis = np.zeros(len(xs))
+    ro = P + N * 0.5                                                   # RayTracedShadows bias (ray_traced_shadows.h:69)
+    for _ in range(n_ref):
+        r = (lrad / dist) * np.sqrt(rng.rand(len(xs))); a = rng.rand(len(xs)) * 2 * np.pi
+        Wi = ldir + (r * np.cos(a))[:, None] * T + (r * np.sin(a))[:, None] * B
+        Wi /= np.linalg.norm(Wi, axis=1, keepdims=True)
+        facing = (N * Wi).sum(1) > 0                                   # attenuation > 0 <=> a ray is fired; else unlit
+        rays = np.zeros((len(xs), 8), np.float32)
+        rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = ro, dist, Wi, 0.01
+        vis += np.where(facing, 1 - osc.any_hit(rays).astype(np.float64), 0.0)
+    ref = np.zeros((H, W)); ref[ys, xs] = vis / n_ref
+    diff = np.abs(mean_gpu - ref)[geo]
+    pen = ((ref > 0.05) & (ref < 0.95))[geo]
+    assert pen.sum() > 200                                            # the test scene has real penumbrae
+    # Monte-Carlo noise: sigma <= 0.5 / sqrt(128) = 0.044 per pixel on each side
+    assert diff.mean() < 0.02 and np.percentile(diff, 99) < 0.2 and abs(mean_gpu[geo].mean() - ref[geo].mean()) < 0.01, (diff.mean(), np.percentile(diff, 99))
+    assert diff[pen].mean() < 0.07
