@@ -100,6 +100,16 @@ def exchange_plan(height: int, world: int, rank: int, rows: int, bounds: Sequenc
     return plan
 
 
+def _host_backend_fence(tensors, group=None):
+    """RCCL orders its transfers after the kernels already enqueued on the current stream.  gloo (only used to exercise this
+    code on CPUs, or with several ranks on one GPU) reads device memory from the host at call time instead: wait for the
+    producers first."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) != "nccl" and any(getattr(t, "is_cuda", False) for t in tensors):
+        torch.cuda.synchronize()
+
+
 def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None, wait: bool = True, bounds: Sequence[int] = None):
     """Grouped neighbour exchange of ``rows`` halo rows for every [H, W, ...] tensor in ``images`` (all ranks
     pass the same list in the same order).  Works on any backend (nccl on GPUs, gloo in the CPU tests).
@@ -108,6 +118,7 @@ def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: in
     import torch.distributed as dist
     if world == 1:
         return []
+    _host_backend_fence(images, group)
     ops, recvs = [], []
     for peer, (s0, s1), (r0, r1) in exchange_plan(height, world, rank, rows, bounds):
         for img in images:
@@ -261,6 +272,7 @@ def allgather_slabs(atlas, side: int, cz: int, world: int, rank: int, group=None
     if world == 1:
         return
     rows = [slab_rows(side, *probe_slabs(cz, world, r)) for r in range(world)]
+    _host_backend_fence([atlas], group)
     if len({b - a for a, b in rows}) == 1:
         outs = [atlas[a:b] for a, b in rows]
         dist.all_gather(outs, atlas[rows[rank][0]:rows[rank][1]].clone(), group=group)

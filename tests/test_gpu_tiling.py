@@ -159,3 +159,26 @@ def test_reflections_bands_and_ddgi_shards_match_single_gpu(oracle, hr, ctx, wor
             assert np.array_equal(got[b0:b1], ref[b0:b1]), f"frame {f} band {r}: reflections output differs"
         assert sum(g.pass_.ray_count() for g in gis) == whole_gi.ray_count()
         ping = not ping
+
+
+def test_two_processes_hybrid_frame_bit_identical():
+    """The REAL multi-process path: two ranks (both on the one GPU of the test box, gloo instead of RCCL) render their
+    cost-balanced bands / probe slabs of the same frames with tiling.Tiled* and ShardedDDGI — neighbour exchange with the
+    deferred wait, atlas all-gather — and every rank compares its band rows of all four passes with an un-tiled render."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HR_DIST_BACKEND="gloo", HR_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tools", "frame_bench.py"), "--gpus", "2", "--width", "960", "--height", "544", "--frames", "2", "--warmup", "1",
+           "--detail", "0.25", "--probes", "6,3,4", "--rays-per-probe", "64", "--check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["bit_identical_to_untiled"] is True, line + out.stderr[-2000:]
+    assert len(j["bands"]) == 3 and j["rays_per_frame"] > 100_000
