@@ -1,4 +1,4 @@
-"""Asset ingestion: Wavefront OBJ/MTL -> the triangle / normal / material arrays hr_scene_desc takes
+"""Asset ingestion: Wavefront OBJ/MTL and glTF 2.0 (.gltf / .glb) -> the triangle / normal / material arrays hr_scene_desc takes
 (the layout of scene_descriptor_set.glsl:5-34 after instance flattening), and PNG -> the Heitz-2019 blue-noise tables
 (blue_noise.cpp:5-19: ``sobol_256_4d.png`` row 0 and a 128x128 ``scrambling_ranking_128x128_2d_*spp.png``).
 
@@ -193,3 +193,115 @@ def load_blue_noise(sobol_png: str, scrambling_ranking_png: str):
     if s.shape[1] < 256 or r.shape[0] < 128 or r.shape[1] < 128:
         raise ValueError("blue-noise tables must be at least 256 wide (sobol) and 128x128 (scrambling/ranking)")
     return np.ascontiguousarray(s[0, :256]), np.ascontiguousarray(r[:128, :128])
+
+
+# ------------------------------------------------------------------------------------------------ glTF 2.0
+def _quat_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+
+
+def load_gltf(path: str, scale: float = 1.0) -> SceneData:
+    """glTF 2.0 (.gltf with external / base64 buffers, or .glb) -> SceneData: the scene's node hierarchy is flattened to world
+    space (matrix or TRS nodes), every TRIANGLES primitive contributes its (indexed) triangles, NORMAL is transformed by the
+    inverse transpose (missing: geometric normal), materials come from pbrMetallicRoughness (baseColorFactor, metallicFactor,
+    roughnessFactor) + emissiveFactor.  One mesh id per (node, primitive).  The reference loads meshes/*.gltf through assimp
+    (common.cpp:347-488); textures are not read (the passes here use untextured materials)."""
+    import base64
+    import json
+    raw = open(path, "rb").read()
+    base = os.path.dirname(os.path.abspath(path))
+    glb_bin = None
+    if raw[:4] == b"glTF":
+        _, _, total = struct.unpack("<4sII", raw[:12])
+        o, doc = 12, None
+        while o < total:
+            n, typ = struct.unpack("<II", raw[o:o + 8])
+            body = raw[o + 8:o + 8 + n]
+            if typ == 0x4E4F534A:
+                doc = json.loads(body.decode("utf-8"))
+            elif typ == 0x004E4942 and glb_bin is None:
+                glb_bin = bytes(body)
+            o += 8 + n
+    else:
+        doc = json.loads(raw.decode("utf-8"))
+    buffers = []
+    for b in doc.get("buffers", []):
+        uri = b.get("uri")
+        if uri is None:
+            buffers.append(glb_bin)
+        elif uri.startswith("data:"):
+            buffers.append(base64.b64decode(uri.split(",", 1)[1]))
+        else:
+            buffers.append(open(os.path.join(base, uri), "rb").read())
+    comp = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+    ncomp = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+    def accessor(i):
+        a = doc["accessors"][i]
+        dt, nc, cnt = np.dtype(comp[a["componentType"]]), ncomp[a["type"]], a["count"]
+        if "bufferView" not in a:
+            return np.zeros((cnt, nc), dt)
+        bv = doc["bufferViews"][a["bufferView"]]
+        off = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0) or dt.itemsize * nc
+        buf = np.frombuffer(buffers[bv["buffer"]], np.uint8)
+        rows = np.lib.stride_tricks.as_strided(buf[off:], shape=(cnt, dt.itemsize * nc), strides=(stride, 1))
+        return np.ascontiguousarray(rows).view(dt).reshape(cnt, nc)
+
+    mats = []
+    for m in doc.get("materials", []):
+        pbr = m.get("pbrMetallicRoughness", {})
+        bc = pbr.get("baseColorFactor", [1, 1, 1, 1])
+        em = m.get("emissiveFactor", [0, 0, 0])
+        mats.append([bc[0], bc[1], bc[2], pbr.get("metallicFactor", 1.0), pbr.get("roughnessFactor", 1.0), em[0], em[1], em[2]])
+    default_mat = len(mats)
+    mats.append([0.8, 0.8, 0.8, 0.0, 0.5, 0.0, 0.0, 0.0])
+
+    verts, norms, tmat, tmesh = [], [], [], []
+    mesh_id = [0]
+
+    def visit(ni, parent):
+        node = doc["nodes"][ni]
+        if "matrix" in node:
+            local = np.asarray(node["matrix"], np.float64).reshape(4, 4).T
+        else:
+            local = np.eye(4)
+            local[:3, :3] = _quat_to_mat(node.get("rotation", [0, 0, 0, 1])) @ np.diag(node.get("scale", [1, 1, 1]))
+            local[:3, 3] = node.get("translation", [0, 0, 0])
+        M = parent @ local
+        if "mesh" in node:
+            nm = np.linalg.inv(M[:3, :3]).T
+            for prim in doc["meshes"][node["mesh"]]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue
+                pos = accessor(prim["attributes"]["POSITION"]).astype(np.float64)
+                idx = accessor(prim["indices"]).reshape(-1).astype(np.int64) if "indices" in prim else np.arange(len(pos))
+                idx = idx[: len(idx) // 3 * 3].reshape(-1, 3)
+                wp = (pos @ M[:3, :3].T + M[:3, 3]) * scale
+                tri = wp[idx]
+                if "NORMAL" in prim["attributes"]:
+                    n = accessor(prim["attributes"]["NORMAL"]).astype(np.float64) @ nm.T
+                    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+                    tn = n[idx]
+                else:
+                    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+                    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+                    tn = np.repeat(fn[:, None, :], 3, axis=1)
+                mesh_id[0] += 1
+                verts.append(tri); norms.append(tn)
+                tmat.append(np.full(len(tri), prim.get("material", default_mat), np.uint32))
+                tmesh.append(np.full(len(tri), mesh_id[0], np.uint32))
+        for c in node.get("children", []):
+            visit(c, M)
+
+    scenes = doc.get("scenes") or [{"nodes": list(range(len(doc.get("nodes", []))))}]
+    for root in scenes[doc.get("scene", 0)]["nodes"]:
+        visit(root, np.eye(4))
+    if not verts:
+        raise ValueError(f"{path}: no triangle primitives")
+    return SceneData(verts=np.ascontiguousarray(np.concatenate(verts), np.float32), normals=np.ascontiguousarray(np.concatenate(norms), np.float32),
+                     tri_material=np.concatenate(tmat), tri_mesh_id=np.concatenate(tmesh), materials=np.asarray(mats, np.float32),
+                     name=os.path.basename(path), meta=dict(n_materials=len(mats) - 1))

@@ -140,3 +140,59 @@ def test_obj_scene_builds_and_traces(tmp_path, oracle):
     rays = np.array([[0.5, 0.5, 0.5, 10.0, 0, -1, 0, 0.001], [0.5, 0.5, 0.5, 1.0, 0, 1, 0, 0.001]], np.float32)   # origin, t_max, direction, t_min
     hit = sc.any_hit(rays)
     assert list(np.asarray(hit).astype(int)) == [1, 0]
+
+
+def _gltf_doc(tmp_path, embed):
+    import base64
+    import json
+    # buffer: quad positions (4 x vec3 f32) | indices (6 x u16) | interleaved triangle: pos+normal per vertex (stride 24)
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    inter = np.array([[0, 0, 0, 0, 0, 1], [2, 0, 0, 0, 0, 1], [0, 2, 0, 0, 0, 1]], np.float32)
+    blob = quad.tobytes() + idx.tobytes() + inter.tobytes()
+    uri = ("data:application/octet-stream;base64," + base64.b64encode(blob).decode()) if embed else "geo.bin"
+    if not embed:
+        (tmp_path / "geo.bin").write_bytes(blob)
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "nodes": [{"children": [1, 2], "translation": [10, 0, 0]},
+                  {"mesh": 0, "scale": [2, 2, 2]},
+                  {"mesh": 1, "rotation": [0, 0, 0.70710678, 0.70710678], "translation": [0, 5, 0]}],   # 90 deg about z
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]},
+                   {"primitives": [{"attributes": {"POSITION": 2, "NORMAL": 3}}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1], "metallicFactor": 0.0, "roughnessFactor": 0.3}, "emissiveFactor": [1, 0, 0]}],
+        "buffers": [{"byteLength": len(blob), "uri": uri}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 0, "byteOffset": 48, "byteLength": 12},
+                        {"buffer": 0, "byteOffset": 60, "byteLength": 72, "byteStride": 24}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5123, "count": 6, "type": "SCALAR"},
+                      {"bufferView": 2, "byteOffset": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                      {"bufferView": 2, "byteOffset": 12, "componentType": 5126, "count": 3, "type": "VEC3"}],
+    }
+    return doc, blob
+
+
+@pytest.mark.parametrize("form", ["external", "embedded", "glb"])
+def test_gltf_loader(tmp_path, form):
+    import json
+    doc, blob = _gltf_doc(tmp_path, embed=(form == "embedded"))
+    if form == "glb":
+        del doc["buffers"][0]["uri"]
+        js = json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        bn = blob + b"\0" * (-len(blob) % 4)
+        data = struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(bn)) + struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(bn), 0x004E4942) + bn
+        path = tmp_path / "scene.glb"
+        path.write_bytes(data)
+    else:
+        path = tmp_path / "scene.gltf"
+        path.write_text(json.dumps(doc))
+    sd = assets.load_gltf(str(path))
+    assert sd.n_tris == 3 and list(sd.tri_material) == [0, 0, 1] and list(sd.tri_mesh_id) == [1, 1, 2]
+    # quad: scaled by 2 then translated by (10,0,0)
+    assert np.allclose(sd.verts[0], [[10, 0, 0], [12, 0, 0], [12, 2, 0]]) and np.allclose(sd.verts[1], [[10, 0, 0], [12, 2, 0], [10, 2, 0]])
+    assert np.allclose(sd.normals[:2], [0, 0, 1])                                   # generated face normal
+    # interleaved triangle: rotated 90 deg about z ((x,y) -> (-y,x)), then +(0,5,0), then parent +(10,0,0)
+    assert np.allclose(sd.verts[2], [[10, 5, 0], [10, 7, 0], [8, 5, 0]], atol=1e-5)
+    assert np.allclose(sd.normals[2], [0, 0, 1], atol=1e-6)                         # NORMAL accessor through the byteStride
+    assert np.allclose(sd.materials[0], [0.2, 0.4, 0.6, 0.0, 0.3, 1, 0, 0]) and sd.materials.shape == (2, 8)
