@@ -1,12 +1,13 @@
 // Host-side builder of the compressed 8-wide BVH (see bvh.h).  Replaces the driver's
 // acceleration-structure build behind dw::RayTracedScene (reference: main.cpp:74,
-// common.cpp:355-521).  Steps: binned-SAH binary tree -> greedy surface-area collapse to
-// 8-wide -> breadth-first layout with contiguous children / leaf triangles -> 8-bit
-// conservative quantisation.
+// common.cpp:355-521).  Steps: binned-SAH binary tree down to single triangles -> SAH-optimal
+// collapse to 8-wide nodes with leaf children of <= 4 triangles (dynamic programme) ->
+// breadth-first layout with contiguous children / leaf triangles -> 8-bit conservative quantisation.
 #include "bvh.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <queue>
@@ -50,7 +51,7 @@ struct Bin2
 };
 
 constexpr int kBins    = 32;
-constexpr int kMaxLeaf = 4;
+constexpr int kMaxLeaf = 4;   // triangles per leaf CHILD of an 8-wide node (count field of the meta byte, 8 x 4 = 32-bit mask)
 
 struct Builder
 {
@@ -60,6 +61,7 @@ struct Builder
     std::vector<int32_t>  idx;
     std::vector<int32_t>  prim;   // reference -> original triangle
     std::vector<Bin2>     n2;
+    int                   bvh2_leaf = kMaxLeaf;   // binary-tree leaf size (1 for the optimal collapse: it forms the leaves)
 
     int32_t split(int32_t first, int32_t count)
     {
@@ -74,7 +76,7 @@ struct Builder
         n2[me].box   = nb;
         n2[me].first = first;
         n2[me].count = count;
-        if (count <= kMaxLeaf) return me;
+        if (count <= bvh2_leaf) return me;
 
         double  best     = DBL_MAX;
         int     bax      = -1;
@@ -316,8 +318,60 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         out.nodes.push_back(n);
         return;
     }
-    B.n2.reserve((size_t)n_refs);
+    B.bvh2_leaf = getenv("HR_BVH_GREEDY") ? kMaxLeaf : 1;
+    B.n2.reserve((size_t)n_refs * 2);
     int32_t root2 = B.split(0, n_refs);
+
+    // ---- optimal collapse (Ylitie, Karras, Laine 2017, sec. 3.1): dynamic programme over the binary tree -----------------
+    // c(n, i) = least SAH cost of representing the subtree of n by a forest of at most i roots, a root being either a leaf
+    // child (<= kMaxLeaf triangles: area * count * C_prim) or an 8-wide node (area * C_node + the best forest of <= 8 roots
+    // below it).  The greedy largest-area-first collapse left 45% of the nodes with two children (bottom nodes holding two
+    // leaves): every slot of a node is box-tested anyway, so half-empty nodes are pure overhead.
+    const bool optimal = !getenv("HR_BVH_GREEDY");   // developer switch: the previous greedy collapse
+    std::vector<float>   cost;
+    std::vector<uint8_t> best_k, use_split, as_leaf;
+    if (optimal)
+    {
+        const size_t nn = B.n2.size();
+        // one node step ~230 VALU + 80 B, one triangle test ~80 VALU + 48 B; the result is flat in C_prim (0.15 .. 1.2: 0.253-0.256 ms)
+        const double C_node = 1.0, C_prim = 0.35;
+        cost.assign(nn * 8, 0.0f); best_k.assign(nn * 8, 0); use_split.assign(nn * 8, 0); as_leaf.assign(nn, 0);
+        for (size_t r = nn; r-- > 0;)   // children are allocated after their parent: reverse order is bottom-up
+        {
+            const Bin2& c = B.n2[r];
+            const double area = c.box.half_area();
+            const double leaf = c.count <= kMaxLeaf ? area * c.count * C_prim : 1e300;
+            if (c.a < 0)
+            {
+                for (int i = 0; i < 8; i++) cost[r * 8 + i] = (float)leaf;
+                as_leaf[r] = 1;
+                continue;
+            }
+            double dist[9];   // dist[j]: children of r as a forest of <= j roots, j = 2..8
+            for (int j = 2; j <= 8; j++)
+            {
+                double b = 1e300; int bk = 1;
+                for (int k = 1; k < j; k++)
+                {
+                    const double v = (double)cost[(size_t)c.a * 8 + (k - 1)] + (double)cost[(size_t)c.b * 8 + (j - k - 1)];
+                    if (v < b) { b = v; bk = k; }
+                }
+                dist[j] = b;
+                best_k[r * 8 + (j - 1)] = (uint8_t)bk;
+            }
+            const double internal = dist[8] + area * C_node;
+            as_leaf[r] = leaf <= internal;
+            double prev = leaf <= internal ? leaf : internal;
+            cost[r * 8 + 0] = (float)prev;
+            for (int i = 2; i <= 7; i++)
+            {
+                if (dist[i] < prev) { prev = dist[i]; use_split[r * 8 + (i - 1)] = 1; }
+                cost[r * 8 + (i - 1)] = (float)prev;
+            }
+            cost[r * 8 + 7] = cost[r * 8 + 6];   // budget 8 only ever splits (used for the children of a node: best_k[.][7])
+            use_split[r * 8 + 7] = 1;
+        }
+    }
 
     // ---- collapse to 8-wide, breadth-first -----------------------------------------------
     struct Pending { int32_t n2; int32_t n8; int depth; };
@@ -331,7 +385,41 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         q.pop();
         if (pd.depth > out.max_depth) out.max_depth = pd.depth;
         int32_t kids[8];
+        bool    kid_internal[8];
         int     nk = 0;
+        if (optimal)
+        {
+            // children of this 8-wide node = the minimum-cost forest of at most 8 roots under the binary node (dp below)
+            if (B.n2[pd.n2].a < 0) { kids[nk] = pd.n2; kid_internal[nk++] = false; }
+            else
+            {
+                struct Item { int32_t n; int budget; };
+                Item stack[32];
+                int  sp = 0;
+                auto push_split = [&](int32_t n, int budget) {
+                    const int k = best_k[(size_t)n * 8 + (budget - 1)];
+                    stack[sp++] = { B.n2[n].b, budget - k };
+                    stack[sp++] = { B.n2[n].a, k };
+                };
+                push_split(pd.n2, 8);
+                while (sp > 0)
+                {
+                    Item it = stack[--sp];
+                    const Bin2& c = B.n2[it.n];
+                    int budget = it.budget;
+                    if (c.a < 0) { kids[nk] = it.n; kid_internal[nk++] = false; continue; }
+                    while (budget > 1 && !use_split[(size_t)it.n * 8 + (budget - 1)]) budget--;   // c(n,i) == c(n,i-1)
+                    if (budget == 1)
+                    {
+                        kids[nk] = it.n;
+                        kid_internal[nk++] = !as_leaf[it.n];
+                    }
+                    else push_split(it.n, budget);
+                }
+            }
+        }
+        else
+        {
         if (B.n2[pd.n2].a < 0) kids[nk++] = pd.n2; // root is itself a leaf
         else { kids[nk++] = B.n2[pd.n2].a; kids[nk++] = B.n2[pd.n2].b; }
         while (nk < 8)
@@ -349,9 +437,20 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
             kids[best]  = B.n2[k].a;
             kids[nk++]  = B.n2[k].b;
         }
+        for (int i = 0; i < nk; i++) kid_internal[i] = B.n2[kids[i]].a >= 0;
+        }
+        // kids[] and kid_internal[] are permuted together below
+        {
+            int32_t ki[8], kl[8];
+            int     ni_ = 0, nl_ = 0;
+            for (int i = 0; i < nk; i++) (kid_internal[i] ? ki[ni_++] : kl[nl_++]) = kids[i];
+            for (int i = 0; i < ni_; i++) { kids[i] = ki[i]; kid_internal[i] = true; }
+            for (int i = 0; i < nl_; i++) { kids[ni_ + i] = kl[i]; kid_internal[ni_ + i] = false; }
+        }
+        const int n_int_kids = (int)std::count(kid_internal, kid_internal + nk, true);
         // slots: internal children first (slot i <-> node child_base + i), then the leaves — the traversal keeps
         // one (child_base, hit mask) stack entry per node instead of one entry per child
-        int32_t* kids_mid = std::stable_partition(kids, kids + nk, [&](int32_t k) { return B.n2[k].a >= 0; });
+        int32_t* kids_mid = kids + n_int_kids;
         Box nb;
         for (int i = 0; i < nk; i++) nb.add(B.n2[kids[i]].box);
         Node8 n;
@@ -393,7 +492,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
                 n.qlo[a][i] = (uint8_t)ql;
                 n.qhi[a][i] = (uint8_t)qh;
             }
-            if (c.a >= 0)
+            if (i < n_int_kids)
             {
                 n.meta[i] = (uint8_t)(0x10 | n_internal);
                 n_internal++;
@@ -423,7 +522,17 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         out.nodes[pd.n8] = n;
         int slot = 0;
         for (int i = 0; i < nk; i++)
-            if (B.n2[kids[i]].a >= 0) q.push({ kids[i], (int32_t)(base + slot++), pd.depth + 1 });
+            if (i < n_int_kids) q.push({ kids[i], (int32_t)(base + slot++), pd.depth + 1 });
+    }
+    if (getenv("HR_BVH_STATS"))
+    {
+        long hist[9] = { 0 }, ihist[9] = { 0 };
+        for (const Node8& n : out.nodes) { hist[n.counts >> 4]++; ihist[n.counts & 15]++; }
+        fprintf(stderr, "bvh8: %zu nodes, %zu tri refs, depth %d; children/node histogram:", out.nodes.size(), out.tris.size(), out.max_depth);
+        for (int i = 0; i <= 8; i++) fprintf(stderr, " %d:%ld", i, hist[i]);
+        fprintf(stderr, "; internal children/node:");
+        for (int i = 0; i <= 8; i++) fprintf(stderr, " %d:%ld", i, ihist[i]);
+        fprintf(stderr, "\n");
     }
 }
 
