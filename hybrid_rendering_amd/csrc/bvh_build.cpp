@@ -50,7 +50,7 @@ struct Bin2
     int32_t first = 0, count = 0;
 };
 
-constexpr int kBins    = 32;
+constexpr int kBins    = 64;   // 32 -> 64: nodes per shadow ray 6.38 -> 6.30, frame -1.3% (8 bins: 7.25, +5%)
 constexpr int kMaxLeaf = 4;   // triangles per leaf CHILD of an 8-wide node (count field of the meta byte, 8 x 4 = 32-bit mask)
 
 struct Builder
