@@ -20,6 +20,18 @@ void* orc_scene_create(const float* verts, int n_tris, const float* normals, con
 void orc_scene_destroy(void* scene) { delete (Scene*)scene; }
 int  orc_scene_num_nodes(const void* scene) { return (int)((const Scene*)scene)->nodes.size(); }
 
+// single-ray entry points: the ray-query / traceRay mock of oracle/refshim calls these through a function pointer
+int orc_any_hit_one(void* scene, const float* o, const float* d, float t_min, float t_max)
+{
+    return ((const Scene*)scene)->any_hit(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), t_min, t_max) ? 1 : 0;
+}
+int orc_closest_hit_one(void* scene, const float* o, const float* d, float t_min, float t_max, float* tuv)
+{
+    Hit h = ((const Scene*)scene)->closest_hit(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), t_min, t_max);
+    tuv[0] = h.t; tuv[1] = h.u; tuv[2] = h.v;
+    return h.prim;
+}
+
 void orc_any_hit_batch(const void* scene, int n, const float* rays, uint8_t* out, int brute_force, uint64_t* stats)
 {
     const Scene& s = *(const Scene*)scene;

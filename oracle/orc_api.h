@@ -14,6 +14,8 @@ void*    orc_scene_create(const float* verts, int n_tris, const float* normals, 
 void     orc_scene_destroy(void* scene);
 int      orc_scene_num_nodes(const void* scene);
 // rays: [n][8] = origin xyz, t_max, dir xyz, t_min.  out: [n] uint8 (1 = occluded).
+int      orc_any_hit_one(void* scene, const float* o, const float* d, float t_min, float t_max);
+int      orc_closest_hit_one(void* scene, const float* o, const float* d, float t_min, float t_max, float* tuv /*[3]*/);
 void     orc_any_hit_batch(const void* scene, int n, const float* rays, uint8_t* out, int brute_force, uint64_t* stats /*[2] nodes,tris; nullable*/);
 // out: [n][4] float = t, u, v, prim (as float bits of int32; -1 miss)
 void     orc_closest_hit_batch(const void* scene, int n, const float* rays, float* out_tuv, int32_t* out_prim, int brute_force);
