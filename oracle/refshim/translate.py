@@ -19,7 +19,9 @@ OUT_DIR = os.path.join(os.path.dirname(HERE), "_ref", "gen")
 RESOURCE_TYPES = ("sampler2D", "usampler2D", "samplerCube", "image2D", "uimage2D", "accelerationStructureEXT")
 # spots where GLSL is laxer than C++ (scalar swizzles, names that are C++ keywords ...): pure token substitutions
 TOKEN_PATCHES = {
-    "shadows/shadows_denoise_atrous.comp": [(r"\bvar\.r\b", "var")],
+    "shadows/shadows_denoise_atrous.comp": [(r"\bvar\.r\b", "var")],          # .r of a scalar
+    "reflections/reflections_denoise_atrous.comp": [(r"\bvar\.r\b", "var")],
+    "*": [(r"\bbase_grid_coord\s*\(", "base_grid_coord_fn("), (r"\bsrand\s*\(", "srand_fn(")],               # a local variable shadows the function it is initialised from
 }
 
 
@@ -57,7 +59,7 @@ def match_paren(t, i):
 
 def translate(rel, defines=()):
     t = expand(os.path.join(REF_SHADERS, rel))
-    for pat, rep in TOKEN_PATCHES.get(rel, []):
+    for pat, rep in TOKEN_PATCHES.get(rel, []) + TOKEN_PATCHES["*"]:
         t = re.sub(pat, rep, t)
     regs = []
 
@@ -72,6 +74,14 @@ def translate(rel, defines=()):
     # interface blocks (uniform / buffer / push constants)
     def block(m):
         name, body, inst, inst_dims = m.group(2), m.group(3), m.group(4), m.group(5)
+        if not inst:
+            # no instance name: the members are globals
+            out = []
+            for mm in re.finditer(r"(\w+)\s+(\w+)\s*((?:\[[^\]]*\])*)\s*;", body):
+                ty, mn, dims = mm.groups()
+                out.append("static %s %s%s;" % (ty, mn, dims))
+                regs.append(mn)
+            return "\n".join(out)
         members = []
         for mm in re.finditer(r"(\w+)\s+(\w+)\s*((?:\[[^\]]*\])*)\s*;", body):
             ty, mn, dims = mm.groups()
@@ -85,7 +95,7 @@ def translate(rel, defines=()):
         if inst_dims and inst_dims.replace(" ", "") == "[]":
             inst_dims = "[1024]"   # unsized descriptor arrays: a fixed table
         return "struct %s_block { %s };\nstatic %s_block %s%s;" % (name, " ".join(members), name, inst, inst_dims or "")
-    t = re.sub(r"layout\s*\(([^)]*)\)\s*(?:(?:readonly|writeonly|restrict|coherent)\s+)*(?:uniform|buffer)\s+(\w+)\s*\{([^}]*)\}\s*(\w+)\s*(\[[^\]]*\])?\s*;", block, t)
+    t = re.sub(r"layout\s*\(([^)]*)\)\s*(?:(?:readonly|writeonly|restrict|coherent)\s+)*(?:uniform|buffer)\s+(\w+)\s*\{([^}]*)\}\s*(\w+)?\s*(\[[^\]]*\])?\s*;", block, t)
 
     # opaque resources
     def resource(m):

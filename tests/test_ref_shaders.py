@@ -1,0 +1,125 @@
+"""THE PIN: the reference's own shaders, compiled for the CPU through oracle/refshim (GLSL-in-C++) and run on the same
+seeded inputs as the oracle restatement — every stage image must be bit-identical.  With /root/reference mounted the
+shaders are (re)translated from where they lie; otherwise a prebuilt oracle/_ref/*.so is used; with neither the module
+is skipped (the committed golden fixtures, which test_golden_fixtures_* proves to be reference-shader outputs, then
+carry the pin to the GPU box: tests/test_gpu_golden.py).
+
+What the shim binds (GLSL leaves it implementation-defined): the fp32 built-ins of orc_math.h, nearest/bilinear
+sampling, and ray queries answered by the oracle's watertight triangle test — the reference's traversal is the Vulkan
+driver.  Everything else executed here is the reference's code."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from hybrid_rendering_amd import synth, synth_env
+from oracle import pyref
+
+pytestmark = pytest.mark.skipif(not pyref.available(), reason="neither /root/reference nor a prebuilt oracle/_ref")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def rh():
+    import ref_harness
+    return ref_harness
+
+
+def _frames(oracle, name, w, h, n, dolly, light_kind="default", mips=0):
+    sd = helpers.scene_data(name)
+    osc = oracle.Scene(sd)
+    return sd, osc, helpers.make_frames(oracle, osc, name, w, h, n, dolly, light_kind, scale_mips=mips)
+
+
+@pytest.mark.parametrize("name,light_kind,dolly", [("cornell", "soft", 0.05), ("sponza_small", "default", 0.5), ("sponza_small", "point", 0.5),
+                                                   ("sponza_small", "spot", 0.5)])
+def test_shadows_pass(oracle, rh, name, light_kind, dolly):
+    """shadows_ray_trace.comp, shadows_denoise_reprojection.comp, shadows_denoise_copy_shadow_tiles.comp and
+    shadows_denoise_atrous.comp x4, 4 frames with camera motion and temporal feedback"""
+    w, h = 96, 64
+    sd, osc, frames = _frames(oracle, name, w, h, 4, dolly, light_kind)
+    sob, sr = synth.blue_noise_tables()
+    op, rp = oracle.ShadowsPass(w, h), rh.RefShadowsPass(w, h)
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["gb"] if k else fr["gb"]
+        op.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        rp.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        a, b = op.stages, rp.stages
+        assert np.array_equal(a["mask"], b["mask"]), f"frame {k}: visibility mask"
+        assert np.array_equal(a["temporal"], b["temporal"]) and np.array_equal(a["moments"], b["moments"]), f"frame {k}: reprojection"
+        assert np.array_equal(a["tiles"], b["tiles"]), f"frame {k}: tile classification"
+        assert len(b["denoise_tiles"]) + len(b["shadow_tiles"]) == a["tiles"].size
+        for i, (x, y) in enumerate(zip(a["atrous"], b["atrous"])):
+            assert np.array_equal(x, y), f"frame {k}: a-trous iteration {i}"
+    assert 0 < a["tiles"].sum() and np.unpackbits(a["mask"].view(np.uint8)).sum() > 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza_small"])
+def test_ao_pass(oracle, rh, name):
+    """ao_ray_trace.comp, ao_denoise_reprojection.comp, ao_denoise_bilateral_blur.comp (both directions), 4 frames"""
+    w, h = 96, 64
+    sd, osc, frames = _frames(oracle, name, w, h, 4, 0.05 if name == "cornell" else 0.5)
+    sob, sr = synth.blue_noise_tables()
+    zbp = synth.z_buffer_params()
+    op, rp = oracle.AOPass(w, h, zbp=zbp), rh.RefAOPass(w, h, zbp)
+    if name != "cornell":
+        op.p["ray_length"] = rp.p["ray_length"] = 60.0
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["gb"] if k else fr["gb"]
+        op.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        rp.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        a, b = op.stages, rp.stages
+        assert np.array_equal(a["mask"][0], b["mask"]), f"frame {k}: hit mask"
+        assert np.array_equal(a["temporal"], b["temporal"]) and np.array_equal(a["length"], b["length"]), f"frame {k}: reprojection"
+        assert np.array_equal(a["tiles"], b["tiles"]), f"frame {k}: tiles"
+        assert np.array_equal(a["blur0"], b["blur0"]) and np.array_equal(a["blur1"], b["blur1"]), f"frame {k}: bilateral blur"
+    assert 0 < a["tiles"].sum() < a["tiles"].size or name == "cornell"
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_upsample(oracle, rh, level):
+    """ao_upsample.comp and shadows_upsample.comp from half / quarter resolution"""
+    W, H = 96, 64
+    sd, osc, frames = _frames(oracle, "sponza_small", W, H, 2, 0.5, mips=2)
+    sob, sr = synth.blue_noise_tables()
+    zbp = synth.z_buffer_params()
+    w, h = W >> level, H >> level
+    ap, sp = oracle.AOPass(w, h, zbp=zbp), oracle.ShadowsPass(w, h)
+    ap.p["ray_length"] = 60.0
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["mips"][level] if k else fr["mips"][level]
+        ap.render(osc, fr["ubo"], fr["mips"][level], prev, sob, sr, k, full=fr["mips"][0])
+        sp.render(osc, fr["ubo"], fr["mips"][level], prev, sob, sr, k)
+    fr = frames[-1]
+    ref = rh.upsample("ao/ao_upsample.comp", fr["mips"][:level + 1], level, ap.stages["blur1"], "r16f", power=1.2)
+    assert np.array_equal(ref[..., 0], ap.stages["upsample"][..., 0])
+    up = oracle.upsample(fr["mips"][0], fr["mips"][level], sp.stages["output"], channels=1, sky_value=0.0, power=0.0)
+    ref = rh.upsample("shadows/shadows_upsample.comp", fr["mips"][:level + 1], level, sp.stages["output"], "r16f")
+    assert np.array_equal(ref[..., 0], up[..., 0])
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza_small"])
+def test_ddgi_probe_update_border_and_sampling(oracle, rh, name):
+    """gi_irradiance_probe_update.comp, gi_depth_probe_update.comp, both border updates and gi_sample_probe_grid.comp,
+    3 frames with hysteresis feedback (the probe rays come from the oracle's trace stage)"""
+    from oracle import pyoracle_ddgi as od
+    w, h = 64, 48
+    sd, osc, frames = _frames(oracle, name, w, h, 3, 1.0)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(4, 3, 4), rays_per_probe=96, normal_bias=1.0 if name == "cornell" else 0.1)
+    sky = synth_env.sky_cubemap(16)
+    op = od.DDGIPass(ddgi)
+    rng = np.random.RandomState(42)
+    for f in range(3):
+        rd = int(not op.ping_pong)
+        pirr, pdep, first = op.irr[rd].copy(), op.dep[rd].copy(), op.first_frame
+        op.render(osc, frames[f]["ubo"], frames[f]["gb"], sky, synth_env.random_orientation(rng), f)
+        st = op.stages
+        irr = rh.ddgi_border_update(ddgi, False, rh.ddgi_probe_update(ddgi, False, first, st["radiance"], st["direction_distance"], pirr, pdep))
+        dep = rh.ddgi_border_update(ddgi, True, rh.ddgi_probe_update(ddgi, True, first, st["radiance"], st["direction_distance"], pirr, pdep))
+        assert np.array_equal(irr, st["irradiance"]), f"frame {f}: irradiance atlas"
+        assert np.array_equal(dep, st["depth"]), f"frame {f}: depth atlas"
+        out = rh.ddgi_sample_probe_grid(frames[f]["ubo"], ddgi, frames[f]["gb"], op.p["gi_intensity"], st["irradiance"], st["depth"])
+        assert np.array_equal(out, st["output"]), f"frame {f}: sampled irradiance"
+    assert (oracle.f16(st["output"][..., :3]) > 0).mean() > 0.2
