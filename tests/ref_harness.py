@@ -297,3 +297,80 @@ def ddgi_sample_probe_grid(ubo, ddgi, gb, gi_intensity, irr, dep):
     sh.set_f("u_PushConstants.gi_intensity", gi_intensity)
     sh.dispatch((w + 7) // 8, (h + 7) // 8)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ reflections (denoiser)
+
+def reflections_temporal(ubo, inp, cur, prev, hist_color, hist_moments, camera_delta, alpha, moments_alpha, approx):
+    sh = shader("reflections/reflections_denoise_reprojection.comp")
+    h, w = cur["depth"].shape
+    th, tw = (h + 7) // 8, (w + 7) // 8
+    oc, om = np.zeros((h, w, 4), np.uint16), np.zeros((h, w, 4), np.uint16)
+    den, cpy = np.zeros((th * tw, 2), np.int32), np.zeros((th * tw, 2), np.int32)
+    set_ubo(sh, ubo)
+    sh.bind("i_Output", pyref.Tex(oc, "rgba16f"))
+    sh.bind("i_Moments", pyref.Tex(om, "rgba16f"))
+    bind_gbuffer(sh, cur)
+    bind_gbuffer(sh, prev, "s_PrevGBuffer")
+    sh.bind("s_Input", pyref.Tex(inp, "rgba16f"))
+    sh.bind("s_HistoryOutput", pyref.Tex(hist_color, "rgba16f"))
+    sh.bind("s_HistoryMoments", pyref.Tex(hist_moments, "rgba16f"))
+    sh.bind_buffer("DenoiseTileData.coord", den)
+    sh.bind_buffer("CopyTileData.coord", cpy)
+    for blk in ("DenoiseTileDispatchArgs", "CopyTileDispatchArgs"):
+        sh.set(blk, np.array([0, 1, 1], np.uint32))       # reflections_denoise_reset_args.comp
+    sh.set("u_PushConstants.camera_delta", np.asarray(camera_delta, np.float32))
+    sh.set_f("u_PushConstants.frame_time", 0.0)
+    sh.set_f("u_PushConstants.alpha", alpha)
+    sh.set_f("u_PushConstants.moments_alpha", moments_alpha)
+    sh.set_i("u_PushConstants.g_buffer_mip", 0)
+    sh.set_i("u_PushConstants.approximate_with_ddgi", int(approx))
+    sh.dispatch(tw, th)
+    nd = int(np.frombuffer(C.string_at(sh.regs["DenoiseTileDispatchArgs"][0], 12), np.uint32)[0])
+    nc = int(np.frombuffer(C.string_at(sh.regs["CopyTileDispatchArgs"][0], 12), np.uint32)[0])
+    return oc, om, den[:nd].copy(), cpy[:nc].copy()
+
+
+def reflections_atrous(inp, gb, den, cpy, step, radius, phi_color, phi_normal, sigma_depth, approx):
+    sh, cp = shader("reflections/reflections_denoise_atrous.comp"), shader("reflections/reflections_denoise_copy_tiles.comp")
+    h, w = inp.shape[:2]
+    out = np.zeros((h, w, 4), np.uint16)
+    tout, tin = pyref.Tex(out, "rgba16f"), pyref.Tex(inp, "rgba16f")
+    if len(cpy):
+        cp.bind("i_Output", tout)
+        cp.bind("s_Input", tin)
+        cp.bind_buffer("CopyTileData.coord", np.ascontiguousarray(cpy))
+        cp.dispatch(len(cpy))
+    if len(den):
+        sh.bind("i_Output", tout)
+        sh.bind("s_Input", tin)
+        bind_gbuffer(sh, gb)
+        sh.bind_buffer("DenoiseTileData.coord", np.ascontiguousarray(den))
+        for k, v in (("radius", radius), ("step_size", step), ("g_buffer_mip", 0), ("approximate_with_ddgi", int(approx))):
+            sh.set_i("u_PushConstants." + k, v)
+        for k, v in (("phi_color", phi_color), ("phi_normal", phi_normal), ("sigma_depth", sigma_depth)):
+            sh.set_f("u_PushConstants." + k, v)
+        sh.dispatch(len(den))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ TAA
+
+def taa_resolve(color, prev, gb, jitter, feedback_min=0.88, feedback_max=0.97, sharpen=True):
+    """taa.comp (temporal_aa.cpp:118-150): s_Current / s_Prev bilinear (:255), velocity / depth nearest"""
+    sh = shader("taa.comp")
+    h, w = color.shape[:2]
+    out = np.zeros((h, w, 4), np.uint16)
+    sh.bind("i_Color", pyref.Tex(out, "rgba16f"))
+    sh.bind("s_Current", pyref.Tex(color, "rgba16f", linear=True))
+    sh.bind("s_Prev", pyref.Tex(prev, "rgba16f", linear=True))
+    sh.bind("s_Velocity", pyref.Tex(gb["gb2"], "rgba16f"))
+    sh.bind("s_Depth", pyref.Tex(gb["depth"], "r32f"))
+    sh.set("u_TexelSize", np.array([np.float32(1.0) / np.float32(w), np.float32(1.0) / np.float32(h), w, h], np.float32))
+    sh.set("u_CurrentPrevJitter", np.asarray(jitter, np.float32))
+    sh.set("u_TimeParams", np.zeros(4, np.float32))
+    sh.set_f("u_FeedbackMin", feedback_min)
+    sh.set_f("u_FeedbackMax", feedback_max)
+    sh.set_i("u_Sharpen", int(sharpen))
+    sh.dispatch((w + 31) // 32, (h + 31) // 32)
+    return out

@@ -123,3 +123,64 @@ def test_ddgi_probe_update_border_and_sampling(oracle, rh, name):
         out = rh.ddgi_sample_probe_grid(frames[f]["ubo"], ddgi, frames[f]["gb"], op.p["gi_intensity"], st["irradiance"], st["depth"])
         assert np.array_equal(out, st["output"]), f"frame {f}: sampled irradiance"
     assert (oracle.f16(st["output"][..., :3]) > 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("scale,approx", [(0, True), (1, True), (0, False)])
+def test_reflections_denoiser(oracle, rh, scale, approx):
+    """reflections_denoise_reprojection.comp, reflections_denoise_copy_tiles.comp, reflections_denoise_atrous.comp x4 and
+    reflections_upsample.comp over 3 frames (the traced image and the DDGI atlases come from the oracle's stages)"""
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf
+    W, H = 64, 48
+    sd, osc, frames = _frames(oracle, "sponza_small", W, H, 3, 1.0, mips=scale)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    sob, sr = synth.blue_noise_tables()
+    w, h = W >> scale, H >> scale
+    dp, op = od.DDGIPass(ddgi), orf.ReflectionsPass(w, h, approximate_with_ddgi=approx)
+    rng = np.random.RandomState(7)
+    ping = False
+    for f in range(3):
+        lvl = (lambda fr: fr["mips"][scale] if scale else fr["gb"])
+        cur, prev, full = lvl(frames[f]), lvl(frames[f - 1] if f else frames[f]), frames[f]["gb"]
+        dp.render(osc, frames[f]["ubo"], full, sky, synth_env.random_orientation(rng), f)
+        irr, dep = dp.current_read()
+        cd = (0.0, 0.0, 0.0) if f == 0 else (-1.0, 0.0, 0.0)
+        hist, hm = op.color[1 - int(ping)].copy(), op.moments[1 - int(ping)].copy()
+        op.render(osc, frames[f]["ubo"], ddgi, cur, prev, sob, sr, f, env, irr, dep, camera_delta=cd, full=full if scale else None, ping_pong=ping)
+        st, p = op.stages, op.p
+        oc, om, den, cpy = rh.reflections_temporal(frames[f]["ubo"], st["trace"], cur, prev, hist, hm, cd, p["alpha"], p["moments_alpha"], approx)
+        tiles = np.zeros_like(st["tiles"])
+        tiles[den[:, 1] // 8, den[:, 0] // 8] = 1
+        assert np.array_equal(oc, st["temporal"]) and np.array_equal(om, st["moments"]), f"frame {f}: reprojection"
+        assert np.array_equal(tiles, st["tiles"]) and len(den) + len(cpy) == tiles.size, f"frame {f}: tile lists"
+        img = st["temporal"]
+        for i in range(p["filter_iterations"]):
+            out = rh.reflections_atrous(img, cur, den, cpy, 1 << i, p["radius"], p["phi_color"], p["phi_normal"], p["sigma_depth"], approx)
+            assert np.array_equal(out, st["atrous"][i]), f"frame {f}: a-trous iteration {i}"
+            img = st["atrous"][i]
+        if scale:
+            up = rh.upsample("reflections/reflections_upsample.comp", frames[f]["mips"][:scale + 1], scale, st["atrous"][-1], "rgba16f")
+            assert np.array_equal(up, st["upsample"]), f"frame {f}: upsample"
+        ping = not ping
+
+
+def test_taa_resolve(oracle, rh):
+    """taa.comp over 3 frames with jitter, history feedback and sharpening"""
+    from oracle import pyoracle_post as opost
+    W, H = 80, 48
+    sd, osc, frames = _frames(oracle, "sponza_small", W, H, 3, 0.5)
+    rng = np.random.RandomState(5)
+    t = opost.TAAPass(W, H)
+    for k in range(3):
+        gb = frames[k]["gb"]
+        col = np.zeros((H, W, 4), np.float16)
+        col[..., :3] = gb["gb1"][..., :3].astype(np.float32) / 255.0 * rng.uniform(0.2, 2.5, (H, W, 1))   # HDR colours with structure
+        col[..., 3] = 1
+        col = np.ascontiguousarray(col).view(np.uint16)
+        t.reset = (k == 0)
+        t.update(k)
+        t.render(col, gb, k & 1)
+        ref = rh.taa_resolve(col, t.images[int(not (k & 1))], gb, t.jitter, t.feedback_min, t.feedback_max, t.sharpen)
+        assert np.array_equal(ref, t.output(k & 1)), f"frame {k}"
