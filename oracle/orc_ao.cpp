@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the ray-traced ambient-occlusion pass:
 //   A1 ao/ao_ray_trace.comp:90-126 (+ brdf.glsl:8-32 sample_cosine_lobe / make_rotation_matrix,
 //      ray_query.glsl:6-30 query_visibility)

@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C entry points of the CPU oracle (loaded with ctypes by
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product).
-// Parity unpinned by the reference (no tests / golden vectors upstream).
+// Pinned against the reference's own shaders run on the CPU (oracle/refshim, tests/test_ref_shaders.py); upstream has no
+// tests / golden vectors of its own.
 #pragma once
 #include <cstdint>
 

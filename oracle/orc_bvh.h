@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 //
 // Ray/scene intersection.  In the reference this arithmetic is NOT in the tree: it is the
 // Vulkan driver behind VK_KHR_acceleration_structure / GL_EXT_ray_query

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Data contract shared by the restated shaders: UBO / Light structs, image views with the
 // pinned out-of-bounds rule (texelFetch outside the image returns 0 — SURVEY.md §8a quirk 3),
 // the blue-noise sampler and the scene handle.

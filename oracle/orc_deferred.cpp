@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the deferred composite (SURVEY.md §8f "next" row 1): shaders/deferred.frag:177-205
 // (+ evaluate_sh9_irradiance :115-141, project_onto_sh9 :96-113, indirect_lighting :151-173,
 // direct_lighting of lighting.glsl:117-196 WITHOUT RAY_TRACING / SOFT_SHADOWS).  No sky test: the reference

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the ground-truth path tracer:
 //   ground_truth/ground_truth_path_trace.rgen:52-112  primary ray with RNG jitter, running mean in RGBA16F
 //   ground_truth/ground_truth_path_trace.rchit:114-142 direct lighting at the first hit: punctual light with

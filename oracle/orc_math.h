@@ -3,10 +3,13 @@
 // shaders (/root/reference/src/shaders).  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load this; the product (hybrid_rendering_amd/) never does.
 //
-// PARITY STATUS: "parity unpinned" — the reference ships no tests / golden vectors and
-// its BVH traversal lives in the Vulkan driver.  This file pins the GLSL
-// built-ins to ONE fp32 definition (below); the HIP kernels implement the same definition
-// independently, so integer/bit outputs can be compared bit-exactly.
+// PARITY STATUS: pinned.  The reference ships no tests / golden vectors and cannot be built here (Vulkan), so the pin is
+// the reference's OWN SHADER SOURCES executed on the CPU: oracle/refshim translates them (read where they lie under
+// /root/reference/src/shaders, output only into oracle/_ref/) into C++ over a GLSL runtime, and tests/test_ref_shaders.py
+// requires every stage of this restatement — and every committed golden fixture — to equal them bit for bit.
+// What stays a CONTRACT rather than reference behaviour is exactly what GLSL / Vulkan leave implementation-defined:
+// the fp32 built-ins below, sampler filtering, and the BVH traversal (the Vulkan driver).  The shim
+// binds the shaders' built-ins to the definitions in this file; the HIP kernels implement them independently.
 //
 // Numerical contract:
 //   * every fp32 op is an individually rounded IEEE-754 binary32 op (compile with

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the ray-traced reflections pass:
 //   R1 reflections/reflections_ray_trace.rgen:119-171 (+ importance_sample_ggx :78-105),
 //      .rchit:117-150 (+ indirect_lighting :87-111), .rmiss:26-30

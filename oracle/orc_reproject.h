@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of /root/reference/src/shaders/reprojection.glsl (whole file) with its three
 // compile-time variants expressed as template flags:
 //   SINGLE  = REPROJECTION_SINGLE_COLOR_CHANNEL   (shadows, AO)

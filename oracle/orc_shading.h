@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Hit shading shared by the reflection and DDGI closest-hit shaders:
 //   brdf.glsl:36-142          GGX / Schlick terms, evaluate_uber_brdf
 //   lighting.glsl:6-196       fetch_light_properties (non-soft) + direct_lighting (+ SAMPLE_SKY_LIGHT)

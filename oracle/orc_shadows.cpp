@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the ray-traced soft-shadow pass:
 //   S1 shadows/shadows_ray_trace.comp:89-132  (+ lighting.glsl:6-111 SOFT_SHADOWS|SHADOW_RAY_ONLY,
 //      ray_query.glsl:34-59 query_distance)

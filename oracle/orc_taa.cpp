@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Parity unpinned by the reference.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_math.h header).  Pinned against the reference's own shaders: tests/test_ref_shaders.py.
 // Restatement of the temporal anti-aliasing resolve:
 //   taa.comp:378-420 main, :245-372 temporal_reprojection (defines USE_DILATION, MINMAX_3X3_ROUNDED, USE_CLIPPING,
 //   UNJITTER_*, HDR_CORRECTION; no YCoCg, no USE_OPTIMIZATIONS), :123-151 clip_aabb, :155-187 find_closest_fragment_3x3

@@ -1,7 +1,8 @@
 """ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
-The product package (hybrid_rendering_amd) never does.  Parity unpinned by the reference.
+The product package (hybrid_rendering_amd) never does.  Every stage is pinned bit for bit against the reference's own
+shaders executed through oracle/refshim (oracle/pyref.py, tests/test_ref_shaders.py).
 """
 from __future__ import annotations
 

@@ -77,18 +77,46 @@ def build(rel: str, defines=(), force=False) -> str:
         if not os.path.exists(os.path.join(_SHIM, "swizzles.inc")):
             subprocess.check_call([sys.executable, os.path.join(_SHIM, "gen_swizzles.py")])
         src = translate.translate(rel, list(defines))
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-w", "-I" + _SHIM, "-o", so, src])
+        _compile(src, so)
+    return so
+
+
+def _compile(src, so):
+    # GLSL evaluates function and constructor arguments left to right (vec2(next_float(rng), next_float(rng)) in the
+    # reference's random.glsl depends on it); C++ leaves the order unspecified.  clang evaluates left to right, g++ right
+    # to left, so the translated shaders are built with ROCm's clang; RefShader checks the order at load time.
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = "clang++"
+    subprocess.check_call([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-w", "-I" + _SHIM, "-o", so, src])
+
+
+def build_pipeline(name: str, stages, force=False) -> str:
+    """a ray-tracing pipeline: stages = [(rel, kind)], kind 0 = ray generation, 1 = closest hit, 2 = miss"""
+    so = os.path.join(_REF_DIR, name + ".so")
+    if not os.path.isdir(REFERENCE_SHADERS):
+        if not os.path.exists(so):
+            raise FileNotFoundError(f"{so}: not prebuilt and /root/reference is absent")
+        return so
+    deps = [os.path.join(_SHIM, f) for f in ("glsl.h", "runtime.inc", "runtime_rt.inc", "translate.py", "swizzles.inc")]
+    deps += [os.path.join(REFERENCE_SHADERS, r) for r, _ in stages]
+    if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        sys.path.insert(0, _SHIM)
+        import translate  # noqa: E402
+        sys.path.pop(0)
+        _compile(translate.translate_pipeline(name, list(stages)), so)
     return so
 
 
 class RefShader:
     """One compiled reference shader: set block members / bind textures by their GLSL names, then dispatch."""
 
-    def __init__(self, rel: str, defines=()):
-        self.lib = C.CDLL(build(rel, defines))
+    def __init__(self, rel: str, defines=(), so=None):
+        self.lib = C.CDLL(so or build(rel, defines))
 
         class Reg(C.Structure):
             _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p), ("size", C.c_size_t)]
+        assert self.lib.ref_eval_order_ok() == 1, "translated shader was compiled with right-to-left argument evaluation"
         self.lib.ref_regs.restype = C.POINTER(Reg)
         n = C.c_int(0)
         regs = self.lib.ref_regs(C.byref(n))
@@ -104,6 +132,13 @@ class RefShader:
         b = value if isinstance(value, (bytes, bytearray)) else np.ascontiguousarray(value).tobytes()
         assert len(b) == size, f"{name}: {len(b)} bytes given, member has {size}"
         C.memmove(ptr, b, size)
+
+    def set_at(self, name, value, offset=0):
+        """writes value's bytes at a byte offset inside a registered variable (descriptor arrays)"""
+        ptr, size = self.regs[name]
+        b = value if isinstance(value, (bytes, bytearray)) else np.ascontiguousarray(value).tobytes()
+        assert offset + len(b) <= size
+        C.memmove(ptr + offset, b, len(b))
 
     def set_f(self, name, v):
         self.set(name, np.float32(v))
@@ -127,5 +162,67 @@ class RefShader:
         self._keep["any_hit"] = fn
         self.lib.ref_set_any_hit(fn)
 
+    def fragments(self, w, h, tex_coord_name, out_name):
+        """full-screen pass of a fragment shader; returns the vec4 output as float32 [h][w][4]"""
+        out = np.zeros((h, w, 4), np.float32)
+        self.lib.ref_fragments(C.c_int(w), C.c_int(h), C.c_void_p(self.regs[tex_coord_name][0]), C.c_void_p(self.regs[out_name][0]),
+                               out.ctypes.data_as(C.c_void_p))
+        return out
+
     def dispatch(self, gx, gy=1, gz=1):
         self.lib.ref_dispatch(C.c_int(gx), C.c_int(gy), C.c_int(gz))
+
+
+class RefPipeline(RefShader):
+    """A ray-tracing pipeline (ray generation + closest hit + miss stages in one library).  Registry names carry the
+    stage index ('0:ubo.view_proj', '1:s_Cubemap'); the *_all helpers address a name in every stage that declares it."""
+
+    def __init__(self, name, stages):
+        super().__init__(None, so=build_pipeline(name, stages))
+        self.n_stages = len(stages)
+
+    def stages_with(self, name):
+        return [i for i in range(self.n_stages) if f"{i}:{name}" in self.regs]
+
+    def set_all(self, name, value):
+        for i in self.stages_with(name):
+            self.set(f"{i}:{name}", value)
+
+    def bind_all(self, name, tex):
+        for i in self.stages_with(name):
+            self.bind(f"{i}:{name}", tex)
+
+    def set_at_all(self, name, value, offset=0):
+        for i in self.stages_with(name):
+            self.set_at(f"{i}:{name}", value, offset)
+
+    def trace_rays(self, w, h, d=1):
+        self.lib.ref_trace_rays(C.c_int(w), C.c_int(h), C.c_int(d))
+
+
+# every reference shader the tests run (SURVEY.md §8a/§8f): the recipe behind oracle/_ref/
+COMPUTE_SHADERS = (
+    "shadows/shadows_ray_trace.comp", "shadows/shadows_denoise_reprojection.comp", "shadows/shadows_denoise_copy_shadow_tiles.comp",
+    "shadows/shadows_denoise_atrous.comp", "shadows/shadows_upsample.comp",
+    "ao/ao_ray_trace.comp", "ao/ao_denoise_reprojection.comp", "ao/ao_denoise_bilateral_blur.comp", "ao/ao_upsample.comp",
+    "reflections/reflections_denoise_reprojection.comp", "reflections/reflections_denoise_copy_tiles.comp",
+    "reflections/reflections_denoise_atrous.comp", "reflections/reflections_upsample.comp",
+    "gi/gi_irradiance_probe_update.comp", "gi/gi_depth_probe_update.comp", "gi/gi_irradiance_border_update.comp",
+    "gi/gi_depth_border_update.comp", "gi/gi_sample_probe_grid.comp", "taa.comp", "deferred.frag")
+PIPELINES = {
+    "gi_ray_trace": [("gi/gi_ray_trace.rgen", 0), ("gi/gi_ray_trace.rchit", 1), ("gi/gi_ray_trace.rmiss", 2)],
+    "reflections_ray_trace": [("reflections/reflections_ray_trace.rgen", 0), ("reflections/reflections_ray_trace.rchit", 1),
+                              ("reflections/reflections_ray_trace.rmiss", 2)],
+    "ground_truth_path_trace": [("ground_truth/ground_truth_path_trace.rgen", 0), ("ground_truth/ground_truth_path_trace.rchit", 1),
+                                ("ground_truth/ground_truth_path_trace.rmiss", 2)],
+}
+
+
+def build_all(force=False):
+    """translate + compile every reference shader into oracle/_ref/ (needs /root/reference); returns the .so paths"""
+    return [build(rel, force=force) for rel in COMPUTE_SHADERS] + [build_pipeline(n, st, force=force) for n, st in PIPELINES.items()]
+
+
+if __name__ == "__main__":
+    for so in build_all("--force" in sys.argv):
+        print(so)

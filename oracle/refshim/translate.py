@@ -30,13 +30,22 @@ def strip_comments(t):
     return re.sub(r"//[^\n]*", "", t)
 
 
-def expand(path, depth=0):
+def expand(path, seen=None):
+    """the file with its #include directives expanded; include guards become include-once bookkeeping here, so that
+    several stages of a pipeline can be translated into one C++ file"""
+    seen = set() if seen is None else seen
+    if path in seen:
+        return ""
+    seen.add(path)
     text = strip_comments(open(path).read())
+    g = re.match(r"\s*#\s*ifndef\s+(\w+)\s*\n\s*#\s*define\s+\1[ \t]*\n", text)
+    if g and text.rstrip().endswith("#endif"):
+        text = text[g.end():text.rstrip().rfind("#endif")]
     out = []
     for line in text.split("\n"):
         m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
         if m:
-            out.append(expand(os.path.normpath(os.path.join(os.path.dirname(path), m.group(1))), depth + 1))
+            out.append(expand(os.path.normpath(os.path.join(os.path.dirname(path), m.group(1))), seen))
         elif re.match(r"\s*#\s*(version|extension)\b", line):
             continue
         else:
@@ -57,18 +66,26 @@ def match_paren(t, i):
     raise ValueError("unbalanced parentheses")
 
 
-def translate(rel, defines=()):
+def translate_body(rel, regs, stage=None):
+    """(translated text, has_local_size); regs collects the (registry name, C++ lvalue) pairs"""
     t = expand(os.path.join(REF_SHADERS, rel))
     for pat, rep in TOKEN_PATCHES.get(rel, []) + TOKEN_PATCHES["*"]:
         t = re.sub(pat, rep, t)
-    regs = []
+    pre = "" if stage is None else "st%d::" % stage
+    if stage is not None:
+        # ray-tracing interface variables (see glsl.h: ray-tracing pipelines)
+        t = re.sub(r"layout\s*\(\s*location\s*=\s*(\d+)\s*\)\s*rayPayloadEXT\s+(\w+)\s+(\w+)\s*;",
+                   lambda m: "static %s %s; static int _rp%s = rt_register_payload(%d, %s, &%s, sizeof(%s));" % (m.group(2), m.group(3), m.group(1), stage, m.group(1), m.group(3), m.group(3)), t)
+        t = re.sub(r"layout\s*\(\s*location\s*=\s*(\d+)\s*\)\s*rayPayloadInEXT\s+(\w+)\s+(\w+)\s*;",
+                   lambda m: "static %s %s; static int _ri%s = rt_register_incoming(%d, &%s, sizeof(%s));" % (m.group(2), m.group(3), m.group(1), stage, m.group(3), m.group(3)), t)
+        t = re.sub(r"hitAttributeEXT\s+vec2\s+(\w+)\s*;", r"#define \1 g_hit_attribs", t)
 
     # workgroup size
     def local_size(m):
         d = dict((k.strip(), v.strip()) for k, v in (kv.split("=") for kv in m.group(1).split(",")))
         return "\n".join("#define SHADER_LOCAL_%s (%s)" % (a.upper(), d.get("local_size_" + a, "1")) for a in "xyz")
     t, n_local = re.subn(r"layout\s*\(([^)]*local_size_x[^)]*)\)\s*in\s*;", local_size, t)
-    if not n_local:
+    if not n_local and stage is None:
         t += "\n#define SHADER_LOCAL_X 1\n#define SHADER_LOCAL_Y 1\n#define SHADER_LOCAL_Z 1\n"
 
     # interface blocks (uniform / buffer / push constants)
@@ -80,7 +97,7 @@ def translate(rel, defines=()):
             for mm in re.finditer(r"(\w+)\s+(\w+)\s*((?:\[[^\]]*\])*)\s*;", body):
                 ty, mn, dims = mm.groups()
                 out.append("static %s %s%s;" % (ty, mn, dims))
-                regs.append(mn)
+                regs.append((mn, pre + mn))
             return "\n".join(out)
         members = []
         for mm in re.finditer(r"(\w+)\s+(\w+)\s*((?:\[[^\]]*\])*)\s*;", body):
@@ -90,8 +107,8 @@ def translate(rel, defines=()):
             else:
                 members.append("%s %s%s;" % (ty, mn, dims))
             if not inst_dims:
-                regs.append("%s.%s" % (inst, mn))
-        regs.append(inst)
+                regs.append(("%s.%s" % (inst, mn), "%s%s.%s" % (pre, inst, mn)))
+        regs.append((inst, pre + inst))
         if inst_dims and inst_dims.replace(" ", "") == "[]":
             inst_dims = "[1024]"   # unsized descriptor arrays: a fixed table
         return "struct %s_block { %s };\nstatic %s_block %s%s;" % (name, " ".join(members), name, inst, inst_dims or "")
@@ -100,9 +117,15 @@ def translate(rel, defines=()):
     # opaque resources
     def resource(m):
         ty, name, arr = m.group(1), m.group(2), m.group(3)
-        regs.append(name)
+        regs.append((name, pre + name))
         return ("static %s* %s;" if arr else "static %s %s;") % (ty, name)
     t = re.sub(r"layout\s*\([^)]*\)\s*uniform\s+(?:(?:readonly|writeonly|restrict|coherent)\s+)*(%s)\s+(\w+)\s*(\[\s*\])?\s*;" % "|".join(RESOURCE_TYPES), resource, t)
+
+    # fragment-shader interface variables: plain statics the harness writes / reads around every invocation
+    def io_var(m):
+        regs.append((m.group(2), pre + m.group(2)))
+        return "static %s %s;" % (m.group(1), m.group(2))
+    t = re.sub(r"layout\s*\(\s*location\s*=\s*\d+\s*\)\s*(?:in|out)\s+(\w+)\s+(\w+)\s*;", io_var, t)
 
     t = re.sub(r"\bshared\s+", "static ", t)
     # parameter qualifiers
@@ -118,19 +141,44 @@ def translate(rel, defines=()):
     # float literals: GLSL's are fp32
     t = re.sub(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+)(?![\w.])", r"\1f", t)
     t = re.sub(r"\bvoid\s+main\s*\(\s*\)", "void shader_main()", t)
+    return t
 
-    name = re.sub(r"\W", "_", os.path.splitext(os.path.basename(rel))[0]) + "".join("_" + re.sub(r"\W", "_", d.split("=")[0]) for d in defines)
-    head = ['// GENERATED by oracle/refshim/translate.py from the reference shader %s — do not commit.' % rel, '#include "glsl.h"', "#undef M_PI"]
+
+def _write(name, rel_desc, defines, body, regs, runtime):
+    head = ['// GENERATED by oracle/refshim/translate.py from the reference shader(s) %s — do not commit.' % rel_desc, '#include "glsl.h"', "#undef M_PI"]
     for d in defines:
         k, _, v = d.partition("=")
         head.append("#define %s %s" % (k, v))
-    reg_lines = ",\n".join('    { "%s", (void*)&%s, sizeof(%s) }' % (r, r, r) for r in regs)
-    tail = "\nstatic const Reg g_regs[] = {\n%s\n};\n#include \"runtime.inc\"\n} // namespace glsl\n" % reg_lines
+    reg_lines = ",\n".join('    { "%s", (void*)&%s, sizeof(%s) }' % (n, lv, lv) for n, lv in regs)
+    tail = "\nstatic const Reg g_regs[] = {\n%s\n};\n%s\n} // namespace glsl\n" % (reg_lines, runtime)
     os.makedirs(OUT_DIR, exist_ok=True)
     out = os.path.join(OUT_DIR, name + ".cpp")
     with open(out, "w") as f:
-        f.write("\n".join(head) + "\nnamespace glsl {\n" + t + tail)
+        f.write("\n".join(head) + "\nnamespace glsl {\n" + body + tail)
     return out
+
+
+def translate(rel, defines=()):
+    regs = []
+    t = translate_body(rel, regs)
+    name = re.sub(r"\W", "_", os.path.splitext(os.path.basename(rel))[0]) + "".join("_" + re.sub(r"\W", "_", d.split("=")[0]) for d in defines)
+    return _write(name, rel, defines, t, regs, '#include "runtime.inc"')
+
+
+def translate_pipeline(name, stages, defines=()):
+    """stages: [(rel, kind)] with kind 0 = ray generation (first), 1 = closest hit, 2 = miss (in SBT order per kind).
+    Every stage is translated into its own namespace st<i>; registry names are '<i>:<glsl name>'."""
+    regs, body, table = [], [], []
+    for i, (rel, kind) in enumerate(stages):
+        sregs = []
+        t = translate_body(rel, sregs, stage=i)
+        macros = sorted(set(re.findall(r"^\s*#\s*define\s+(\w+)", t, flags=re.M)))
+        body.append("namespace st%d {\n%s\n}\n%s\n" % (i, t, "\n".join("#undef " + m for m in macros)))
+        regs += [("%d:%s" % (i, n), lv) for n, lv in sregs]
+        table.append("{ st%d::shader_main, %d }" % (i, kind))
+    runtime = ("#define SHADER_LOCAL_X 1\n#define SHADER_LOCAL_Y 1\n#define SHADER_LOCAL_Z 1\nstatic void shader_main() {}\n#include \"runtime.inc\"\n"
+               "#define RT_STAGE_TABLE { %s }\n#include \"runtime_rt.inc\"" % ", ".join(table))
+    return _write(name, " + ".join(r for r, _ in stages), defines, "\n".join(body), regs, runtime)
 
 
 if __name__ == "__main__":

@@ -2,8 +2,9 @@
 
     python tests/golden/make_golden.py
 
-The reference cannot be built or run here (no Vulkan SDK / framework / assets — SURVEY.md §8c), so these vectors
-pin the ORACLE (they catch unintended changes to it) rather than the reference; both the oracle and the HIP path
+The reference (a Vulkan application) cannot be built or run here, but its SHADERS can: make_ref_golden.py computes the
+same cases with the reference's own shader sources through oracle/refshim, and tests/test_ref_shaders.py requires the
+two to agree bit for bit — these vectors are therefore reference-shader outputs; the oracle and the HIP path
 are checked against them.  One small multi-frame case per pass; everything is stored as exact bit patterns.
 """
 import hashlib

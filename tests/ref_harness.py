@@ -374,3 +374,241 @@ def taa_resolve(color, prev, gb, jitter, feedback_min=0.88, feedback_max=0.97, s
     sh.set_i("u_Sharpen", int(sharpen))
     sh.dispatch((w + 31) // 32, (h + 31) // 32)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ ray-tracing pipelines
+
+_pipes = {}
+
+
+def pipeline(name, stages):
+    if name not in _pipes:
+        _pipes[name] = pyref.RefPipeline(name, stages)
+    return _pipes[name]
+
+
+class RefScene:
+    """The reference's scene descriptor set (scene_descriptor_set.glsl:58-91) built from a synth.SceneData: one instance
+    with an identity model matrix, one mesh, one BLAS geometry per triangle (SubmeshInfo = (triangle, material)), no
+    textures (all texture indices -1).  Layouts are the shim's C++ structs (members in declaration order, no padding)."""
+
+    def __init__(self, sd):
+        n = sd.n_tris
+        v = np.zeros((n * 3, 5, 4), np.float32)               # Vertex: position, tex_coord, normal, tangent, bitangent
+        v[:, 0, :3], v[:, 0, 3] = sd.verts.reshape(-1, 3), 1.0
+        v[:, 2, :3] = sd.normals.reshape(-1, 3)
+        v[:, 3, 0], v[:, 4, 1] = 1.0, 1.0
+        self.vertices = np.ascontiguousarray(v)
+        self.indices = np.arange(n * 3, dtype=np.uint32)
+        self.submesh = np.ascontiguousarray(np.stack([np.arange(n, dtype=np.uint32), sd.tri_material.astype(np.uint32)], 1))
+        m = np.zeros((len(sd.materials), 20), np.float32)     # Material: 2 x ivec4, albedo, emissive, roughness_metallic
+        mi = m.view(np.int32)
+        mi[:, 0:8] = -1
+        m[:, 8:11], m[:, 11] = sd.materials[:, 0:3], 1.0
+        m[:, 12:15] = sd.materials[:, 5:8]
+        m[:, 16], m[:, 17] = sd.materials[:, 4], sd.materials[:, 3]
+        self.materials = np.ascontiguousarray(m)
+        inst = np.zeros(17, np.float32)
+        inst[[0, 5, 10, 15]] = 1.0
+        self.instances = np.ascontiguousarray(inst)            # mat4 model + uint mesh_idx (= 0)
+
+    def bind(self, pipe, oscene):
+        pipe.set_all("Materials.data", np.uint64(self.materials.ctypes.data))
+        pipe.set_all("Instances.data", np.uint64(self.instances.ctypes.data))
+        pipe.set_at_all("Vertices", np.uint64(self.vertices.ctypes.data))
+        pipe.set_at_all("Indices", np.uint64(self.indices.ctypes.data))
+        pipe.set_at_all("SubmeshInfo", np.uint64(self.submesh.ctypes.data))
+        pipe.set_all("u_TopLevelAS", np.uint64(oscene.h.value))
+        pipe.lib.ref_set_any_hit(C.cast(oracle.lib().orc_any_hit_one, C.c_void_p))
+        pipe.lib.ref_set_closest_hit(C.cast(oracle.lib().orc_closest_hit_one, C.c_void_p))
+        pipe._keep["scene"] = self
+
+
+def cube_tex(sky):
+    """[6][S][S][4] fp16 -> a cube texture of the shim (faces stacked along y)"""
+    S = sky.shape[1]
+    return pyref.Tex(np.ascontiguousarray(sky.reshape(6 * S, S, 4)), "rgba16f", layers=6)
+
+
+def mat4_from_3x3(cm9):
+    m = np.zeros((4, 4), np.float32)
+    m[:3, :3] = np.asarray(cm9, np.float32).reshape(3, 3)     # column-major in, column-major out
+    m[3, 3] = 1.0
+    return np.ascontiguousarray(m.reshape(16))
+
+
+def ddgi_ray_trace(oscene, rscene, ubo, ddgi, orientation, num_frames, infinite_bounces, gi_intensity, sky, prev_irr, prev_dep):
+    """gi_ray_trace.rgen / .rchit / .rmiss (ddgi.cpp:788-812): returns (radiance, direction_distance) [probes][rays][4] fp16"""
+    pipe = pipeline("gi_ray_trace", [("gi/gi_ray_trace.rgen", 0), ("gi/gi_ray_trace.rchit", 1), ("gi/gi_ray_trace.rmiss", 2)])
+    n_probes, R = int(np.prod(ddgi["probe_counts"])), int(ddgi["rays_per_probe"])
+    rad, dd = np.zeros((n_probes, R, 4), np.uint16), np.zeros((n_probes, R, 4), np.uint16)
+    rscene.bind(pipe, oscene)
+    for f in UBO_FIELDS:
+        pipe.set_all("ubo." + f, ubo[f])
+    pipe.set_all("ddgi", ddgi.tobytes())
+    pipe.bind_all("i_Radiance", pyref.Tex(rad, "rgba16f"))
+    pipe.bind_all("i_DirectionDistance", pyref.Tex(dd, "rgba16f"))
+    pipe.bind_all("s_Cubemap", cube_tex(sky))
+    pipe.bind_all("s_Irradiance", pyref.Tex(prev_irr, "rgba16f", linear=True))
+    pipe.bind_all("s_Depth", pyref.Tex(prev_dep, "rg16f", linear=True))
+    pipe.set_all("u_PushConstants.random_orientation", mat4_from_3x3(orientation))
+    pipe.set_all("u_PushConstants.num_frames", np.uint32(num_frames))
+    pipe.set_all("u_PushConstants.infinite_bounces", np.uint32(int(infinite_bounces)))
+    pipe.set_all("u_PushConstants.gi_intensity", np.float32(gi_intensity))
+    pipe.trace_rays(R, n_probes)
+    return rad, dd
+
+
+def prefiltered_tex(pre, size, levels):
+    """concatenated [6][s][s][4] levels (s = size >> level) -> a cube texture with a mip chain"""
+    lv, off = [], 0
+    flat = pre.reshape(-1)
+    for l in range(levels):
+        s = size >> l
+        n = 6 * s * s * 4
+        lv.append(np.ascontiguousarray(flat[off:off + n].reshape(6 * s, s, 4)))
+        off += n
+    return pyref.Tex(lv, "rgba16f", layers=6)
+
+
+def reflections_ray_trace(oscene, rscene, ubo, ddgi, cur, sobol, sr, prm, env, irr, dep):
+    """reflections_ray_trace.rgen / .rchit / .rmiss (ray_traced_reflections.cpp ray_trace()): prm = oracle TraceParams"""
+    pipe = pipeline("reflections_ray_trace", [("reflections/reflections_ray_trace.rgen", 0), ("reflections/reflections_ray_trace.rchit", 1),
+                                              ("reflections/reflections_ray_trace.rmiss", 2)])
+    h, w = cur["depth"].shape
+    out = np.zeros((h, w, 4), np.uint16)
+    rscene.bind(pipe, oscene)
+    for f in UBO_FIELDS:
+        pipe.set_all("ubo." + f, ubo[f])
+        pipe.set_all("u_GlobalUBO." + f, ubo[f])
+    pipe.set_all("ddgi", ddgi.tobytes())
+    pipe.bind_all("i_Color", pyref.Tex(out, "rgba16f"))
+    for name, key, fmt in (("1", "gb1", "rgba8"), ("2", "gb2", "rgba16f"), ("3", "gb3", "rgba16f"), ("Depth", "depth", "r32f")):
+        pipe.bind_all("s_GBuffer" + name, pyref.Tex(cur[key], fmt))
+    pipe.bind_all("s_SobolSequence", pyref.Tex(np.ascontiguousarray(sobol.reshape(1, 256, 4)), "rgba8"))
+    pipe.bind_all("s_ScramblingRankingTile", pyref.Tex(np.ascontiguousarray(sr.reshape(128, 128, 4)), "rgba8"))
+    pipe.bind_all("s_Cubemap", cube_tex(env["sky"]))
+    pipe.bind_all("s_Prefiltered", prefiltered_tex(env["prefiltered"], env["pre_size"], env["pre_levels"]))
+    pipe.bind_all("s_BRDF", pyref.Tex(env["lut"], "rg16f"))
+    pipe.bind_all("s_Irradiance", pyref.Tex(irr, "rgba16f", linear=True))
+    pipe.bind_all("s_Depth", pyref.Tex(dep, "rg16f", linear=True))
+    for k, v in (("bias", np.float32(prm.bias)), ("trim", np.float32(prm.trim)), ("num_frames", np.uint32(prm.num_frames)), ("g_buffer_mip", np.int32(0)),
+                 ("sample_gi", np.int32(prm.sample_gi)), ("approximate_with_ddgi", np.int32(prm.approximate_with_ddgi)),
+                 ("gi_intensity", np.float32(prm.gi_intensity)), ("rough_ddgi_intensity", np.float32(prm.rough_ddgi_intensity)),
+                 ("ibl_indirect_specular_intensity", np.float32(prm.ibl_indirect_specular_intensity))):
+        pipe.set_all("u_PushConstants." + k, v)
+    pipe.trace_rays(w, h)
+    return out
+
+
+def ground_truth(oscene, rscene, ubo, sky, w, h, num_frames, prev, roughness_multiplier=1.0, max_ray_bounces=2):
+    """ground_truth_path_trace.rgen / .rchit / .rmiss (ground_truth_path_tracer.cpp:44-111); prev / result [h][w][4] fp16"""
+    pipe = pipeline("ground_truth_path_trace", [("ground_truth/ground_truth_path_trace.rgen", 0), ("ground_truth/ground_truth_path_trace.rchit", 1),
+                                                ("ground_truth/ground_truth_path_trace.rmiss", 2)])
+    out = np.zeros((h, w, 4), np.uint16)
+    rscene.bind(pipe, oscene)
+    for f in UBO_FIELDS:
+        pipe.set_all("ubo." + f, ubo[f])
+    pipe.bind_all("i_CurrentColor", pyref.Tex(out, "rgba16f"))
+    pipe.bind_all("i_PreviousColor", pyref.Tex(prev, "rgba16f"))
+    pipe.bind_all("s_Cubemap", cube_tex(sky))
+    pipe.set_all("u_PushConstants.num_frames", np.uint32(num_frames))
+    pipe.set_all("u_PushConstants.max_ray_bounces", np.uint32(max_ray_bounces))
+    pipe.set_all("u_PushConstants.roughness_multiplier", np.float32(roughness_multiplier))
+    pipe.trace_rays(w, h)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ deferred composite
+
+def deferred_shade(ubo, gb, shadow, ao, reflections, gi, flags, sh9, env):
+    """deferred.frag as a full-screen pass (deferred_shading.cpp); flags: bit0 shadow, 1 ao, 2 reflections, 3 gi.
+    Returns RGBA16F bit patterns (the colour attachment is RGBA16F: fp32 -> fp16 round to nearest even)."""
+    sh = shader("deferred.frag")
+    h, w = gb["depth"].shape
+    set_ubo(sh, ubo)
+    bind_gbuffer(sh, gb)
+    as_tex = lambda a, fmts: pyref.Tex(np.ascontiguousarray(a), fmts[1 if a.ndim == 2 else a.shape[2]])
+    f1 = {1: "r16f", 2: "rg16f", 4: "rgba16f"}
+    zero = np.zeros((h, w, 4), np.uint16)
+    sh.bind("s_Shadow", as_tex(shadow if shadow is not None else zero, f1))
+    sh.bind("s_AO", as_tex(ao if ao is not None else zero, f1))
+    sh.bind("s_Reflections", as_tex(reflections if reflections is not None else zero, f1))
+    sh.bind("s_GI", as_tex(gi if gi is not None else zero, f1))
+    sh.bind("s_IrradianceSH", pyref.Tex(np.ascontiguousarray(np.asarray(sh9, np.float32).reshape(1, 9, 4)), "rgba32f"))
+    sh.bind("s_Prefiltered", prefiltered_tex(env["prefiltered"], env["pre_size"], env["pre_levels"]))
+    sh.bind("s_BRDF", pyref.Tex(env["lut"], "rg16f"))
+    for i, k in enumerate(("shadow", "ao", "reflections", "gi")):
+        sh.set_i("u_PushConstants." + k, (flags >> i) & 1)
+    out = sh.fragments(w, h, "FS_IN_TexCoord", "FS_OUT_Color")
+    return np.ascontiguousarray(out.astype(np.float16)).view(np.uint16)
+
+
+# ------------------------------------------------------------------------------------------------ whole passes on the reference shaders
+
+class RefDDGIPass:
+    """DDGI::render (ddgi.cpp:89-104): ray trace -> probe updates -> border updates -> sample grid, reference shaders only"""
+
+    def __init__(self, ddgi, sd, **params):
+        from oracle import pyoracle_ddgi as od
+        self.o = od.DDGIPass(ddgi, **params)          # parameter defaults + atlas allocation only
+        self.ddgi, self.p = ddgi, self.o.p
+        self.irr, self.dep = self.o.irr, self.o.dep
+        self.first_frame, self.ping_pong = True, False
+        self.rscene = RefScene(sd)
+        self.stages = {}
+
+    def current_read(self):
+        i = int(not self.ping_pong)
+        return self.irr[i], self.dep[i]
+
+    def render(self, oscene, ubo, cur, sky, orientation, num_frames):
+        p, d = self.p, self.ddgi
+        rd, wr = int(not self.ping_pong), int(self.ping_pong)
+        inf = p["infinite_bounces"] and not self.first_frame
+        rad, dd = ddgi_ray_trace(oscene, self.rscene, ubo, d, orientation, num_frames, inf, p["infinite_bounce_intensity"], sky, self.irr[rd], self.dep[rd])
+        self.irr[wr] = ddgi_border_update(d, False, ddgi_probe_update(d, False, self.first_frame, rad, dd, self.irr[rd], self.dep[rd]))
+        self.dep[wr] = ddgi_border_update(d, True, ddgi_probe_update(d, True, self.first_frame, rad, dd, self.irr[rd], self.dep[rd]))
+        out = ddgi_sample_probe_grid(ubo, d, cur, p["gi_intensity"], self.irr[wr], self.dep[wr])
+        self.stages = dict(radiance=rad, direction_distance=dd, irradiance=self.irr[wr], depth=self.dep[wr], output=out)
+        self.first_frame = False
+        self.ping_pong = not self.ping_pong
+        return out
+
+
+class RefReflectionsPass:
+    """RayTracedReflections::render (ray_traced_reflections.cpp:107-123), reference shaders only"""
+
+    def __init__(self, w, h, sd, **params):
+        from oracle import pyoracle_reflections as orf
+        self.orf = orf
+        self.o = orf.ReflectionsPass(w, h, **params)   # parameter defaults + image allocation only
+        self.p = self.o.p
+        self.color, self.moments, self.prev_image = self.o.color, self.o.moments, self.o.prev_image
+        self.ping_pong = False
+        self.rscene = RefScene(sd)
+        self.stages = {}
+
+    def render(self, oscene, ubo, ddgi, cur, prev, sobol, sr, num_frames, env, irr, dep, camera_delta=(0, 0, 0), full_mips=None):
+        p = self.p
+        pp = int(self.ping_pong)
+        tp = self.orf.TraceParams(p["bias"], p["trim"], num_frames, int(p["sample_gi"]), int(p["approximate_with_ddgi"]), p["gi_intensity"],
+                                  p["rough_ddgi_intensity"], p["ibl_indirect_specular_intensity"])
+        traced = reflections_ray_trace(oscene, self.rscene, ubo, ddgi, cur, sobol, sr, tp, env, irr, dep)
+        hist = self.prev_image if p["blur_as_input"] else self.color[1 - pp]
+        oc, om, den, cpy = reflections_temporal(ubo, traced, cur, prev, hist, self.moments[1 - pp], camera_delta, p["alpha"], p["moments_alpha"],
+                                                p["approximate_with_ddgi"])
+        self.color[pp], self.moments[pp] = oc, om
+        img, its = oc, []
+        for i in range(p["filter_iterations"]):
+            img = reflections_atrous(img, cur, den, cpy, 1 << i, p["radius"], p["phi_color"], p["phi_normal"], p["sigma_depth"], p["approximate_with_ddgi"])
+            its.append(img)
+            if i == p["feedback_iteration"] and p["blur_as_input"]:
+                self.prev_image = img.copy()
+        up = upsample("reflections/reflections_upsample.comp", full_mips, len(full_mips) - 1, img, "rgba16f") if full_mips else None
+        h, w = cur["depth"].shape
+        tiles = np.zeros(((h + 7) // 8, (w + 7) // 8), np.uint8)
+        tiles[den[:, 1] // 8, den[:, 0] // 8] = 1
+        self.stages = dict(trace=traced, temporal=oc, moments=om, tiles=tiles, atrous=its, upsample=up, output=img if up is None else up)
+        self.ping_pong = not self.ping_pong
+        return self.stages["output"]

@@ -1,5 +1,6 @@
 """The oracle reproduces the committed golden fixtures bit for bit (tests/golden/*.npz, made by make_golden.py).
-The reference itself ships no golden vectors and cannot run here: these fixtures pin the oracle."""
+The reference ships no golden vectors of its own; tests/test_ref_shaders.py proves these fixtures equal the outputs of the
+reference's shaders run on the CPU (tests/golden/make_ref_golden.py), so oracle == fixtures == reference shaders."""
 import os
 import sys
 

@@ -184,3 +184,107 @@ def test_taa_resolve(oracle, rh):
         t.render(col, gb, k & 1)
         ref = rh.taa_resolve(col, t.images[int(not (k & 1))], gb, t.jitter, t.feedback_min, t.feedback_max, t.sharpen)
         assert np.array_equal(ref, t.output(k & 1)), f"frame {k}"
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza_small"])
+def test_ddgi_ray_trace_pipeline(oracle, rh, name):
+    """gi_ray_trace.rgen + .rchit + .rmiss through the traceRayEXT mock: probe rays, direct + sky lighting with shadow ray
+    queries, infinite bounces from the previous atlases — 3 frames"""
+    from oracle import pyoracle_ddgi as od
+    sd, osc, frames = _frames(oracle, name, 32, 24, 3, 1.0)
+    rsc = rh.RefScene(sd)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=48, normal_bias=1.0 if name == "cornell" else 0.1)
+    sky = synth_env.sky_cubemap(16)
+    op = od.DDGIPass(ddgi)
+    rng = np.random.RandomState(42)
+    for f in range(3):
+        orient = synth_env.random_orientation(rng)
+        rd = int(not op.ping_pong)
+        pirr, pdep, inf = op.irr[rd].copy(), op.dep[rd].copy(), op.p["infinite_bounces"] and not op.first_frame
+        op.render(osc, frames[f]["ubo"], frames[f]["gb"], sky, orient, f)
+        rad, dd = rh.ddgi_ray_trace(osc, rsc, frames[f]["ubo"], ddgi, orient, f, inf, op.p["infinite_bounce_intensity"], sky, pirr, pdep)
+        assert np.array_equal(dd, op.stages["direction_distance"]), f"frame {f}: ray directions / hit distances"
+        assert np.array_equal(rad, op.stages["radiance"]), f"frame {f}: radiance"
+    assert (oracle.f16(rad[..., :3]) > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("name,approx", [("sponza_small", 1), ("sponza_small", 0), ("cornell", 1)])
+def test_reflections_ray_trace_pipeline(oracle, rh, name, approx):
+    """reflections_ray_trace.rgen + .rchit + .rmiss: mirror, GGX-sampled and DDGI-approximated regimes in one frame"""
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf
+    W, H = 64, 48
+    sd, osc, frames = _frames(oracle, name, W, H, 2, 1.0)
+    rsc = rh.RefScene(sd)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=1.0 if name == "cornell" else 0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    r01, r003 = np.float16(0.1).view(np.uint16), np.float16(0.03).view(np.uint16)
+    for fr in frames:                                   # roughness_multiplier 0.3 on the polished materials: mirror regime
+        ch = fr["gb"]["gb3"][..., 0]
+        ch[ch == r01] = r003
+    sob, sr = synth.blue_noise_tables()
+    dp = od.DDGIPass(ddgi)
+    rng = np.random.RandomState(7)
+    for f in range(2):
+        cur = frames[f]["gb"]
+        dp.render(osc, frames[f]["ubo"], cur, sky, synth_env.random_orientation(rng), f)
+        irr, dep = dp.current_read()
+        tp = orf.TraceParams(0.5, 0.8, f, 1, approx, 0.5, 0.5, 0.05)
+        a, rays = orf.ray_trace(osc, frames[f]["ubo"], ddgi, cur, sob, sr, tp, env, irr, dep)
+        b = rh.reflections_ray_trace(osc, rsc, frames[f]["ubo"], ddgi, cur, sob, sr, tp, env, irr, dep)
+        assert np.array_equal(a, b), f"frame {f}: {int((a != b).any(-1).sum())} texels differ"
+    rough, geo = oracle.f16(cur["gb3"][..., 0]), cur["depth"] != 1.0
+    assert ((rough < 0.05) & geo).any() and ((rough > 0.75) & geo).any() and rays > 0
+
+
+@pytest.mark.parametrize("name,kind", [("cornell", "soft"), ("sponza_small", "default"), ("sponza_small", "spot")])
+def test_ground_truth_pipeline(oracle, rh, name, kind):
+    """ground_truth_path_trace.rgen + .rchit + .rmiss: 4 accumulated frames"""
+    from oracle import pyoracle_post as opost
+    W, H = 48, 32
+    sd, osc, frames = _frames(oracle, name, W, H, 1, 0.0, kind)
+    rsc = rh.RefScene(sd)
+    sky = synth_env.sky_cubemap(8)
+    gt = opost.GroundTruthPass(W, H)
+    for k in range(4):
+        prev, fi = gt.images[int(gt.ping_pong) if gt.frame_idx else 0].copy(), gt.frame_idx
+        out = gt.render(osc, frames[0]["ubo"], sky).copy()
+        assert np.array_equal(rh.ground_truth(osc, rsc, frames[0]["ubo"], sky, W, H, fi, prev), out), f"frame {k}"
+
+
+def test_deferred_composite(oracle, rh):
+    """deferred.frag as a full-screen pass, every light type and feature-flag combination"""
+    from oracle import pyoracle_deferred as odf
+    W, H = 64, 48
+    sky = synth_env.sky_cubemap(16)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 5), pre_size=16, pre_levels=5, lut=synth_env.brdf_lut(16))
+    sh9 = synth_env.sh9_from_cubemap(sky)
+    rng = np.random.RandomState(3)
+    h16 = lambda a: np.ascontiguousarray(a.astype(np.float16)).view(np.uint16)
+    shadow, ao = h16(rng.uniform(0, 1, (H, W))), h16(rng.uniform(0, 1, (H, W)))
+    refl, gi = h16(rng.uniform(0, 0.7, (H, W, 4))), h16(rng.uniform(0, 2, (H, W, 4)))
+    for kind in ("default", "point", "spot"):
+        sd, osc, frames = _frames(oracle, "sponza_small", W, H, 1, 0.0, kind)
+        for flags in (0, 15, 5, 10):
+            a = odf.shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env)
+            b = rh.deferred_shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env)
+            assert np.array_equal(a, b), f"{kind} light, flags {flags}"
+
+
+def test_golden_fixtures_are_reference_shader_outputs():
+    """tests/golden/*.npz — what tests/test_gpu_golden.py holds the HIP kernels to on the GPU box — recomputed with the
+    reference's shaders only (tests/golden/make_ref_golden.py): every array identical"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_ref_golden
+    cases = make_ref_golden.build_cases()
+    assert set(cases) == {"shadows_cornell64", "ao_cornell64_half", "ddgi_sponza", "reflections_sponza", "ground_truth_sponza", "taa_sponza"}
+    n = 0
+    for name, arrs in cases.items():
+        gold = np.load(os.path.join(HERE, "golden", name + ".npz"))
+        for k, v in arrs.items():
+            assert gold[k].shape == v.shape and np.array_equal(gold[k].view(np.uint8), np.ascontiguousarray(v).view(np.uint8)), f"{name}/{k}"
+            n += 1
+    assert n >= 23
