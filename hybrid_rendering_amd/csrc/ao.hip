@@ -61,14 +61,15 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool  active = false;
     f3    ro = mk3(0, 0, 0), N = mk3(0, 0, 1);
-    if (x < a.w && y >= a.y0 && y < a.y1)
+    const int kind = trace_lane_kind(x, y, a.w, a.h, a.y0, a.y1);   // 2: edge thread of a ragged image (device_math.h)
+    if (kind)
     {
-        const float d = a.depth[(size_t)y * a.w + x];
+        const float d = kind == 1 ? a.depth[(size_t)y * a.w + x] : 0.0f;
         if (d != 1.0f)
         {
             const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
             const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
-            const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+            const uint2 g2 = kind == 1 ? a.gb2[(size_t)y * a.w + x] : make_uint2(0u, 0u);
             N      = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
             ro     = add3(P, scale3(N, a.bias));
             active = true;

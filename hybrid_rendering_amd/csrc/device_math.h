@@ -211,6 +211,19 @@ HR_DEV void oct_encode(f3 n, float& ox, float& oy)
 }
 
 // common.glsl:169-184 world_position_from_depth
+// Threads of a ray-trace dispatch.  The reference launches ceil(w/8) x ceil(h/4) groups of 8x4 threads WITHOUT a bounds
+// check (shadows_ray_trace.comp:89-132, ao_ray_trace.comp:90-126): a thread past the right / bottom edge of a ragged
+// image fetches depth 0 and normal (0,0) (pinned rule: texel fetches outside an image return 0), so it traces a ray
+// and contributes its mask bit — and the 17x17 neighbourhood mean of the denoiser reads those bits.
+//   0: no such thread (past the last 8x4 group, or rows another band owns)   1: image pixel   2: edge thread
+HR_DEV int trace_lane_kind(int x, int y, int w, int h, int y0, int y1)
+{
+    const int gy = (y >> 2) << 2; // first row of the thread's 8x4 group
+    if (gy >= h) return 0;
+    if (y < h) return (y < y0 || y >= y1) ? 0 : (x < w ? 1 : 2);
+    return (gy >= y0 && gy < y1) ? 2 : 0;
+}
+
 HR_DEV f3 world_pos_from_depth(float u, float v, float ndc_depth, const float* __restrict__ view_proj_inverse)
 {
     f4 wp = mul_m4(view_proj_inverse, u * 2.0f - 1.0f, v * 2.0f - 1.0f, ndc_depth, 1.0f);

@@ -59,19 +59,19 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
     uint32_t  nn = 0, nt = 0, wave_max = 0;
     // depth, normal and blue-noise texel of the pixel in ONE round trip (a lane outside the image reads a valid address and
     // ignores the values) instead of depth -> normal -> noise one after the other
-    const bool   in_img = x < a.w && y >= a.y0 && y < a.y1;
-    const size_t pix    = in_img ? (size_t)y * a.w + x : (size_t)a.y0 * a.w;
+    const int    kind = trace_lane_kind(x, y, a.w, a.h, a.y0, a.y1);
+    const size_t pix  = kind == 1 ? (size_t)y * a.w + x : (size_t)a.y0 * a.w;
     const float    d_pre  = a.depth[pix];
     const uint2    g2_pre = a.gb2[pix];
     const uint32_t bn_pre = blue_noise_texel(x, y, a.sr);
-    if (in_img)
+    if (kind)
     {
-        const float d = d_pre;
+        const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
         if (d != 1.0f)
         {
             const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
             const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
-            const uint2 g2 = g2_pre;
+            const uint2 g2 = kind == 1 ? g2_pre : make_uint2(0u, 0u);
             const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
             const f3    ro = add3(P, scale3(N, a.bias));
             const float r0 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 0, a.sobol);
@@ -163,14 +163,15 @@ __global__ __launch_bounds__(256) void k_shadows_trace_pw(TraceArgs a)
         {
             tx = tile % a.tiles_x; ty = tile / a.tiles_x + a.tile_y0;
             const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-            if (x < a.w && y >= a.y0 && y < a.y1)
+            const int kind = trace_lane_kind(x, y, a.w, a.h, a.y0, a.y1);
+            if (kind)
             {
-                const float d = a.depth[(size_t)y * a.w + x];
+                const float d = kind == 1 ? a.depth[(size_t)y * a.w + x] : 0.0f;
                 if (d != 1.0f)
                 {
                     const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
                     const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
-                    const uint2 g2 = a.gb2[(size_t)y * a.w + x];
+                    const uint2 g2 = kind == 1 ? a.gb2[(size_t)y * a.w + x] : make_uint2(0u, 0u);
                     const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
                     ro = add3(P, scale3(N, a.bias));
                     const float r0 = sample_blue_noise(x, y, (int)a.num_frames, 0, a.sobol, a.sr);

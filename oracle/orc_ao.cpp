@@ -66,8 +66,8 @@ void orc_ao_ray_trace(const void* scene_, const void* ubo_, int w, int h, const 
                     for (int lx = 0; lx < 8; lx++)
                     {
                         int x = mx * 8 + lx, y = my * 4 + ly;
-                        if (x >= w || y >= h) continue;
-                        float    d      = depth[(size_t)y * w + x];
+                        // no bounds check in ao_ray_trace.comp:90-126: edge threads read depth 0 / normal (0,0) and trace
+                        float    d      = (x < w && y < h) ? depth[(size_t)y * w + x] : 0.0f;
                         uint32_t result = 0;
                         if (d != 1.0f)
                         {

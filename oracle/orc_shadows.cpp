@@ -61,8 +61,10 @@ void fetch_light_properties_shadow(const Light& light, vec3 P, vec3 N, float rx,
 
 extern "C" {
 
-// S1.  mask: [ceil(h/4)][ceil(w/8)] uint32, bit (y&3)*8 + (x&7).  Pixels outside the image
-// contribute 0 (pin for SURVEY.md quirk 7).  rays_out (optional): number of rays fired.
+// S1.  mask: [ceil(h/4)][ceil(w/8)] uint32, bit (y&3)*8 + (x&7).  The shader has no bounds check
+// (shadows_ray_trace.comp:89-132): a thread of a ragged edge group fetches depth 0 and normal (0,0) (pinned rule: texel
+// fetches outside the image return 0), fires its ray and contributes its bit (verified against the
+// reference shader at ragged sizes by tests/test_ref_shaders.py).  rays_out (optional): number of rays fired.
 void orc_shadows_ray_trace(const void* scene_, const void* ubo_, int w, int h, const float* depth, const uint16_t* gb2,
                            const uint8_t* sobol, const uint8_t* scrambling_ranking, float bias, uint32_t num_frames,
                            uint32_t* mask, uint64_t* rays_out)
@@ -82,8 +84,7 @@ void orc_shadows_ray_trace(const void* scene_, const void* ubo_, int w, int h, c
                 for (int lx = 0; lx < 8; lx++)
                 {
                     int x = mx * 8 + lx, y = my * 4 + ly;
-                    if (x >= w || y >= h) continue;
-                    float d = depth[(size_t)y * w + x];
+                    float d = (x < w && y < h) ? depth[(size_t)y * w + x] : 0.0f;
                     uint32_t result = 0;
                     if (d != 1.0f)
                     {

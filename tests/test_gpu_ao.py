@@ -67,6 +67,13 @@ def test_ao_ragged_half_res(oracle, hr, ctx):
     _run_case(oracle, hr, ctx, "sponza_small", 240, 140, 1, 2, 1.0)
 
 
+def test_ao_ragged_width_and_height_edge_threads(oracle, hr, ctx):
+    """122x70 AO image: edge threads right of and below the image trace rays too (device_math.h trace_lane_kind), and the
+    denoiser's neighbourhood statistics read their bits — as the reference shader does (tests/test_ref_shaders.py)"""
+    _run_case(oracle, hr, ctx, "sponza_small", 244, 140, 1, 3, 1.0)
+    _run_case(oracle, hr, ctx, "sponza_small", 61, 45, 0, 3, 1.0)
+
+
 def test_ao_4spp_extension(oracle, hr, ctx):
     _run_case(oracle, hr, ctx, "sponza_small", 256, 144, 0, 3, 1.0, spp=4)
 

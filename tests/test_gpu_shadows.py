@@ -80,6 +80,7 @@ def test_sponza_small_punctual(oracle, hr, ctx, kind):
 def test_ragged_size(oracle, hr, ctx):
     """Width/height not multiples of the 8x8 / 8x4 tiles."""
     _run_case(oracle, hr, ctx, "cornell", 150, 101, 3, 1.0, light_kind="soft")
+    _run_case(oracle, hr, ctx, "sponza_small", 61, 45, 3, 1.0)       # edge threads of the ragged groups trace rays too
 
 
 def test_params_variants(oracle, hr, ctx):

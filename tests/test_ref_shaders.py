@@ -288,3 +288,58 @@ def test_golden_fixtures_are_reference_shader_outputs():
             assert gold[k].shape == v.shape and np.array_equal(gold[k].view(np.uint8), np.ascontiguousarray(v).view(np.uint8)), f"{name}/{k}"
             n += 1
     assert n >= 23
+
+
+@pytest.mark.parametrize("w,h", [(61, 45), (70, 33), (5, 3)])
+def test_ragged_image_sizes(oracle, rh, w, h):
+    """sizes that are not multiples of the 8x4 / 8x8 workgroups.  The reference's ray-trace shaders have no bounds check:
+    their edge threads read depth 0 / normal (0,0) (pinned out-of-image fetch), trace a ray and set mask bits that the
+    denoiser's 17x17 neighbourhood statistics then read — restated in the oracle and the HIP kernels (trace_lane_kind)."""
+    sd, osc, frames = _frames(oracle, "sponza_small", w, h, 3, 0.5)
+    sob, sr = synth.blue_noise_tables()
+    zbp = synth.z_buffer_params()
+    op, rp = oracle.ShadowsPass(w, h), rh.RefShadowsPass(w, h)
+    oa, ra = oracle.AOPass(w, h, zbp=zbp), rh.RefAOPass(w, h, zbp)
+    oa.p["ray_length"] = ra.p["ray_length"] = 60.0
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["gb"] if k else fr["gb"]
+        for o, r in ((op, rp), (oa, ra)):
+            o.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+            r.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        a, b = op.stages, rp.stages
+        assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["temporal"], b["temporal"]) and np.array_equal(a["tiles"], b["tiles"]), f"shadows frame {k}"
+        assert all(np.array_equal(x, y) for x, y in zip(a["atrous"], b["atrous"])), f"shadows frame {k}: a-trous"
+        c, d = oa.stages, ra.stages
+        assert np.array_equal(c["mask"][0], d["mask"]), f"AO frame {k}: mask (edge threads)"
+        assert np.array_equal(c["temporal"], d["temporal"]) and np.array_equal(c["tiles"], d["tiles"]) and np.array_equal(c["blur1"], d["blur1"]), f"AO frame {k}"
+    if w % 8:
+        edge = d["mask"][:, -1] >> np.uint32(w % 8)
+        assert (edge & np.uint32((1 << (8 - w % 8)) - 1)).any()      # edge threads really contributed visibility bits
+
+
+def test_ragged_half_resolution_reflections_and_ddgi(oracle, rh):
+    """70x34 full frame, 35x17 reflections: whole DDGI and reflections passes on the reference shaders vs the oracle"""
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf
+    W, H, scale = 70, 34, 1
+    sd, osc, frames = _frames(oracle, "sponza_small", W, H, 3, 1.0, mips=scale)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    sob, sr = synth.blue_noise_tables()
+    w, h = W >> scale, H >> scale
+    dp, op = od.DDGIPass(ddgi), orf.ReflectionsPass(w, h)
+    rd, rp = rh.RefDDGIPass(ddgi, sd), rh.RefReflectionsPass(w, h, sd)
+    rng, rng2 = np.random.RandomState(7), np.random.RandomState(7)
+    for f in range(3):
+        cur, prev, full = frames[f]["mips"][scale], (frames[f - 1] if f else frames[f])["mips"][scale], frames[f]["gb"]
+        dp.render(osc, frames[f]["ubo"], full, sky, synth_env.random_orientation(rng), f)
+        rd.render(osc, frames[f]["ubo"], full, sky, synth_env.random_orientation(rng2), f)
+        for k in ("radiance", "direction_distance", "irradiance", "depth", "output"):
+            assert np.array_equal(dp.stages[k], rd.stages[k]), f"frame {f}: DDGI {k}"
+        irr, dep = dp.current_read()
+        cd = (0.0, 0.0, 0.0) if f == 0 else (-1.0, 0.0, 0.0)
+        op.render(osc, frames[f]["ubo"], ddgi, cur, prev, sob, sr, f, env, irr, dep, camera_delta=cd, full=full)
+        rp.render(osc, frames[f]["ubo"], ddgi, cur, prev, sob, sr, f, env, irr, dep, camera_delta=cd, full_mips=frames[f]["mips"][:scale + 1])
+        for k in ("trace", "temporal", "moments", "tiles", "upsample"):
+            assert np.array_equal(op.stages[k], rp.stages[k]), f"frame {f}: reflections {k}"
