@@ -256,6 +256,28 @@ def main():
         out["cpu_baseline"] = {"value": round(nrays / dt / 1e6, 3), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"{nf} full {W}x{H} frames (trace + SVGF denoise) of the same workload through oracle/ (OpenMP, {os.cpu_count()} threads)",
                                "frames_per_s": round(nf / dt, 3)}
+        # the reference's OWN shaders (oracle/_ref, one host thread): a small frame of the same view, trace + denoise
+        try:
+            from oracle import pyref, ref_harness as rh
+            if pyref.available():
+                rw, rhh = 240, 136
+                rcams = [synth.sponza_camera(rw / rhh, frame=f, dolly=0.5) for f in range(3)]
+                rubos = [synth.make_ubo(rcams[i + 1], rcams[i], light) for i in range(2)]
+                rgb = [{n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in scene.gbuffer(u, rw, rhh).items()}
+                       for u in rubos]
+                rp, orp = rh.RefShadowsPass(rw, rhh), po.ShadowsPass(rw, rhh)
+                rp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
+                orp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
+                t0r = time.perf_counter()
+                rp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
+                dtr = time.perf_counter() - t0r
+                orp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
+                out["cpu_baseline"]["reference_shaders"] = {
+                    "value": round(orp.stages["rays"] / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                    "sample": f"one {rw}x{rhh} frame of the same view through the reference's shaders compiled for the CPU (oracle/_ref)",
+                    "bit_identical_to_port": bool(np.array_equal(rp.stages["output"], orp.stages["output"]))}
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            out["cpu_baseline"]["reference_shaders"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

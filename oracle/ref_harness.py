@@ -1,6 +1,9 @@
-"""Host-side sequencing of the REFERENCE'S OWN SHADERS (compiled for the CPU by oracle/pyref.py) — the same dispatch
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Host-side sequencing of the REFERENCE'S OWN SHADERS (compiled for the CPU by oracle/pyref.py) — the same dispatch
 order the reference's C++ records (ray_traced_shadows.cpp:100-116, ray_traced_ao.cpp:98-112, ...), with numpy arrays in
-the oracle's layouts bound as descriptors.  Test infrastructure: used by test_ref_shaders.py and golden/make_ref_golden.py.
+the oracle's layouts bound as descriptors.  Used by tests/test_ref_shaders.py, tests/golden/make_ref_golden.py and the
+cpu_baseline leg of bench.py ("reference_shaders").
 """
 from __future__ import annotations
 
@@ -8,8 +11,8 @@ import ctypes as C
 
 import numpy as np
 
-from oracle import pyoracle as oracle
-from oracle import pyref
+from . import pyoracle as oracle
+from . import pyref
 
 UBO_FIELDS = ("view_inverse", "proj_inverse", "view_proj_inverse", "prev_view_proj", "view_proj", "cam_pos", "current_prev_jitter", "light")
 _cache = {}

@@ -1,4 +1,4 @@
-"""The golden cases of make_golden.py computed with the REFERENCE'S OWN SHADERS (oracle/refshim + tests/ref_harness.py)
+"""The golden cases of make_golden.py computed with the REFERENCE'S OWN SHADERS (oracle/refshim + oracle/ref_harness.py)
 instead of the oracle restatement.  tests/test_ref_shaders.py::test_golden_fixtures_are_reference_shader_outputs checks
 that this reproduces the committed tests/golden/*.npz bit for bit — so the fixtures the GPU tests compare the HIP
 kernels with (tests/test_gpu_golden.py, on a box without /root/reference) ARE outputs of the reference's shaders.
@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def build_cases():
     import helpers
-    import ref_harness as rh
+    from oracle import ref_harness as rh
     from make_golden import hdr_color
     from hybrid_rendering_amd import synth, synth_env
     from oracle import pyoracle as po, pyoracle_post as opost

@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def rh():
-    import ref_harness
+    from oracle import ref_harness
     return ref_harness
 
 
@@ -343,3 +343,30 @@ def test_ragged_half_resolution_reflections_and_ddgi(oracle, rh):
         rp.render(osc, frames[f]["ubo"], ddgi, cur, prev, sob, sr, f, env, irr, dep, camera_delta=cd, full_mips=frames[f]["mips"][:scale + 1])
         for k in ("trace", "temporal", "moments", "tiles", "upsample"):
             assert np.array_equal(op.stages[k], rp.stages[k]), f"frame {f}: reflections {k}"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_pass_parameters(oracle, rh, seed):
+    """the GUI-exposed parameters of the shadows and AO passes drawn at random (non-integer and > 64 phi_normal take the
+    exp/log pow, integer ones the repeated-squaring pow; radius 2; 1..5 a-trous iterations; blur radius 1..6)"""
+    W, H = 64, 40
+    sd, osc, frames = _frames(oracle, "sponza_small", W, H, 3, 0.7, "point")
+    sob, sr = synth.blue_noise_tables()
+    zbp = synth.z_buffer_params()
+    rng = np.random.RandomState(seed)
+    sp = dict(bias=float(rng.uniform(0.05, 1.0)), alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)),
+              phi_visibility=float(rng.uniform(1, 20)), phi_normal=float(rng.choice([8.0, 32.0, 64.0, 12.5, 128.0])), sigma_depth=float(rng.uniform(0.2, 3)),
+              power=float(rng.choice([0.0, 1.2, 2.0, 0.7])), radius=int(rng.choice([1, 2])), filter_iterations=int(rng.choice([1, 3, 5])),
+              feedback_iteration=int(rng.choice([0, 1])))
+    ap = dict(bias=float(rng.uniform(0.05, 1.0)), ray_length=float(rng.uniform(5, 100)), alpha=float(rng.uniform(0.005, 0.3)), blur_radius=int(rng.choice([1, 2, 4, 6])))
+    op, rp = oracle.ShadowsPass(W, H, **sp), rh.RefShadowsPass(W, H, **sp)
+    oa, ra = oracle.AOPass(W, H, zbp=zbp, **ap), rh.RefAOPass(W, H, zbp, **ap)
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["gb"] if k else fr["gb"]
+        for o, r in ((op, rp), (oa, ra)):
+            o.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+            r.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        a, b, c, d = op.stages, rp.stages, oa.stages, ra.stages
+        assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["temporal"], b["temporal"]), (sp, k)
+        assert all(np.array_equal(x, y) for x, y in zip(a["atrous"], b["atrous"])), (sp, k)
+        assert np.array_equal(c["mask"][0], d["mask"]) and np.array_equal(c["temporal"], d["temporal"]) and np.array_equal(c["blur1"], d["blur1"]), (ap, k)
