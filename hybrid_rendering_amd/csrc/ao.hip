@@ -173,10 +173,11 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
     if (!tile_ok) return;
     const float mean = __fdiv_rn((float)sum, 289.0f * (float)a.spp);
     const bool  in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    const bool  edge = x >= a.w || y >= a.h;   // no pixel, but the unguarded shader thread (:191-260) still votes (see k_shadows_temporal)
     bool        flag = false;
-    if (in_image)
+    if (in_image || edge)
     {
-        const float d = a.depth.p[(size_t)y * a.w + x];
+        const float d = edge ? 0.0f : a.depth.p[(size_t)y * a.w + x];
         float out = 1.0f, hlen = 0.0f;
         if (d != 1.0f)
         {
@@ -198,8 +199,11 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
             const float al = success ? max2(a.alpha, __fdiv_rn(1.0f, hlen)) : 1.0f;
             out = mix1(hao, ao, al);
         }
-        a.out[(size_t)y * a.w + x]     = f2h(out);
-        a.out_len[(size_t)y * a.w + x] = f2h(hlen);
+        if (in_image)
+        {
+            a.out[(size_t)y * a.w + x]     = f2h(out);
+            a.out_len[(size_t)y * a.w + x] = f2h(hlen);
+        }
         flag = out < 1.0f;
     }
     const unsigned long long any = __ballot(flag);

@@ -323,13 +323,18 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
     const float mean = __fdiv_rn((float)sum, 289.0f);
 
     const bool in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    // A thread right of / below a ragged image has no pixel, but the shader has no bounds check (:196-293): it reads depth 0
+    // and G-buffer 0 (pinned out-of-image fetch), runs the body (its stores are dropped) and still votes in
+    // g_should_denoise — e.g. with the mask bit its twin in the ray-trace dispatch produced (device_math.h trace_lane_kind).
+    const bool edge = x >= a.w || y >= a.h;
     float      out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
     bool       flag = false;
-    if (in_image)
+    if (in_image || edge)
     {
-        const float d = a.depth.p[(size_t)y * a.w + x];
+        const size_t pix = in_image ? (size_t)y * a.w + x : (size_t)a.y0 * a.w;
+        const float d = edge ? 0.0f : a.depth.p[pix];
         // centre G-buffer texel: fetched and decoded ONCE, for the reprojection and for the a-trous iterations (nd)
-        const uint2 cg2 = a.gb2.p[(size_t)y * a.w + x], cg3 = a.gb3.p[(size_t)y * a.w + x];
+        const uint2 cg2 = edge ? make_uint2(0u, 0u) : a.gb2.p[pix], cg3 = edge ? make_uint2(0u, 0u) : a.gb3.p[pix];
         const f3    cn  = oct_decode(h2f_lo(cg2.x), h2f_hi(cg2.x));
         if (d != 1.0f)
         {
@@ -362,10 +367,13 @@ __global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
             out_v   = mix1(hv, visibility, al);
             flag    = out_v > 0.0f;
         }
-        a.out_moments[(size_t)y * a.w + x] = make_uint2(pack_h2(m0, m1), pack_h2(hlen, 0.0f));
-        // the a-trous iterations read every pixel's normal 9x4 times: store the decoded one
-        a.nd[(size_t)y * a.w + x] = make_float4(cn.x, cn.y, cn.z, h2f_hi(cg3.y));
-        a.out[(size_t)y * a.w + x]         = pack_h2(out_v, out_var);
+        if (in_image)
+        {
+            a.out_moments[pix] = make_uint2(pack_h2(m0, m1), pack_h2(hlen, 0.0f));
+            // the a-trous iterations read every pixel's normal 9x4 times: store the decoded one
+            a.nd[pix]  = make_float4(cn.x, cn.y, cn.z, h2f_hi(cg3.y));
+            a.out[pix] = pack_h2(out_v, out_var);
+        }
     }
     // tile classification (:275-291): any lit pixel => the tile needs the à-trous filter
     const unsigned long long any = __ballot(flag);

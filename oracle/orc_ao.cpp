@@ -118,7 +118,8 @@ void orc_ao_temporal(const void* ubo_, int w, int h, int spp, const uint32_t* ma
                 for (int lx = 0; lx < 8; lx++)
                 {
                     int x = tx * 8 + lx, y = ty * 8 + ly;
-                    if (x >= w || y >= h) continue; // pinned: threads outside the image are inert
+                    // no bounds check in the shader (:191-260): edge threads of ragged groups read depth 0 / G-buffer 0, run
+                    // the body (stores dropped) and vote in g_should_denoise
                     // neighbourhood mean (:157-185); out-of-image MASK TEXELS read all-ones (:111-112)
                     float sum = 0.0f;
                     for (int s = 0; s < spp; s++)
@@ -128,7 +129,7 @@ void orc_ao_temporal(const void* ubo_, int w, int h, int spp, const uint32_t* ma
                             for (int xx = -8; xx <= 8; xx++) sum += unpack_bit(m, x + xx, y + yy, 0xFFFFFFFFu);
                     }
                     const float mean = sum / (289.0f * (float)spp);
-                    const float d = depth[(size_t)y * w + x];
+                    const float d = (x < w && y < h) ? depth[(size_t)y * w + x] : 0.0f;
                     float out = 1.0f, history_length = 0.0f;
                     if (d != 1.0f)
                     {

@@ -184,10 +184,12 @@ void orc_shadows_temporal(const void* ubo_, int w, int h, const uint32_t* mask, 
                         for (int xx = -8; xx <= 8; xx++) sum += unpack_hit(m, x + xx, y + yy, 0u);
                     float mean = sum / 289.0f;
 
+                    // no bounds check in the shader (:196-293): a thread of a ragged edge group reads depth 0 / G-buffer 0
+                    // (pinned out-of-image fetch), runs the whole body — its image stores are dropped, but its result
+                    // still votes in g_should_denoise (verified against the reference shader at ragged sizes)
                     float d = (x < w && y < h) ? depth[(size_t)y * w + x] : 0.0f;
-                    bool  in_image = (x < w && y < h);
                     float visibility = 0.0f, out_v = 0.0f, out_var = 0.0f, mom0 = 0.0f, mom1 = 0.0f, history_length = 0.0f;
-                    if (in_image && d != 1.0f)
+                    if (d != 1.0f)
                     {
                         visibility = unpack_hit(m, x, y, 0u);
                         float history_visibility, history_moments[2];
@@ -218,7 +220,7 @@ void orc_shadows_temporal(const void* ubo_, int w, int h, const uint32_t* mask, 
                     }
                     om.store(x, y, 0, mom0); om.store(x, y, 1, mom1); om.store(x, y, 2, history_length); om.store(x, y, 3, 0.0f);
                     ov.store(x, y, 0, out_v); ov.store(x, y, 1, out_var);
-                    if (in_image && d != 1.0f && out_v > 0.0f) should_denoise = true;
+                    if (d != 1.0f && out_v > 0.0f) should_denoise = true;
                 }
             tile_class[(size_t)ty * tw + tx] = should_denoise ? 1 : 0;
         }

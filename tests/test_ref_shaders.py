@@ -290,12 +290,13 @@ def test_golden_fixtures_are_reference_shader_outputs():
     assert n >= 23
 
 
-@pytest.mark.parametrize("w,h", [(61, 45), (70, 33), (5, 3)])
-def test_ragged_image_sizes(oracle, rh, w, h):
-    """sizes that are not multiples of the 8x4 / 8x8 workgroups.  The reference's ray-trace shaders have no bounds check:
-    their edge threads read depth 0 / normal (0,0) (pinned out-of-image fetch), trace a ray and set mask bits that the
-    denoiser's 17x17 neighbourhood statistics then read — restated in the oracle and the HIP kernels (trace_lane_kind)."""
-    sd, osc, frames = _frames(oracle, "sponza_small", w, h, 3, 0.5)
+@pytest.mark.parametrize("w,h,light", [(61, 45, "default"), (70, 33, "spot"), (5, 3, "default"), (122, 70, "point"), (120, 68, "default")])
+def test_ragged_image_sizes(oracle, rh, w, h, light):
+    """sizes that are not multiples of the 8x4 / 8x8 workgroups (the reference's own default hits this: half resolution of
+    1080p is 960x540 and 540 / 8 = 67.5).  Its ray-trace and reprojection shaders have no bounds check: edge threads read
+    depth 0 / G-buffer 0 (pinned out-of-image fetch), trace a ray and set mask bits that the denoiser's 17x17 statistics
+    read, and they vote in the tile classification — restated in the oracle and in the HIP kernels."""
+    sd, osc, frames = _frames(oracle, "sponza_small", w, h, 3, 0.5, light)
     sob, sr = synth.blue_noise_tables()
     zbp = synth.z_buffer_params()
     op, rp = oracle.ShadowsPass(w, h), rh.RefShadowsPass(w, h)
