@@ -46,9 +46,15 @@ class hr_image_view(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("row_pitch_bytes", C.c_int32), ("format", C.c_int)]
 
 
+class hr_texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class hr_scene_desc(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tri_material", C.c_void_p), ("tri_mesh_id", C.c_void_p),
-                ("n_tris", C.c_int32), ("materials", C.c_void_p), ("n_materials", C.c_int32)]
+                ("n_tris", C.c_int32), ("materials", C.c_void_p), ("n_materials", C.c_int32),
+                ("uvs", C.c_void_p), ("tangents", C.c_void_p), ("material_textures", C.c_void_p), ("textures", C.POINTER(hr_texture)),
+                ("n_textures", C.c_int32)]
 
 
 class hr_scene_info(C.Structure):
@@ -163,6 +169,15 @@ class Scene:
                       np.ascontiguousarray(sd.materials, np.float32)]
         v, n, m, i, mats = self._keep
         d = hr_scene_desc(v.ctypes.data, n.ctypes.data if n is not None else None, m.ctypes.data, i.ctypes.data, sd.n_tris, mats.ctypes.data, len(mats))
+        if getattr(sd, "material_textures", None) is not None:        # textured materials (optional)
+            uv = None if sd.uvs is None else np.ascontiguousarray(sd.uvs, np.float32)
+            tg = None if sd.tangents is None else np.ascontiguousarray(sd.tangents, np.float32)
+            mt = np.ascontiguousarray(sd.material_textures, np.int32)
+            tex = [np.ascontiguousarray(t, np.uint8) for t in sd.textures]
+            arr = (hr_texture * len(tex))(*[hr_texture(t.ctypes.data, t.shape[1], t.shape[0]) for t in tex])
+            self._keep += [uv, tg, mt, tex, arr]
+            d.uvs, d.tangents = (uv.ctypes.data if uv is not None else None), (tg.ctypes.data if tg is not None else None)
+            d.material_textures, d.textures, d.n_textures = mt.ctypes.data, arr, len(tex)
         self.h = C.c_void_p()
         _check(lib().hr_scene_create(ctx.h, C.byref(d), C.byref(self.h)), "hr_scene_create")
         self.info = hr_scene_info()

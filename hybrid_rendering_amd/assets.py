@@ -120,7 +120,10 @@ _PNG_SIG = b"\x89PNG\r\n\x1a\n"
 
 def load_png(path: str) -> np.ndarray:
     """[H, W, C] uint8 (C = 1, 2, 3 or 4).  8-bit, non-interlaced."""
-    data = open(path, "rb").read()
+    return decode_png(open(path, "rb").read(), path)
+
+
+def decode_png(data: bytes, path: str = "<memory>") -> np.ndarray:
     if data[:8] != _PNG_SIG:
         raise ValueError(f"{path}: not a PNG")
     o, idat, ihdr = 8, [], None
@@ -208,7 +211,9 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
     space (matrix or TRS nodes), every TRIANGLES primitive contributes its (indexed) triangles, NORMAL is transformed by the
     inverse transpose (missing: geometric normal), materials come from pbrMetallicRoughness (baseColorFactor, metallicFactor,
     roughnessFactor) + emissiveFactor.  One mesh id per (node, primitive).  The reference loads meshes/*.gltf through assimp
-    (common.cpp:347-488); textures are not read (the passes here use untextured materials)."""
+    (common.cpp:347-488).  TEXCOORD_0, TANGENT and the PNG images behind baseColorTexture / normalTexture /
+    metallicRoughnessTexture (roughness = G, metallic = B) become SceneData.uvs / tangents / material_textures / textures
+    (the hit shaders' fetch_* inputs); images in other encodings (JPEG) are skipped, the factor then applies."""
     import base64
     import json
     raw = open(path, "rb").read()
@@ -251,16 +256,43 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
         rows = np.lib.stride_tricks.as_strided(buf[off:], shape=(cnt, dt.itemsize * nc), strides=(stride, 1))
         return np.ascontiguousarray(rows).view(dt).reshape(cnt, nc)
 
-    mats = []
+    textures, image_slot = [], {}
+
+    def texture_slot(tex_info):
+        """glTF textureInfo -> index into `textures` (-1: absent or not a PNG)"""
+        if not tex_info:
+            return -1
+        src = doc["textures"][tex_info["index"]].get("source")
+        if src is None:
+            return -1
+        if src not in image_slot:
+            img, data = doc["images"][src], None
+            if "uri" in img:
+                data = base64.b64decode(img["uri"].split(",", 1)[1]) if img["uri"].startswith("data:") else open(os.path.join(base, img["uri"]), "rb").read()
+            elif "bufferView" in img:
+                bv = doc["bufferViews"][img["bufferView"]]
+                data = bytes(buffers[bv["buffer"]][bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]])
+            if data is not None and data[:8] == _PNG_SIG:
+                image_slot[src] = len(textures)
+                textures.append(np.ascontiguousarray(_rgba(decode_png(data))))
+            else:
+                image_slot[src] = -1
+        return image_slot[src]
+
+    mats, mat_tex = [], []
     for m in doc.get("materials", []):
         pbr = m.get("pbrMetallicRoughness", {})
         bc = pbr.get("baseColorFactor", [1, 1, 1, 1])
         em = m.get("emissiveFactor", [0, 0, 0])
         mats.append([bc[0], bc[1], bc[2], pbr.get("metallicFactor", 1.0), pbr.get("roughnessFactor", 1.0), em[0], em[1], em[2]])
+        bct, nrm = texture_slot(pbr.get("baseColorTexture")), texture_slot(m.get("normalTexture"))
+        mr = texture_slot(pbr.get("metallicRoughnessTexture"))
+        mat_tex.append([bct, nrm, mr, mr, 1, 2])
     default_mat = len(mats)
     mats.append([0.8, 0.8, 0.8, 0.0, 0.5, 0.0, 0.0, 0.0])
+    mat_tex.append([-1, -1, -1, -1, 1, 2])
 
-    verts, norms, tmat, tmesh = [], [], [], []
+    verts, norms, tmat, tmesh, uvs, tans = [], [], [], [], [], []
     mesh_id = [0]
 
     def visit(ni, parent):
@@ -290,6 +322,15 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
                     fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
                     fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
                     tn = np.repeat(fn[:, None, :], 3, axis=1)
+                uv = accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32)[idx] if "TEXCOORD_0" in prim["attributes"] else np.zeros((len(tri), 3, 2), np.float32)
+                if "TANGENT" in prim["attributes"]:
+                    tg = accessor(prim["attributes"]["TANGENT"]).astype(np.float64)[:, :3] @ M[:3, :3].T
+                    tg /= np.maximum(np.linalg.norm(tg, axis=1, keepdims=True), 1e-20)
+                    tg = tg[idx]
+                else:
+                    tg = np.zeros_like(tn)
+                    tg[..., 0] = 1.0
+                uvs.append(uv); tans.append(tg)
                 mesh_id[0] += 1
                 verts.append(tri); norms.append(tn)
                 tmat.append(np.full(len(tri), prim.get("material", default_mat), np.uint32))
@@ -302,6 +343,12 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
         visit(root, np.eye(4))
     if not verts:
         raise ValueError(f"{path}: no triangle primitives")
-    return SceneData(verts=np.ascontiguousarray(np.concatenate(verts), np.float32), normals=np.ascontiguousarray(np.concatenate(norms), np.float32),
-                     tri_material=np.concatenate(tmat), tri_mesh_id=np.concatenate(tmesh), materials=np.asarray(mats, np.float32),
-                     name=os.path.basename(path), meta=dict(n_materials=len(mats) - 1))
+    sd = SceneData(verts=np.ascontiguousarray(np.concatenate(verts), np.float32), normals=np.ascontiguousarray(np.concatenate(norms), np.float32),
+                   tri_material=np.concatenate(tmat), tri_mesh_id=np.concatenate(tmesh), materials=np.asarray(mats, np.float32),
+                   name=os.path.basename(path), meta=dict(n_materials=len(mats) - 1, n_textures=len(textures)))
+    if textures:
+        sd.uvs = np.ascontiguousarray(np.concatenate(uvs), np.float32)
+        sd.tangents = np.ascontiguousarray(np.concatenate(tans), np.float32)
+        sd.material_textures = np.asarray(mat_tex, np.int32)
+        sd.textures = textures
+    return sd

@@ -266,6 +266,30 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
     if (d->tri_material) { UP(tri_material, d->tri_material, n * 4) s->has_material = true; }
     if (d->tri_mesh_id) { UP(tri_mesh_id, d->tri_mesh_id, n * 4) s->has_mesh_id = true; }
     UP(positions, d->positions, n * 36)
+    if (d->material_textures && d->materials && d->n_textures > 0 && d->textures)
+    {
+        // one buffer of texels + a table {texel offset, width, height, 0} per texture
+        std::vector<uint32_t> table;
+        std::vector<uint8_t>  texels;
+        for (int i = 0; i < d->n_textures; i++)
+        {
+            const hr_texture& t = d->textures[i];
+            if (!t.rgba8 || t.width <= 0 || t.height <= 0) { delete s; return HR_ERR_INVALID_ARG; }
+            table.insert(table.end(), { (uint32_t)(texels.size() / 4), (uint32_t)t.width, (uint32_t)t.height, 0u });
+            texels.insert(texels.end(), t.rgba8, t.rgba8 + (size_t)t.width * t.height * 4);
+        }
+        for (int i = 0; i < d->n_materials * 4; i++)
+        {
+            const int32_t ti = d->material_textures[(i / 4) * 6 + (i % 4)];
+            if (ti >= d->n_textures) { delete s; return HR_ERR_INVALID_ARG; }
+        }
+        UP(mat_tex, d->material_textures, (size_t)d->n_materials * 24)
+        UP(tex_table, table.data(), table.size() * 4)
+        UP(tex_data, texels.data(), texels.size())
+        if (d->uvs) { UP(tri_uvs, d->uvs, n * 24) s->has_uvs = true; }
+        if (d->tangents) { UP(tri_tangents, d->tangents, n * 36) s->has_tangents = true; }
+        s->has_textures = true;
+    }
 #undef UP
     s->n_materials      = d->materials ? d->n_materials : 0;
     s->info.n_tris      = d->n_tris;

@@ -337,10 +337,7 @@ hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays)
 
 static void scene_shading(const hr_scene* scene, SceneShading& sh)
 {
-    sh.positions    = (const float*)scene->positions.p;
-    sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
-    sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
-    sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
+    scene_shading_from(scene, sh);
 }
 
 hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* prm, void* stream_)

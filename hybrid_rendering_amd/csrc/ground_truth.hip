@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64) void k_ground_truth(GTArgs a)
         if (h.prim < 0) L = a.sky.fetch(d);
         else
         {
-            const SurfaceHit s = surface_at(a.sh, h);
+            SurfaceHit s = surface_at(a.sh, h);
+            s.N = normalize3(s.N);   // rchit:131 normalises fetch_normal()'s result once more (observable with normal maps)
             const float roughness = s.roughness * a.roughness_multiplier;
             const f3 Wo = neg3(d);
             const f3 F0 = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
@@ -170,10 +171,7 @@ hr_status hr_ground_truth_render(hr_ground_truth* p, const hr_scene* scene, cons
     for (int i = 0; i < 16; i++) { a.view_inverse[i] = ubo->view_inverse[i]; a.proj_inverse[i] = ubo->proj_inverse[i]; }
     a.light = ubo->light;
     a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
-    a.sh.positions    = (const float*)scene->positions.p;
-    a.sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
-    a.sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
-    a.sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
+    scene_shading_from(scene, a.sh);
     a.sky = CubeMap { (const uint2*)env->sky, env->sky_size };
     a.prev = (const uint2*)p->image[read_idx].p; a.cur = (uint2*)p->image[write_idx].p;
     a.ray_slots = (uint32_t*)p->ray_slots.p;

@@ -183,6 +183,8 @@ struct hr_scene
     hr_ctx*       ctx = nullptr;
     hr::DevBuf    nodes, tris;
     hr::DevBuf    tri_normals, tri_material, tri_mesh_id, materials, positions; // shading data (by original triangle index)
+    hr::DevBuf    tri_uvs, tri_tangents, mat_tex, tex_table, tex_data;          // textured materials (optional)
+    bool          has_uvs = false, has_tangents = false, has_textures = false;
     hr_scene_info info;
     int           n_materials = 0;
     bool          has_normals = false, has_material = false, has_mesh_id = false;

@@ -491,10 +491,7 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     a.depth = in->cur.depth; a.gb2 = (const uint2*)in->cur.gb2; a.gb3 = (const uint2*)in->cur.gb3;
     a.sobol = in->sobol; a.sr = in->scrambling_ranking;
     a.nodes = (const Node8*)scene->nodes.p; a.tris = (const TriGPU*)scene->tris.p;
-    a.sh.positions    = (const float*)scene->positions.p;
-    a.sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
-    a.sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
-    a.sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
+    scene_shading_from(scene, a.sh);
     a.env.sky = CubeMap { (const uint2*)env->sky, env->sky_size };
     a.env.prefiltered = (const uint2*)env->prefiltered; a.env.pre_size = env->prefiltered_size; a.env.pre_levels = env->prefiltered_levels;
     a.env.lut = (const uint32_t*)env->brdf_lut; a.env.lut_size = env->brdf_lut_size;

@@ -281,12 +281,57 @@ struct SceneShading
     const float*    normals;     // [n][3][3] or null
     const uint32_t* tri_material;
     const float*    materials;   // [m][8]
+    // textured materials (all null when the scene has none)
+    const float*    uvs;         // [n][3][2] or null
+    const float*    tangents;    // [n][3][3] or null
+    const int32_t*  mat_tex;     // [m][6]: albedo, normal, roughness, metallic texture (-1 none), roughness channel, metallic channel
+    const uint4*    tex_table;   // per texture: texel offset, width, height
+    const uint32_t* tex_data;    // RGBA8 texels
 };
+// fills the members above from a scene (host)
+static inline void scene_shading_from(const hr_scene* scene, SceneShading& sh)
+{
+    sh.positions    = (const float*)scene->positions.p;
+    sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
+    sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
+    sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
+    sh.uvs          = scene->has_uvs ? (const float*)scene->tri_uvs.p : nullptr;
+    sh.tangents     = scene->has_tangents ? (const float*)scene->tri_tangents.p : nullptr;
+    sh.mat_tex      = scene->has_textures ? (const int32_t*)scene->mat_tex.p : nullptr;
+    sh.tex_table    = scene->has_textures ? (const uint4*)scene->tex_table.p : nullptr;
+    sh.tex_data     = scene->has_textures ? (const uint32_t*)scene->tex_data.p : nullptr;
+}
 struct SurfaceHit
 {
     f3    P, N, albedo;
     float roughness, metallic;
 };
+// texture(s_Textures[i], uv) in a ray-tracing stage: level 0; pinned sampler: bilinear with fp32 weights at uv*size - 0.5,
+// REPEAT addressing, UNORM8 texel = b / 255 (checked against the reference's hit shaders by
+// tests/test_ref_shaders.py::test_textured_materials_in_hit_shaders).  out[4] = r, g, b, a.
+HR_DEV void sample_texture(const SceneShading& s, int tex, float u, float v, float* out)
+{
+    const uint4 t  = s.tex_table[tex];
+    const int   w  = (int)t.y, h = (int)t.z;
+    const float px = u * (float)w - 0.5f, py = v * (float)h - 0.5f;
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    const float fx = px - fx0, fy = py - fy0;
+    int x0 = (int)fx0 % w, x1 = ((int)fx0 + 1) % w, y0 = (int)fy0 % h, y1 = ((int)fy0 + 1) % h;
+    x0 = x0 < 0 ? x0 + w : x0; x1 = x1 < 0 ? x1 + w : x1; y0 = y0 < 0 ? y0 + h : y0; y1 = y1 < 0 ? y1 + h : y1;
+    const uint32_t* base = s.tex_data + t.x;
+    const uint32_t t00 = base[(size_t)y0 * w + x0], t10 = base[(size_t)y0 * w + x1], t01 = base[(size_t)y1 * w + x0], t11 = base[(size_t)y1 * w + x1];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+        const float a = __fdiv_rn((float)((t00 >> (8 * c)) & 0xffu), 255.0f), b = __fdiv_rn((float)((t10 >> (8 * c)) & 0xffu), 255.0f);
+        const float e = __fdiv_rn((float)((t01 >> (8 * c)) & 0xffu), 255.0f), g = __fdiv_rn((float)((t11 >> (8 * c)) & 0xffu), 255.0f);
+        const float top = a * (1.0f - fx) + b * fx, bot = e * (1.0f - fx) + g * fx;
+        out[c] = top * (1.0f - fy) + bot * fy;
+    }
+}
+// interpolated_vertex + transform_vertex (identity model) + fetch_albedo / fetch_roughness / fetch_metallic / fetch_normal
+// (scene_descriptor_set.glsl:133-220).  Quirk kept: the hit shaders call fetch_normal(material, tangent, TANGENT, normal, uv)
+// (reflections_ray_trace.rchit:134, gi_ray_trace.rchit:112, ground_truth_path_trace.rchit:131): TBN = (T, T, N).
 HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
 {
     SurfaceHit o;
@@ -310,6 +355,35 @@ HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
         o.albedo = mk3(m[0], m[1], m[2]); o.metallic = m[3]; o.roughness = max2(m[4], 0.1f);
     }
     else { o.albedo = mk3(0.8f, 0.8f, 0.8f); o.metallic = 0.0f; o.roughness = 0.5f; }
+    if (s.mat_tex)
+    {
+        const int32_t* mt = s.mat_tex + (size_t)mat * 6;
+        float tu = 0.0f, tv = 0.0f;
+        if (s.uvs)
+        {
+            const float* q = s.uvs + (size_t)h.prim * 6;
+            tu = (q[0] * b0 + q[2] * b1) + q[4] * b2;
+            tv = (q[1] * b0 + q[3] * b1) + q[5] * b2;
+        }
+        float c[4];
+        if (mt[0] >= 0) { sample_texture(s, mt[0], tu, tv, c); o.albedo = mk3(c[0], c[1], c[2]); }
+        if (mt[2] >= 0) { sample_texture(s, mt[2], tu, tv, c); o.roughness = max2(c[mt[4] & 3], 0.1f); }
+        if (mt[3] >= 0) { sample_texture(s, mt[3], tu, tv, c); o.metallic = c[mt[5] & 3]; }
+        if (mt[1] >= 0)
+        {
+            f3 tg = mk3(1.0f, 0.0f, 0.0f);
+            if (s.tangents)
+            {
+                const float* q = s.tangents + (size_t)h.prim * 9;
+                tg = add3(add3(scale3(mk3(q[0], q[1], q[2]), b0), scale3(mk3(q[3], q[4], q[5]), b1)), scale3(mk3(q[6], q[7], q[8]), b2));
+            }
+            tg = normalize3(normalize3(tg));                       // interpolated_vertex, then transform_vertex
+            const f3 T = normalize3(tg), Nn = normalize3(o.N);     // get_normal_from_map: TBN = (T, T, N)
+            sample_texture(s, mt[1], tu, tv, c);
+            const f3 tn = normalize3(sub3(scale3(mk3(c[0], c[1], c[2]), 2.0f), one3()));
+            o.N = normalize3(add3(add3(scale3(T, tn.x), scale3(T, tn.y)), scale3(Nn, tn.z)));
+        }
+    }
     return o;
 }
 

@@ -32,6 +32,11 @@ class SceneData:
     materials: np.ndarray      # [m,8] float32: albedo rgb, metallic, roughness, emissive rgb
     name: str = "scene"
     meta: dict = field(default_factory=dict)
+    # textured materials (scene_descriptor_set.glsl:20-27): all optional
+    uvs: np.ndarray = None                # [n,3,2] float32
+    tangents: np.ndarray = None           # [n,3,3] float32 (normal-mapped materials only)
+    material_textures: np.ndarray = None  # [m,6] int32: albedo, normal, roughness, metallic texture (-1 none), roughness channel, metallic channel
+    textures: list = None                 # list of [h,w,4] uint8 (RGBA8 UNORM)
 
     @property
     def n_tris(self) -> int:
@@ -168,6 +173,53 @@ class _Builder:
     def finish(self, materials, name, **meta) -> SceneData:
         return SceneData(np.concatenate(self.v), np.concatenate(self.n), np.concatenate(self.mat), np.concatenate(self.mid),
                          np.asarray(materials, np.float32), name, dict(meta))
+
+
+def with_textures(sd: SceneData, seed: int = 5) -> SceneData:
+    """A textured variant of a scene: planar texture coordinates along the dominant axis of every triangle, Gram-Schmidt
+    vertex tangents, three procedural RGBA8 textures (colour checker, bump normal map, roughness/metallic noise) and a
+    material -> texture table that exercises every fetch_* branch (none / albedo / albedo+normal / all four)."""
+    rng = np.random.RandomState(seed)
+    v, n = sd.verts.astype(np.float32), sd.normals.astype(np.float32)
+    fn = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    axis = np.argmax(np.abs(fn), axis=1)
+    ua, va = (axis + 1) % 3, (axis + 2) % 3
+    lo, hi = sd.bounds()
+    scale = np.float32(8.0 / max(float((hi - lo).max()), 1e-6))
+    idx = np.arange(len(v))
+    uvs = np.stack([v[idx, :, ua] * scale + np.float32(0.13), v[idx, :, va] * scale - np.float32(0.29)], -1).astype(np.float32)   # [n,3,2]
+    e = np.zeros((len(v), 3), np.float32)
+    e[idx, ua] = 1.0
+    t = e[:, None, :] - n * np.sum(n * e[:, None, :], -1, keepdims=True)
+    t = (t / np.maximum(np.linalg.norm(t, axis=-1, keepdims=True), 1e-8)).astype(np.float32)
+    yy, xx = np.mgrid[0:64, 0:64]
+    alb = np.zeros((64, 64, 4), np.uint8)
+    chk = ((xx // 8 + yy // 8) & 1).astype(bool)
+    alb[..., 0] = np.where(chk, 220, 60) + rng.randint(-20, 20, (64, 64))
+    alb[..., 1] = np.where(chk, 90, 200) + rng.randint(-20, 20, (64, 64))
+    alb[..., 2] = 128 + (64 * np.sin(xx * 0.4)).astype(np.int32)
+    alb[..., 3] = 255
+    y2, x2 = np.mgrid[0:32, 0:32]
+    hx, hy = 0.6 * np.cos(x2 * 0.7), 0.6 * np.sin(y2 * 0.9)
+    nm = np.stack([-hx, -hy, np.ones_like(hx)], -1)
+    nm /= np.linalg.norm(nm, axis=-1, keepdims=True)
+    nmap = np.concatenate([np.clip((nm * 0.5 + 0.5) * 255.0 + 0.5, 0, 255), np.full((32, 32, 1), 255.0)], -1).astype(np.uint8)
+    rm = rng.randint(0, 256, (16, 16, 4)).astype(np.uint8)
+    rm[..., 1] = rng.randint(10, 240, (16, 16))      # roughness channel g
+    m = len(sd.materials)
+    mt = np.full((m, 6), -1, np.int32)
+    mt[:, 4], mt[:, 5] = 1, 2
+    for i in range(m):
+        k = (3, 1, 2, 0)[i % 4]      # material 0 (usually the largest surfaces) gets all four textures
+        if k >= 1:
+            mt[i, 0] = 0
+        if k >= 2:
+            mt[i, 1] = 1
+        if k == 3:
+            mt[i, 2] = mt[i, 3] = 2
+    return SceneData(sd.verts, sd.normals, sd.tri_material, sd.tri_mesh_id, sd.materials, sd.name + "_textured", dict(sd.meta),
+                     uvs=np.ascontiguousarray(uvs), tangents=np.ascontiguousarray(t), material_textures=mt,
+                     textures=[np.ascontiguousarray(alb), np.ascontiguousarray(nmap), np.ascontiguousarray(rm)])
 
 
 # --------------------------------------------------------------------------- scenes

@@ -121,6 +121,12 @@ hr_status hr_ctx_destroy(hr_ctx* ctx);
  * on the host and uploads it.  All host pointers; data is copied. */
 typedef struct
 {
+    const uint8_t* rgba8;         /* [height][width][4] */
+    int32_t        width, height;
+} hr_texture;
+
+typedef struct
+{
     const float*    positions;    /* [n_tris][3][3] world-space vertex positions               */
     const float*    normals;      /* [n_tris][3][3] vertex normals, or NULL (geometric)         */
     const uint32_t* tri_material; /* [n_tris] or NULL                                           */
@@ -128,6 +134,15 @@ typedef struct
     int32_t         n_tris;
     const float*    materials;    /* [n_materials][8]: albedo rgb, metallic, roughness, emissive rgb */
     int32_t         n_materials;
+    /* Textured materials (scene_descriptor_set.glsl:20-27 Material.texture_indices0/1, :168-220 fetch_*), all optional
+     * (NULL / 0 = the material constants above).  Sampling is what a ray-tracing stage gets from texture(): level 0;
+     * the sampler (created in the reference's un-vendored framework) is pinned to bilinear, REPEAT, UNORM8 = b / 255. */
+    const float*      uvs;               /* [n_tris][3][2] texture coordinates                                            */
+    const float*      tangents;          /* [n_tris][3][3] vertex tangents (normal-mapped materials only)                 */
+    const int32_t*    material_textures; /* [n_materials][6]: albedo, normal, roughness, metallic texture index (-1 = none),
+                                            roughness channel, metallic channel (texture_indices1.z / .w)                 */
+    const hr_texture* textures;          /* [n_textures] host RGBA8 images, copied                                        */
+    int32_t           n_textures;
 } hr_scene_desc;
 
 typedef struct

@@ -17,6 +17,22 @@ void* orc_scene_create(const float* verts, int n_tris, const float* normals, con
     if (materials) s->materials.assign(materials, materials + (size_t)n_materials * 8);
     return s;
 }
+// textured materials: uvs [n][3][2], tangents [n][3][3] (nullable), mat_tex [m][6], textures: n_tex RGBA8 images
+void orc_scene_set_textures(void* scene, const float* uvs, const float* tangents, const int32_t* mat_tex, int n_materials, int n_tex,
+                            const uint8_t* const* tex_rgba, const int32_t* tex_w, const int32_t* tex_h)
+{
+    Scene*       s = (Scene*)scene;
+    const size_t n = s->tris.size();
+    if (uvs) s->tri_uvs.assign(uvs, uvs + n * 6);
+    if (tangents) s->tri_tangents.assign(tangents, tangents + n * 9);
+    s->mat_tex.assign(mat_tex, mat_tex + (size_t)n_materials * 6);
+    s->textures.resize(n_tex);
+    for (int i = 0; i < n_tex; i++)
+    {
+        s->textures[i].w = tex_w[i]; s->textures[i].h = tex_h[i];
+        s->textures[i].rgba.assign(tex_rgba[i], tex_rgba[i] + (size_t)tex_w[i] * tex_h[i] * 4);
+    }
+}
 void orc_scene_destroy(void* scene) { delete (Scene*)scene; }
 int  orc_scene_num_nodes(const void* scene) { return (int)((const Scene*)scene)->nodes.size(); }
 

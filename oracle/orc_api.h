@@ -12,6 +12,8 @@ extern "C" {
 // tri_material / tri_mesh_id (nullable): per triangle.  materials (nullable): [m][8] =
 // albedo rgb, metallic, roughness, emissive rgb.
 void*    orc_scene_create(const float* verts, int n_tris, const float* normals, const uint32_t* tri_material, const uint32_t* tri_mesh_id, const float* materials, int n_materials);
+void     orc_scene_set_textures(void* scene, const float* uvs, const float* tangents, const int32_t* mat_tex, int n_materials, int n_tex,
+                                const uint8_t* const* tex_rgba, const int32_t* tex_w, const int32_t* tex_h);
 void     orc_scene_destroy(void* scene);
 int      orc_scene_num_nodes(const void* scene);
 // rays: [n][8] = origin xyz, t_max, dir xyz, t_min.  out: [n] uint8 (1 = occluded).

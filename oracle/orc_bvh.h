@@ -106,6 +106,12 @@ struct Scene
     std::vector<float>    tri_normals;  // [n][3][3] vertex normals (optional; else geometric)
     std::vector<float>    materials;    // [m][8]: albedo rgb, metallic, roughness, emissive rgb
     std::vector<uint32_t> tri_mesh_id;
+    // textured materials (scene_descriptor_set.glsl:20-27, :168-220); all optional
+    std::vector<float>    tri_uvs;       // [n][3][2]
+    std::vector<float>    tri_tangents;  // [n][3][3]
+    std::vector<int32_t>  mat_tex;       // [m][6]: albedo, normal, roughness, metallic texture (-1 = none), roughness channel, metallic channel
+    struct Texture { std::vector<uint8_t> rgba; int w, h; };
+    std::vector<Texture>  textures;      // RGBA8 UNORM
 
     void build(const float* verts, int n_tris);
     bool any_hit(vec3 o, vec3 d, float t_min, float t_max) const;

@@ -46,7 +46,8 @@ void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_
             if (hit.prim < 0) L = cube.fetch(d);
             else
             {
-                const SurfaceHit sh = surface_at(scene, hit);
+                SurfaceHit sh = surface_at(scene, hit);
+                sh.N = normalize(sh.N);   // rchit:131 normalises fetch_normal()'s result once more (observable with normal maps)
                 const float roughness = sh.roughness * roughness_multiplier;
                 const vec3  Wo = -d;
                 const vec3  F0 = mix3(v3(0.04f, 0.04f, 0.04f), sh.albedo, sh.metallic);

@@ -262,7 +262,31 @@ struct SurfaceHit
     float roughness, metallic;
 };
 
-// interpolated_vertex + transform_vertex (identity model) + fetch_* with untextured materials
+// texture(s_Textures[i], uv) in a ray-tracing stage: no derivatives, so level 0.  Pinned sampler (the reference's is made
+// in the un-vendored framework): bilinear with fp32 weights at uv*size - 0.5, REPEAT addressing, UNORM8 texel = b / 255.
+static inline vec4 sample_texture(const Scene::Texture& t, float u, float v)
+{
+    const float px = u * (float)t.w - 0.5f, py = v * (float)t.h - 0.5f;
+    const float fx0 = std::floor(px), fy0 = std::floor(py);
+    const float fx = px - fx0, fy = py - fy0;
+    auto wrap = [](int c, int n) { c %= n; return c < 0 ? c + n : c; };
+    const int x0 = wrap((int)fx0, t.w), x1 = wrap((int)fx0 + 1, t.w), y0 = wrap((int)fy0, t.h), y1 = wrap((int)fy0 + 1, t.h);
+    auto texel = [&](int x, int y, int c) { return (float)t.rgba[((size_t)y * t.w + x) * 4 + c] / 255.0f; };
+    float r[4];
+    for (int c = 0; c < 4; c++)
+    {
+        const float top = texel(x0, y0, c) * (1.0f - fx) + texel(x1, y0, c) * fx;
+        const float bot = texel(x0, y1, c) * (1.0f - fx) + texel(x1, y1, c) * fx;
+        r[c] = top * (1.0f - fy) + bot * fy;
+    }
+    return vec4 { r[0], r[1], r[2], r[3] };
+}
+static inline float comp4(vec4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// interpolated_vertex + transform_vertex (identity model) + fetch_albedo / fetch_roughness / fetch_metallic / fetch_normal
+// (scene_descriptor_set.glsl:133-220).  Quirk kept: every hit shader calls fetch_normal(material, tangent, TANGENT, normal, uv)
+// (reflections_ray_trace.rchit:134, gi_ray_trace.rchit:112, ground_truth_path_trace.rchit:131), so the TBN matrix of a
+// normal-mapped material is (T, T, N).
 static inline SurfaceHit surface_at(const Scene& s, const Hit& h)
 {
     SurfaceHit o;
@@ -285,6 +309,34 @@ static inline SurfaceHit surface_at(const Scene& s, const Hit& h)
         o.albedo = v3(m[0], m[1], m[2]); o.metallic = m[3]; o.roughness = fmax2(m[4], 0.1f);
     }
     else { o.albedo = v3(0.8f, 0.8f, 0.8f); o.metallic = 0.0f; o.roughness = 0.5f; }
+    if (!s.mat_tex.empty())
+    {
+        const int32_t* mt = &s.mat_tex[(size_t)mat * 6];
+        float tu = 0.0f, tv = 0.0f;
+        if (!s.tri_uvs.empty())
+        {
+            const float* q = &s.tri_uvs[(size_t)h.prim * 6];
+            tu = (q[0] * b0 + q[2] * b1) + q[4] * b2;
+            tv = (q[1] * b0 + q[3] * b1) + q[5] * b2;
+        }
+        if (mt[0] >= 0) { vec4 c = sample_texture(s.textures[mt[0]], tu, tv); o.albedo = v3(c.x, c.y, c.z); }
+        if (mt[2] >= 0) o.roughness = fmax2(comp4(sample_texture(s.textures[mt[2]], tu, tv), mt[4]), 0.1f);
+        if (mt[3] >= 0) o.metallic = comp4(sample_texture(s.textures[mt[3]], tu, tv), mt[5]);
+        if (mt[1] >= 0)
+        {
+            vec3 tg = v3(1.0f, 0.0f, 0.0f);
+            if (!s.tri_tangents.empty())
+            {
+                const float* q = &s.tri_tangents[(size_t)h.prim * 9];
+                tg = (v3(q[0], q[1], q[2]) * b0 + v3(q[3], q[4], q[5]) * b1) + v3(q[6], q[7], q[8]) * b2;
+            }
+            tg = normalize(normalize(tg));                       // interpolated_vertex, then transform_vertex
+            const vec3 T = normalize(tg), Nn = normalize(o.N);   // get_normal_from_map: TBN = (T, T, N) (quirk above)
+            vec4 c  = sample_texture(s.textures[mt[1]], tu, tv);
+            vec3 tn = normalize(v3(c.x, c.y, c.z) * 2.0f - v3(1.0f, 1.0f, 1.0f));
+            o.N     = normalize((T * tn.x + T * tn.y) + Nn * tn.z);
+        }
+    }
     return o;
 }
 

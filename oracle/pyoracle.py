@@ -80,6 +80,17 @@ class Scene:
         self.h = C.c_void_p(lib().orc_scene_create(
             _p(self.verts, c_f32p), C.c_int(sd.n_tris), _p(self.normals, c_f32p), _p(self.tri_material, c_u32p),
             _p(self.tri_mesh_id, c_u32p), _p(self.materials, c_f32p), C.c_int(len(self.materials))))
+        if getattr(sd, "material_textures", None) is not None:
+            self.uvs = np.ascontiguousarray(sd.uvs, np.float32) if sd.uvs is not None else None
+            self.tangents = np.ascontiguousarray(sd.tangents, np.float32) if sd.tangents is not None else None
+            self.mat_tex = np.ascontiguousarray(sd.material_textures, np.int32)
+            self.textures = [np.ascontiguousarray(t, np.uint8) for t in sd.textures]
+            nt = len(self.textures)
+            ptrs = (C.c_void_p * nt)(*[t.ctypes.data for t in self.textures])
+            tw = np.array([t.shape[1] for t in self.textures], np.int32)
+            th = np.array([t.shape[0] for t in self.textures], np.int32)
+            lib().orc_scene_set_textures(self.h, _p(self.uvs, c_f32p), _p(self.tangents, c_f32p), _p(self.mat_tex, c_i32p), C.c_int(len(self.mat_tex)),
+                                         C.c_int(nt), ptrs, _p(tw, c_i32p), _p(th, c_i32p))
 
     def __del__(self):
         try:

@@ -410,6 +410,20 @@ class RefScene:
         m[:, 8:11], m[:, 11] = sd.materials[:, 0:3], 1.0
         m[:, 12:15] = sd.materials[:, 5:8]
         m[:, 16], m[:, 17] = sd.materials[:, 4], sd.materials[:, 3]
+        self.textures = []
+        if getattr(sd, "material_textures", None) is not None:
+            if sd.uvs is not None:
+                v[:, 1, :2] = sd.uvs.reshape(-1, 2)
+            if sd.tangents is not None:
+                v[:, 3, :3] = sd.tangents.reshape(-1, 3)
+                v[:, 4, :3] = sd.tangents.reshape(-1, 3)
+            self.vertices = np.ascontiguousarray(v)
+            mtx = np.asarray(sd.material_textures, np.int32)
+            mi[:, 0:4] = mtx[:, 0:4]            # texture_indices0: albedo, normals, roughness, metallic
+            mi[:, 6], mi[:, 7] = mtx[:, 4], mtx[:, 5]   # texture_indices1.z / .w: roughness / metallic channel
+            # pinned sampler of s_Textures[]: bilinear, repeat (see orc_shading.h sample_texture)
+            self.textures = [pyref.Tex(np.ascontiguousarray(t, np.uint8), "rgba8", linear=True, repeat=True) for t in sd.textures]
+            self.texture_table = np.array([t.ptr for t in self.textures], np.uint64)
         self.materials = np.ascontiguousarray(m)
         inst = np.zeros(17, np.float32)
         inst[[0, 5, 10, 15]] = 1.0
@@ -421,6 +435,8 @@ class RefScene:
         pipe.set_at_all("Vertices", np.uint64(self.vertices.ctypes.data))
         pipe.set_at_all("Indices", np.uint64(self.indices.ctypes.data))
         pipe.set_at_all("SubmeshInfo", np.uint64(self.submesh.ctypes.data))
+        if self.textures:
+            pipe.set_all("s_Textures", np.uint64(self.texture_table.ctypes.data))
         pipe.set_all("u_TopLevelAS", np.uint64(oscene.h.value))
         pipe.lib.ref_set_any_hit(C.cast(oracle.lib().orc_any_hit_one, C.c_void_p))
         pipe.lib.ref_set_closest_hit(C.cast(oracle.lib().orc_closest_hit_one, C.c_void_p))

@@ -196,3 +196,59 @@ def test_gltf_loader(tmp_path, form):
     assert np.allclose(sd.verts[2], [[10, 5, 0], [10, 7, 0], [8, 5, 0]], atol=1e-5)
     assert np.allclose(sd.normals[2], [0, 0, 1], atol=1e-6)                         # NORMAL accessor through the byteStride
     assert np.allclose(sd.materials[0], [0.2, 0.4, 0.6, 0.0, 0.3, 1, 0, 0]) and sd.materials.shape == (2, 8)
+
+
+def _png_bytes(img):
+    """minimal 8-bit RGBA PNG encoder (filter 0) for the tests"""
+    import zlib
+    h, w, c = img.shape
+    assert c == 4
+    raw = b"".join(b"\0" + img[y].tobytes() for y in range(h))
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+def test_gltf_textures_reach_the_hit_shading(tmp_path, oracle):
+    """TEXCOORD_0 + baseColorTexture / metallicRoughnessTexture PNGs (one as a data URI, one as a file) -> SceneData.uvs /
+    material_textures / textures -> the oracle's (reference-pinned) fetch_albedo: a ground-truth frame changes colour"""
+    import base64
+    import json
+    from oracle import pyoracle_post as opost
+    from hybrid_rendering_amd import synth, synth_env
+    doc, blob = _gltf_doc(tmp_path, embed=True)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    blob2 = blob + uv.tobytes()
+    doc["buffers"][0] = {"byteLength": len(blob2), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob2).decode()}
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": len(blob), "byteLength": 32})
+    doc["accessors"].append({"bufferView": 3, "componentType": 5126, "count": 4, "type": "VEC2"})
+    doc["meshes"][0]["primitives"][0]["attributes"]["TEXCOORD_0"] = 4
+    red = np.zeros((4, 4, 4), np.uint8); red[..., 0] = 255; red[..., 3] = 255
+    mr = np.zeros((2, 2, 4), np.uint8); mr[..., 1] = 200; mr[..., 2] = 0; mr[..., 3] = 255
+    (tmp_path / "mr.png").write_bytes(_png_bytes(mr))
+    doc["images"] = [{"uri": "data:image/png;base64," + base64.b64encode(_png_bytes(red)).decode()}, {"uri": "mr.png"}, {"uri": "photo.jpg"}]
+    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0 not decodable here")
+    doc["textures"] = [{"source": 0}, {"source": 1}, {"source": 2}]
+    doc["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    doc["materials"][0]["pbrMetallicRoughness"]["metallicRoughnessTexture"] = {"index": 1}
+    doc["materials"][0]["normalTexture"] = {"index": 2}        # JPEG: skipped
+    path = tmp_path / "tex.gltf"
+    path.write_text(json.dumps(doc))
+    sd = assets.load_gltf(str(path))
+    assert sd.uvs.shape == (3, 3, 2) and np.allclose(sd.uvs[0], [[0, 0], [1, 0], [1, 1]]) and np.all(sd.uvs[2] == 0)
+    assert len(sd.textures) == 2 and sd.textures[0].shape == (4, 4, 4) and np.array_equal(sd.textures[1], mr)
+    assert sd.material_textures.tolist() == [[0, -1, 1, 1, 1, 2], [-1, -1, -1, -1, 1, 2]]
+    # the textured quad (z = 0 plane, x 10..12, y 0..2) seen head-on under a light from the front
+    cam = synth.Camera((11.0, 1.0, 6.0), (11.0, 1.0, 0.0), fov=40.0, aspect=1.0)
+    light = synth.make_light(direction_to_light=(0.2, 0.3, 1.0), radius=0.0, intensity=3.0)
+    ubo = synth.make_ubo(cam, None, light)
+    sky = synth_env.sky_cubemap(8)
+    plain = assets.load_gltf(str(path))
+    plain.material_textures = None
+    outs = []
+    for s in (sd, plain):
+        gt = opost.GroundTruthPass(32, 32)
+        outs.append(oracle.f16(gt.render(oracle.Scene(s), ubo, sky))[12:20, 12:20, :3].mean((0, 1)))
+    assert outs[0][0] > 4 * outs[0][2] and outs[0][0] > 4 * outs[0][1]            # red albedo texture
+    assert not np.allclose(outs[0], outs[1])                                        # factor (0.2, 0.4, 0.6) without the textures

@@ -371,3 +371,44 @@ def test_random_pass_parameters(oracle, rh, seed):
         assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["temporal"], b["temporal"]), (sp, k)
         assert all(np.array_equal(x, y) for x, y in zip(a["atrous"], b["atrous"])), (sp, k)
         assert np.array_equal(c["mask"][0], d["mask"]) and np.array_equal(c["temporal"], d["temporal"]) and np.array_equal(c["blur1"], d["blur1"]), (ap, k)
+
+
+@pytest.mark.parametrize("name", ["cornell", "sponza_small"])
+def test_textured_materials_in_hit_shaders(oracle, rh, name):
+    """fetch_albedo / fetch_roughness / fetch_metallic / fetch_normal with s_Textures[] bound (scene_descriptor_set.glsl:
+    133-220): interpolated texture coordinates, channel selects, the (T, T, N) normal-map quirk — in the closest-hit shaders
+    of DDGI, reflections and the ground-truth path tracer.  Sampler pinned: bilinear, repeat, level 0."""
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf, pyoracle_post as opost
+    W, H = 64, 48
+    base = helpers.scene_data(name)
+    sd = synth.with_textures(base)
+    osc, osc_plain = oracle.Scene(sd), oracle.Scene(base)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=1.0 if name == "cornell" else 0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    frames = helpers.make_frames(oracle, osc, name, W, H, 3, 1.0)
+    sob, sr = synth.blue_noise_tables()
+    dp, rdp = od.DDGIPass(ddgi), rh.RefDDGIPass(ddgi, sd)
+    orp, rrp = orf.ReflectionsPass(W, H), rh.RefReflectionsPass(W, H, sd)
+    r1, r2 = np.random.RandomState(3), np.random.RandomState(3)
+    for k, fr in enumerate(frames):
+        cur, prev = fr["gb"], frames[k - 1]["gb"] if k else fr["gb"]
+        dp.render(osc, fr["ubo"], cur, sky, synth_env.random_orientation(r1), k)
+        rdp.render(osc, fr["ubo"], cur, sky, synth_env.random_orientation(r2), k)
+        for q in ("radiance", "direction_distance", "irradiance", "depth", "output"):
+            assert np.array_equal(dp.stages[q], rdp.stages[q]), f"frame {k}: DDGI {q}"
+        irr, dep = dp.current_read()
+        orp.render(osc, fr["ubo"], ddgi, cur, prev, sob, sr, k, env, irr, dep)
+        rrp.render(osc, fr["ubo"], ddgi, cur, prev, sob, sr, k, env, irr, dep)
+        for q in ("trace", "temporal", "output"):
+            assert np.array_equal(orp.stages[q], rrp.stages[q]), f"frame {k}: reflections {q}"
+    rsc = rh.RefScene(sd)
+    gt, gt_plain = opost.GroundTruthPass(W, H), opost.GroundTruthPass(W, H)
+    for k in range(3):
+        prevg, fi = gt.images[int(gt.ping_pong) if gt.frame_idx else 0].copy(), gt.frame_idx
+        out = gt.render(osc, frames[0]["ubo"], sky).copy()
+        assert np.array_equal(rh.ground_truth(osc, rsc, frames[0]["ubo"], sky, W, H, fi, prevg), out), f"ground truth frame {k}"
+    plain = gt_plain.render(osc_plain, frames[0]["ubo"], sky)
+    first = opost.GroundTruthPass(W, H).render(osc, frames[0]["ubo"], sky)
+    assert (plain != first).any(-1).mean() > 0.1          # the textures really change what the hit shaders return
