@@ -85,7 +85,18 @@ class TemporalAA:
             self.h = C.c_void_p()
 
 
-api.ABI_SYMBOLS += ["hr_ground_truth_default_params", "hr_ground_truth_create", "hr_ground_truth_render", "hr_ground_truth_output",
+def tone_map(ctx, color, single_channel=False, exposure=1.0, want_rgba8=True, stream=None):
+    """ToneMap::render (tone_map.cpp:98-143): color cuda fp16 [H,W,4] -> (fp32 [H,W,4], uint8 [H,W,4] or None)"""
+    import torch
+    h, w = color.shape[:2]
+    out_f = torch.empty((h, w, 4), dtype=torch.float32, device=color.device)
+    out_b = torch.empty((h, w, 4), dtype=torch.uint8, device=color.device) if want_rgba8 else None
+    _check(lib().hr_tone_map(ctx.h, C.byref(_view(color)), C.c_int32(int(single_channel)), C.c_float(exposure), api._ptr(out_f), api._ptr(out_b),
+                             _stream_ptr(stream)), "hr_tone_map")
+    return out_f, out_b
+
+
+api.ABI_SYMBOLS += ["hr_tone_map", "hr_ground_truth_default_params", "hr_ground_truth_create", "hr_ground_truth_render", "hr_ground_truth_output",
                     "hr_ground_truth_restart_accumulation", "hr_ground_truth_ray_count", "hr_ground_truth_set_profiling",
                     "hr_ground_truth_get_stage_times", "hr_ground_truth_destroy",
                     "hr_taa_default_params", "hr_taa_create", "hr_taa_update", "hr_taa_render", "hr_taa_output", "hr_taa_set_profiling",

@@ -74,6 +74,42 @@ struct TAAArgs
     int          sharpen;
 };
 
+struct ToneMapArgs
+{
+    TexRGBA src;
+    float4* out_f;
+    uchar4* out_b;
+    int     single_channel;
+    float   exposure;
+};
+HR_DEV float aces_film(float x) // tone_map.frag:36-44
+{
+    const float num = x * (2.51f * x + 0.03f), den = x * (2.43f * x + 0.59f) + 0.14f;
+    return clamp1(__fdiv_rn(num, den), 0.0f, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_tone_map(ToneMapArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.src.w || y >= a.src.h) return;
+    const f4 c = bilinear(a.src, __fdiv_rn((float)x + 0.5f, (float)a.src.w), __fdiv_rn((float)y + 0.5f, (float)a.src.h));
+    float r, g, b;
+    if (a.single_channel == 1) r = g = b = c.x;
+    else
+    {
+        const float ig = __fdiv_rn(1.0f, 2.2f);
+        r = det_pow(aces_film(c.x * a.exposure), ig);
+        g = det_pow(aces_film(c.y * a.exposure), ig);
+        b = det_pow(aces_film(c.z * a.exposure), ig);
+    }
+    const size_t i = (size_t)y * a.src.w + x;
+    if (a.out_f) a.out_f[i] = make_float4(r, g, b, 1.0f);
+    if (a.out_b)
+    {
+        auto q = [](float v) { v = clamp1(v, 0.0f, 1.0f); return (unsigned char)floorf(v * 255.0f + 0.5f); };
+        a.out_b[i] = make_uchar4(q(r), q(g), q(b), 255);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_taa(TAAArgs a)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
@@ -246,6 +282,22 @@ hr_status hr_taa_render(hr_taa* p, const hr_image_view* color, const hr_gbuffer_
     int ev = p->prof.begin("taa", st, (uint64_t)p->w * p->h * 36);
     hipLaunchKernelGGL(k_taa, dim3(cdiv(p->w, 32), cdiv(p->h, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+// ToneMap::render (tone_map.cpp:98-143, shaders/tone_map.frag:50-68): a stateless full-screen pass over the (TAA) colour
+// image — exposure, ACES film curve, pow(1/2.2) — read through the same bilinear sampler at the pixel centres; out_rgba32f
+// (nullable) receives FS_OUT_Color, out_rgba8 (nullable) its UNORM8 conversion floor(c * 255 + 0.5) (swap-chain write).
+hr_status hr_tone_map(hr_ctx* ctx, const hr_image_view* color, int32_t single_channel, float exposure, float* out_rgba32f, uint8_t* out_rgba8,
+                      void* stream_)
+{
+    HR_CHECK_ARG(ctx && color && color->data && color->format == HR_FORMAT_RGBA16F && color->width > 0 && color->height > 0 && (out_rgba32f || out_rgba8));
+    HR_HIP(hipSetDevice(ctx->device));
+    ToneMapArgs a;
+    a.src = TexRGBA { (const uint2*)color->data, color->width, color->height };
+    a.out_f = (float4*)out_rgba32f; a.out_b = (uchar4*)out_rgba8; a.single_channel = single_channel; a.exposure = exposure;
+    hipLaunchKernelGGL(k_tone_map, dim3(cdiv(color->width, 32), cdiv(color->height, 8)), dim3(256), 0, (hipStream_t)stream_, a);
     HR_HIP(hipGetLastError());
     return HR_OK;
 }

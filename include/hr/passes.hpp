@@ -339,4 +339,20 @@ private:
     bool    m_ping_pong = false;
 };
 
+// src/tone_map.h:16-40.  render() reads the (TAA) colour image and writes the displayable image: out_rgba8 (device, nullable)
+// is what the reference renders into the swap chain, out_rgba32f (device, nullable) the unquantised FS_OUT_Color.
+class ToneMap
+{
+public:
+    explicit ToneMap(Context& ctx) : m_ctx(ctx) {}
+    void render(Stream cmd_buf, const ImageView& color, uint8_t* out_rgba8, float* out_rgba32f = nullptr, bool single_channel = false)
+    {
+        check(hr_tone_map(m_ctx.handle(), &color, single_channel ? 1 : 0, exposure, out_rgba32f, out_rgba8, cmd_buf), "ToneMap::render");
+    }
+    float exposure = 1.0f;   // tone_map.h:38 m_exposure
+
+private:
+    Context& m_ctx;
+};
+
 } // namespace hr

@@ -491,6 +491,13 @@ hr_status hr_taa_set_profiling(hr_taa* p, int32_t enable);
 hr_status hr_taa_get_stage_times(hr_taa* p, hr_stage_times* out);
 hr_status hr_taa_destroy(hr_taa* p);
 
+/* ToneMap::render (src/tone_map.cpp:98-143, shaders/tone_map.frag:50-68): exposure, ACES film curve, pow(1/2.2) over an
+ * RGBA16F colour image read through the bilinear sampler at the pixel centres; single_channel = 1 shows .rrr (the
+ * shadows / AO visualisations, tone_map.cpp:131).  Stateless.  out_rgba32f (device [h][w][4] float, nullable) receives
+ * FS_OUT_Color; out_rgba8 (device [h][w][4] uint8, nullable) its UNORM8 conversion floor(c * 255 + 0.5). */
+hr_status hr_tone_map(hr_ctx* ctx, const hr_image_view* color, int32_t single_channel, float exposure, float* out_rgba32f, uint8_t* out_rgba8,
+                      void* stream);
+
 /* ---- self test ------------------------------------------------------------------------------------ */
 /* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
  * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)

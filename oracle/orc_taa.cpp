@@ -177,4 +177,31 @@ void orc_taa_resolve(int w, int h, const uint16_t* color, const uint16_t* prev, 
         }
 }
 
+// tone_map.frag:50-68 (ToneMap::render, tone_map.cpp:98-143).  color RGBA16F read through the bilinear sampler at the pixel
+// centres (the descriptor is TemporalAA's output_ds, temporal_aa.cpp:255); out: [h][w][4] fp32 = FS_OUT_Color.
+void orc_tone_map(int w, int h, const uint16_t* color, int single_channel, float exposure, float* out)
+{
+    const Tex4 src { color, w, h };
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const V4 c = src.bilinear(((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h);
+            float rgb[3];
+            if (single_channel == 1) rgb[0] = rgb[1] = rgb[2] = c.x;
+            else
+            {
+                const float in[3] = { c.x * exposure, c.y * exposure, c.z * exposure };
+                for (int k = 0; k < 3; k++)
+                {
+                    const float v = in[k];
+                    const float aces = clampf((v * (2.51f * v + 0.03f)) / (v * (2.43f * v + 0.59f) + 0.14f), 0.0f, 1.0f);
+                    rgb[k] = det_pow_auto(aces, 1.0f / 2.2f);
+                }
+            }
+            float* o = out + ((size_t)y * w + x) * 4;
+            o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = 1.0f;
+        }
+}
+
 } // extern "C"

@@ -72,3 +72,11 @@ class TAAPass:
 
     def output(self, ping_pong):
         return self.images[int(bool(ping_pong))]
+
+
+def tone_map(color, single_channel=False, exposure=1.0):
+    """ToneMap::render (tone_map.cpp:98-143, tone_map.frag:50-68): color [h][w][4] fp16 bits -> FS_OUT_Color [h][w][4] fp32"""
+    h, w = color.shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    lib().orc_tone_map(C.c_int(w), C.c_int(h), _p(color, c_u16p), C.c_int(int(single_channel)), C.c_float(exposure), _p(out, c_f32p))
+    return out

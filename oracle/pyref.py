@@ -208,7 +208,7 @@ COMPUTE_SHADERS = (
     "reflections/reflections_denoise_reprojection.comp", "reflections/reflections_denoise_copy_tiles.comp",
     "reflections/reflections_denoise_atrous.comp", "reflections/reflections_upsample.comp",
     "gi/gi_irradiance_probe_update.comp", "gi/gi_depth_probe_update.comp", "gi/gi_irradiance_border_update.comp",
-    "gi/gi_depth_border_update.comp", "gi/gi_sample_probe_grid.comp", "taa.comp", "deferred.frag")
+    "gi/gi_depth_border_update.comp", "gi/gi_sample_probe_grid.comp", "taa.comp", "deferred.frag", "tone_map.frag")
 PIPELINES = {
     "gi_ray_trace": [("gi/gi_ray_trace.rgen", 0), ("gi/gi_ray_trace.rchit", 1), ("gi/gi_ray_trace.rmiss", 2)],
     "reflections_ray_trace": [("reflections/reflections_ray_trace.rgen", 0), ("reflections/reflections_ray_trace.rchit", 1),

@@ -631,3 +631,13 @@ class RefReflectionsPass:
         self.stages = dict(trace=traced, temporal=oc, moments=om, tiles=tiles, atrous=its, upsample=up, output=img if up is None else up)
         self.ping_pong = not self.ping_pong
         return self.stages["output"]
+
+
+def tone_map(color, single_channel=False, exposure=1.0):
+    """tone_map.frag as a full-screen pass; s_Color is TemporalAA's output descriptor (bilinear, temporal_aa.cpp:255)"""
+    sh = shader("tone_map.frag")
+    h, w = color.shape[:2]
+    sh.bind("s_Color", pyref.Tex(color, "rgba16f", linear=True))
+    sh.set_i("u_PushConstants.single_channel", int(single_channel))
+    sh.set_f("u_PushConstants.exposure", exposure)
+    return sh.fragments(w, h, "inUV", "FS_OUT_Color")

@@ -121,3 +121,23 @@ def test_taa_golden_and_disabled(oracle, hr, ctx):
     gp.render(torch.from_numpy(make_golden.hdr_color(frames[0]["gb"])).cuda().view(torch.float16), helpers.to_cuda(frames[0]["gb"]), 0)
     torch.cuda.synchronize()
     assert np.array_equal(helpers.bits16(gp.output(0)), before)
+
+
+def test_tone_map_matches_oracle(oracle, hr, ctx):
+    """hr_tone_map (ToneMap::render): fp32 FS_OUT_Color bit for bit, UNORM8 = floor(c * 255 + 0.5)"""
+    import torch
+    from hybrid_rendering_amd import api_post
+    from oracle import pyoracle_post as opost
+    rng = np.random.RandomState(2)
+    W, H = 203, 117
+    col = rng.uniform(0.0, 6.0, (H, W, 4)).astype(np.float16)
+    col[0, :8, :3] = [0.0, 1e-7, 60000.0]
+    col = np.ascontiguousarray(col)
+    col_d = torch.from_numpy(col).cuda()
+    for single, exposure in ((False, 1.0), (False, 0.37), (True, 1.0)):
+        ref = opost.tone_map(col.view(np.uint16), single, exposure)
+        f, b = api_post.tone_map(ctx, col_d, single, exposure)
+        torch.cuda.synchronize()
+        assert np.array_equal(f.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (single, exposure)
+        q = np.floor(np.clip(ref, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        assert np.array_equal(b.cpu().numpy(), q)

@@ -412,3 +412,17 @@ def test_textured_materials_in_hit_shaders(oracle, rh, name):
     plain = gt_plain.render(osc_plain, frames[0]["ubo"], sky)
     first = opost.GroundTruthPass(W, H).render(osc, frames[0]["ubo"], sky)
     assert (plain != first).any(-1).mean() > 0.1          # the textures really change what the hit shaders return
+
+
+def test_tone_map(oracle, rh):
+    """tone_map.frag (exposure, ACES, pow 1/2.2; single-channel visualisation) on an HDR image with 0, huge and fp16-subnormal values"""
+    from oracle import pyoracle_post as opost
+    rng = np.random.RandomState(2)
+    W, H = 53, 31
+    col = rng.uniform(0.0, 6.0, (H, W, 4)).astype(np.float16)
+    col[0, :8, :3] = [0.0, 1e-7, 60000.0]
+    col = np.ascontiguousarray(col).view(np.uint16)
+    for single, exposure in ((False, 1.0), (False, 0.37), (True, 1.0)):
+        a, b = opost.tone_map(col, single, exposure), rh.tone_map(col, single, exposure)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (single, exposure)
+    assert 0.0 <= a.min() and opost.tone_map(col, False, 1.0)[..., :3].max() <= 1.0
