@@ -426,3 +426,68 @@ def test_tone_map(oracle, rh):
         a, b = opost.tone_map(col, single, exposure), rh.tone_map(col, single, exposure)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (single, exposure)
     assert 0.0 <= a.min() and opost.tone_map(col, False, 1.0)[..., :3].max() <= 1.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_ddgi_uniforms(oracle, rh, seed):
+    """the whole DDGI pass with random grids, 16..256 rays per probe (the 64-ray cache loop), hysteresis, integer and
+    non-integer depth sharpness, visibility test on/off, infinite bounces on/off"""
+    from oracle import pyoracle_ddgi as od
+    rng = np.random.RandomState(100 + seed)
+    name = str(rng.choice(["cornell", "sponza_small"]))
+    sd = helpers.scene_data(name)
+    osc = oracle.Scene(sd)
+    lo, hi = sd.bounds()
+    counts = (int(rng.randint(2, 5)), int(rng.randint(1, 4)), int(rng.randint(2, 5)))
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=counts, rays_per_probe=int(rng.choice([16, 64, 100, 256])), normal_bias=float(rng.uniform(0.05, 1.5)),
+                                   hysteresis=float(rng.uniform(0.5, 0.99)), depth_sharpness=float(rng.choice([50.0, 20.0, 7.5])),
+                                   energy_preservation=float(rng.uniform(0.5, 1.0)), visibility_test=bool(rng.randint(2)))
+    sky = synth_env.sky_cubemap(8)
+    frames = helpers.make_frames(oracle, osc, name, 40, 24, 3, 1.0)
+    kw = dict(infinite_bounces=bool(rng.randint(2)), infinite_bounce_intensity=float(rng.uniform(0.5, 2.0)), gi_intensity=float(rng.uniform(0.3, 2.0)))
+    dp, rdp = od.DDGIPass(ddgi, **kw), rh.RefDDGIPass(ddgi, sd, **kw)
+    r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+    for k, fr in enumerate(frames):
+        dp.render(osc, fr["ubo"], fr["gb"], sky, synth_env.random_orientation(r1), k)
+        rdp.render(osc, fr["ubo"], fr["gb"], sky, synth_env.random_orientation(r2), k)
+        for q in ("radiance", "direction_distance", "irradiance", "depth", "output"):
+            assert np.array_equal(dp.stages[q], rdp.stages[q]), (k, q, counts, kw)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_reflections_parameters(oracle, rh, seed):
+    """the whole reflections pass with every GUI parameter drawn at random (sample_gi, approximate_with_ddgi, blur_as_input,
+    trim, bias, alphas, phis, radius 1/2, 1..5 iterations) and a moving / static camera"""
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf
+    rng = np.random.RandomState(200 + seed)
+    sd = helpers.scene_data("sponza_small")
+    osc = oracle.Scene(sd)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 2, 3), rays_per_probe=32, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(8)
+    env = dict(sky=sky, prefiltered=synth_env.prefiltered_chain(sky, 4), pre_size=8, pre_levels=4, lut=synth_env.brdf_lut(8))
+    W, H = int(rng.randint(20, 80)), int(rng.randint(16, 60))
+    frames = helpers.make_frames(oracle, osc, "sponza_small", W, H, 3, float(rng.uniform(0, 2)), str(rng.choice(["default", "point", "spot"])))
+    r01, r003 = np.float16(0.1).view(np.uint16), np.float16(0.03).view(np.uint16)
+    for fr in frames:
+        ch = fr["gb"]["gb3"][..., 0]
+        ch[ch == r01] = r003
+    sob, sr = synth.blue_noise_tables()
+    kw = dict(sample_gi=bool(rng.randint(2)), approximate_with_ddgi=bool(rng.randint(2)), gi_intensity=float(rng.uniform(0.1, 1)),
+              rough_ddgi_intensity=float(rng.uniform(0.1, 1)), ibl_indirect_specular_intensity=float(rng.uniform(0, 0.2)), bias=float(rng.uniform(0.05, 1)),
+              trim=float(rng.uniform(0.3, 1)), alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)),
+              blur_as_input=bool(rng.randint(2)), phi_color=float(rng.uniform(1, 20)), phi_normal=float(rng.choice([32.0, 8.0, 12.5, 128.0])),
+              sigma_depth=float(rng.uniform(0.2, 3)), radius=int(rng.choice([1, 2])), filter_iterations=int(rng.choice([1, 3, 5])),
+              feedback_iteration=int(rng.choice([0, 1])))
+    dp = od.DDGIPass(ddgi)
+    orp, rrp = orf.ReflectionsPass(W, H, **kw), rh.RefReflectionsPass(W, H, sd, **kw)
+    r1 = np.random.RandomState(seed)
+    for k, fr in enumerate(frames):
+        cur, prev = fr["gb"], frames[k - 1]["gb"] if k else fr["gb"]
+        dp.render(osc, fr["ubo"], cur, sky, synth_env.random_orientation(r1), k)
+        irr, dep = dp.current_read()
+        cd = (0.0, 0.0, 0.0) if (k == 0 or seed % 2) else (-1.0, 0.5, 0.0)
+        orp.render(osc, fr["ubo"], ddgi, cur, prev, sob, sr, k, env, irr, dep, camera_delta=cd)
+        rrp.render(osc, fr["ubo"], ddgi, cur, prev, sob, sr, k, env, irr, dep, camera_delta=cd)
+        for q in ("trace", "temporal", "moments", "tiles", "output"):
+            assert np.array_equal(orp.stages[q], rrp.stages[q]), (k, q, kw)
