@@ -62,7 +62,16 @@ HR_DEV f4 mul_m4(const float* __restrict__ M, float x, float y, float z, float w
 
 // ---- fp16 ------------------------------------------------------------------------------------
 HR_DEV float    h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-HR_DEV uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// fp32 -> fp16, round to nearest even, as its own instruction.  A plain (_Float16) cast lets the AMDGPU back end fold a
+// preceding fp32 multiply into v_fma_mixlo_f16 (ONE rounding of the exact product instead of fp32 then fp16) and pair two
+// casts into v_cvt_pk_f16_f32 — found by tools/fuzz_gpu.py as 1-ulp fp16 differences in the DDGI sample pass whenever
+// gi_intensity != 1.  The contract rounds every fp32 op first, as the CPU and the reference's SPIR-V do.
+HR_DEV uint16_t f2h(float f)
+{
+    uint32_t r;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(f));
+    return (uint16_t)r;
+}
 HR_DEV float    h2f_lo(uint32_t packed) { return h2f((uint16_t)(packed & 0xffffu)); }
 HR_DEV float    h2f_hi(uint32_t packed) { return h2f((uint16_t)(packed >> 16)); }
 HR_DEV uint32_t pack_h2(float a, float b) { return (uint32_t)f2h(a) | ((uint32_t)f2h(b) << 16); }

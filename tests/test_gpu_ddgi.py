@@ -63,3 +63,10 @@ def test_ddgi_sponza_small(oracle, hr, ctx):
 
 def test_ddgi_no_visibility_point_light(oracle, hr, ctx):
     _run(oracle, hr, ctx, "sponza_small", 96, 64, (4, 3, 4), 96, 2, light_kind="point", params=dict(infinite_bounce_intensity=0.8, gi_intensity=2.0))
+
+
+def test_ddgi_intensities_not_one(oracle, hr, ctx):
+    """gi_intensity / infinite_bounce_intensity != 1: the final fp32 multiply must be rounded BEFORE the fp16 store (the
+    back end once fused it into v_fma_mixlo_f16 — one rounding of the exact product; found by tools/fuzz_gpu.py)"""
+    _run(oracle, hr, ctx, "sponza_small", 139, 108, (3, 2, 3), 24, 2, params=dict(infinite_bounces=True, infinite_bounce_intensity=1.7469917, gi_intensity=0.9183527))
+    _run(oracle, hr, ctx, "sponza_small", 171, 121, (3, 2, 3), 24, 2, params=dict(infinite_bounces=False, infinite_bounce_intensity=1.58, gi_intensity=1.4340005))
