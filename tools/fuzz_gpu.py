@@ -52,4 +52,77 @@ for trial in range(n):
                 res.append(label + " MISMATCH: " + str(e)[:100])
                 bad += 1
     print(trial, name, (W, H), kind, "scale", scale, "dolly %.2f" % dolly, "random params" if sp else "default params", res, flush=True)
+
+
+# ---- second half: the downstream passes (deferred composite, TAA, tone map, ground truth) and textured hit shading ---------
+import torch
+import helpers
+from hybrid_rendering_amd import api_deferred, api_gi, api_post, synth, synth_env
+from oracle import pyoracle_deferred as odf, pyoracle_post as opost
+
+for trial in range(n):
+    name = str(rng.choice(["cornell", "sponza_small"]))
+    W, H = int(rng.randint(9, 200)), int(rng.randint(9, 140))
+    kind = str(rng.choice(["default", "point", "spot"]) if name != "cornell" else rng.choice(["default", "soft"]))
+    sd = helpers.scene_data(name)
+    if trial % 2:
+        sd = synth.with_textures(sd, seed=trial)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, W, H, 3, float(rng.uniform(0, 2)), kind)
+    sky = synth_env.sky_cubemap(8)
+    pre, lut, sh9 = synth_env.prefiltered_chain(sky, 4), synth_env.brdf_lut(8), synth_env.sh9_from_cubemap(sky)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=8, pre_levels=4, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 8, 4, f16(lut))
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    h16 = lambda a: np.ascontiguousarray(a.astype(np.float16)).view(np.uint16)
+    res = []
+    # deferred composite on random auxiliary images
+    shadow, ao = h16(rng.uniform(0, 1, (H, W))), h16(rng.uniform(0, 1, (H, W)))
+    refl, gi = h16(rng.uniform(0, 0.7, (H, W, 4))), h16(rng.uniform(0, 2, (H, W, 4)))
+    flags = int(rng.randint(16))
+    g_df = api_deferred.DeferredShading(ctx, W, H)
+    g_df.set_sh9(sh9)
+    g_df.params.use_ray_traced_shadows, g_df.params.use_ray_traced_ao = flags & 1, (flags >> 1) & 1
+    g_df.params.use_ray_traced_reflections, g_df.params.use_ddgi = (flags >> 2) & 1, (flags >> 3) & 1
+    fi = hr.frame_inputs(helpers.to_cuda(frames[0]["gb"]), None, frames[0]["ubo"], 0, 0, sob_d, sr_d)
+    t16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    g_df.render(fi, env, shadow=t16(shadow), ao=t16(ao), reflections=t16(refl), gi=t16(gi))
+    torch.cuda.synchronize()
+    ref = odf.shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env_np)
+    res.append("deferred " + ("ok" if np.array_equal(helpers.bits16(g_df.output()), ref) else "MISMATCH"))
+    # TAA with random feedback parameters on the composite, then the tone map
+    o_t, g_t = opost.TAAPass(W, H, reset=bool(rng.randint(2)), sharpen=bool(rng.randint(2)), feedback_min=float(rng.uniform(0.5, 0.9)), feedback_max=float(rng.uniform(0.9, 0.99))), api_post.TemporalAA(ctx, W, H)
+    g_t.params.reset, g_t.params.sharpen, g_t.params.feedback_min, g_t.params.feedback_max = int(o_t.reset), int(o_t.sharpen), o_t.feedback_min, o_t.feedback_max
+    ok = True
+    for f in range(3):
+        col = np.zeros((H, W, 4), np.float16)
+        col[..., :3] = frames[f]["gb"]["gb1"][..., :3].astype(np.float32) / 255.0 * rng.uniform(0.2, 2.5, (H, W, 1))
+        col[..., 3] = 1
+        col = np.ascontiguousarray(col)
+        o_t.update(f); g_t.update(f)
+        o_t.render(col.view(np.uint16), frames[f]["gb"], f & 1)
+        g_t.render(torch.from_numpy(col).cuda(), helpers.to_cuda(frames[f]["gb"]), f & 1)
+        torch.cuda.synchronize()
+        ok &= bool(np.array_equal(helpers.bits16(g_t.output(f & 1)), o_t.output(f & 1)))
+    res.append("taa " + ("ok" if ok else "MISMATCH"))
+    exposure, single = float(rng.uniform(0.2, 3.0)), bool(rng.randint(4) == 0)
+    tm_f, _ = api_post.tone_map(ctx, g_t.output(0), single, exposure)
+    torch.cuda.synchronize()
+    res.append("tone_map " + ("ok" if np.array_equal(tm_f.cpu().numpy().view(np.uint32), opost.tone_map(o_t.output(0), single, exposure).view(np.uint32)) else "MISMATCH"))
+    # ground truth (textured on odd trials), 3 accumulated frames
+    o_g, g_g = opost.GroundTruthPass(W, H, roughness_multiplier=float(rng.uniform(0.3, 1.0))), api_post.GroundTruthPathTracer(ctx, W, H)
+    g_g.params.roughness_multiplier = o_g.roughness_multiplier
+    ok = True
+    for k in range(3):
+        ref = o_g.render(osc, frames[0]["ubo"], sky)
+        g_g.render(gsc, frames[0]["ubo"], env)
+        torch.cuda.synchronize()
+        ok &= bool(np.array_equal(helpers.bits16(g_g.output()), ref))
+    res.append("ground_truth " + ("ok" if ok else "MISMATCH"))
+    bad += sum("MISMATCH" in r for r in res)
+    print("post", trial, name, (W, H), kind, "textured" if trial % 2 else "plain", "flags", flags, res, flush=True)
+    for p in (g_df, g_t, g_g, gsc):
+        p.close()
 print("mismatches:", bad)
