@@ -1,0 +1,66 @@
+"""GPU developer tool: random frame sizes (ragged widths / heights), band counts and cost-like random band boundaries —
+every band of TiledShadows / TiledAO (hosted on this one GPU, the neighbour exchange emulated with device copies along
+tiling.exchange_plan) must equal the un-tiled pass on its rows, over several frames with a moving camera.
+    python tools/fuzz_tiling.py [seed] [n_configs]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers
+from hybrid_rendering_amd import api as hr, synth, tiling
+from oracle import pyoracle as oracle
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ctx = hr.Context(0)
+name = "sponza_small"
+sd = helpers.scene_data(name)
+osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+sob, sr = synth.blue_noise_tables()
+sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+bad = 0
+for trial in range(n):
+    world = int(rng.randint(2, 5))
+    W, H = int(rng.randint(60, 260)), int(rng.randint(40 * world, 110 * world))
+    bounds = None
+    if rng.randint(2):
+        cuts = np.sort(rng.choice(np.arange(4, (H + 7) // 8 - 4), world - 1, replace=False)) * 8
+        if np.all(np.diff(np.concatenate([[0], cuts, [H]])) >= 32):
+            bounds = [0] + [int(c) for c in cuts] + [H]
+    frames = helpers.make_frames(oracle, osc, name, W, H, 4, float(rng.uniform(0.5, 2.5)), str(rng.choice(["default", "point"])))
+    res = []
+    for label in ("shadows", "ao"):
+        if label == "shadows":
+            whole = hr.RayTracedShadows(ctx, W, H)
+            bands = [tiling.TiledShadows(ctx, W, H, r, world, bounds=bounds) for r in range(world)]
+            out_id = hr.OUTPUT_ATROUS
+        else:
+            whole = hr.RayTracedAO(ctx, W, H, 0)
+            bands = [tiling.TiledAO(ctx, W, H, r, world, scale=0, bounds=bounds) for r in range(world)]
+            out_id = hr.OUTPUT_UPSAMPLE
+        for b in bands:
+            b.world = 1
+        ok, ping = True, False
+        for f in range(4):
+            fi = hr.frame_inputs(helpers.to_cuda(frames[f]["gb"]), helpers.to_cuda(frames[f - 1]["gb"] if f else frames[f]["gb"]), frames[f]["ubo"], f, ping,
+                                 sob_d, sr_d, z_buffer_params=synth.z_buffer_params())
+            whole.render(gsc, fi)
+            for b in bands:
+                b.render(gsc, fi)
+            for r, b in enumerate(bands):
+                for peer, (s0, s1), (r0, r1) in tiling.exchange_plan(H, world, r, b.history_rows, bounds):
+                    for mine, theirs in zip(b.history_images(int(ping)), bands[peer].history_images(int(ping))):
+                        mine[r0:r1].copy_(theirs[r0:r1])
+            torch.cuda.synchronize()
+            ref = helpers.bits16(whole.output(out_id))
+            for b in bands:
+                ok &= bool(np.array_equal(helpers.bits16(b.pass_.output(out_id))[b.b0:b.b1], ref[b.b0:b.b1]))
+            ping = not ping
+        res.append(label + (" ok" if ok else " MISMATCH"))
+        bad += (not ok)
+        whole.close()
+        for b in bands:
+            b.pass_.close()
+    print(trial, (W, H), "world", world, "bounds", bounds, res, flush=True)
+print("mismatches:", bad)
