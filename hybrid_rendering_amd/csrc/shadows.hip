@@ -284,13 +284,16 @@ struct TemporalArgs
     int             debug_skip_reproject; // developer ablation switch (HR_DEBUG_SKIP_REPROJECT)
 };
 
-__global__ __launch_bounds__(256) void k_shadows_temporal(TemporalArgs a)
+#ifndef TEMPORAL_WAVES
+#define TEMPORAL_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * TEMPORAL_WAVES) void k_shadows_temporal(TemporalArgs a)
 {
-    __shared__ uint32_t s_mask[4][18];
-    __shared__ uint32_t s_rows[4][24];
+    __shared__ uint32_t s_mask[TEMPORAL_WAVES][18];
+    __shared__ uint32_t s_rows[TEMPORAL_WAVES][24];
     __shared__ float    s_vpi[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * TEMPORAL_WAVES + wave;
     const bool tile_ok = tile < a.tiles_x * a.tiles_y;
     const int tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
     if (threadIdx.x < 16) s_vpi[threadIdx.x] = a.vpi[threadIdx.x];
@@ -776,7 +779,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
-    hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, TEMPORAL_WAVES)), dim3(64 * TEMPORAL_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
