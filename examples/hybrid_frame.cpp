@@ -98,7 +98,7 @@ double mean_of(const hr::ImageView& v, int nch, int c)
 
 } // namespace
 
-int main()
+int main(int argc, char** argv)
 {
     const int W = 320, H = 192;
     // ---- scene: Cornell-style room with two boxes; materials: white, red, green, polished grey ----------------------
@@ -238,9 +238,26 @@ int main()
             std::printf("frame %u: shadow %.4f  ao %.4f  gi %.4f  reflections %.4f  composite %.4f  taa %.4f  ground truth %.4f\n", f, m_shadow, m_ao,
                         m_gi, m_refl, m_final, m_taa, m_gt);
         }
+        // ToneMap::render (main.cpp:99): the anti-aliased HDR frame -> the displayable 8-bit image, written as a PPM
+        hr::ToneMap tone_map(ctx);
+        uint8_t*    ldr = nullptr;
+        HIP_OK(hipMalloc(&ldr, (size_t)W * H * 4));
+        tone_map.render(nullptr, taa.output_ds(), ldr);
+        std::vector<uint8_t> host((size_t)W * H * 4);
+        HIP_OK(hipMemcpy(host.data(), ldr, host.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipFree(ldr));
+        double m_ldr = 0.0;
+        if (FILE* fp = std::fopen(argc > 1 ? argv[1] : "/tmp/hybrid_frame.ppm", "wb"))
+        {
+            std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
+            for (size_t i = 0; i < (size_t)W * H; i++) { std::fwrite(&host[i * 4], 1, 3, fp); m_ldr += host[i * 4] + host[i * 4 + 1] + host[i * 4 + 2]; }
+            std::fclose(fp);
+        }
+        m_ldr /= 3.0 * 255.0 * W * H;
+        std::printf("tone-mapped frame: mean %.4f\n", m_ldr);
         std::printf("hybrid_frame: %d triangles, %dx%d, all passes ran\n", n_tris, W, H);
         const bool ok = m_shadow > 0.05 && m_shadow < 1.0 && m_ao > 0.2 && m_ao <= 1.0 && m_gi > 0.0 && m_final > 0.0 && m_taa > 0.0 && m_gt > 0.0 &&
-                        std::isfinite(m_refl) && std::isfinite(m_final);
+                        std::isfinite(m_refl) && std::isfinite(m_final) && m_ldr > 0.02 && m_ldr < 0.98;
         return ok ? 0 : 1;
     }
     catch (const hr::Error& e)

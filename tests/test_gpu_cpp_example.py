@@ -34,4 +34,4 @@ def test_cpp_hybrid_frame_example_runs(hr):
     """every pass of the reference's frame loop (main.cpp:80-99) + composite + TAA + ground truth, driven from C++ only"""
     out = _run_example("hybrid_frame")
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "all passes ran" in out.stdout and out.stdout.count("frame ") == 3
+    assert "all passes ran" in out.stdout and out.stdout.count("frame ") == 3 and "tone-mapped frame" in out.stdout
