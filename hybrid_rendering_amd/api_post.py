@@ -12,7 +12,7 @@ from .api_deferred import _view
 
 
 class hr_ground_truth_params(C.Structure):
-    _fields_ = [("max_ray_bounces", C.c_int32), ("roughness_multiplier", C.c_float)]
+    _fields_ = [("max_ray_bounces", C.c_int32), ("roughness_multiplier", C.c_float), ("trace_indirect", C.c_int32)]
 
 
 class hr_taa_params(C.Structure):

@@ -3,7 +3,8 @@
 // One wave = one 8x8 pixel tile, one lane = one pixel: jittered primary ray (closest hit), direct lighting at the hit
 // (punctual light with soft shadows + one cosine-lobe sky sample, each with a visibility ray), running mean into the
 // ping-pong RGBA16F images.  indirect_lighting (rchit:67-108) contributes nothing upstream — its recursive traceRayEXT
-// is commented out (rchit:95-105) and p_IndirectPayload.L stays 0 — so max_ray_bounces is carried but unused.
+// is commented out (rchit:95-105) and p_IndirectPayload.L stays 0.  hr_ground_truth_params.trace_indirect = 1 re-enables
+// that call (SURVEY §8f row 3's optional extension): up to max_ray_bounces path segments with Russian roulette.
 #include "hr_internal.h"
 #include "shading.h"
 
@@ -23,8 +24,30 @@ struct GTArgs
     int          w, h, y0, y1, tiles_x, tile_y0;
     uint32_t     num_frames;
     float        roughness_multiplier;
+    uint32_t     max_ray_bounces;
+    int          trace_indirect;
 };
 
+#define GT_MAX_DEPTH 32
+// GLSL max(x, y) = (x < y) ? y : x: keeps a NaN first argument (the indirect path can produce 0/0), unlike max2
+HR_DEV float glsl_max(float x, float y) { return (x < y) ? y : x; }
+// brdf.glsl:96-112
+HR_DEV f3 sample_specular_ggx_lobe(f3 n, float alpha, float xi_x, float xi_y)
+{
+    const float phi = 2.0f * HR_M_PI * xi_x;
+    const float ct  = hr_sqrt(__fdiv_rn(1.0f - xi_y, 1.0f + (alpha * alpha - 1.0f) * xi_y));
+    const float st  = hr_sqrt(1.0f - ct * ct);
+    float s, c;
+    det_sincos(phi, s, c);
+    const f3 t   = mk3(st * c, st * s, ct);
+    const f3 ref = fabsf(dot3(n, mk3(0.0f, 1.0f, 0.0f))) > 0.99f ? mk3(0.0f, 0.0f, 1.0f) : mk3(0.0f, 1.0f, 0.0f);
+    const f3 x   = normalize3(cross3(ref, n));
+    const f3 y   = cross3(n, x);
+    return normalize3(mk3((x.x * t.x + y.x * t.y) + n.x * t.z, (x.y * t.x + y.y * t.y) + n.y * t.z, (x.z * t.x + y.z * t.y) + n.z * t.z));
+}
+
+// INDIRECT = false is the reference as shipped (one invocation per pixel: no payload chain to keep)
+template <bool INDIRECT>
 __global__ __launch_bounds__(64) void k_ground_truth(GTArgs a)
 {
     __shared__ uint32_t s_stack[HR_STACK_ENTRIES * 64];
@@ -42,13 +65,27 @@ __global__ __launch_bounds__(64) void k_ground_truth(GTArgs a)
         const f4 target = mul_m4(a.proj_inverse, tcx, tcy, 1.0f, 1.0f);
         const f3 tn     = normalize3(mk3(target.x, target.y, target.z));
         const f4 dir4   = mul_m4(a.view_inverse, tn.x, tn.y, tn.z, 0.0f);
-        const f3 o = mk3(origin.x, origin.y, origin.z), d = mk3(dir4.x, dir4.y, dir4.z);
-        f3 L;
-        rays++;
-        const HitRec h = trace_closest(a.nodes, a.tris, o, d, 0.001f, 10000.0f, s_stack, lane);
-        if (h.prim < 0) L = a.sky.fetch(d);
-        else
+        // The payload chain of the recursive shader, unrolled.  Every nested invocation starts with L = 0 and its L is ADDED to
+        // its caller's (p_Payload.L += indirect_lighting()), innermost first: adds[k] is what invocation k adds.  With
+        // trace_indirect = 0 (the reference as shipped: the recursive traceRayEXT of rchit:95-105 is commented out) the loop
+        // runs once.  trace_indirect = 1 re-enables that call (SURVEY 8f row 3's optional extension), rchit:67-108 verbatim.
+        f3       o = mk3(origin.x, origin.y, origin.z), d = mk3(dir4.x, dir4.y, dir4.z);
+        f3       T = one3();
+        float    t_min = 0.001f;
+        f3       adds[INDIRECT ? GT_MAX_DEPTH : 1];
+        int      depth = 0;
+        uint32_t nn = 0, nt = 0;
+        for (;; depth++)
         {
+            adds[depth] = mk3(0.0f, 0.0f, 0.0f);
+            rays++;
+            const HitRec h = trace_closest(a.nodes, a.tris, o, d, t_min, 10000.0f, s_stack, lane);
+            if (h.prim < 0)
+            {
+                const f3 env = a.sky.fetch(d);
+                adds[depth]  = depth == 0 ? env : mul3(T, env);   // rmiss:26-34
+                break;
+            }
             SurfaceHit s = surface_at(a.sh, h);
             s.N = normalize3(s.N);   // rchit:131 normalises fetch_normal()'s result once more (observable with normal maps)
             const float roughness = s.roughness * a.roughness_multiplier;
@@ -56,10 +93,8 @@ __global__ __launch_bounds__(64) void k_ground_truth(GTArgs a)
             const f3 F0 = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
             const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
             const float r1x = next_float(rng), r1y = next_float(rng), r2x = next_float(rng), r2y = next_float(rng);
-            const f3 T = one3();
             f3       Lo = mk3(0.0f, 0.0f, 0.0f);
             const f3 ray_origin = add3(s.P, scale3(s.N, 0.1f));
-            uint32_t nn = 0, nt = 0;
             {
                 f3    Wi;
                 float t_max, attenuation;
@@ -83,8 +118,40 @@ __global__ __launch_bounds__(64) void k_ground_truth(GTArgs a)
                 const f3 brdf = evaluate_uber_brdf(c_diffuse, roughness, s.N, F0, Wo, Wh, Wi);
                 Lo = add3(Lo, mul3(mul3(T, brdf), Li));
             }
-            L = Lo;
+            adds[depth] = Lo;
+            if (!INDIRECT || !((uint32_t)(depth + 1) < a.max_ray_bounces) || depth + 1 >= GT_MAX_DEPTH - 1) break;
+            // indirect_lighting (rchit:67-108); sample_uber_brdf takes the RNG BY VALUE (brdf.glsl:146): the lobe sample re-uses
+            // the numbers the Russian roulette and the next bounce draw
+            Rng copy = rng;
+            const float rvx = next_float(copy), rvy = next_float(copy), rvz = next_float(copy);
+            const float alpha = roughness * roughness;
+            f3 Wi, Wh;
+            if (rvx < 0.5f)
+            {
+                Wh = sample_specular_ggx_lobe(s.N, alpha, rvy, rvz);
+                const f3 I = neg3(Wo);
+                Wi = roughness < 0.05f ? sub3(I, scale3(s.N, 2.0f * dot3(s.N, I))) : sub3(I, scale3(Wh, 2.0f * dot3(Wh, I)));
+            }
+            else
+            {
+                Wi = sample_cosine_lobe_n(s.N, rvy, rvz);
+                Wh = normalize3(add3(Wo, Wi));
+            }
+            const float NdotL = glsl_max(dot3(s.N, Wi), 0.0f), NdotH = glsl_max(dot3(s.N, Wh), 0.0f), VdotH = glsl_max(dot3(Wi, Wh), 0.0f);
+            const float pd  = __fdiv_rn(NdotL, HR_M_PI);
+            const float ps  = __fdiv_rn(D_ggx(NdotH, alpha) * NdotH, glsl_max(HR_EPSILON, 4.0f * VdotH));
+            const float pdf = mix1(pd, ps, 0.5f);
+            const f3    brdf = evaluate_uber_brdf(c_diffuse, roughness, s.N, F0, Wo, Wh, Wi);
+            const float cos_theta = clamp1(dot3(s.N, Wi), 0.0f, 1.0f);
+            const f3    tb = mul3(T, scale3(brdf, cos_theta));
+            f3 Tn = mk3(__fdiv_rn(tb.x, pdf), __fdiv_rn(tb.y, pdf), __fdiv_rn(tb.z, pdf));
+            const float probability = glsl_max(Tn.x, glsl_max(Tn.y, Tn.z));
+            if (next_float(rng) > probability) break;
+            Tn = scale3(Tn, __fdiv_rn(1.0f, probability));
+            T = Tn; o = s.P; d = Wi; t_min = 0.0001f;
         }
+        f3 L = adds[depth];
+        for (int k = depth - 1; k >= 0; k--) L = add3(adds[k], L);
         const f3 clamped = mk3(L.x < 1.0f ? L.x : 1.0f, L.y < 1.0f ? L.y : 1.0f, L.z < 1.0f ? L.z : 1.0f); // RADIANCE_CLAMP_COLOR
         f3 out = clamped;
         const size_t i = (size_t)y * a.w + x;
@@ -118,6 +185,7 @@ void hr_ground_truth_default_params(hr_ground_truth_params* p)
 {
     p->max_ray_bounces = 2;         // ground_truth_path_tracer.h:30
     p->roughness_multiplier = 1.0f; // CommonResources::roughness_multiplier
+    p->trace_indirect = 0;          // the reference ships the recursive trace commented out (rchit:95-105)
 }
 
 hr_status hr_ground_truth_create(hr_ctx* ctx, int32_t width, int32_t height, const hr_band* band, hr_ground_truth** out)
@@ -178,10 +246,12 @@ hr_status hr_ground_truth_render(hr_ground_truth* p, const hr_scene* scene, cons
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.tiles_x = p->tiles_x; a.tile_y0 = p->y0 / 8;
     a.num_frames = p->frame_idx++;
     a.roughness_multiplier = prm->roughness_multiplier;
+    a.max_ray_bounces = (uint32_t)prm->max_ray_bounces; a.trace_indirect = prm->trace_indirect ? 1 : 0;
     const int tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     int ev = p->prof.begin("path_trace", st, px * 16);
-    hipLaunchKernelGGL(k_ground_truth, dim3(p->tiles_x * tiles_y), dim3(64), 0, st, a);
+    if (a.trace_indirect) hipLaunchKernelGGL(k_ground_truth<true>, dim3(p->tiles_x * tiles_y), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_ground_truth<false>, dim3(p->tiles_x * tiles_y), dim3(64), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     p->ping_pong = !p->ping_pong;

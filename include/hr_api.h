@@ -447,8 +447,10 @@ hr_status hr_deferred_destroy(hr_deferred* p);
 typedef struct hr_ground_truth hr_ground_truth;
 typedef struct
 {
-    int32_t max_ray_bounces;      /* PathTrace::max_ray_bounces = 2 (ground_truth_path_tracer.h:30); carried, unused: the bounce is commented out upstream (rchit:95-105) */
+    int32_t max_ray_bounces;      /* PathTrace::max_ray_bounces = 2 (ground_truth_path_tracer.h:30); only read when trace_indirect != 0 (< 32) */
     float   roughness_multiplier; /* CommonResources::roughness_multiplier */
+    int32_t trace_indirect;       /* 0 (default) = the reference as shipped: the recursive traceRayEXT of rchit:95-105 is commented out.
+                                     1 = that call re-enabled (rchit:67-108 verbatim): a multi-bounce on-device reference */
 } hr_ground_truth_params;
 
 void      hr_ground_truth_default_params(hr_ground_truth_params* p);

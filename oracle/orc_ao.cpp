@@ -17,7 +17,7 @@ using namespace orc;
 namespace orc {
 
 // brdf.glsl:8-16
-static inline void make_rotation_matrix(vec3 z, vec3* x, vec3* y)
+void make_rotation_matrix(vec3 z, vec3* x, vec3* y)
 {
     const vec3 ref = std::fabs(dot(z, v3(0, 1, 0))) > 0.99f ? v3(0, 0, 1) : v3(0, 1, 0);
     *x = normalize(cross(ref, z));

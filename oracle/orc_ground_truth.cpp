@@ -19,9 +19,32 @@ void fetch_light_properties_shadow(const Light& light, vec3 P, vec3 N, float rx,
 
 extern "C" {
 
+// GLSL max(x, y) = (x < y) ? y : x  — keeps a NaN first argument, unlike fmax2 (the indirect path can produce 0/0)
+static inline float glsl_max(float x, float y) { return (x < y) ? y : x; }
+
+// brdf.glsl:96-112 sample_specular_ggx_lobe
+static inline vec3 sample_specular_ggx_lobe(vec3 n, float alpha, float xi_x, float xi_y)
+{
+    const float phi       = 2.0f * ORC_M_PI * xi_x;
+    const float cos_theta = std::sqrt((1.0f - xi_y) / (1.0f + (alpha * alpha - 1.0f) * xi_y));
+    const float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+    float s, c;
+    det_sincos(phi, &s, &c);
+    const vec3 d = v3(sin_theta * c, sin_theta * s, cos_theta);
+    vec3 x, y;
+    make_rotation_matrix(n, &x, &y);
+    return normalize(v3((x.x * d.x + y.x * d.y) + n.x * d.z, (x.y * d.x + y.y * d.y) + n.y * d.z, (x.z * d.x + y.z * d.y) + n.z * d.z));
+}
+
 // prev / cur: [h][w][4] fp16 bit patterns.  rows [y0, y1) are rendered.
-void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_t* sky, int sky_size, int w, int h, int y0, int y1, uint32_t num_frames,
-                             float roughness_multiplier, const uint16_t* prev, uint16_t* cur, uint64_t* rays_out)
+// trace_indirect = 0 is the reference as shipped (the recursive traceRayEXT of rchit:95-105 is commented out, so
+// indirect_lighting only draws random numbers and returns 0).  trace_indirect = 1 is SURVEY.md section 8f row 3's optional
+// extension: that call re-enabled — rchit:67-108 verbatim, including its quirks (sample_uber_brdf takes the RNG BY VALUE, so
+// the lobe sample re-uses the numbers the Russian roulette and the next bounce draw; throughput (T * brdf * cos) / pdf).
+// Checked against the reference's shaders with those lines un-commented (tests/test_ref_shaders.py).
+void orc_ground_truth_render_ex(const void* scene_, const void* ubo_, const uint16_t* sky, int sky_size, int w, int h, int y0, int y1, uint32_t num_frames,
+                                float roughness_multiplier, int max_ray_bounces, int trace_indirect, const uint16_t* prev, uint16_t* cur,
+                                uint64_t* rays_out)
 {
     const Scene& scene = *(const Scene*)scene_;
     const UBO&   ubo   = *(const UBO*)ubo_;
@@ -39,13 +62,24 @@ void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_
             const vec4  target = mul(ubo.proj_inverse, vec4 { tx, ty, 1.0f, 1.0f });
             const vec3  tn     = normalize(v3(target.x, target.y, target.z));
             const vec4  dir4   = mul(ubo.view_inverse, vec4 { tn.x, tn.y, tn.z, 0.0f });
-            const vec3  o = v3(origin.x, origin.y, origin.z), d = v3(dir4.x, dir4.y, dir4.z);
-            vec3 L;
-            rays++;
-            const Hit hit = scene.closest_hit(o, d, 0.001f, 10000.0f);
-            if (hit.prim < 0) L = cube.fetch(d);
-            else
+            vec3  o = v3(origin.x, origin.y, origin.z), d = v3(dir4.x, dir4.y, dir4.z);
+            // the payload chain of the recursive shader, unrolled: every nested invocation starts with L = 0 and its L is
+            // ADDED to its caller's, so the pixel's L is the sum of what each invocation adds, innermost first
+            vec3  T = v3(1.0f, 1.0f, 1.0f);
+            float t_min = 0.001f;
+            vec3  adds[32];
+            int   depth = 0;
+            for (;; depth++)
             {
+                adds[depth] = v3(0, 0, 0);
+                rays++;
+                const Hit hit = scene.closest_hit(o, d, t_min, 10000.0f);
+                if (hit.prim < 0)
+                {
+                    const vec3 env = cube.fetch(d);
+                    adds[depth] = depth == 0 ? env : T * env;   // rmiss:26-34
+                    break;
+                }
                 SurfaceHit sh = surface_at(scene, hit);
                 sh.N = normalize(sh.N);   // rchit:131 normalises fetch_normal()'s result once more (observable with normal maps)
                 const float roughness = sh.roughness * roughness_multiplier;
@@ -53,7 +87,6 @@ void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_
                 const vec3  F0 = mix3(v3(0.04f, 0.04f, 0.04f), sh.albedo, sh.metallic);
                 const vec3  c_diffuse = mix3(sh.albedo * (v3(1.0f, 1.0f, 1.0f) - F0), v3(0, 0, 0), sh.metallic);
                 const float r1x = next_float(rng), r1y = next_float(rng), r2x = next_float(rng), r2y = next_float(rng);
-                const vec3  T = v3(1.0f, 1.0f, 1.0f);
                 vec3        Lo = v3(0, 0, 0);
                 const vec3  ray_origin = sh.P + sh.N * 0.1f;
                 {
@@ -79,8 +112,39 @@ void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_
                     const vec3 brdf = evaluate_uber_brdf(c_diffuse, roughness, sh.N, F0, Wo, Wh, Wi);
                     Lo = Lo + (T * brdf) * Li;
                 }
-                L = Lo;
+                adds[depth] = Lo;   // p_Payload.L += direct_lighting(...) on a payload whose L is still 0
+                if (!trace_indirect || !((uint32_t)(depth + 1) < (uint32_t)max_ray_bounces) || depth + 1 >= 31) break;
+                // indirect_lighting (rchit:67-108)
+                RNG   copy = rng;                                       // `in RNG rng`: by value
+                const float rvx = next_float(copy), rvy = next_float(copy), rvz = next_float(copy);
+                const float alpha = roughness * roughness;
+                vec3 Wi, Wh;
+                if (rvx < 0.5f)
+                {
+                    Wh = sample_specular_ggx_lobe(sh.N, alpha, rvy, rvz);
+                    const vec3 I = -Wo;
+                    Wi = roughness < 0.05f ? I - sh.N * (2.0f * dot(sh.N, I)) : I - Wh * (2.0f * dot(Wh, I));
+                }
+                else
+                {
+                    Wi = sample_cosine_lobe(sh.N, rvy, rvz);
+                    Wh = normalize(Wo + Wi);
+                }
+                const float NdotL = glsl_max(dot(sh.N, Wi), 0.0f), NdotH = glsl_max(dot(sh.N, Wh), 0.0f), VdotH = glsl_max(dot(Wi, Wh), 0.0f);
+                const float pd  = NdotL / ORC_M_PI;
+                const float ps  = (D_ggx(NdotH, alpha) * NdotH) / glsl_max(ORC_EPSILON, 4.0f * VdotH);
+                const float pdf = mixf(pd, ps, 0.5f);
+                const vec3  brdf = evaluate_uber_brdf(c_diffuse, roughness, sh.N, F0, Wo, Wh, Wi);
+                const float cos_theta = clampf(dot(sh.N, Wi), 0.0f, 1.0f);
+                vec3 Tn = (T * (brdf * cos_theta)) / pdf;
+                const float probability = glsl_max(Tn.x, glsl_max(Tn.y, Tn.z));
+                if (next_float(rng) > probability) break;
+                Tn = Tn * (1.0f / probability);
+                T = Tn; o = sh.P; d = Wi; t_min = 0.0001f;
             }
+            // unwind: L_k = adds[k] + L_{k+1}
+            vec3 L = adds[depth];
+            for (int k = depth - 1; k >= 0; k--) L = adds[k] + L;
             const vec3 clamped = v3(fmin2(L.x, 1.0f), fmin2(L.y, 1.0f), fmin2(L.z, 1.0f)); // RADIANCE_CLAMP_COLOR (common.glsl:19)
             vec3 out = clamped;
             const size_t o4 = ((size_t)y * w + x) * 4;
@@ -93,6 +157,12 @@ void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_
             cur[o4 + 0] = f32_to_f16(out.x); cur[o4 + 1] = f32_to_f16(out.y); cur[o4 + 2] = f32_to_f16(out.z); cur[o4 + 3] = f32_to_f16(1.0f);
         }
     if (rays_out) *rays_out = rays;
+}
+
+void orc_ground_truth_render(const void* scene_, const void* ubo_, const uint16_t* sky, int sky_size, int w, int h, int y0, int y1, uint32_t num_frames,
+                             float roughness_multiplier, const uint16_t* prev, uint16_t* cur, uint64_t* rays_out)
+{
+    orc_ground_truth_render_ex(scene_, ubo_, sky, sky_size, w, h, y0, y1, num_frames, roughness_multiplier, 2, 0, prev, cur, rays_out);
 }
 
 } // extern "C"

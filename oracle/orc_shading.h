@@ -111,6 +111,7 @@ static inline vec3 fresnel_schlick_roughness(float cos_theta, vec3 F0, float rou
     return F0 + (m - F0) * p;
 }
 vec3 sample_cosine_lobe(vec3 n, float rx, float ry); // orc_ao.cpp (brdf.glsl:20-32)
+void make_rotation_matrix(vec3 z, vec3* x, vec3* y);   // orc_ao.cpp (brdf.glsl:8-16)
 
 // ------------------------------------------------------------------------------------------- DDGI
 struct DDGIUniforms // ddgi.cpp:14-32 == gi_common.glsl:10-28, scalar layout, 88 bytes

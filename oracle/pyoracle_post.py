@@ -11,9 +11,11 @@ from .pyoracle import _p, _ubo_ptr, c_f32p, c_u16p, lib
 class GroundTruthPass:
     """Host sequencing of GroundTruthPathTracer::render (ground_truth_path_tracer.cpp:44-111) on the oracle."""
 
-    def __init__(self, w, h, roughness_multiplier=1.0, band=None):
+    def __init__(self, w, h, roughness_multiplier=1.0, band=None, max_ray_bounces=2, trace_indirect=False):
         self.w, self.h = w, h
         self.roughness_multiplier = roughness_multiplier
+        # trace_indirect: the recursive traceRayEXT the reference ships commented out (rchit:95-105), re-enabled (extension)
+        self.max_ray_bounces, self.trace_indirect = max_ray_bounces, trace_indirect
         self.y0, self.y1 = band if band else (0, h)
         self.images = [np.zeros((h, w, 4), np.uint16) for _ in range(2)]
         self.frame_idx, self.ping_pong = 0, False
@@ -27,9 +29,10 @@ class GroundTruthPass:
             self.ping_pong = False
         rd, wr = int(self.ping_pong), int(not self.ping_pong)
         rays = C.c_uint64(0)
-        lib().orc_ground_truth_render(scene.h, _ubo_ptr(ubo), _p(sky, c_u16p), C.c_int(sky.shape[1]), C.c_int(self.w), C.c_int(self.h),
-                                      C.c_int(self.y0), C.c_int(self.y1), C.c_uint32(self.frame_idx), C.c_float(self.roughness_multiplier),
-                                      _p(self.images[rd], c_u16p), _p(self.images[wr], c_u16p), C.byref(rays))
+        lib().orc_ground_truth_render_ex(scene.h, _ubo_ptr(ubo), _p(sky, c_u16p), C.c_int(sky.shape[1]), C.c_int(self.w), C.c_int(self.h),
+                                         C.c_int(self.y0), C.c_int(self.y1), C.c_uint32(self.frame_idx), C.c_float(self.roughness_multiplier),
+                                         C.c_int(self.max_ray_bounces), C.c_int(int(self.trace_indirect)),
+                                         _p(self.images[rd], c_u16p), _p(self.images[wr], c_u16p), C.byref(rays))
         self.frame_idx += 1
         self.rays = rays.value
         self.ping_pong = not self.ping_pong

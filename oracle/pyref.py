@@ -91,7 +91,7 @@ def _compile(src, so):
     subprocess.check_call([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-w", "-I" + _SHIM, "-o", so, src])
 
 
-def build_pipeline(name: str, stages, force=False) -> str:
+def build_pipeline(name: str, stages, force=False, variant=None) -> str:
     """a ray-tracing pipeline: stages = [(rel, kind)], kind 0 = ray generation, 1 = closest hit, 2 = miss"""
     so = os.path.join(_REF_DIR, name + ".so")
     if not os.path.isdir(REFERENCE_SHADERS):
@@ -104,7 +104,7 @@ def build_pipeline(name: str, stages, force=False) -> str:
         sys.path.insert(0, _SHIM)
         import translate  # noqa: E402
         sys.path.pop(0)
-        _compile(translate.translate_pipeline(name, list(stages)), so)
+        _compile(translate.translate_pipeline(name, list(stages), variant=variant), so)
     return so
 
 
@@ -177,8 +177,8 @@ class RefPipeline(RefShader):
     """A ray-tracing pipeline (ray generation + closest hit + miss stages in one library).  Registry names carry the
     stage index ('0:ubo.view_proj', '1:s_Cubemap'); the *_all helpers address a name in every stage that declares it."""
 
-    def __init__(self, name, stages):
-        super().__init__(None, so=build_pipeline(name, stages))
+    def __init__(self, name, stages, variant=None):
+        super().__init__(None, so=build_pipeline(name, stages, variant=variant))
         self.n_stages = len(stages)
 
     def stages_with(self, name):
@@ -220,7 +220,8 @@ PIPELINES = {
 
 def build_all(force=False):
     """translate + compile every reference shader into oracle/_ref/ (needs /root/reference); returns the .so paths"""
-    return [build(rel, force=force) for rel in COMPUTE_SHADERS] + [build_pipeline(n, st, force=force) for n, st in PIPELINES.items()]
+    return ([build(rel, force=force) for rel in COMPUTE_SHADERS] + [build_pipeline(n, st, force=force) for n, st in PIPELINES.items()]
+            + [build_pipeline("ground_truth_path_trace_bounces", PIPELINES["ground_truth_path_trace"], force=force, variant="bounces")])
 
 
 if __name__ == "__main__":

@@ -384,9 +384,9 @@ def taa_resolve(color, prev, gb, jitter, feedback_min=0.88, feedback_max=0.97, s
 _pipes = {}
 
 
-def pipeline(name, stages):
+def pipeline(name, stages, variant=None):
     if name not in _pipes:
-        _pipes[name] = pyref.RefPipeline(name, stages)
+        _pipes[name] = pyref.RefPipeline(name, stages, variant=variant)
     return _pipes[name]
 
 
@@ -520,10 +520,11 @@ def reflections_ray_trace(oscene, rscene, ubo, ddgi, cur, sobol, sr, prm, env, i
     return out
 
 
-def ground_truth(oscene, rscene, ubo, sky, w, h, num_frames, prev, roughness_multiplier=1.0, max_ray_bounces=2):
-    """ground_truth_path_trace.rgen / .rchit / .rmiss (ground_truth_path_tracer.cpp:44-111); prev / result [h][w][4] fp16"""
-    pipe = pipeline("ground_truth_path_trace", [("ground_truth/ground_truth_path_trace.rgen", 0), ("ground_truth/ground_truth_path_trace.rchit", 1),
-                                                ("ground_truth/ground_truth_path_trace.rmiss", 2)])
+def ground_truth(oscene, rscene, ubo, sky, w, h, num_frames, prev, roughness_multiplier=1.0, max_ray_bounces=2, trace_indirect=False):
+    """ground_truth_path_trace.rgen / .rchit / .rmiss (ground_truth_path_tracer.cpp:44-111); prev / result [h][w][4] fp16.
+    trace_indirect: the variant with the recursive traceRayEXT of rchit:95-105 un-commented (translate.VARIANTS["bounces"])"""
+    stages = [("ground_truth/ground_truth_path_trace.rgen", 0), ("ground_truth/ground_truth_path_trace.rchit", 1), ("ground_truth/ground_truth_path_trace.rmiss", 2)]
+    pipe = pipeline("ground_truth_path_trace_bounces", stages, variant="bounces") if trace_indirect else pipeline("ground_truth_path_trace", stages)
     out = np.zeros((h, w, 4), np.uint16)
     rscene.bind(pipe, oscene)
     for f in UBO_FIELDS:

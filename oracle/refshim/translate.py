@@ -25,19 +25,31 @@ TOKEN_PATCHES = {
 }
 
 
+# source-level variants, applied BEFORE comments are stripped: { variant: [(file suffix, regex, replacement)] }
+VARIANTS = {
+    # SURVEY.md section 8f row 3's optional extension: the recursive traceRayEXT the reference ships commented out in
+    # ground_truth_path_trace.rchit:95-105, un-commented (the lines are the reference's own)
+    "bounces": [("ground_truth_path_trace.rchit", r"(?m)^(\s*)//(traceRayEXT\(.*|\s{12}\S.*)$", r"\1\2")],
+}
+
+
 def strip_comments(t):
     t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
     return re.sub(r"//[^\n]*", "", t)
 
 
-def expand(path, seen=None):
+def expand(path, seen=None, variant=None):
     """the file with its #include directives expanded; include guards become include-once bookkeeping here, so that
     several stages of a pipeline can be translated into one C++ file"""
     seen = set() if seen is None else seen
     if path in seen:
         return ""
     seen.add(path)
-    text = strip_comments(open(path).read())
+    text = open(path).read()
+    for suffix, pat, rep in VARIANTS.get(variant, []):
+        if path.endswith(suffix):
+            text = re.sub(pat, rep, text)
+    text = strip_comments(text)
     g = re.match(r"\s*#\s*ifndef\s+(\w+)\s*\n\s*#\s*define\s+\1[ \t]*\n", text)
     if g and text.rstrip().endswith("#endif"):
         text = text[g.end():text.rstrip().rfind("#endif")]
@@ -45,7 +57,7 @@ def expand(path, seen=None):
     for line in text.split("\n"):
         m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
         if m:
-            out.append(expand(os.path.normpath(os.path.join(os.path.dirname(path), m.group(1))), seen))
+            out.append(expand(os.path.normpath(os.path.join(os.path.dirname(path), m.group(1))), seen, variant))
         elif re.match(r"\s*#\s*(version|extension)\b", line):
             continue
         else:
@@ -66,9 +78,9 @@ def match_paren(t, i):
     raise ValueError("unbalanced parentheses")
 
 
-def translate_body(rel, regs, stage=None):
+def translate_body(rel, regs, stage=None, variant=None):
     """(translated text, has_local_size); regs collects the (registry name, C++ lvalue) pairs"""
-    t = expand(os.path.join(REF_SHADERS, rel))
+    t = expand(os.path.join(REF_SHADERS, rel), variant=variant)
     for pat, rep in TOKEN_PATCHES.get(rel, []) + TOKEN_PATCHES["*"]:
         t = re.sub(pat, rep, t)
     pre = "" if stage is None else "st%d::" % stage
@@ -165,13 +177,13 @@ def translate(rel, defines=()):
     return _write(name, rel, defines, t, regs, '#include "runtime.inc"')
 
 
-def translate_pipeline(name, stages, defines=()):
+def translate_pipeline(name, stages, defines=(), variant=None):
     """stages: [(rel, kind)] with kind 0 = ray generation (first), 1 = closest hit, 2 = miss (in SBT order per kind).
     Every stage is translated into its own namespace st<i>; registry names are '<i>:<glsl name>'."""
     regs, body, table = [], [], []
     for i, (rel, kind) in enumerate(stages):
         sregs = []
-        t = translate_body(rel, sregs, stage=i)
+        t = translate_body(rel, sregs, stage=i, variant=variant)
         macros = sorted(set(re.findall(r"^\s*#\s*define\s+(\w+)", t, flags=re.M)))
         body.append("namespace st%d {\n%s\n}\n%s\n" % (i, t, "\n".join("#undef " + m for m in macros)))
         regs += [("%d:%s" % (i, n), lv) for n, lv in sregs]

@@ -141,3 +141,33 @@ def test_tone_map_matches_oracle(oracle, hr, ctx):
         assert np.array_equal(f.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (single, exposure)
         q = np.floor(np.clip(ref, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
         assert np.array_equal(b.cpu().numpy(), q)
+
+
+@pytest.mark.parametrize("name,bounces,textured", [("cornell", 3, False), ("sponza_small", 6, True)])
+def test_ground_truth_with_the_indirect_bounce_reenabled(oracle, hr, ctx, name, bounces, textured):
+    """hr_ground_truth_params.trace_indirect = 1: the recursive traceRayEXT of rchit:95-105 un-commented (extension; the
+    oracle's version is pinned to the reference's shaders with those lines un-commented by tests/test_ref_shaders.py)"""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_post
+    from oracle import pyoracle_post as opost
+    W, H = 120, 72
+    sd = helpers.scene_data(name)
+    if textured:
+        sd = synth.with_textures(sd)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    fr = helpers.make_frames(oracle, osc, name, W, H, 1, 0.0, "soft" if name == "cornell" else "point")[0]
+    sky = synth_env.sky_cubemap(8)
+    env = api_gi.environment(torch.from_numpy(sky).cuda().view(torch.float16))
+    o, g = opost.GroundTruthPass(W, H, max_ray_bounces=bounces, trace_indirect=True), api_post.GroundTruthPathTracer(ctx, W, H)
+    g.params.max_ray_bounces, g.params.trace_indirect = bounces, 1
+    base = opost.GroundTruthPass(W, H)
+    for k in range(4):
+        ref = o.render(osc, fr["ubo"], sky)
+        g.render(gsc, fr["ubo"], env)
+        torch.cuda.synchronize()
+        assert np.array_equal(helpers.bits16(g.output()), ref), f"frame {k}"
+        assert g.ray_count() == o.rays
+    first = base.render(osc, fr["ubo"], sky)
+    multi = opost.GroundTruthPass(W, H, max_ray_bounces=bounces, trace_indirect=True).render(osc, fr["ubo"], sky)
+    assert oracle.f16(multi[..., :3]).mean() > oracle.f16(first[..., :3]).mean()       # the bounces add light
+    g.close(); gsc.close()

@@ -491,3 +491,25 @@ def test_random_reflections_parameters(oracle, rh, seed):
         rrp.render(osc, fr["ubo"], ddgi, cur, prev, sob, sr, k, env, irr, dep, camera_delta=cd)
         for q in ("trace", "temporal", "moments", "tiles", "output"):
             assert np.array_equal(orp.stages[q], rrp.stages[q]), (k, q, kw)
+
+
+@pytest.mark.parametrize("name,kind,textured,bounces", [("cornell", "soft", False, 2), ("sponza_small", "default", False, 3), ("sponza_small", "point", True, 6)])
+def test_ground_truth_with_the_reference_bounce_uncommented(oracle, rh, name, kind, textured, bounces):
+    """SURVEY 8f row 3's optional extension: the reference's rchit with its commented-out recursive traceRayEXT (rchit:95-105)
+    un-commented by the translator (translate.VARIANTS["bounces"]) — payload recursion, Russian roulette, the by-value RNG of
+    sample_uber_brdf — vs the oracle's unrolled loop, 3 accumulated frames"""
+    from oracle import pyoracle_post as opost
+    W, H = 48, 32
+    sd = helpers.scene_data(name)
+    if textured:
+        sd = synth.with_textures(sd)
+    osc, rsc = oracle.Scene(sd), rh.RefScene(sd)
+    fr = helpers.make_frames(oracle, osc, name, W, H, 1, 0.0, kind)[0]
+    sky = synth_env.sky_cubemap(8)
+    gt, base = opost.GroundTruthPass(W, H, max_ray_bounces=bounces, trace_indirect=True), opost.GroundTruthPass(W, H)
+    for k in range(3):
+        prev, fi = gt.images[int(gt.ping_pong) if gt.frame_idx else 0].copy(), gt.frame_idx
+        out = gt.render(osc, fr["ubo"], sky).copy()
+        ref = rh.ground_truth(osc, rsc, fr["ubo"], sky, W, H, fi, prev, max_ray_bounces=bounces, trace_indirect=True)
+        assert np.array_equal(ref, out), f"frame {k}"
+        assert (out != base.render(osc, fr["ubo"], sky)).any(-1).mean() > 0.05
