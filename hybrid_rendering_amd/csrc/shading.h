@@ -2,7 +2,7 @@
 //   brdf.glsl:36-142 (GGX / Schlick / evaluate_uber_brdf), lighting.glsl:6-196 (fetch_light_properties
 //   without SOFT_SHADOWS, direct_lighting with RAY_THROUGHPUT / SAMPLE_SKY_LIGHT),
 //   gi_common.glsl:39-320 (probe addressing, oct coding, sample_irradiance), random.glsl:11-56,
-//   scene_descriptor_set.glsl:102-220 (interpolated_vertex / transform_vertex / fetch_* for untextured
+//   scene_descriptor_set.glsl:102-220 (interpolated_vertex / transform_vertex / fetch_* with constant or textured
 //   materials; instances are flattened at scene build, so the model matrix is the identity).
 // Pinned where the reference defers to samplers / absent assets: environment cubemaps
 // are fetched NEAREST with the Vulkan face-selection rule; DDGI atlases are sampled bilinearly

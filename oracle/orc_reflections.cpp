@@ -167,7 +167,7 @@ void orc_reflections_temporal(const void* ubo_, int w, int h, const uint16_t* in
                 for (int lx = 0; lx < 8; lx++)
                 {
                     const int x = tx * 8 + lx, y = ty * 8 + ly;
-                    if (x >= w || y >= h) continue; // pinned: threads outside the image are inert
+                    if (x >= w || y >= h) continue; // edge threads read roughness 0 (< 0.05): they can never vote for denoising, stores dropped
                     const float d = depth[(size_t)y * w + x];
                     const float roughness = g3.fetch(x, y, 0);
                     float orad[4] = { 0, 0, 0, 0 }, omom[4] = { 0, 0, 0, 0 };

@@ -4,8 +4,8 @@
 //   lighting.glsl:6-196       fetch_light_properties (non-soft) + direct_lighting (+ SAMPLE_SKY_LIGHT)
 //   gi_common.glsl:10-320     DDGIUniforms, probe addressing, oct coding, sample_irradiance
 //   random.glsl:11-56         xoroshiro64* RNG
-//   scene_descriptor_set.glsl:102-220  interpolated_vertex / transform_vertex / fetch_* (untextured
-//                             materials: texture indices == -1, instances flattened => identity model)
+//   scene_descriptor_set.glsl:102-220  interpolated_vertex / transform_vertex / fetch_* (constant or textured
+//                             materials; instances flattened => identity model)
 // Pinned where the reference leaves it to samplers / absent assets:
 //   * the sky / prefiltered environment cubemaps are INPUTS ([6][S][S] RGBA16F), fetched NEAREST
 //     with the Vulkan face-selection rule;
