@@ -9,7 +9,7 @@ from .api import _check, _stream_ptr, hr_image_view, lib, view_to_tensor
 
 class hr_deferred_params(C.Structure):
     _fields_ = [("use_ray_traced_shadows", C.c_int32), ("use_ray_traced_ao", C.c_int32), ("use_ray_traced_reflections", C.c_int32),
-                ("use_ddgi", C.c_int32), ("irradiance_sh9", (C.c_float * 4) * 9)]
+                ("use_ddgi", C.c_int32), ("irradiance_sh9", (C.c_float * 4) * 9), ("draw_skybox", C.c_int32)]
 
 
 def _view(t):

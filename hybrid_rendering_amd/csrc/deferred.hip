@@ -24,6 +24,9 @@ struct DeferredArgs
     float           sh9[9][4];
     uint2*          out;
     int             w, h, flags;
+    // render_skybox (deferred_shading.cpp:734-789, skybox.vert/.frag): sky texels (depth == 1) take the cubemap colour
+    const uint2*    sky; int sky_size;      // null: not drawn
+    float           view_inverse[16], proj_inverse[16];
 };
 
 __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a)
@@ -100,6 +103,20 @@ __global__ __launch_bounds__(256) void k_deferred(DeferredArgs a)
         const f3 specular = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), 2.0f);
         Lo = add3(Lo, scale3(add3(mul3(kD, diffuse), specular), aov));
     }
+    if (a.sky && a.depth[i] == 1.0f)
+    {
+        // The skybox cube is drawn after the shading with depth test LEQUAL at z = w: it covers exactly the texels the
+        // G-buffer left at depth 1.  The fragment's interpolated cube position lies on the ray through the pixel centre
+        // (the rasteriser's own interpolation is not reproducible), so the lookup direction is pinned to that ray, computed as
+        // the reference computes a pixel's ray elsewhere (ground_truth_path_trace.rgen:70-72); NEAREST cube fetch (contract).
+        const f4 target = mul_m4(a.proj_inverse, tu * 2.0f - 1.0f, tv * 2.0f - 1.0f, 1.0f, 1.0f);
+        const f3 tn     = normalize3(mk3(target.x, target.y, target.z));
+        const f4 dir    = mul_m4(a.view_inverse, tn.x, tn.y, tn.z, 0.0f);
+        const CubeMap cm { a.sky, a.sky_size };
+        const f3 env = cm.fetch(mk3(dir.x, dir.y, dir.z));
+        a.out[i] = make_uint2(pack_h2(env.x, env.y), pack_h2(env.z, 1.0f));
+        return;
+    }
     a.out[i] = make_uint2(pack_h2(Lo.x, Lo.y), pack_h2(Lo.z, 1.0f));
 }
 
@@ -117,6 +134,7 @@ void hr_deferred_default_params(hr_deferred_params* p)
     p->use_ray_traced_shadows = p->use_ray_traced_ao = p->use_ray_traced_reflections = p->use_ddgi = 1;
     for (int k = 0; k < 9; k++)
         for (int c = 0; c < 4; c++) p->irradiance_sh9[k][c] = 0.0f;
+    p->draw_skybox = 1;   // DeferredShading::render = render_shading + render_skybox (deferred_shading.cpp:58-70)
 }
 
 hr_status hr_deferred_create(hr_ctx* ctx, int32_t width, int32_t height, hr_deferred** out)
@@ -171,6 +189,8 @@ hr_status hr_deferred_render(hr_deferred* p, const hr_frame_inputs* in, const hr
     for (int k = 0; k < 9; k++)
         for (int c = 0; c < 4; c++) a.sh9[k][c] = prm->irradiance_sh9[k][c];
     a.out = (uint2*)p->out.p; a.w = p->w; a.h = p->h;
+    a.sky = (prm->draw_skybox && env->sky) ? (const uint2*)env->sky : nullptr; a.sky_size = env->sky_size;
+    for (int i = 0; i < 16; i++) { a.view_inverse[i] = in->ubo.view_inverse[i]; a.proj_inverse[i] = in->ubo.proj_inverse[i]; }
     hipLaunchKernelGGL(k_deferred, dim3(cdiv(p->w, 32), cdiv(p->h, 8)), dim3(256), 0, (hipStream_t)stream, a);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -419,7 +419,7 @@ hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);
 
 /* ---- DeferredShading composite (src/deferred_shading.h; SURVEY.md §8f "next" row 1) ------------------- */
 /* The consumer of the four passes: shaders/deferred.frag:177-205 as a per-pixel kernel.  Inputs are full-resolution views
- * (the passes' OUTPUT_UPSAMPLE outputs).  No sky test — like the reference, every pixel is shaded (the skybox is drawn later). */
+ * (the passes' OUTPUT_UPSAMPLE outputs).  Like the reference every pixel is shaded; render_skybox then covers the sky texels. */
 typedef struct hr_deferred hr_deferred;
 
 typedef struct
@@ -429,6 +429,8 @@ typedef struct
     int32_t use_ray_traced_reflections; /* true                                        */
     int32_t use_ddgi;                   /* true                                        */
     float   irradiance_sh9[9][4];       /* s_IrradianceSH (9x1 texels, rgb used) — dw::CubemapSHProjection output */
+    int32_t draw_skybox;                /* 1 (default): render_skybox (deferred_shading.cpp:734-789) — texels the G-buffer left at
+                                           depth 1 take hr_environment.sky along the ray through the pixel centre; 0: shading only */
 } hr_deferred_params;
 
 void      hr_deferred_default_params(hr_deferred_params* p);

@@ -16,6 +16,34 @@ extern "C" {
 void orc_deferred_shade(const void* ubo_, int w, int h, const uint8_t* gb1, const uint16_t* gb2, const uint16_t* gb3, const float* depth,
                         const uint16_t* shadow, int shadow_channels, const uint16_t* ao, int ao_channels, const uint16_t* reflections,
                         const uint16_t* gi, int flags, const float* sh9, const uint16_t* prefiltered, int pre_size, int pre_levels,
+                        const uint16_t* lut, int lut_size, uint16_t* out);
+
+// render_skybox (deferred_shading.cpp:734-789; skybox.vert/.frag): the cube drawn after the shading passes the depth test
+// exactly where the G-buffer left depth 1.  The interpolated cube position lies on the ray through the pixel centre; the
+// rasteriser's interpolation itself is not reproducible, so the lookup direction is PINNED to that ray, computed as the
+// reference computes a pixel's ray elsewhere (ground_truth_path_trace.rgen:70-72).  sky: [6][S][S][4] fp16, NEAREST.
+void orc_deferred_skybox(const void* ubo_, int w, int h, const float* depth, const uint16_t* sky, int sky_size, uint16_t* out)
+{
+    const UBO& ubo = *(const UBO*)ubo_;
+    CubeH      cube { sky, sky_size };
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const size_t i = (size_t)y * w + x;
+            if (depth[i] != 1.0f) continue;
+            const float tu = ((float)x + 0.5f) / (float)w, tv = ((float)y + 0.5f) / (float)h;
+            const vec4  target = mul(ubo.proj_inverse, vec4 { tu * 2.0f - 1.0f, tv * 2.0f - 1.0f, 1.0f, 1.0f });
+            const vec3  tn     = normalize(v3(target.x, target.y, target.z));
+            const vec4  dir    = mul(ubo.view_inverse, vec4 { tn.x, tn.y, tn.z, 0.0f });
+            const vec3  env    = cube.fetch(v3(dir.x, dir.y, dir.z));
+            out[i * 4 + 0] = f32_to_f16(env.x); out[i * 4 + 1] = f32_to_f16(env.y); out[i * 4 + 2] = f32_to_f16(env.z); out[i * 4 + 3] = f32_to_f16(1.0f);
+        }
+}
+
+void orc_deferred_shade(const void* ubo_, int w, int h, const uint8_t* gb1, const uint16_t* gb2, const uint16_t* gb3, const float* depth,
+                        const uint16_t* shadow, int shadow_channels, const uint16_t* ao, int ao_channels, const uint16_t* reflections,
+                        const uint16_t* gi, int flags, const float* sh9, const uint16_t* prefiltered, int pre_size, int pre_levels,
                         const uint16_t* lut, int lut_size, uint16_t* out)
 {
     const UBO& ubo = *(const UBO*)ubo_;

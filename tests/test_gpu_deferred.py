@@ -67,3 +67,38 @@ def test_hybrid_frame_end_to_end(oracle, hr, ctx, flags):
         ping = not ping
     img = oracle.f16(ref[..., :3])
     assert np.isfinite(img).all() and img.mean() > 0.01
+
+
+def test_skybox_covers_exactly_the_sky_texels(oracle, hr, ctx):
+    """DeferredShading::render = render_shading + render_skybox: texels at depth 1 take the sky cubemap along the ray through
+    the pixel centre (draw_skybox = 1, the default); with draw_skybox = 0 they keep the (meaningless) shaded value"""
+    import torch
+    from hybrid_rendering_amd import api_deferred, api_gi
+    from oracle import pyoracle_deferred as odf
+    name, W, H = "sponza_small", 160, 96
+    sd = helpers.scene_data(name)
+    osc = oracle.Scene(sd)
+    fr = helpers.make_frames(oracle, osc, name, W, H, 1, 0.0)[0]
+    sky = synth_env.sky_cubemap(16)
+    pre, lut, sh9 = synth_env.prefiltered_chain(sky, 5), synth_env.brdf_lut(16), synth_env.sh9_from_cubemap(sky)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=16, pre_levels=5, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 16, 5, f16(lut))
+    sob, sr = synth.blue_noise_tables()
+    fi = hr.frame_inputs(helpers.to_cuda(fr["gb"]), None, fr["ubo"], 0, 0, torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda())
+    g = api_deferred.DeferredShading(ctx, W, H)
+    g.set_sh9(sh9)
+    g.params.use_ray_traced_shadows = g.params.use_ray_traced_ao = g.params.use_ray_traced_reflections = g.params.use_ddgi = 0
+    sky_px = fr["gb"]["depth"] == 1.0
+    assert 0.005 < sky_px.mean() < 0.9
+    outs = {}
+    for draw in (1, 0):
+        g.params.draw_skybox = draw
+        g.render(fi, env)
+        torch.cuda.synchronize()
+        outs[draw] = helpers.bits16(g.output()).copy()
+        assert np.array_equal(outs[draw], odf.shade(fr["ubo"], fr["gb"], None, None, None, None, 0, sh9, env_np, skybox=bool(draw))), f"draw_skybox {draw}"
+    assert np.array_equal(outs[1][~sky_px], outs[0][~sky_px]) and (outs[1][sky_px] != outs[0][sky_px]).any()
+    col = oracle.f16(outs[1][sky_px][:, :3])
+    assert col[:, 2].mean() > col[:, 0].mean()          # the procedural sky is blue
+    g.close()

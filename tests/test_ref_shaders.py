@@ -268,7 +268,7 @@ def test_deferred_composite(oracle, rh):
     for kind in ("default", "point", "spot"):
         sd, osc, frames = _frames(oracle, "sponza_small", W, H, 1, 0.0, kind)
         for flags in (0, 15, 5, 10):
-            a = odf.shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env)
+            a = odf.shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env, skybox=False)   # render_shading alone
             b = rh.deferred_shade(frames[0]["ubo"], frames[0]["gb"], shadow, ao, refl, gi, flags, sh9, env)
             assert np.array_equal(a, b), f"{kind} light, flags {flags}"
 
