@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_gbuffer_mip_nearest", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -216,6 +216,14 @@ class Scene:
         _check(lib().hr_gbuffer_raycast(self.h, C.byref(u), C.c_int32(w), C.c_int32(h), _ptr(gb1), _ptr(gb2), _ptr(gb3), _ptr(depth), _stream_ptr(stream)),
                "hr_gbuffer_raycast")
         return dict(gb1=gb1, gb2=gb2, gb3=gb3, depth=depth)
+
+
+def bvh_build_info(verts) -> hr_scene_info:
+    """Host-only BVH build (no GPU): the shape hr_scene_create would produce for triangles ``verts`` [n,3,3]."""
+    v = np.ascontiguousarray(verts, np.float32)
+    info = hr_scene_info()
+    _check(lib().hr_bvh_build_info(v.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(v.shape[0]), C.byref(info)), "hr_bvh_build_info")
+    return info
 
 
 def gbuffer_mip(g, level, stream=None):

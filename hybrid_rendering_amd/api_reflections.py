@@ -36,6 +36,8 @@ class RayTracedReflections(_Pass):
             self.params.camera_delta[i] = float(d[i])
 
     def render(self, scene, inputs, env, ddgi, stream=None):
+        if ddgi is None or not getattr(ddgi, "h", None):
+            raise api.HRError("RayTracedReflections.render needs the DDGI pass (ray_traced_reflections.h:27: render(cmd_buf, DDGI*))")
         _check(lib().hr_reflections_render(self.h, scene.h, C.byref(inputs), C.byref(env), ddgi.h, C.byref(self.params), _stream_ptr(stream)),
                "hr_reflections_render")
 

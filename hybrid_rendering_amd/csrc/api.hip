@@ -1,5 +1,7 @@
 // C-ABI glue: context, scene (BVH build + upload), raw ray queries, G-buffer synthesis.
 #include "hr_internal.h"
+#include <memory>
+#include <new>
 #include "traverse.h"
 #include <cstring>
 
@@ -230,9 +232,16 @@ hr_status hr_ctx_create(int device_ordinal, hr_ctx** out)
     }
     HR_CHECK_ARG(device_ordinal >= 0 && device_ordinal < n);
     HR_HIP(hipSetDevice(device_ordinal));
-    hr_ctx* c = new hr_ctx();
+    hr_ctx* c = new (std::nothrow) hr_ctx();
+    if (!c) return HR_ERR_OUT_OF_MEMORY;
     c->device = device_ordinal;
-    HR_HIP(hipGetDeviceProperties(&c->props, device_ordinal));
+    e = hipGetDeviceProperties(&c->props, device_ordinal);
+    if (e != hipSuccess)
+    {
+        set_last_error(std::string("hipGetDeviceProperties failed: ") + hipGetErrorString(e));
+        delete c;
+        return HR_ERR_HIP;
+    }
     *out = c;
     return HR_OK;
 }
@@ -243,20 +252,89 @@ hr_status hr_ctx_destroy(hr_ctx* ctx)
     return HR_OK;
 }
 
+static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out);
+
+// Host-only: build the 8-wide BVH of a triangle soup and report its shape (no device, no upload).  What hr_scene_create
+// would build for the same positions — lets an integrator (and the CPU test-suite) check depth / size limits up front.
+hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_info* info)
+{
+    HR_CHECK_ARG(info && n_tris >= 0 && (positions || n_tris == 0));
+    try
+    {
+        BuiltBVH b;
+        build_bvh8(positions, n_tris, b);
+        std::memset(info, 0, sizeof(*info));
+        info->n_tris     = n_tris;
+        info->n_nodes    = (int32_t)b.nodes.size();
+        info->max_depth  = b.max_depth;
+        info->node_bytes = b.nodes.size() * sizeof(Node8);
+        info->tri_bytes  = b.tris.size() * sizeof(TriGPU);
+        info->box_pad    = b.pad;
+        for (int a = 0; a < 3; a++) { info->bounds_lo[a] = b.lo[a]; info->bounds_hi[a] = b.hi[a]; }
+        return (b.nodes.size() >= (1u << 23) || b.max_depth >= kMaxTraversalDepth) ? HR_ERR_UNSUPPORTED : HR_OK;
+    }
+    catch (const std::bad_alloc&)
+    {
+        set_last_error("hr_bvh_build_info: host allocation failed");
+        return HR_ERR_OUT_OF_MEMORY;
+    }
+}
+
+// No exception crosses the C ABI: the builder's and the staging vectors' allocation failures become HR_ERR_OUT_OF_MEMORY.
 hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
 {
+    try
+    {
+        return scene_create_impl(ctx, d, out);
+    }
+    catch (const std::bad_alloc&)
+    {
+        set_last_error("hr_scene_create: host allocation failed");
+        return HR_ERR_OUT_OF_MEMORY;
+    }
+    catch (const std::exception& e)
+    {
+        set_last_error(std::string("hr_scene_create: ") + e.what());
+        return HR_ERR_UNSUPPORTED;
+    }
+}
+
+static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
+{
     HR_CHECK_ARG(ctx && d && out && d->n_tris >= 0 && (d->positions || d->n_tris == 0));
+    HR_CHECK_ARG(d->n_materials >= 0 && (d->materials || d->n_materials == 0));
+    // every triangle's material index is dereferenced by the hit shading (shading.h surface_at: materials[m * 8], mat_tex[m * 6])
+    if (d->tri_material)
+    {
+        if (!d->materials) { set_last_error("hr_scene_create: tri_material given without materials"); return HR_ERR_INVALID_ARG; }
+        for (int i = 0; i < d->n_tris; i++)
+            if (d->tri_material[i] >= (uint32_t)d->n_materials)
+            {
+                set_last_error("hr_scene_create: tri_material[" + std::to_string(i) + "] = " + std::to_string(d->tri_material[i]) + " >= n_materials");
+                return HR_ERR_INVALID_ARG;
+            }
+    }
     HR_HIP(hipSetDevice(ctx->device));
     BuiltBVH b;
     build_bvh8(d->positions, d->n_tris, b);
-    if (b.nodes.size() >= (1u << 23)) return HR_ERR_UNSUPPORTED;   // traversal stack entries hold child_base in 23 bits
-    hr_scene* s = new hr_scene();
+    if (b.nodes.size() >= (1u << 23))   // traversal stack entries hold child_base in 23 bits
+    {
+        set_last_error("hr_scene_create: more than 2^23 BVH nodes");
+        return HR_ERR_UNSUPPORTED;
+    }
+    if (b.max_depth >= kMaxTraversalDepth)   // one stack entry per level (traverse.h); the builder's depth cap keeps real input below it
+    {
+        set_last_error("hr_scene_create: BVH depth " + std::to_string(b.max_depth) + " exceeds the traversal stack (" + std::to_string(kMaxTraversalDepth) + ")");
+        return HR_ERR_UNSUPPORTED;
+    }
+    std::unique_ptr<hr_scene> guard(new hr_scene());
+    hr_scene* s = guard.get();
     s->ctx      = ctx;
     hr_status st;
 #define UP(buf, src, nbytes)                                                                     \
-    if ((st = s->buf.alloc(nbytes)) != HR_OK) { delete s; return st; }                           \
+    if ((st = s->buf.alloc(nbytes)) != HR_OK) return st;                                         \
     if ((nbytes) > 0) { hipError_t e_ = hipMemcpy(s->buf.p, src, nbytes, hipMemcpyHostToDevice); \
-        if (e_ != hipSuccess) { set_last_error(std::string("hipMemcpy H2D failed: ") + hipGetErrorString(e_)); delete s; return HR_ERR_HIP; } }
+        if (e_ != hipSuccess) { set_last_error(std::string("hipMemcpy H2D failed: ") + hipGetErrorString(e_)); return HR_ERR_HIP; } }
     UP(nodes, b.nodes.data(), b.nodes.size() * sizeof(Node8))
     UP(tris, b.tris.data(), b.tris.size() * sizeof(TriGPU))
     const size_t n = (size_t)d->n_tris;
@@ -274,14 +352,14 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
         for (int i = 0; i < d->n_textures; i++)
         {
             const hr_texture& t = d->textures[i];
-            if (!t.rgba8 || t.width <= 0 || t.height <= 0) { delete s; return HR_ERR_INVALID_ARG; }
+            if (!t.rgba8 || t.width <= 0 || t.height <= 0) { set_last_error("hr_scene_create: empty texture"); return HR_ERR_INVALID_ARG; }
             table.insert(table.end(), { (uint32_t)(texels.size() / 4), (uint32_t)t.width, (uint32_t)t.height, 0u });
             texels.insert(texels.end(), t.rgba8, t.rgba8 + (size_t)t.width * t.height * 4);
         }
         for (int i = 0; i < d->n_materials * 4; i++)
         {
             const int32_t ti = d->material_textures[(i / 4) * 6 + (i % 4)];
-            if (ti >= d->n_textures) { delete s; return HR_ERR_INVALID_ARG; }
+            if (ti >= d->n_textures) { set_last_error("hr_scene_create: material texture index out of range"); return HR_ERR_INVALID_ARG; }
         }
         UP(mat_tex, d->material_textures, (size_t)d->n_materials * 24)
         UP(tex_table, table.data(), table.size() * 4)
@@ -299,7 +377,7 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
     s->info.tri_bytes   = b.tris.size() * sizeof(TriGPU);
     s->info.box_pad     = b.pad;
     for (int a = 0; a < 3; a++) { s->info.bounds_lo[a] = b.lo[a]; s->info.bounds_hi[a] = b.hi[a]; }
-    *out = s;
+    *out = guard.release();
     return HR_OK;
 }
 

@@ -41,6 +41,9 @@ struct alignas(16) TriGPU
 };
 static_assert(sizeof(TriGPU) == 48, "TriGPU must be 48 bytes");
 
+// deepest 8-wide tree the traversal's per-lane stack can walk (one entry per level, traverse.h LaneStack)
+constexpr int kMaxTraversalDepth = 64;
+
 struct BuiltBVH
 {
     std::vector<Node8>  nodes;

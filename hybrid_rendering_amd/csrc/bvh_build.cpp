@@ -53,6 +53,16 @@ struct Bin2
 constexpr int kBins    = 64;   // 32 -> 64: nodes per shadow ray 6.38 -> 6.30, frame -1.3% (8 bins: 7.25, +5%)
 constexpr int kMaxLeaf = 4;   // triangles per leaf CHILD of an 8-wide node (count field of the meta byte, 8 x 4 = 32-bit mask)
 
+// SAH bin of a centroid.  `k` = kBins / extent overflows to +inf when the extent is subnormal and the product is then inf or
+// NaN (0 * inf): compare in a way that sends both to a valid bin instead of converting them to int (undefined).
+static inline int bin_of(float c, float lo, float k)
+{
+    const float f = (c - lo) * k;
+    if (!(f > 0.0f)) return 0;               // also NaN
+    if (f >= (float)(kBins - 1)) return kBins - 1;
+    return (int)f;
+}
+
 struct Builder
 {
     const float*          pos;
@@ -63,7 +73,14 @@ struct Builder
     std::vector<Bin2>     n2;
     int                   bvh2_leaf = kMaxLeaf;   // binary-tree leaf size (1 for the optimal collapse: it forms the leaves)
 
-    int32_t split(int32_t first, int32_t count)
+    // SAH splits down to binary depth kSahDepth, object-median splits below it: a median split halves the count, so the
+    // binary tree is never deeper than kSahDepth + ceil(log2 n) <= 40 + 24 = 64 levels.  The 8-wide collapse only removes
+    // levels, and the traversal keeps ONE stack entry per level (traverse.h: walk_expand), so HR_STACK_ENTRIES +
+    // HR_SPILL_ENTRIES = 64 entries always suffice — also for adversarial input (a chain of slivers of geometrically growing
+    // size makes the SAH peel one triangle per level, n levels deep; tests/test_gpu_trace.py::test_degenerate_sliver_chain).
+    static constexpr int kSahDepth = 40;
+    int sah_depth = kSahDepth;   // HR_BVH_SAH_DEPTH lowers it (developer switch: exercises the median fallback in tests)
+    int32_t split(int32_t first, int32_t count, int depth = 0)
     {
         int32_t me = (int32_t)n2.size();
         n2.emplace_back();
@@ -81,6 +98,22 @@ struct Builder
         double  best     = DBL_MAX;
         int     bax      = -1;
         int     bsplit   = 0;
+        if (depth >= sah_depth)
+        {
+            int ax = 0;
+            for (int k = 1; k < 3; k++)
+                if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+            const int32_t mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count, [&](int32_t a, int32_t b) {
+                const float ca = tcen[(size_t)a * 3 + ax], cb_ = tcen[(size_t)b * 3 + ax];
+                return ca < cb_ || (ca == cb_ && a < b);
+            });
+            const int32_t l = split(first, mid - first, depth + 1);
+            const int32_t r = split(mid, first + count - mid, depth + 1);
+            n2[me].a = l;
+            n2[me].b = r;
+            return me;
+        }
         for (int ax = 0; ax < 3; ax++)
         {
             float ext = cb.hi[ax] - cb.lo[ax];
@@ -91,8 +124,7 @@ struct Builder
             for (int32_t i = first; i < first + count; i++)
             {
                 int t = idx[i];
-                int b = (int)((tcen[(size_t)t * 3 + ax] - cb.lo[ax]) * k);
-                if (b > kBins - 1) b = kBins - 1;
+                const int b = bin_of(tcen[(size_t)t * 3 + ax], cb.lo[ax], k);
                 bbox[b].add(tbox[t]);
                 bcnt[b]++;
             }
@@ -126,15 +158,13 @@ struct Builder
             float k   = (float)kBins / ext;
             float lo  = cb.lo[bax];
             auto  it  = std::partition(idx.begin() + first, idx.begin() + first + count, [&](int32_t t) {
-                int b = (int)((tcen[(size_t)t * 3 + bax] - lo) * k);
-                if (b > kBins - 1) b = kBins - 1;
-                return b <= bsplit;
+                return bin_of(tcen[(size_t)t * 3 + bax], lo, k) <= bsplit;
             });
             mid = (int32_t)(it - idx.begin());
             if (mid == first || mid == first + count) mid = first + count / 2;
         }
-        int32_t l = split(first, mid - first);
-        int32_t r = split(mid, first + count - mid);
+        int32_t l = split(first, mid - first, depth + 1);
+        int32_t r = split(mid, first + count - mid, depth + 1);
         n2[me].a  = l;
         n2[me].b  = r;
         return me;
@@ -319,6 +349,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         return;
     }
     B.bvh2_leaf = getenv("HR_BVH_GREEDY") ? kMaxLeaf : 1;
+    if (const char* e = getenv("HR_BVH_SAH_DEPTH")) { const int v = atoi(e); if (v >= 0 && v < Builder::kSahDepth) B.sah_depth = v; }
     B.n2.reserve((size_t)n_refs * 2);
     int32_t root2 = B.split(0, n_refs);
 
@@ -328,14 +359,14 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     // below it).  The greedy largest-area-first collapse left 45% of the nodes with two children (bottom nodes holding two
     // leaves): every slot of a node is box-tested anyway, so half-empty nodes are pure overhead.
     const bool optimal = !getenv("HR_BVH_GREEDY");   // developer switch: the previous greedy collapse
-    std::vector<float>   cost;
+    std::vector<double>  cost;   // double: areas of a scene spanning many orders of magnitude overflow a float (inf <= inf made over-full leaves)
     std::vector<uint8_t> best_k, use_split, as_leaf;
     if (optimal)
     {
         const size_t nn = B.n2.size();
         // one node step ~230 VALU + 80 B, one triangle test ~80 VALU + 48 B; the result is flat in C_prim (0.15 .. 1.2: 0.253-0.256 ms)
         const double C_node = 1.0, C_prim = 0.35;
-        cost.assign(nn * 8, 0.0f); best_k.assign(nn * 8, 0); use_split.assign(nn * 8, 0); as_leaf.assign(nn, 0);
+        cost.assign(nn * 8, 0.0); best_k.assign(nn * 8, 0); use_split.assign(nn * 8, 0); as_leaf.assign(nn, 0);
         for (size_t r = nn; r-- > 0;)   // children are allocated after their parent: reverse order is bottom-up
         {
             const Bin2& c = B.n2[r];
@@ -343,7 +374,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
             const double leaf = c.count <= kMaxLeaf ? area * c.count * C_prim : 1e300;
             if (c.a < 0)
             {
-                for (int i = 0; i < 8; i++) cost[r * 8 + i] = (float)leaf;
+                for (int i = 0; i < 8; i++) cost[r * 8 + i] = leaf;
                 as_leaf[r] = 1;
                 continue;
             }
@@ -353,20 +384,20 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
                 double b = 1e300; int bk = 1;
                 for (int k = 1; k < j; k++)
                 {
-                    const double v = (double)cost[(size_t)c.a * 8 + (k - 1)] + (double)cost[(size_t)c.b * 8 + (j - k - 1)];
+                    const double v = cost[(size_t)c.a * 8 + (k - 1)] + cost[(size_t)c.b * 8 + (j - k - 1)];
                     if (v < b) { b = v; bk = k; }
                 }
                 dist[j] = b;
                 best_k[r * 8 + (j - 1)] = (uint8_t)bk;
             }
             const double internal = dist[8] + area * C_node;
-            as_leaf[r] = leaf <= internal;
-            double prev = leaf <= internal ? leaf : internal;
-            cost[r * 8 + 0] = (float)prev;
+            as_leaf[r] = c.count <= kMaxLeaf && leaf <= internal;
+            double prev = as_leaf[r] ? leaf : internal;
+            cost[r * 8 + 0] = prev;
             for (int i = 2; i <= 7; i++)
             {
                 if (dist[i] < prev) { prev = dist[i]; use_split[r * 8 + (i - 1)] = 1; }
-                cost[r * 8 + (i - 1)] = (float)prev;
+                cost[r * 8 + (i - 1)] = prev;
             }
             cost[r * 8 + 7] = cost[r * 8 + 6];   // budget 8 only ever splits (used for the children of a node: best_k[.][7])
             use_split[r * 8 + 7] = 1;

@@ -388,8 +388,9 @@ hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
     hipLaunchKernelGGL(k_ddgi_probe_update<true>, grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
     p->prof.end(ev, st);
     ev = p->prof.begin("border_update", st, 0);
-    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(64), 0, st, p->d, p->irr[wr].p, p->z0);
-    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(128), 0, st, p->d, p->dep[wr].p, p->z0);
+    // one thread per border texel: 4 * side + 4 (hr_ddgi_create bounds the sides), rounded up to whole waves
+    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(cdiv(4 * p->d.irradiance_probe_side_length + 4, 64) * 64), 0, st, p->d, p->irr[wr].p, p->z0);
+    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(cdiv(4 * p->d.depth_probe_side_length + 4, 64) * 64), 0, st, p->d, p->dep[wr].p, p->z0);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -536,6 +536,11 @@ struct hr_shadows
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
     bool          persistent_waves = false; // HR_TRACE_KERNEL=queue selects the persistent-wave ray-queue kernel (A/B measurements)
+    // developer switches (tools/timeline.py, tools/stagebench.py), read from the environment ONCE in hr_shadows_create — the
+    // render path never calls getenv
+    int           dbg_only_tx = -1, dbg_only_ty = -1;
+    bool          dbg_skip_traversal = false, dbg_skip_reproject = false, dbg_timeline_stats = false;
+    std::string   dbg_timeline;             // HR_DEBUG_TIMELINE=<file>
     uint64_t      last_wave_max_steps = 0; // sum over waves of the slowest lane's (node + triangle) steps
 };
 
@@ -554,6 +559,11 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     hr_shadows* p = new hr_shadows();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     { const char* e = getenv("HR_TRACE_KERNEL"); p->persistent_waves = (e && std::string(e) == "queue"); }
+    if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &p->dbg_only_tx, &p->dbg_only_ty);
+    p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
+    p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
+    p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
+    if (const char* e = getenv("HR_DEBUG_TIMELINE")) p->dbg_timeline = e;
     // m_width = extent / 2^scale (ray_traced_shadows.cpp:80-83: float divide then truncation)
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h; p->band_y0 = 0; p->band_y1 = p->h; p->ry0 = 0; p->ry1 = p->h;
@@ -689,9 +699,8 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.bias = prm->bias; a.num_frames = in->num_frames;
     const int n_tiles = a.tiles_x * a.tiles_y;
     const int n_slots = n_tiles;
-    a.debug_only_tx = a.debug_only_ty = -1;
-    if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &a.debug_only_tx, &a.debug_only_ty); // developer switch (tools/timeline.py)
-    a.debug_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") ? 1 : 0; // developer ablation switch (tools/)
+    a.debug_only_tx = p->dbg_only_tx; a.debug_only_ty = p->dbg_only_ty;
+    a.debug_skip_traversal = p->dbg_skip_traversal ? 1 : 0;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
     {
@@ -703,14 +712,15 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
-    if (const char* tl = getenv("HR_DEBUG_TIMELINE"))
+    if (!p->dbg_timeline.empty())
     {
+        const char* tl = p->dbg_timeline.c_str();
         // developer switch (tools/timeline.py): per-wave start/end ticks of ONE launch of the tile kernel, written to the file
         DevBuf buf;
         hr_status bs = buf.alloc((size_t)n_tiles * 32);
         if (bs != HR_OK) return bs;
         a.timeline = (unsigned long long*)buf.p;
-        if (getenv("HR_DEBUG_TIMELINE_STATS")) hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        if (p->dbg_timeline_stats) hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         HR_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> host((size_t)n_tiles * 4);
@@ -775,7 +785,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
-    a.debug_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") ? 1 : 0;
+    a.debug_skip_reproject = p->dbg_skip_reproject ? 1 : 0;
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);

@@ -19,6 +19,7 @@ namespace hr {
 
 #define HR_STACK_ENTRIES 16   // LDS entries per lane (16 KB per 4-wave block => 8 waves/SIMD); deeper pushes spill to scratch
 #define HR_SPILL_ENTRIES 48
+static_assert(HR_STACK_ENTRIES + HR_SPILL_ENTRIES >= hr::kMaxTraversalDepth, "traversal stack shallower than the deepest BVH hr_scene_create accepts");
 
 struct RayPre
 {
@@ -168,10 +169,14 @@ struct LaneStack
     uint32_t* spill; // private overflow array, HR_SPILL_ENTRIES entries
     int       sp;
     HR_DEV void init(uint32_t* wave_region, int lane, uint32_t* spill_array) { lds = wave_region + lane; spill = spill_array; sp = 0; }
+    // The walk keeps one entry per BVH level and hr_scene_create refuses trees deeper than kMaxTraversalDepth (bvh.h; the
+    // builder caps the depth, bvh_build.cpp kSahDepth), so `sp` never reaches the capacity.  Belt and braces: a push beyond
+    // it is dropped WITHOUT advancing sp — push and pop stay paired and no index ever leaves the arrays.
     HR_DEV void push(uint32_t v)
     {
         if (sp < HR_STACK_ENTRIES) lds[sp * 64] = v;
-        else if (sp - HR_STACK_ENTRIES < HR_SPILL_ENTRIES) spill[sp - HR_STACK_ENTRIES] = v;
+        else if (sp < HR_STACK_ENTRIES + HR_SPILL_ENTRIES) spill[sp - HR_STACK_ENTRIES] = v;
+        else return;
         sp++;
     }
     HR_DEV uint32_t pop()

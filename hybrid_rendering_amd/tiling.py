@@ -146,6 +146,13 @@ class _TiledPass:
         self.bounds = list(bounds) if bounds is not None else None
         self.b0, self.b1 = band_rows(height, world, rank, bounds=self.bounds)
         self.history_rows = history_rows
+        # the exchange only talks to the two direct neighbours: a neighbour band shorter than the history apron would leave
+        # apron rows owned by the SECOND neighbour unrefreshed (stale history => bands silently differ from one GPU)
+        if world > 1:
+            short = [r for r in range(world) if (lambda b: b[1] - b[0])(band_rows(height, world, r, bounds=self.bounds)) < history_rows]
+            if short:
+                raise ValueError(f"bands {short} of a {height}-row image cut {world} ways are shorter than the {history_rows}-row history apron; "
+                                 "use fewer bands (or pass bounds= with taller bands)")
 
     def history_images(self, ping_pong: int) -> List:
         raise NotImplementedError
@@ -165,6 +172,13 @@ class _TiledPass:
         self._pending = []
 
     def render(self, scene, inputs, *extra, stream=None):
+        """``stream``: torch stream to record on (default: the current one).  torch.distributed orders its RCCL operations and
+        req.wait() against torch's CURRENT stream, so a caller-supplied stream is made current for the whole frame — kernels,
+        exchange and waits then share one ordering domain."""
+        import torch
+        if stream is not None and torch.cuda.is_available() and stream != torch.cuda.current_stream():
+            with torch.cuda.stream(stream):
+                return self.render(scene, inputs, *extra, stream=None)
         self._render(scene, inputs, stream, *extra)
         if self.world > 1:
             # torch.distributed orders the NCCL/RCCL ops after the kernels already enqueued on the current stream.  The
@@ -248,7 +262,7 @@ class TiledReflections(_TiledPass):
         p = self.pass_
         return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
 
-    def _render(self, scene, inputs, stream, env, ddgi=None):
+    def _render(self, scene, inputs, stream, env, ddgi):
         self.wait_exchange()
         self.pass_.render(scene, inputs, env, ddgi, stream=stream)
 

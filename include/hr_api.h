@@ -153,8 +153,13 @@ typedef struct
     float    box_pad;
 } hr_scene_info;
 
+/* HR_ERR_INVALID_ARG: a tri_material entry >= n_materials or a texture index >= n_textures (both are dereferenced by the hit
+ * shading); HR_ERR_UNSUPPORTED: >= 2^23 BVH nodes, or a BVH deeper than the traversal stack (64 levels — the builder caps its
+ * depth, so no triangle soup reaches it); HR_ERR_OUT_OF_MEMORY: host or device allocation failed.  Never throws. */
 hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* desc, hr_scene** out);
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info);
+/* Host only (no device needed): the shape of the BVH hr_scene_create would build over `positions` ([n_tris][3][3] floats). */
+hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_info* info);
 hr_status hr_scene_destroy(hr_scene* scene);
 
 /* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).

@@ -1,0 +1,287 @@
+"""GPU parity at the configurations round 1 left untested ("next round" item 1):
+
+ (a) RayTracedShadows at HALF and QUARTER resolution — every stage and OUTPUT_UPSAMPLE (shadows_upsample.comp:62-109 through
+     the RG16F -> R16F variant of the upsample kernel, ray_traced_shadows.cpp:1219-1255) vs the oracle, and the upsample vs the
+     reference's own shader;
+ (b) BASELINE configs[3]: 1920x1080 reflections (reference default half-res, and full-res) with DDGI feeding it, vs the oracle;
+ (c) BASELINE configs[4]: one 3840x2160 frame of shadows + DDGI probe-grid sample vs the oracle, and one 270-row band (+ halo)
+     of all four passes vs the oracle's rows of the whole frame;
+ (d) the random-parameter / ragged-size seeds of tools/fuzz_gpu.py as a parametrised test, so the driver's run sees them.
+
+Everything is compared bit for bit (exact mode)."""
+import numpy as np
+import pytest
+
+import helpers
+from hybrid_rendering_amd import synth, synth_env, tiling
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables():
+    import torch
+    sob, sr = synth.blue_noise_tables()
+    return sob, sr, torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ (a)
+@pytest.mark.parametrize("name,W,H,scale,light", [("sponza_small", 320, 176, 1, "default"), ("sponza_small", 328, 184, 2, "point"),
+                                                  ("cornell", 250, 166, 1, "soft")])
+def test_shadows_low_res_upsample(oracle, hr, ctx, name, W, H, scale, light):
+    import torch
+    from oracle import pyref
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    n_frames = 3
+    frames = helpers.make_frames(oracle, osc, name, W, H, n_frames, 1.0, light, scale_mips=scale)
+    sob, sr, sob_d, sr_d = _tables()
+    w, h = W >> scale, H >> scale
+    gp, op = hr.RayTracedShadows(ctx, W, H, scale), oracle.ShadowsPass(w, h)
+    assert (gp.width, gp.height) == (w, h)
+    for f in range(n_frames):
+        cur, prev, full = frames[f]["mips"][scale], (frames[f - 1] if f else frames[f])["mips"][scale], frames[f]["gb"]
+        op.render(osc, frames[f]["ubo"], cur, prev, sob, sr, f)
+        st = op.stages
+        up = oracle.upsample(full, cur, st["output"], channels=1, sky_value=0.0, power=0.0)[..., 0]
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), frames[f]["ubo"], f, f & 1, sob_d, sr_d, cur_full=helpers.to_cuda(full)))
+        torch.cuda.synchronize()
+        assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), st["mask"]), f"frame {f}: mask"
+        assert gp.ray_count() == st["rays"]
+        assert np.array_equal(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"]), f"frame {f}: tile classes"
+        assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"]), f"frame {f}: temporal"
+        assert np.array_equal(helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), st["output"]), f"frame {f}: a-trous"
+        got = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
+        assert got.shape == (H, W)
+        assert np.array_equal(got, up), f"frame {f}: upsample differs in {(got != up).sum()} halfs"
+        if pyref.available():
+            # the reference's own shader on the same low-res image (RG16F in, R16F out)
+            from oracle import ref_harness as rh
+            ref_up = rh.upsample("shadows/shadows_upsample.comp", frames[f]["mips"][:scale + 1], scale, st["output"], "r16f")
+            assert np.array_equal(got, ref_up[..., 0]), f"frame {f}: upsample vs shadows_upsample.comp"
+    lit = helpers.unpack_mask(op.stages["mask"], w, h).mean()
+    assert 0.02 < lit < 0.98
+    up_f = oracle.f16(up)
+    assert up_f.max() > 0.5 and (up_f == 0).any()
+    gp.close(); gsc.close()
+
+
+# ------------------------------------------------------------------------------------------------ (b)
+def _reflection_setup(oracle, hr, ctx, sd, counts, rays):
+    import torch
+    from hybrid_rendering_amd import api_gi
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=counts, rays_per_probe=rays, normal_bias=0.25)
+    sky = synth_env.sky_cubemap(32)
+    pre, lut = synth_env.prefiltered_chain(sky, 6), synth_env.brdf_lut(32)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=32, pre_levels=6, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 32, 6, f16(lut))
+    return ddgi, sky, env_np, env
+
+
+def _polish(g):
+    """g_buffer.frag:106: emulate roughness_multiplier 0.3 on the polished materials so the mirror regime exists"""
+    r01, r003 = np.float16(0.1).view(np.uint16), np.float16(0.03).view(np.uint16)
+    ch = g["gb3"][..., 0]
+    ch[ch == r01] = r003
+
+
+def _host(gb):
+    import torch
+    return {n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in gb.items()}
+
+
+@pytest.fixture(scope="module")
+def sponza_full(hr, ctx):
+    sd = helpers.scene_data("sponza")
+    return dict(sd=sd, scene=hr.Scene(ctx, sd))
+
+
+@pytest.mark.parametrize("scale", [1, 0])
+def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
+    """BASELINE configs[3]: 1920x1080, the 278k-triangle scene, reflections + SVGF (+ upsample), 2 frames with camera motion,
+    DDGI (8x4x8 probes) feeding the rough regime; every stage image bit for bit."""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections
+    from oracle import pyoracle_ddgi as od
+    from oracle import pyoracle_reflections as orf
+    W, H = 1920, 1080
+    sd, gsc = sponza_full["sd"], sponza_full["scene"]
+    osc = oracle.Scene(sd)
+    ddgi, sky, env_np, env = _reflection_setup(oracle, hr, ctx, sd, (8, 4, 8), 64)
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(3)]
+    ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(2)]
+    sob, sr, sob_d, sr_d = _tables()
+    w, h = W >> scale, H >> scale
+    g_ddgi, o_ddgi = api_gi.DDGI(ctx, W, H, ddgi), od.DDGIPass(ddgi)
+    gp, op = api_reflections.RayTracedReflections(ctx, W, H, scale), orf.ReflectionsPass(w, h)
+    rng = np.random.RandomState(3)
+    fulls = []
+    for f in range(2):
+        g = _host(gsc.gbuffer(ubos[f], W, H))
+        _polish(g)
+        fulls.append(g)
+    lvl = (lambda g: helpers.nearest_mip(g, scale) if scale else g)
+    lows = [lvl(g) for g in fulls]
+    for f in range(2):
+        cur, prev, full = lows[f], lows[f - 1 if f else 0], fulls[f]
+        orient = synth_env.random_orientation(rng)
+        cam_delta = (0.0, 0.0, 0.0) if f == 0 else (-0.5, 0.0, 0.0)
+        o_ddgi.render(osc, ubos[f], full, sky, orient, f)
+        irr, dep = o_ddgi.current_read()
+        op.render(osc, ubos[f], ddgi, cur, prev, sob, sr, f, env_np, irr, dep, camera_delta=cam_delta, full=full if scale else None, ping_pong=bool(f & 1))
+        full_d = helpers.to_cuda(full)
+        g_ddgi.render(gsc, hr.frame_inputs(full_d, None, ubos[f], f, f & 1, sob_d, sr_d), env, orient)
+        gp.set_camera_delta(cam_delta)
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), ubos[f], f, f & 1, sob_d, sr_d, cur_full=full_d), env, g_ddgi)
+        torch.cuda.synchronize()
+        st = op.stages
+        tr = helpers.bits16(gp.image(gp.IMG_TRACE))
+        assert np.array_equal(tr, st["trace"]), f"frame {f}: trace differs in {(tr != st['trace']).sum()} halfs"
+        assert gp.ray_count() == st["rays"] and st["rays"] > (300_000 if scale else 1_200_000)
+        assert np.array_equal(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"]), f"frame {f}: tiles"
+        tc = helpers.bits16(gp.image(gp.IMG_COLOR1 if f & 1 else gp.IMG_COLOR0))
+        assert np.array_equal(tc, st["temporal"]), f"frame {f}: temporal differs in {(tc != st['temporal']).sum()} halfs"
+        at = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
+        assert np.array_equal(at, st["atrous"][-1]), f"frame {f}: a-trous differs in {(at != st['atrous'][-1]).sum()} halfs"
+        out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
+        assert np.array_equal(out, st["output"]), f"frame {f}: output differs in {(out != st['output']).sum()} halfs"
+    rough = oracle.f16(lows[-1]["gb3"][..., 0])
+    geo = lows[-1]["depth"] != 1.0
+    assert ((rough < 0.05) & geo).any() and ((rough > 0.75) & geo).any() and ((rough > 0.1) & (rough < 0.7) & geo).any()
+    gp.close(); g_ddgi.close()
+
+
+# ------------------------------------------------------------------------------------------------ (c)
+@pytest.fixture(scope="module")
+def frame4k(oracle, hr, ctx, sponza_full):
+    """one 3840x2160 view (+ its predecessor for the motion vectors) of the bench scene, on host and device"""
+    W, H = 3840, 2160
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(2)]
+    ubo = synth.make_ubo(cams[1], cams[0], light)
+    gb_d = sponza_full["scene"].gbuffer(ubo, W, H)
+    gb = _host(gb_d)
+    _polish(gb)
+    gb_d = helpers.to_cuda(gb)
+    return dict(W=W, H=H, ubo=ubo, gb=gb, gb_d=gb_d, osc=oracle.Scene(sponza_full["sd"]))
+
+
+def test_4k_shadows_and_ddgi_sample_match_oracle(oracle, hr, ctx, sponza_full, frame4k):
+    """BASELINE configs[4] on one GPU: the 3840x2160 shadows frame (trace + temporal + 4 a-trous) and the DDGI probe-grid
+    sample of the same frame (16x8x16 probes, 64 rays: the oracle traces them in seconds) — bit for bit."""
+    import torch
+    from hybrid_rendering_amd import api_gi
+    from oracle import pyoracle_ddgi as od
+    W, H, ubo, gb, gb_d, osc = (frame4k[k] for k in ("W", "H", "ubo", "gb", "gb_d", "osc"))
+    sob, sr, sob_d, sr_d = _tables()
+    gsc = sponza_full["scene"]
+    op, gp = oracle.ShadowsPass(W, H), hr.RayTracedShadows(ctx, W, H)
+    op.render(osc, ubo, gb, gb, sob, sr, 0)
+    fi = hr.frame_inputs(gb_d, gb_d, ubo, 0, 0, sob_d, sr_d)
+    gp.render(gsc, fi)
+    torch.cuda.synchronize()
+    st = op.stages
+    assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), st["mask"]), "4K mask"
+    assert gp.ray_count() == st["rays"] and st["rays"] > 2_000_000
+    assert np.array_equal(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"])
+    assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"]), "4K temporal"
+    assert np.array_equal(helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), st["output"]), "4K a-trous output"
+    gp.close()
+    lo, hi = sponza_full["sd"].bounds()
+    u = synth_env.ddgi_uniforms(lo, hi, probe_counts=(16, 8, 16), rays_per_probe=64, normal_bias=0.25)
+    sky = synth_env.sky_cubemap(32)
+    env = api_gi.environment(torch.from_numpy(sky).cuda().view(torch.float16))
+    orient = synth_env.random_orientation(np.random.RandomState(5))
+    g_ddgi, o_ddgi = api_gi.DDGI(ctx, W, H, u), od.DDGIPass(u)
+    o_ddgi.render(osc, ubo, gb, sky, orient, 0)
+    g_ddgi.render(gsc, fi, env, orient)
+    torch.cuda.synchronize()
+    irr, dep = o_ddgi.current_read()
+    gi, gd = g_ddgi.current_read()
+    assert np.array_equal(helpers.bits16(gi), irr) and np.array_equal(helpers.bits16(gd), dep), "4K DDGI atlases"
+    out = helpers.bits16(g_ddgi.output())
+    assert out.shape[:2] == (H, W)
+    assert np.array_equal(out, o_ddgi.stages["output"]), f"4K DDGI sample differs in {(out != o_ddgi.stages['output']).sum()} halfs"
+    g_ddgi.close()
+
+
+def test_4k_band_of_all_passes_matches_oracle_rows(oracle, hr, ctx, sponza_full, frame4k):
+    """the 8-GPU decomposition of configs[4], one rank of it: rows [1080, 1350) (+ halo) of shadows, AO, reflections (half-res
+    band [536, 680)) and the DDGI sample rendered as a band; the band rows equal the oracle's rows of the WHOLE frame."""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections
+    from oracle import pyoracle_ddgi as od
+    from oracle import pyoracle_reflections as orf
+    W, H, ubo, gb, gb_d, osc = (frame4k[k] for k in ("W", "H", "ubo", "gb", "gb_d", "osc"))
+    sob, sr, sob_d, sr_d = _tables()
+    gsc, sd = sponza_full["scene"], sponza_full["sd"]
+    zbp = synth.z_buffer_params()
+    world, rank = 8, 4
+    b0, b1 = tiling.band_rows(H, world, rank)     # 270-row bands on the 8-row tile grid: rank 4 owns [1080, 1344)
+    assert 264 <= b1 - b0 <= 272
+    band = (b0, b1, tiling.HALO, tiling.HISTORY_HALO)
+    fi = hr.frame_inputs(gb_d, gb_d, ubo, 0, 0, sob_d, sr_d, z_buffer_params=zbp)
+    # shadows
+    o_sh = oracle.ShadowsPass(W, H)
+    o_sh.render(osc, ubo, gb, gb, sob, sr, 0)
+    g_sh = hr.RayTracedShadows(ctx, W, H, 0, band=band)
+    g_sh.render(gsc, fi)
+    torch.cuda.synchronize()
+    assert np.array_equal(helpers.bits16(g_sh.output(hr.OUTPUT_ATROUS))[b0:b1], o_sh.stages["output"][b0:b1]), "shadows band"
+    g_sh.close()
+    # AO (full-res, 1 spp: the oracle's whole 4K frame stays within seconds)
+    o_ao = oracle.AOPass(W, H, zbp=zbp)
+    o_ao.render(osc, ubo, gb, gb, sob, sr, 0)
+    g_ao = hr.RayTracedAO(ctx, W, H, 0, band=band)
+    g_ao.render(gsc, fi)
+    torch.cuda.synchronize()
+    assert np.array_equal(helpers.bits16(g_ao.image(g_ao.IMG_BLUR1))[b0:b1], o_ao.stages["blur1"][b0:b1]), "AO band"
+    g_ao.close()
+    # DDGI (whole probe grid, small ray count) + its per-pixel sample on the band, then reflections at half resolution on the band
+    lo, hi = sd.bounds()
+    u = synth_env.ddgi_uniforms(lo, hi, probe_counts=(8, 4, 8), rays_per_probe=64, normal_bias=0.25)
+    sky = synth_env.sky_cubemap(32)
+    pre, lut = synth_env.prefiltered_chain(sky, 6), synth_env.brdf_lut(32)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=32, pre_levels=6, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 32, 6, f16(lut))
+    orient = synth_env.random_orientation(np.random.RandomState(9))
+    o_gi = od.DDGIPass(u)
+    o_gi.render(osc, ubo, gb, sky, orient, 0)
+    g_gi = api_gi.DDGI(ctx, W, H, u)
+    g_gi.set_shard(0, 8, b0, b1)        # every probe slab, the band's rows of the per-pixel sample
+    g_gi.render(gsc, fi, env, orient)
+    torch.cuda.synchronize()
+    assert np.array_equal(helpers.bits16(g_gi.output())[b0:b1], o_gi.stages["output"][b0:b1]), "DDGI sample band"
+    low = helpers.nearest_mip(gb, 1)
+    w, h = W >> 1, H >> 1
+    o_rf = orf.ReflectionsPass(w, h)
+    irr, dep = o_gi.current_read()
+    o_rf.render(osc, ubo, u, low, low, sob, sr, 0, env_np, irr, dep, camera_delta=(0.0, 0.0, 0.0), full=gb, ping_pong=False)
+    lb0, lb1 = tiling.band_rows(h, world, rank)
+    g_rf = api_reflections.RayTracedReflections(ctx, W, H, 1, band=(lb0, lb1, tiling.HALO, tiling.HISTORY_HALO))
+    low_d = helpers.to_cuda(low)
+    g_rf.set_camera_delta((0.0, 0.0, 0.0))
+    g_rf.render(gsc, hr.frame_inputs(low_d, low_d, ubo, 0, 0, sob_d, sr_d, cur_full=gb_d), env, g_gi)
+    torch.cuda.synchronize()
+    at = helpers.bits16(g_rf.output(hr.OUTPUT_ATROUS))
+    assert np.array_equal(at[lb0:lb1], o_rf.stages["atrous"][-1][lb0:lb1]), "reflections band (a-trous)"
+    up = helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE))
+    assert np.array_equal(up[2 * lb0:2 * lb1], o_rf.stages["output"][2 * lb0:2 * lb1]), "reflections band (upsampled rows)"
+    g_rf.close(); g_gi.close()
+
+
+# ------------------------------------------------------------------------------------------------ (d)
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_seed(oracle, hr, ctx, seed):
+    """tools/fuzz_gpu.py's random configurations (ragged sizes, scenes, lights, camera motion, scales, every GUI parameter):
+    HIP vs oracle, all eight passes, bit for bit"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fz.run_seed(seed, oracle, hr, ctx)

@@ -8,11 +8,11 @@ from hybrid_rendering_amd import api as hr
 from oracle import pyoracle as oracle
 import test_gpu_shadows, test_gpu_ao, test_gpu_ddgi, test_gpu_reflections
 
-rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-ctx = hr.Context(0)
-bad = 0
-for trial in range(n):
+
+
+def run_passes(rng, trial, ctx, log=print):
+    """one random configuration of the four ray-traced passes; returns the list of failure strings"""
+    bad = []
     name = str(rng.choice(["cornell", "sponza_small"]))
     W, H = int(rng.randint(9, 200)), int(rng.randint(9, 140))
     kind = str(rng.choice(["default", "point", "spot"]) if name != "cornell" else rng.choice(["default", "soft"]))
@@ -44,15 +44,15 @@ for trial in range(n):
             res.append(label + " ok")
         except Exception as e:
             if not isinstance(e, AssertionError):
-                res.append(label + " ERROR: " + repr(e)[:120]); bad += 1
+                res.append(label + " ERROR: " + repr(e)[:120]); bad.append(res[-1])
                 continue
             if not str(e).strip():                        # the runners' own scene-coverage checks carry no message: not a parity failure
                 res.append(label + " ok")
             else:
                 res.append(label + " MISMATCH: " + str(e)[:100])
-                bad += 1
-    print(trial, name, (W, H), kind, "scale", scale, "dolly %.2f" % dolly, "random params" if sp else "default params", res, flush=True)
-
+                bad.append(res[-1])
+    log(trial, name, (W, H), kind, "scale", scale, "dolly %.2f" % dolly, "random params" if sp else "default params", res, flush=True)
+    return bad
 
 # ---- second half: the downstream passes (deferred composite, TAA, tone map, ground truth) and textured hit shading ---------
 import torch
@@ -60,7 +60,9 @@ import helpers
 from hybrid_rendering_amd import api_deferred, api_gi, api_post, synth, synth_env
 from oracle import pyoracle_deferred as odf, pyoracle_post as opost
 
-for trial in range(n):
+
+def run_post(rng, trial, ctx, log=print):
+    """one random configuration of the downstream passes; returns the list of failure strings"""
     name = str(rng.choice(["cornell", "sponza_small"]))
     W, H = int(rng.randint(9, 200)), int(rng.randint(9, 140))
     kind = str(rng.choice(["default", "point", "spot"]) if name != "cornell" else rng.choice(["default", "soft"]))
@@ -121,8 +123,29 @@ for trial in range(n):
         torch.cuda.synchronize()
         ok &= bool(np.array_equal(helpers.bits16(g_g.output()), ref))
     res.append("ground_truth " + ("ok" if ok else "MISMATCH"))
-    bad += sum("MISMATCH" in r for r in res)
-    print("post", trial, name, (W, H), kind, "textured" if trial % 2 else "plain", "flags", flags, res, flush=True)
+    log("post", trial, name, (W, H), kind, "textured" if trial % 2 else "plain", "flags", flags, res, flush=True)
     for p in (g_df, g_t, g_g, gsc):
         p.close()
-print("mismatches:", bad)
+    return [r for r in res if "MISMATCH" in r]
+
+
+def run_seed(seed, oracle_=None, hr_=None, ctx=None):
+    """tests/test_gpu_configs.py::test_fuzz_seed: configuration `seed` of both halves; raises on any mismatch"""
+    ctx = ctx or hr.Context(0)
+    rng = np.random.RandomState(7000 + seed)
+    lines = []
+    log = lambda *a, **k: lines.append(" ".join(str(x) for x in a))
+    bad = run_passes(rng, seed, ctx, log) + run_post(rng, seed, ctx, log)
+    assert not bad, "\n".join(lines)
+
+
+if __name__ == "__main__":
+    rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    ctx = hr.Context(0)
+    bad = 0
+    for trial in range(n):
+        bad += len(run_passes(rng, trial, ctx))
+    for trial in range(n):
+        bad += len(run_post(rng, trial, ctx))
+    print("mismatches:", bad)

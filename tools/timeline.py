@@ -17,10 +17,13 @@ fi = hr.frame_inputs(gb, gb, ubo, 0, 0, sob_d, sr_d)
 for _ in range(3):
     p.ray_trace(sc, fi)
 torch.cuda.synchronize()
+# the library reads its developer switches when a pass object is created (never in render): a second pass carries them
 os.environ['HR_DEBUG_TIMELINE'] = path
-p.ray_trace(sc, fi)
-torch.cuda.synchronize()
+pt = hr.RayTracedShadows(ctx, W, H)
 del os.environ['HR_DEBUG_TIMELINE']
+pt.ray_trace(sc, fi)
+torch.cuda.synchronize()
+pt.close()
 t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
 t0 = t[:, 0].min()
 start = (t[:, 0] - t0).astype(np.float64) * 0.01   # us (100 MHz)
@@ -67,7 +70,9 @@ if os.environ.get('HR_DEBUG_TIMELINE_STATS'):
 for i in heavy[:4]:
     os.environ['HR_DEBUG_ONLY_TILE'] = '%d,%d' % (i % tiles_x, i // tiles_x)
     os.environ['HR_DEBUG_TIMELINE'] = path
-    p.ray_trace(sc, fi); torch.cuda.synchronize()
+    pt = hr.RayTracedShadows(ctx, W, H)
     del os.environ['HR_DEBUG_TIMELINE'], os.environ['HR_DEBUG_ONLY_TILE']
+    pt.ray_trace(sc, fi); torch.cuda.synchronize()
+    pt.close()
     t1 = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
     print('tile (%d,%d): %.1f us in the full launch, %.1f us alone' % (i % tiles_x, i // tiles_x, dur[i], (float(t1[i, 1]) - float(t1[i, 0])) * 0.01))
