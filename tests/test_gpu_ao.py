@@ -37,7 +37,7 @@ def _run_case(oracle, hr, ctx, name, W, H, scale, n_frames, dolly, spp=1, params
         mh = (h + 3) // 4
         mask = gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32)[:spp * mh].reshape(spp, mh, -1)
         assert int((mask != st["mask"]).sum()) == 0, f"frame {f}: AO mask differs"
-        assert gp.ray_count() == st["rays"]
+        assert gp.ray_count() == st["rays"], f"frame {f}: ray count"
         assert np.array_equal(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"]), f"frame {f}: tiles"
         assert np.array_equal(helpers.bits16(gp.image(gp.IMG_AO1 if ping else gp.IMG_AO0)), st["temporal"]), f"frame {f}: temporal AO"
         assert np.array_equal(helpers.bits16(gp.image(gp.IMG_LEN1 if ping else gp.IMG_LEN0)), st["length"]), f"frame {f}: history length"

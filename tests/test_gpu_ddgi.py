@@ -46,7 +46,7 @@ def _run(oracle, hr, ctx, name, w, h, counts, rays, n_frames, light_kind="defaul
         assert np.array_equal(helpers.bits16(gp.image(wr)), st["irradiance"]), f"frame {f}: irradiance atlas"
         assert np.array_equal(helpers.bits16(gp.image(wd)), st["depth"]), f"frame {f}: depth atlas"
         ci, cd = gp.current_read()
-        assert np.array_equal(helpers.bits16(ci), st["irradiance"]) and np.array_equal(helpers.bits16(cd), st["depth"])
+        assert np.array_equal(helpers.bits16(ci), st["irradiance"]) and np.array_equal(helpers.bits16(cd), st["depth"]), f"frame {f}: current_read atlases"
         assert np.array_equal(helpers.bits16(gp.output()), st["output"]), f"frame {f}: sampled irradiance"
     assert (oracle.f16(op.stages["output"][..., :3]) > 0).mean() > 0.2
     gp.close()

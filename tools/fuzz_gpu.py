@@ -46,7 +46,9 @@ def run_passes(rng, trial, ctx, log=print):
             if not isinstance(e, AssertionError):
                 res.append(label + " ERROR: " + repr(e)[:120]); bad.append(res[-1])
                 continue
-            if not str(e).strip():                        # the runners' own scene-coverage checks carry no message: not a parity failure
+            # every parity assertion of the runners carries a "frame N: ..." message; their scene-coverage checks carry none (or,
+            # under pytest's assertion rewriting, the rewritten expression): a random 24-row image may not cover every regime
+            if not str(e).lstrip().startswith("frame"):
                 res.append(label + " ok")
             else:
                 res.append(label + " MISMATCH: " + str(e)[:100])
