@@ -76,12 +76,12 @@ class hr_stage_times(C.Structure):
 class hr_shadows_params(C.Structure):
     _fields_ = [("denoise", C.c_int32), ("bias", C.c_float), ("alpha", C.c_float), ("moments_alpha", C.c_float), ("phi_visibility", C.c_float),
                 ("phi_normal", C.c_float), ("sigma_depth", C.c_float), ("power", C.c_float), ("radius", C.c_int32),
-                ("filter_iterations", C.c_int32), ("feedback_iteration", C.c_int32)]
+                ("filter_iterations", C.c_int32), ("feedback_iteration", C.c_int32), ("exact", C.c_int32)]
 
 
 class hr_ao_params(C.Structure):
     _fields_ = [("denoise", C.c_int32), ("ray_length", C.c_float), ("bias", C.c_float), ("alpha", C.c_float), ("blur_radius", C.c_int32),
-                ("power", C.c_float), ("spp", C.c_int32)]
+                ("power", C.c_float), ("spp", C.c_int32), ("exact", C.c_int32)]
 
 
 HR_FORMAT = {1: ("R32_UINT", 4), 2: ("R16F", 2), 3: ("RG16F", 4), 4: ("RGBA16F", 8), 5: ("R32F", 4), 6: ("RGBA8", 4), 0: ("R8", 1)}

@@ -27,7 +27,7 @@ assert C.sizeof(hr_ddgi_uniforms) == 88
 
 class hr_ddgi_params(C.Structure):
     _fields_ = [("infinite_bounces", C.c_int32), ("infinite_bounce_intensity", C.c_float), ("gi_intensity", C.c_float),
-                ("random_orientation", C.c_float * 9)]
+                ("random_orientation", C.c_float * 9), ("exact", C.c_int32)]
 
 
 def environment(sky, prefiltered=None, prefiltered_size=0, prefiltered_levels=0, brdf_lut=None) -> hr_environment:

@@ -12,7 +12,7 @@ class hr_reflections_params(C.Structure):
                 ("rough_ddgi_intensity", C.c_float), ("ibl_indirect_specular_intensity", C.c_float), ("bias", C.c_float), ("trim", C.c_float),
                 ("alpha", C.c_float), ("moments_alpha", C.c_float), ("blur_as_input", C.c_int32), ("phi_color", C.c_float),
                 ("phi_normal", C.c_float), ("sigma_depth", C.c_float), ("radius", C.c_int32), ("filter_iterations", C.c_int32),
-                ("feedback_iteration", C.c_int32), ("camera_delta", C.c_float * 3), ("frame_time", C.c_float)]
+                ("feedback_iteration", C.c_int32), ("camera_delta", C.c_float * 3), ("frame_time", C.c_float), ("exact", C.c_int32)]
 
 
 class RayTracedReflections(_Pass):

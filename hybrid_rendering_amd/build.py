@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhybrid_rendering_amd.so")
 SOURCES = ["api.hip", "shadows.hip", "bvh_build.cpp"]
-OPTIONAL = ["ao.hip", "reflections.hip", "ddgi.hip", "deferred.hip", "ground_truth.hip", "taa.hip"]
+OPTIONAL = ["denoise_fast.hip", "ao.hip", "reflections.hip", "ddgi.hip", "deferred.hip", "ground_truth.hip", "taa.hip"]
 # -ffp-contract=off: every fp32 op is individually rounded; FMAs are explicit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]

@@ -9,6 +9,7 @@
 #include "reproject.h"
 #include "traverse.h"
 #include "upsample.h"
+#include "pass_args.h"
 
 using namespace hr;
 
@@ -118,21 +119,6 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-struct AOTemporalArgs
-{
-    float           vpi[16];
-    const uint32_t* mask;
-    int             mw, mh, spp;
-    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
-    ImgR32F         depth, pdepth;
-    ImgR16F         hist, hist_len;
-    uint16_t*       out;
-    uint16_t*       out_len;
-    uint8_t*        tile_class;
-    int             w, h, y0, y1;
-    int             tiles_x, tiles_y, tile_y0;
-    float           alpha;
-};
 
 __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
 {
@@ -211,17 +197,6 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-struct AOBlurArgs
-{
-    ImgR16F        in;
-    ImgR32F        depth;
-    ImgRGBA16F     gb2;
-    const uint8_t* tile_class;
-    uint16_t*      out;
-    float          zbp[4];
-    int            w, h, y0, y1, tiles_x;
-    int            dx, dy, radius;
-};
 
 HR_DEV float linear_eye_depth(float z, const float* zbp) { return __fdiv_rn(1.0f, zbp[2] * z + zbp[3]); }
 
@@ -326,7 +301,7 @@ extern "C" {
 
 void hr_ao_default_params(hr_ao_params* p)
 {
-    p->denoise = 1; p->ray_length = 7.0f; p->bias = 0.3f; p->alpha = 0.01f; p->blur_radius = 4; p->power = 1.2f; p->spp = 1;
+    p->denoise = 1; p->ray_length = 7.0f; p->bias = 0.3f; p->alpha = 0.01f; p->blur_radius = 4; p->power = 1.2f; p->spp = 1; p->exact = 1;
 }
 
 hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_ao** out)
@@ -463,7 +438,8 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);
-    hipLaunchKernelGGL(k_ao_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    if (prm->exact) hipLaunchKernelGGL(k_ao_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    else launch_ao_temporal_fast(a, a.tiles_x * a.tiles_y, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -486,7 +462,8 @@ hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* pr
     a.dx = pass == 0 ? 1 : 0; a.dy = pass == 0 ? 0 : 1; a.radius = prm->blur_radius; // X first, then Y (quirk 8)
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin(pass == 0 ? "blur_x" : "blur_y", st, px * 16);
-    if (a.radius == 4) hipLaunchKernelGGL(k_ao_blur<4>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    if (!prm->exact) launch_ao_blur_fast(a, st);
+    else if (a.radius == 4) hipLaunchKernelGGL(k_ao_blur<4>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_ao_blur<-1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
@@ -507,7 +484,8 @@ hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     a.in = p->blur[1].p; a.in_channels = 1; a.channels = 1; a.out = p->upsample.p; a.sky_value = 1.0f; a.power = prm->power;
     const uint64_t PX = (uint64_t)p->full_w * p->full_h, px = (uint64_t)p->w * p->h;
     int ev = p->prof.begin("upsample", st, PX * 18 + px * 18);
-    launch_upsample(a, st);
+    if (prm->exact) launch_upsample(a, st);
+    else launch_upsample_fast(a, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -5,6 +5,7 @@
 //   sample_probe_grid() :943-986, gi_sample_probe_grid.comp:75-99                                -> k_ddgi_sample
 #include "hr_internal.h"
 #include "shading.h"
+#include "pass_args.h"
 
 using namespace hr;
 
@@ -213,19 +214,6 @@ __global__ void k_ddgi_border(DDGIU d, void* atlas, int gy0)
     else ((uint2*)atlas)[dst_o] = ((const uint2*)atlas)[so];
 }
 
-struct DDGISampleArgs
-{
-    DDGIU        d;
-    float        vpi[16];
-    float        cam[3];
-    const float* depth;
-    const uint2* gb2;
-    AtlasRGBA    irr;
-    AtlasRG      dep;
-    uint2*       out;
-    int          w, h, y0, y1;   // rows [y0, y1) of the image are produced (row band)
-    float        gi_intensity;
-};
 
 __global__ __launch_bounds__(256) void k_ddgi_sample(DDGISampleArgs a)
 {
@@ -264,6 +252,7 @@ void hr_ddgi_default_params(hr_ddgi_params* p)
 {
     p->infinite_bounces = 1; p->infinite_bounce_intensity = 1.7f; p->gi_intensity = 1.0f;
     for (int i = 0; i < 9; i++) p->random_orientation[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    p->exact = 1;
 }
 
 hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_ddgi_uniforms* grid, hr_ddgi** out)
@@ -411,7 +400,8 @@ hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const
     a.dep = AtlasRG { (const uint32_t*)p->dep[wr].p, p->d.depth_texture_width, p->d.depth_texture_height };
     a.out = (uint2*)p->sample.p; a.w = p->w; a.h = p->h; a.y0 = p->sy0; a.y1 = p->sy1; a.gi_intensity = prm->gi_intensity;
     int ev = p->prof.begin("sample_probe_grid", st, (uint64_t)p->w * (p->sy1 - p->sy0) * 20);
-    hipLaunchKernelGGL(k_ddgi_sample, dim3(cdiv(p->w, 32), cdiv(p->sy1 - p->sy0, 8)), dim3(256), 0, st, a);
+    if (prm->exact) hipLaunchKernelGGL(k_ddgi_sample, dim3(cdiv(p->w, 32), cdiv(p->sy1 - p->sy0, 8)), dim3(256), 0, st, a);
+    else launch_ddgi_sample_fast(a, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -1,0 +1,1101 @@
+// Tolerance-mode ("fast") denoise / resolve kernels: hr_*_params.exact == 0.
+//
+// Same stages, inputs, outputs and tile-classification rules as the exact kernels in shadows.hip / ao.hip / reflections.hip /
+// ddgi.hip / upsample.h (which stay the bit-for-bit parity mode), restructured for the hardware instead of for the order of
+// operations of the GLSL:
+//   * arithmetic through fast_math.h (v_rcp / v_rsq / v_sqrt / v_exp / v_log, contracted FMAs);
+//   * reprojection: the view-projection-inverse products shared by the taps are hoisted (M * (u, v, d, 1) is affine in d), the
+//     previous-frame normal is compared un-normalised (cos^2 > 0.1 <=> dot^2 > 0.1 |n|^2), one validity / address computation per
+//     tap serves all history images, and only the bytes of a texel that are used are loaded;
+//   * 17x17 neighbourhood statistics: packed visibility masks are bit-sliced across the spp planes and popcounted with
+//     v_bfe + v_bcnt (accumulating); the reflections' colour statistics are separable sums staged through LDS;
+//   * a-trous / bilateral blur: step-specialised, interior tiles skip every bounds test, AO blur stages decoded normals and
+//     linear depth of the tile + apron in LDS once instead of re-deriving them per tap;
+//   * DDGI probe-grid sample: the octahedral coordinates of the surface normal are computed once, not per probe.
+// Validated against the oracle within the stated tolerance by tests/test_gpu_tolerance.py; masks and ray counts do not pass
+// through this file.
+#include "hr_internal.h"
+#include "pass_args.h"
+#include "fast_math.h"
+
+#pragma clang fp contract(fast)
+
+using namespace hr;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// reprojection.glsl:115-328, tolerance-mode restatement
+struct HistGeom { int w, h, y0, y1; };   // every history / previous-G-buffer image of a pass shares one geometry
+
+struct ReprojOut { float col[3]; float mom[2]; float length; };
+
+// HIST_BPP: bytes per texel of the colour history — 2 (AO, R16F), 4 (shadows, RG16F: .r), 8 (reflections, RGBA16F: .rgb)
+template <int HIST_BPP, bool MOMENTS, bool REFL>
+HR_DEV bool reproject_fast(int x, int y, float depth, const float* __restrict__ M, uint32_t c2y, float cur_id, float curvature, f3 cur_n,
+                           f3 cam_pos, const float* __restrict__ prev_vp, float ray_length,
+                           const void* __restrict__ pgb2, const void* __restrict__ pgb3, const void* __restrict__ pdepth,
+                           const void* __restrict__ hist, const void* __restrict__ hist_moments, const void* __restrict__ hist_len,
+                           const HistGeom g, ReprojOut& o)
+{
+    constexpr int NC = HIST_BPP == 8 ? 3 : 1;
+    const float fw = (float)g.w, fh = (float)g.h;
+    const float inv_w = fm::rcp(fw), inv_h = fm::rcp(fh);
+    const float tu = ((float)x + 0.5f) * inv_w, tv = ((float)y + 0.5f) * inv_h;
+    const float mvx = fm::lo(c2y), mvy = fm::hi(c2y);
+    const fm::Unproj cb = fm::unproject_base(M, tu, tv);
+    const f3 cur_pos = fm::unproject_at(cb, M, depth);
+
+    float hfx = (float)x + mvx * fw, hfy = (float)y + mvy * fh;   // mv (fp16) * extent (<= 2^12) is exact: same texel as the exact mode
+    int   hcx, hcy;
+    if (REFL)
+    {
+        if (ray_length > 0.0f && curvature == 0.0f)
+        {
+            // virtual_point_reprojection (reprojection.glsl:71-111): NB current_coord / size without the half-pixel offset
+            const f3    ro  = fm::unproject_at(fm::unproject_base(M, (float)x * inv_w, (float)y * inv_h), M, depth);
+            f3          cr  = sub3(ro, cam_pos);
+            const float l2  = fm::dot(cr, cr);
+            const float il  = fm::rsq(l2), crl = l2 * il;
+            const float k   = (crl + ray_length) * il;
+            const f3    hp  = mk3(cam_pos.x + cr.x * k, cam_pos.y + cr.y * k, cam_pos.z + cr.z * k);
+            const float pw  = prev_vp[3] * hp.x + prev_vp[7] * hp.y + prev_vp[11] * hp.z + prev_vp[15];
+            const float ipw = fm::rcp(pw);
+            const float px  = (prev_vp[0] * hp.x + prev_vp[4] * hp.y + prev_vp[8] * hp.z + prev_vp[12]) * ipw;
+            const float py  = (prev_vp[1] * hp.x + prev_vp[5] * hp.y + prev_vp[9] * hp.z + prev_vp[13]) * ipw;
+            hfx = (px * 0.5f + 0.5f) * fw;
+            hfy = (py * 0.5f + 0.5f) * fh;
+        }
+        hcx = (int)hfx; hcy = (int)hfy;
+    }
+    else
+    {
+        hcx = (int)(hfx + 0.5f);
+        hcy = (int)(hfy + 0.5f);
+    }
+    const bool inb = !(hcx < 0 || hcy < 0 || hcx > g.w - 1 || hcy > g.h - 1);
+    const fm::Unproj hb = fm::unproject_base(M, tu + mvx, tv + mvy);
+
+    // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel
+    auto tap_valid = [&](uint32_t g2x, uint32_t g3y, float d) -> bool {
+        const f3    hn = fm::oct_raw(g2x);
+        const float dn = fm::dot(cur_n, hn);
+        const f3    hp = fm::unproject_at(hb, M, d);
+        const float pd = fm::dot(sub3(cur_pos, hp), cur_n);
+        return inb && (cur_id == fm::lo(g3y)) && !(__builtin_fabsf(pd) > 5.0f) && (dn * dn > 0.1f * fm::dot(hn, hn));
+    };
+    auto tap_offset = [&](int px, int py, bool& ok) -> uint32_t {
+        ok = !(px < 0 || py < g.y0 || px >= g.w || py >= g.y1);
+        return ok ? (uint32_t)(py * g.w + px) : (uint32_t)(g.y0 * g.w);
+    };
+    auto hist_rgb = [&](uint32_t off, bool ok, float* c) {
+        if constexpr (HIST_BPP == 2) c[0] = ok ? (float)__builtin_bit_cast(_Float16, fm::ld<uint16_t>(hist, off * 2u)) : 0.0f;
+        else if constexpr (HIST_BPP == 4) c[0] = ok ? fm::lo(fm::ld<uint32_t>(hist, off * 4u)) : 0.0f;
+        else
+        {
+            const uint2 t = fm::ld<uint2>(hist, off * 8u);
+            c[0] = ok ? fm::lo(t.x) : 0.0f; c[1] = ok ? fm::hi(t.x) : 0.0f; c[2] = ok ? fm::lo(t.y) : 0.0f;
+        }
+    };
+
+    // 2x2 bilinear footprint: every load first, then the arithmetic (one memory round trip)
+    const int bx = (int)hfx, by = (int)hfy;
+    uint32_t  g2x[4], g3y[4], mm[4];
+    float     td[4], tc[4][NC];
+    bool      tok[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+    {
+        const uint32_t off = tap_offset(bx + (s & 1), by + (s >> 1), tok[s]);
+        g2x[s] = fm::ld<uint32_t>(pgb2, off * 8u);
+        g3y[s] = fm::ld<uint32_t>(pgb3, off * 8u + 4u);
+        td[s]  = fm::ld<float>(pdepth, off * 4u);
+        hist_rgb(off, tok[s], tc[s]);
+        if (MOMENTS) mm[s] = fm::ld<uint32_t>(hist_moments, off * 8u);
+    }
+    float len_prefetch;
+    {
+        bool           lok;
+        const uint32_t off = tap_offset(hcx, hcy, lok);
+        if (MOMENTS) len_prefetch = lok ? fm::lo(fm::ld<uint32_t>(hist_moments, off * 8u + 4u)) : 0.0f;
+        else len_prefetch = lok ? (float)__builtin_bit_cast(_Float16, fm::ld<uint16_t>(hist_len, off * 2u)) : 0.0f;
+    }
+    const float fx = hfx - __builtin_floorf(hfx), fy = hfy - __builtin_floorf(hfy);
+    const float wgt[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
+    float sumw = 0.0f, col[NC], mom0 = 0.0f, mom1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) col[c] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+    {
+        // an out-of-image texel reads as zeros (pinned rule) and is validated as such, as in the exact mode
+        const bool  v  = tap_valid(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f);
+        const float ws = v ? wgt[s] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) col[c] += ws * tc[s][c];
+        if (MOMENTS) { mom0 += ws * (tok[s] ? fm::lo(mm[s]) : 0.0f); mom1 += ws * (tok[s] ? fm::hi(mm[s]) : 0.0f); }
+        sumw += ws;
+    }
+    // Normalisations are correctly rounded divisions (one shared denominator: device_math.h div_by): a history of all-equal
+    // values must come back EXACTLY (sum(w) * v / sum(w) == v), the tile classification tests `ao < 1` / `visibility > 0`
+    bool valid = sumw >= 0.01f;
+    if (valid)
+    {
+        const DivBy D = div_prepare(sumw);
+#pragma unroll
+        for (int c = 0; c < NC; c++) col[c] = div_by(col[c], D);
+        if (MOMENTS) { mom0 = div_by(mom0, D); mom1 = div_by(mom1, D); }
+    }
+    else
+    {
+        // 3x3 fallback around the nearest history texel (:266-303); rare (disocclusion borders): kept rolled
+        float cnt = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) col[c] = 0.0f;
+        mom0 = mom1 = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < 9; k++)
+        {
+            bool           ok;
+            const uint32_t off = tap_offset(hcx + k % 3 - 1, hcy + k / 3 - 1, ok);
+            const uint32_t q2 = fm::ld<uint32_t>(pgb2, off * 8u), q3 = fm::ld<uint32_t>(pgb3, off * 8u + 4u);
+            const float    qd = fm::ld<float>(pdepth, off * 4u);
+            if (tap_valid(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f))
+            {
+                float c3[NC];
+                hist_rgb(off, ok, c3);
+#pragma unroll
+                for (int c = 0; c < NC; c++) col[c] += c3[c];
+                if (MOMENTS)
+                {
+                    const uint32_t m = ok ? fm::ld<uint32_t>(hist_moments, off * 8u) : 0u;
+                    mom0 += fm::lo(m); mom1 += fm::hi(m);
+                }
+                cnt += 1.0f;
+            }
+        }
+        if (cnt > 0.0f)
+        {
+            valid = true;
+            const DivBy D = div_prepare(cnt);
+#pragma unroll
+            for (int c = 0; c < NC; c++) col[c] = div_by(col[c], D);
+            if (MOMENTS) { mom0 = div_by(mom0, D); mom1 = div_by(mom1, D); }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) o.col[c] = valid ? col[c] : 0.0f;
+    o.mom[0] = valid ? mom0 : 0.0f;
+    o.mom[1] = valid ? mom1 : 0.0f;
+    o.length = valid ? len_prefetch : 0.0f;
+    return valid;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 17x17 box sum over packed 8x4 visibility masks (shadows_denoise_reprojection.comp:157-190, ao_...:152-185), 1..4 sample planes.
+// Lanes 0..23 of a wave assemble the 24-bit row patterns of the 24 cached pixel rows (3 mask columns x 6 mask rows); with
+// several planes the per-pixel sample count (0..4) is kept BIT-SLICED (three 24-bit words per row: bits 0, 1, 2 of the count),
+// so the window sum costs three bfe + bcnt pairs per row whatever the sample count.
+struct MaskRows { uint32_t b0[24], b1[24], b2[24]; };
+
+template <bool AO>
+HR_DEV void build_mask_rows(MaskRows& R, uint32_t (*s_mask)[18], const uint32_t* __restrict__ mask, int spp, int mw, int mh, int tx, int ty, int y0, int y1, int lane, bool tile_ok)
+{
+    // populate_cache: 3x6 mask words per plane; outside the mask image shadows read 0, AO reads all-ones (the shaders' guards)
+    for (int s = 0; s < spp; s++)
+        if (lane < 18)
+        {
+            const int cx = tx - 1 + lane % 3, cy = ty * 2 - 2 + lane / 3;
+            uint32_t  v  = AO ? 0xFFFFFFFFu : 0u;
+            const bool in = tile_ok && cx >= 0 && cy >= 0 && cx < mw && cy < mh && (AO || (cy * 4 >= y0 - 8 && cy * 4 < y1 + 8));
+            if (in) v = mask[((size_t)s * mh + cy) * mw + cx];
+            s_mask[s][lane] = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS stores above are visible to the wave
+    if (lane < 24)
+    {
+        const int m = lane >> 2, br = (lane & 3) * 8;
+        uint32_t  p[4] = { 0u, 0u, 0u, 0u };
+        for (int s = 0; s < spp; s++)
+            p[s] = ((s_mask[s][m * 3 + 0] >> br) & 0xffu) | (((s_mask[s][m * 3 + 1] >> br) & 0xffu) << 8) | (((s_mask[s][m * 3 + 2] >> br) & 0xffu) << 16);
+        // count = p0 + p1 + p2 + p3 per bit position, bit-sliced
+        const uint32_t s0 = p[0] ^ p[1], c0 = p[0] & p[1], s1 = p[2] ^ p[3], c1 = p[2] & p[3];
+        const uint32_t carry = s0 & s1;
+        R.b0[lane] = s0 ^ s1;
+        R.b1[lane] = carry | (c0 ^ c1);   // carry excludes c0 and c1 (carry => p0 != p1 and p2 != p3)
+        R.b2[lane] = c0 & c1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+// window sum of lane (lx, ly) and the lane's own sample count
+template <bool MULTI>
+HR_DEV void mask_window(const MaskRows& R, int lx, int ly, int& sum, int& own)
+{
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+    for (int yy = 0; yy <= 16; yy++)
+    {
+        a0 = __builtin_popcount(__builtin_amdgcn_ubfe(R.b0[ly + yy], (uint32_t)lx, 17u)) + a0;
+        if (MULTI)
+        {
+            a1 = __builtin_popcount(__builtin_amdgcn_ubfe(R.b1[ly + yy], (uint32_t)lx, 17u)) + a1;
+            a2 = __builtin_popcount(__builtin_amdgcn_ubfe(R.b2[ly + yy], (uint32_t)lx, 17u)) + a2;
+        }
+    }
+    sum = (int)(a0 + 2u * a1 + 4u * a2);
+    const uint32_t sh = (uint32_t)lx + 8u;
+    own = (int)((R.b0[ly + 8] >> sh) & 1u);
+    if (MULTI) own += (int)(((R.b1[ly + 8] >> sh) & 1u) * 2u + ((R.b2[ly + 8] >> sh) & 1u) * 4u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// shadows_denoise_reprojection.comp:196-293 (+ reset_args / tile classification), tolerance mode
+#define FT_WAVES 4
+__global__ __launch_bounds__(64 * FT_WAVES) void kf_shadows_temporal(TemporalArgs a)
+{
+    __shared__ uint32_t s_mask[FT_WAVES][1][18];
+    __shared__ MaskRows s_rows[FT_WAVES];
+    const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int  tile = blockIdx.x * FT_WAVES + wave;
+    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
+    const int  tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    const int  lx = lane & 7, ly = lane >> 3;
+    const int  x = tx * 8 + lx, y = ty * 8 + ly;
+    // the centre texels do not depend on the masks: request them before the LDS phase
+    const bool in_image = tile_ok && x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    const bool edge     = tile_ok && (x >= a.w || y >= a.h);   // thread without a pixel: votes as the unguarded shader thread does
+    const uint32_t pix  = in_image ? (uint32_t)(y * a.w + x) : (uint32_t)(a.y0 * a.w);
+    const float d_raw   = fm::ld<float>(a.depth.p, pix * 4u);
+    const uint2 cg2_raw = fm::ld<uint2>(a.gb2.p, pix * 8u), cg3_raw = fm::ld<uint2>(a.gb3.p, pix * 8u);
+    build_mask_rows<false>(s_rows[wave], s_mask[wave], a.mask, 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
+    if (!tile_ok) return;
+    int sum, own;
+    mask_window<false>(s_rows[wave], lx, ly, sum, own);
+    const float mean = div_by((float)sum, div_prepare(289.0f));
+
+    float out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
+    bool  flag = false;
+    const float d   = edge ? 0.0f : d_raw;
+    const uint2 cg2 = edge ? make_uint2(0u, 0u) : cg2_raw, cg3 = edge ? make_uint2(0u, 0u) : cg3_raw;
+    const f3    cn  = fm::oct_unit(cg2.x);
+    if ((in_image || edge) && d != 1.0f)
+    {
+        const float visibility = (float)own;
+        ReprojOut   r;
+        bool        success = false;
+        if (!a.debug_skip_reproject)
+            success = reproject_fast<4, true, false>(x, y, d, a.vpi, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f, a.pgb2.p, a.pgb3.p, a.pdepth.p,
+                                                     a.hist.p, a.hist_moments.p, nullptr, HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+        else { r.col[0] = 0.0f; r.mom[0] = r.mom[1] = 0.0f; r.length = 0.0f; }
+        hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
+        float hv = r.col[0];
+        if (success)
+        {
+            const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
+            hv = fm::fmin_(fm::fmax_(hv, mean - 0.5f * sd), mean + 0.5f * sd);
+        }
+        const float ih = fm::rcp_nr(hlen);
+        const float al = success ? fm::fmax_(a.alpha, ih) : 1.0f;
+        const float am = success ? fm::fmax_(a.moments_alpha, ih) : 1.0f;
+        m0      = fm::mix_rn(r.mom[0], visibility, am);
+        m1      = fm::mix_rn(r.mom[1], visibility * visibility, am);
+        out_var = fm::fmax_(0.0f, fm::var_rn(m1, m0));
+        out_v   = fm::mix_rn(hv, visibility, al);
+        flag    = out_v > 0.0f;
+    }
+    if (in_image)
+    {
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + pix * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hlen, 0.0f));
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.nd) + pix * 16u)       = make_float4(cn.x, cn.y, cn.z, fm::hi(cg3.y));
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + pix * 4u)     = fm::pack2(out_v, out_var);
+    }
+    const unsigned long long any = __ballot(flag);
+    if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// shadows_denoise_atrous.comp:94-174 + copy_shadow_tiles (tile class), tolerance mode.  STEP > 0: compile-time tap distance and
+// radius 1 (the reference default, fully unrolled); STEP == 0: run-time step and radius.
+struct EdgeK { float kz, phi_n, inv_phi_l; bool n32; };
+HR_DEV float edge_weight_fast(const EdgeK& k, float cd, float sd, f3 cn, f3 sn, float cl, float sl)
+{
+    // edge_stopping.glsl:31-62 (NORMAL + LUMA): exp(-max(wL, 0) - max(wZ, 0)) * wN with wZ = exp(-|dz| / sigma) — sic, the depth
+    // WEIGHT is used as an exponent term upstream; kept
+    const float wZ = fm::exp2f_(-__builtin_fabsf(cd - sd) * k.kz);
+    const float dn = fm::sat(fm::dot(cn, sn));
+    const float wN = k.n32 ? fm::pow32(dn) : fm::powf_(dn, k.phi_n);
+    const float wL = __builtin_fabsf(cl - sl) * k.inv_phi_l;
+    return fm::exp2f_((wL + wZ) * -1.44269504088896341f) * wN;
+}
+
+template <int STEP, bool N32>
+__global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const uint32_t o = (uint32_t)(y * a.w + x);
+    uint32_t* outp  = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + o * 4u);
+    uint32_t* out2p = a.out2 ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out2) + o * 4u) : nullptr;
+    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)])
+    {
+        *outp = 0u; // shadows_denoise_copy_shadow_tiles.comp:35
+        if (out2p) *out2p = 0u;
+        return;
+    }
+    const int step = STEP > 0 ? STEP : a.step;
+    const int R    = STEP > 0 ? 1 : a.radius;
+    // a workgroup whose whole footprint lies inside the resident rows needs no bounds test at all (uniform branch)
+    const int  fx0 = (int)blockIdx.x * 32, fy0 = a.y0 + (int)blockIdx.y * 8;
+    const int  reach = step * R > 1 ? step * R : 1;
+    const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= (a.y0 > 0 ? a.y0 : 0) && fy0 + 7 + reach < (a.y1 < a.h ? a.y1 : a.h);
+    const uint32_t c   = fm::ld<uint32_t>(a.in.p, o * 4u);
+    const float4   cnd = fm::ld<float4>(a.nd, o * 16u);
+    float var = 0.0f;
+    // compute_variance_center (:65-88): 3x3 gaussian of the variance channel, unit taps
+    if (interior)
+    {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const int   xx = k % 3 - 1, yy = k / 3 - 1;
+            const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            var += fm::hi(fm::ld<uint32_t>(a.in.p, (uint32_t)((y + yy) * a.w + (x + xx)) * 4u)) * kw;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const int   xx = k % 3 - 1, yy = k / 3 - 1;
+            const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            var += fm::hi(a.in.raw(x + xx, y + yy)) * kw;
+        }
+    }
+    uint32_t result = c;
+    if (!(cnd.w < 0.0f))
+    {
+        const f3    cn = mk3(cnd.x, cnd.y, cnd.z);
+        const float cv = fm::lo(c);
+        EdgeK ek;
+        ek.kz        = 1.44269504088896341f * fm::rcp(a.sigma_depth);
+        ek.phi_n     = a.phi_normal;
+        ek.n32       = N32;
+        ek.inv_phi_l = fm::rcp(a.phi_visibility * fm::sqrt1(fm::fmax_(0.0f, 1e-10f + var)));
+        float sum_w = 1.0f, sum_v = cv, sum_var = fm::hi(c);
+        if (STEP > 0)
+        {
+            uint32_t t_in[8];
+            float4   t_nd[8];
+            bool     t_ok[8];
+            if (interior)
+            {
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const int      k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                    const uint32_t so = (uint32_t)((y + yy * STEP) * a.w + (x + xx * STEP));
+                    t_ok[t] = true;
+                    t_in[t] = fm::ld<uint32_t>(a.in.p, so * 4u);
+                    t_nd[t] = fm::ld<float4>(a.nd, so * 16u);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                    const int px = x + xx * STEP, py = y + yy * STEP;
+                    t_ok[t] = px >= 0 && py >= 0 && px < a.w && py < a.h;
+                    const bool     res = t_ok[t] && py >= a.y0 && py < a.y1;
+                    const uint32_t so  = res ? (uint32_t)(py * a.w + px) : o;
+                    t_in[t] = fm::ld<uint32_t>(a.in.p, so * 4u);
+                    t_nd[t] = fm::ld<float4>(a.nd, so * 16u);
+                    if (!res) { t_in[t] = 0u; t_nd[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+            {
+                const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                const float kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
+                const float sv = fm::lo(t_in[t]);
+                float wv = edge_weight_fast(ek, cnd.w, t_nd[t].w, cn, mk3(t_nd[t].x, t_nd[t].y, t_nd[t].z), cv, sv) * kk;
+                if (!t_ok[t]) wv = 0.0f;
+                sum_w += wv;
+                sum_v += wv * sv;
+                sum_var += (wv * wv) * fm::hi(t_in[t]);
+            }
+        }
+        else
+        {
+            for (int yy = -R; yy <= R; yy++)
+                for (int xx = -R; xx <= R; xx++)
+                {
+                    const int px = x + xx * step, py = y + yy * step;
+                    if (px < 0 || py < 0 || px >= a.w || py >= a.h || (xx == 0 && yy == 0)) continue;
+                    const int   axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                    const float kx = axx == 0 ? 1.0f : (axx == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
+                    const float ky = ayy == 0 ? 1.0f : (ayy == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
+                    const bool     res = py >= a.y0 && py < a.y1;
+                    const uint32_t so  = res ? (uint32_t)(py * a.w + px) : o;
+                    uint32_t s  = fm::ld<uint32_t>(a.in.p, so * 4u);
+                    float4   nd = fm::ld<float4>(a.nd, so * 16u);
+                    if (!res) { s = 0u; nd = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                    const float sv = fm::lo(s);
+                    const float wv = edge_weight_fast(ek, cnd.w, nd.w, cn, mk3(nd.x, nd.y, nd.z), cv, sv) * (kx * ky);
+                    sum_w += wv;
+                    sum_v += wv * sv;
+                    sum_var += (wv * wv) * fm::hi(s);
+                }
+        }
+        const float iw = fm::rcp(sum_w);
+        float ov = sum_v * iw;
+        const float ovar = sum_var * (iw * iw);
+        if (a.power != 0.0f) ov = fm::powf_(fm::fmax_(ov, 0.0f), a.power);
+        result = fm::pack2(ov, ovar);
+    }
+    *outp = result;
+    if (out2p) *out2p = result;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ao_denoise_reprojection.comp:191-260, tolerance mode; spp = 1..4 sample planes (BASELINE configs[2]: 4)
+template <bool MULTI>
+__global__ __launch_bounds__(64 * FT_WAVES) void kf_ao_temporal(AOTemporalArgs a)
+{
+    __shared__ uint32_t s_mask[FT_WAVES][4][18];
+    __shared__ MaskRows s_rows[FT_WAVES];
+    const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int  tile = blockIdx.x * FT_WAVES + wave;
+    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
+    const int  tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    const int  lx = lane & 7, ly = lane >> 3;
+    const int  x = tx * 8 + lx, y = ty * 8 + ly;
+    const bool in_image = tile_ok && x < a.w && y < a.h && y >= a.y0 && y < a.y1;
+    const bool edge     = tile_ok && (x >= a.w || y >= a.h);
+    const uint32_t pix  = in_image ? (uint32_t)(y * a.w + x) : (uint32_t)(a.gb2.y0 * a.w);
+    const float d_raw   = fm::ld<float>(a.depth.p, pix * 4u);
+    const uint2 cg2_raw = fm::ld<uint2>(a.gb2.p, pix * 8u);
+    const uint32_t cg3y_raw = fm::ld<uint32_t>(a.gb3.p, pix * 8u + 4u);
+    build_mask_rows<true>(s_rows[wave], s_mask[wave], a.mask, MULTI ? a.spp : 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
+    if (!tile_ok) return;
+    int sum, own;
+    mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);
+    const float mean = div_by((float)sum, div_prepare(289.0f * (float)a.spp));
+    bool flag = false;
+    if (in_image || edge)
+    {
+        const float d = edge ? 0.0f : d_raw;
+        float out = 1.0f, hlen = 0.0f;
+        if (d != 1.0f)
+        {
+            const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_raw;
+            const uint32_t cg3y = edge ? 0u : cg3y_raw;
+            const float    ao   = div_by((float)own, div_prepare((float)a.spp));
+            ReprojOut      r;
+            const bool success = reproject_fast<2, false, false>(x, y, d, a.vpi, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f, a.pgb2.p,
+                                                                 a.pgb3.p, a.pdepth.p, a.hist.p, nullptr, a.hist_len.p, HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+            hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
+            float hao = r.col[0];
+            if (success)
+            {
+                const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
+                hao = fm::fmin_(fm::fmax_(hao, mean - 0.5f * sd), mean + 0.5f * sd);
+            }
+            const float al = success ? fm::fmax_(a.alpha, fm::rcp_nr(hlen)) : 1.0f;
+            out = fm::mix_rn(hao, ao, al);
+        }
+        if (in_image)
+        {
+            *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + pix * 2u)     = fm::half_bits(out);
+            *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out_len) + pix * 2u) = fm::half_bits(hlen);
+        }
+        flag = out < 1.0f;
+    }
+    const unsigned long long any = __ballot(flag);
+    if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ao_denoise_bilateral_blur.comp:75-139, tolerance mode.  LDS-tiled: the tile + its apron along the blur direction is decoded
+// ONCE (linear eye depth, unit normal, AO value: 20 B per texel in LDS) instead of per tap — 8 taps of a radius-4 blur re-derived
+// an octahedral decode + a normalisation + a reciprocal each.
+HR_DEV float gaussian_weight_fast(float offset, float deviation)
+{
+    const float d2 = deviation * deviation;
+    return fm::rsq(2.0f * HR_M_PI * d2) * fm::expf_(-(offset * offset) * fm::rcp(2.0f * d2));
+}
+
+template <int RADIUS>
+__global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
+{
+    constexpr int kMaxTexels = 32 * (8 + 2 * RADIUS);   // the vertical pass is the larger footprint
+    __shared__ float4 s_nz[kMaxTexels];                 // unit normal, linear eye depth
+    __shared__ float  s_ao[kMaxTexels];
+    __shared__ float  s_gauss[2 * RADIUS + 1];
+    const int SW = 32 + 2 * RADIUS * a.dx, SH = 8 + 2 * RADIUS * a.dy;
+    const int ox = (int)blockIdx.x * 32 - RADIUS * a.dx, oy = a.y0 + (int)blockIdx.y * 8 - RADIUS * a.dy;
+    if ((int)threadIdx.x <= 2 * RADIUS) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - RADIUS), (float)RADIUS * (1.0f / 1.5f));
+    for (int i = threadIdx.x; i < SW * SH; i += 256)
+    {
+        const int  sy = i / SW, sx = i - sy * SW;
+        const int  px = ox + sx, py = oy + sy;
+        const bool ok = !(px < 0 || py < a.y0 || px >= a.w || py >= a.y1);
+        const uint32_t off = ok ? (uint32_t)(py * a.w + px) : (uint32_t)(a.y0 * a.w);
+        float    z  = fm::ld<float>(a.depth.p, off * 4u);
+        uint32_t g2 = fm::ld<uint32_t>(a.gb2.p, off * 8u);
+        uint16_t v  = fm::ld<uint16_t>(a.in.p, off * 2u);
+        if (!ok) { z = 0.0f; g2 = 0u; v = 0; }          // texel fetches outside the image read 0 (pinned rule), then decode as usual
+        const f3 n = fm::oct_unit(g2);
+        s_nz[i] = make_float4(n.x, n.y, n.z, fm::rcp_nr(fm::mad_rn(a.zbp[2], z, a.zbp[3])));
+        s_ao[i] = (float)__builtin_bit_cast(_Float16, v);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = (int)blockIdx.x * 32 + lx, y = a.y0 + (int)blockIdx.y * 8 + ly;
+    if (x >= a.w || y >= a.y1) return;
+    const uint32_t o = (uint32_t)(y * a.w + x);
+    uint16_t* outp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * 2u);
+    const uint16_t one = 0x3c00u;
+    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) { *outp = one; return; }   // cleared image (ray_traced_ao.cpp:1048-1055)
+    if (fm::ld<float>(a.depth.p, o * 4u) == 1.0f) { *outp = one; return; }
+    const int    ci = (ly + RADIUS * a.dy) * SW + lx + RADIUS * a.dx, stride = a.dy * SW + a.dx;
+    const float4 c  = s_nz[ci];
+    float total_ao = s_ao[ci], total_w = 1.0f;
+#pragma unroll
+    for (int i = -RADIUS; i <= RADIUS; i++)
+    {
+        if (i == 0) continue;
+        const float4 t  = s_nz[ci + i * stride];
+        const float  wZ = fm::exp2f_(-__builtin_fabsf(c.w - t.w) * 1.44269504088896341f);
+        const float  wN = fm::pow32(fm::sat(c.x * t.x + c.y * t.y + c.z * t.z));
+        const float  w  = s_gauss[i + RADIUS] * (fm::exp2f_((1.0f + wZ) * -1.44269504088896341f) * wN);
+        total_ao += w * s_ao[ci + i * stride];
+        total_w += w;
+    }
+    *outp = fm::half_bits(total_ao * fm::rcp(fm::fmax_(total_w, 0.0001f)));
+}
+
+// run-time radius: plain gathers
+__global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
+{
+    __shared__ float s_gauss[2 * 32 + 1];
+    if ((int)threadIdx.x <= 2 * a.radius) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - a.radius), (float)a.radius * (1.0f / 1.5f));
+    __syncthreads();
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const uint32_t o = (uint32_t)(y * a.w + x);
+    uint16_t* outp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * 2u);
+    const uint16_t one = 0x3c00u;
+    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) { *outp = one; return; }
+    const float d = fm::ld<float>(a.depth.p, o * 4u);
+    if (d == 1.0f) { *outp = one; return; }
+    const float cd = fm::rcp_nr(fm::mad_rn(a.zbp[2], d, a.zbp[3]));
+    const f3    cn = fm::oct_unit(fm::ld<uint32_t>(a.gb2.p, o * 8u));
+    float total_ao = (float)__builtin_bit_cast(_Float16, fm::ld<uint16_t>(a.in.p, o * 2u)), total_w = 1.0f;
+    for (int i = -a.radius; i <= a.radius; i++)
+    {
+        if (i == 0) continue;
+        const int  px = x + a.dx * i, py = y + a.dy * i;
+        const bool ok = !(px < 0 || py < a.y0 || px >= a.w || py >= a.y1);
+        const uint32_t off = ok ? (uint32_t)(py * a.w + px) : o;
+        float    z  = fm::ld<float>(a.depth.p, off * 4u);
+        uint32_t g2 = fm::ld<uint32_t>(a.gb2.p, off * 8u);
+        uint16_t v  = fm::ld<uint16_t>(a.in.p, off * 2u);
+        if (!ok) { z = 0.0f; g2 = 0u; v = 0; }
+        const float sd = fm::rcp_nr(fm::mad_rn(a.zbp[2], z, a.zbp[3]));
+        const float wZ = fm::exp2f_(-__builtin_fabsf(cd - sd) * 1.44269504088896341f);
+        const float wN = fm::pow32(fm::sat(fm::dot(cn, fm::oct_unit(g2))));
+        const float w  = s_gauss[i + a.radius] * (fm::exp2f_((1.0f + wZ) * -1.44269504088896341f) * wN);
+        total_ao += w * (float)__builtin_bit_cast(_Float16, v);
+        total_w += w;
+    }
+    *outp = fm::half_bits(total_ao * fm::rcp(fm::fmax_(total_w, 0.0001f)));
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// reflections_denoise_reprojection.comp, tolerance mode.  32x8 tile per workgroup; the 48x24 input colours around it are staged
+// in LDS as they are (fp16), and the 17x17 neighbourhood mean / standard deviation (:133-157 — 289 taps per pixel in the
+// reference) become SEPARABLE sums: a horizontal pass (each thread forms four adjacent 17-tap row sums from one 20-texel window,
+// sharing the 14-texel core) into LDS, then 17 row sums per pixel.
+#define FR_TW 32
+#define FR_TH 8
+#define FR_R 8
+__global__ __launch_bounds__(256) void kf_refl_temporal(ReflTemporalArgs a)
+{
+    constexpr int CW = FR_TW + 2 * FR_R, CH = FR_TH + 2 * FR_R;   // 48 x 24
+    __shared__ uint2  s_col[CH][CW];        // rgb + ray length, fp16 as stored by the trace
+    __shared__ float4 s_ha[CH][FR_TW];      // horizontal sums: sum r, g, b, sum r^2
+    __shared__ float2 s_hb[CH][FR_TW];      //                  sum g^2, b^2
+    __shared__ int    s_flag[4];
+    const int bx0 = blockIdx.x * FR_TW, by0 = a.y0 + blockIdx.y * FR_TH;
+    if (threadIdx.x < 4) s_flag[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < CH * CW; i += 256)
+    {
+        const int cy = i / CW, cx = i - cy * CW;
+        s_col[cy][cx] = a.in.raw(bx0 - FR_R + cx, by0 - FR_R + cy);
+    }
+    __syncthreads();
+    if (threadIdx.x < CH * (FR_TW / 4))
+    {
+        const int r = threadIdx.x >> 3, g = (threadIdx.x & 7) * 4;   // row, first of four adjacent outputs
+        float c1[3] = { 0, 0, 0 }, c2[3] = { 0, 0, 0 };              // core: texels g+3 .. g+16, in every one of the four windows
+        f3    e[6];                                                  // edge texels g+0, g+1, g+2, g+17, g+18, g+19
+#pragma unroll
+        for (int t = 0; t < 20; t++)
+        {
+            const uint2 q = s_col[r][g + t];
+            const f3    c = mk3(fm::lo(q.x), fm::hi(q.x), fm::lo(q.y));
+            if (t >= 3 && t <= 16)
+            {
+                c1[0] += c.x; c1[1] += c.y; c1[2] += c.z;
+                c2[0] += c.x * c.x; c2[1] += c.y * c.y; c2[2] += c.z * c.z;
+            }
+            else e[t < 3 ? t : t - 14] = c;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            // window j = texels g+j .. g+j+16 = core + edge texels {j, .., 2} + {3, .., 2+j}
+            float s1[3] = { c1[0], c1[1], c1[2] }, s2[3] = { c2[0], c2[1], c2[2] };
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if ((k < 3 && k >= j) || (k >= 3 && k - 3 < j))
+                {
+                    s1[0] += e[k].x; s1[1] += e[k].y; s1[2] += e[k].z;
+                    s2[0] += e[k].x * e[k].x; s2[1] += e[k].y * e[k].y; s2[2] += e[k].z * e[k].z;
+                }
+            s_ha[r][g + j] = make_float4(s1[0], s1[1], s1[2], s2[0]);
+            s_hb[r][g + j] = make_float2(s2[1], s2[2]);
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = bx0 + lx, y = by0 + ly;
+    bool flag = false;
+    if (x < a.w && y < a.y1)
+    {
+        const uint32_t o = (uint32_t)(y * a.w + x);
+        const float    d = fm::ld<float>(a.depth.p, o * 4u);
+        const uint2    cg3 = fm::ld<uint2>(a.gb3.p, o * 8u);
+        const float    roughness = fm::lo(cg3.x);
+        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f, m0 = 0.0f, m1 = 0.0f, hl = 0.0f;
+        if (d != 1.0f)
+        {
+            const uint2 cg2 = fm::ld<uint2>(a.gb2.p, o * 8u);
+            const uint2 cq  = s_col[ly + FR_R][lx + FR_R];
+            const f3    color = mk3(fm::lo(cq.x), fm::hi(cq.x), fm::lo(cq.y));
+            ReprojOut   r;
+            const bool  success = reproject_fast<8, true, true>(x, y, d, a.vpi, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]),
+                                                                a.pvp, fm::hi(cq.y), a.pgb2.p, a.pgb3.p, a.pdepth.p, a.hist.p, a.hist_moments.p, nullptr,
+                                                                HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+            hl = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
+            f3 history = mk3(r.col[0], r.col[1], r.col[2]);
+            if (success)
+            {
+                float s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
+#pragma unroll
+                for (int dy = 0; dy <= 2 * FR_R; dy++)
+                {
+                    const float4 ha = s_ha[ly + dy][lx];
+                    const float2 hb = s_hb[ly + dy][lx];
+                    s1[0] += ha.x; s1[1] += ha.y; s1[2] += ha.z; s2[0] += ha.w; s2[1] += hb.x; s2[2] += hb.y;
+                }
+                float cv[3], ext[3], cen[3], mx = 0.0f;
+                const float hv[3] = { history.x, history.y, history.z };
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                {
+                    const float mean = s1[c] * (1.0f / 289.0f);
+                    const float sd   = fm::sqrt1(fm::fmax_(s2[c] * (1.0f / 289.0f) - mean * mean, 0.0f));
+                    // clip_aabb (:111-129) with aabb = mean -/+ sd: centre = mean, extent = sd + 0.001
+                    cen[c] = mean; ext[c] = sd + 0.001f;
+                    cv[c]  = hv[c] - mean;
+                    mx     = fm::fmax_(mx, __builtin_fabsf(cv[c] * fm::rcp(ext[c])));
+                }
+                if (mx > 1.0f)
+                {
+                    const float im = fm::rcp(mx);
+                    history = mk3(cen[0] + cv[0] * im, cen[1] + cv[1] * im, cen[2] + cv[2] * im);
+                }
+            }
+            const float max_acc = a.moving ? 8.0f : hl;
+            const float ia = fm::rcp_nr(max_acc);
+            const float al = success ? fm::fmax_(a.alpha, ia) : 1.0f;
+            const float am = success ? fm::fmax_(a.moments_alpha, ia) : 1.0f;
+            const float lum = luminance(color);
+            m0 = fm::mix_rn(r.mom[0], lum, am);
+            m1 = fm::mix_rn(r.mom[1], lum * lum, am);
+            r3 = fm::fmax_(0.0f, fm::var_rn(m1, m0));
+            r0 = fm::mix_rn(history.x, color.x, al); r1 = fm::mix_rn(history.y, color.y, al); r2 = fm::mix_rn(history.z, color.z, al);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + o * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hl, 0.0f));
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out) + o * 8u)         = make_uint2(fm::pack2(r0, r1), fm::pack2(r2, r3));
+        if (d != 1.0f && roughness >= 0.05f) flag = (a.approximate_with_ddgi == 1) ? (roughness <= 0.75f) : true;
+    }
+    // tile classification per 8x8 tile (4 tiles per workgroup): :262-272
+    if (flag) atomicOr(&s_flag[lx >> 3], 1);
+    __syncthreads();
+    if (threadIdx.x < 4)
+    {
+        const int tx = (bx0 >> 3) + threadIdx.x, ty = by0 >> 3;
+        if (tx < a.tiles_x) a.tile_class[(size_t)ty * a.tiles_x + tx] = s_flag[threadIdx.x] ? 1 : 0;
+    }
+}
+
+// reflections_denoise_atrous.comp + copy_tiles (tile class), tolerance mode
+template <int STEP, bool N32>
+__global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const uint32_t o = (uint32_t)(y * a.w + x);
+    const uint2    c = fm::ld<uint2>(a.in.p, o * 8u);
+    uint2          result = c;
+    if (a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)])
+    {
+        const int  step = STEP > 0 ? STEP : a.step, R = STEP > 0 ? 1 : a.radius;
+        const int  fx0 = (int)blockIdx.x * 32, fy0 = a.y0 + (int)blockIdx.y * 8, reach = step * R > 1 ? step * R : 1;
+        const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= a.in.y0 && fy0 + 7 + reach < a.in.y1;
+        const f3    cc = mk3(fm::lo(c.x), fm::hi(c.x), fm::lo(c.y));
+        const float center_luma = fm::fmax_(0.299f * cc.x + 0.587f * cc.y + 0.114f * cc.z, 0.0001f);
+        float var = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const int   xx = k % 3 - 1, yy = k / 3 - 1;
+            const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            const uint32_t v = interior ? fm::ld<uint32_t>(a.in.p, (uint32_t)((y + yy) * a.w + (x + xx)) * 8u + 4u) : a.in.raw(x + xx, y + yy).y;
+            var += fm::hi(v) * kw;
+        }
+        const uint32_t g2x = fm::ld<uint32_t>(a.gb2.p, o * 8u);
+        const uint2    g3  = fm::ld<uint2>(a.gb3.p, o * 8u);
+        const float    d = fm::ld<float>(a.depth.p, o * 4u), roughness = fm::lo(g3.x);
+        if (d == 1.0f) result = make_uint2(0u, 0u);
+        else if (!(roughness < 0.05f || (a.approximate_with_ddgi == 1 && roughness > 0.75f)))
+        {
+            const f3    cn = fm::oct_unit(g2x);
+            const float center_depth = fm::hi(g3.y);
+            EdgeK ek;
+            ek.kz        = 1.44269504088896341f * fm::rcp(a.sigma_depth);
+            ek.phi_n     = a.phi_normal;
+            ek.n32       = N32;
+            ek.inv_phi_l = fm::rcp(a.phi_color * fm::sqrt1(fm::fmax_(0.0f, 1e-10f + var)));
+            float sum_w = 1.0f, s0 = cc.x, s1 = cc.y, s2 = cc.z, s3 = fm::hi(c.y);
+            auto tap = [&](uint2 q, uint32_t q2x, uint32_t q3y, float kk, bool ok) {
+                const f3    sc = mk3(fm::lo(q.x), fm::hi(q.x), fm::lo(q.y));
+                const float sl = fm::fmax_(0.299f * sc.x + 0.587f * sc.y + 0.114f * sc.z, 0.0001f);
+                float wc = edge_weight_fast(ek, center_depth, fm::hi(q3y), cn, fm::oct_unit(q2x), center_luma, sl) * kk;
+                if (!ok) wc = 0.0f;
+                sum_w += wc;
+                s0 += wc * sc.x; s1 += wc * sc.y; s2 += wc * sc.z;
+                s3 += (wc * wc) * fm::hi(q.y);
+            };
+            if (STEP > 0)
+            {
+                uint2    t_in[8];
+                uint32_t t_g2[8], t_g3[8];
+                bool     t_ok[8];
+                if (interior)
+                {
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                    {
+                        const int      k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                        const uint32_t so = (uint32_t)((y + yy * STEP) * a.w + (x + xx * STEP));
+                        t_ok[t] = true;
+                        t_in[t] = fm::ld<uint2>(a.in.p, so * 8u); t_g2[t] = fm::ld<uint32_t>(a.gb2.p, so * 8u); t_g3[t] = fm::ld<uint32_t>(a.gb3.p, so * 8u + 4u);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                    {
+                        const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                        const int px = x + xx * STEP, py = y + yy * STEP;
+                        t_ok[t] = px >= 0 && py >= 0 && px < a.w && py < a.h;
+                        t_in[t] = a.in.raw(px, py); t_g2[t] = a.gb2.raw(px, py).x; t_g3[t] = a.gb3.raw(px, py).y;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                {
+                    const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+                    tap(t_in[t], t_g2[t], t_g3[t], (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f), t_ok[t]);
+                }
+            }
+            else
+            {
+                for (int yy = -R; yy <= R; yy++)
+                    for (int xx = -R; xx <= R; xx++)
+                    {
+                        const int px = x + xx * step, py = y + yy * step;
+                        if (px < 0 || py < 0 || px >= a.w || py >= a.h || (xx == 0 && yy == 0)) continue;
+                        const int   axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
+                        const float kx = axx == 0 ? 1.0f : (axx == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
+                        const float ky = ayy == 0 ? 1.0f : (ayy == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
+                        tap(a.in.raw(px, py), a.gb2.raw(px, py).x, a.gb3.raw(px, py).y, kx * ky, true);
+                    }
+            }
+            const float iw = fm::rcp(sum_w);
+            result = make_uint2(fm::pack2(s0 * iw, s1 * iw), fm::pack2(s2 * iw, s3 * (iw * iw)));
+        }
+    }
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out) + o * 8u) = result;
+    if (a.out2) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out2) + o * 8u) = result;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// gi_sample_probe_grid.comp:75-99 + sample_irradiance (gi_common.glsl:188-320), tolerance mode.  Hoisted out of the 8-probe
+// loop: the octahedral texel offset of the surface normal (identical for every probe), the bias vector, 1 / grid_step; the
+// probe's atlas cell needs no division (the atlas is nx * ny probes wide by construction, ddgi.cpp:197-201, checked in
+// hr_ddgi_create); directions are octahedrally encoded without normalising them first (the L1 projection is scale free).
+HR_DEV void oct_encode_any(f3 v, float& ox, float& oy)
+{
+    const float inv = fm::rcp(__builtin_fabsf(v.x) + __builtin_fabsf(v.y) + __builtin_fabsf(v.z));
+    float rx = v.x * inv, ry = v.y * inv;
+    if (v.z < 0.0f)
+    {
+        const float nx = (1.0f - __builtin_fabsf(ry)) * (rx >= 0.0f ? 1.0f : -1.0f);
+        const float ny = (1.0f - __builtin_fabsf(rx)) * (ry >= 0.0f ? 1.0f : -1.0f);
+        rx = nx; ry = ny;
+    }
+    ox = rx; oy = ry;
+}
+
+// Bilinear footprint in an atlas.  A probe cell is framed by a one-texel border and the atlas by a one-texel margin
+// (ddgi.cpp:197-201), so the 2x2 footprint of an in-cell coordinate never leaves the image; the base texel is still clamped
+// (one v_med3 per axis) so that a NaN coordinate cannot produce a wild address.
+struct Bilin { uint32_t o00; float fx, fy; };
+HR_DEV Bilin bilin_setup(float x, float y, int w, int h)   // x, y in texel units, already minus the half texel
+{
+    const float fx0 = __builtin_floorf(x), fy0 = __builtin_floorf(y);
+    Bilin b;
+    b.fx = x - fx0; b.fy = y - fy0;
+    const int x0 = clampi((int)fx0, 0, w - 2), y0 = clampi((int)fy0, 0, h - 2);
+    b.o00 = (uint32_t)(y0 * w + x0);
+    return b;
+}
+
+__global__ __launch_bounds__(256) void kf_ddgi_sample(DDGISampleArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.y1) return;
+    const uint32_t o  = (uint32_t)(y * a.w + x);
+    uint2* outp = reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out) + o * 8u);
+    const float dp = fm::ld<float>(a.depth, o * 4u);
+    if (dp == 1.0f) { *outp = make_uint2(0u, 0u); return; }
+    const DDGIU& d = a.d;
+    const float tu = ((float)x + 0.5f) * fm::rcp((float)a.w), tv = ((float)y + 0.5f) * fm::rcp((float)a.h);
+    const f3 P  = fm::unproject_at(fm::unproject_base(a.vpi, tu, tv), a.vpi, dp);
+    const f3 N  = fm::oct_unit(fm::ld<uint32_t>(a.gb2, o * 8u));
+    f3       Wo = mk3(a.cam[0] - P.x, a.cam[1] - P.y, a.cam[2] - P.z);
+    const float iwo = fm::rsq(fm::dot(Wo, Wo));
+    Wo = mk3(Wo.x * iwo, Wo.y * iwo, Wo.z * iwo);
+    const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]), g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
+    const f3 igs = mk3(fm::rcp(gs.x), fm::rcp(gs.y), fm::rcp(gs.z));
+    const int nx = d.probe_counts[0], ny = d.probe_counts[1], nz = d.probe_counts[2];
+    const int bx = clampi((int)((P.x - g0.x) * igs.x), 0, nx - 1), by = clampi((int)((P.y - g0.y) * igs.y), 0, ny - 1), bz = clampi((int)((P.z - g0.z) * igs.z), 0, nz - 1);
+    const f3 base = mk3(g0.x + gs.x * (float)bx, g0.y + gs.y * (float)by, g0.z + gs.z * (float)bz);
+    const f3 alpha = mk3(fm::sat((P.x - base.x) * igs.x), fm::sat((P.y - base.y) * igs.y), fm::sat((P.z - base.z) * igs.z));
+    const f3 nb = mk3((N.x + 3.0f * Wo.x) * d.normal_bias, (N.y + 3.0f * Wo.y) * d.normal_bias, (N.z + 3.0f * Wo.z) * d.normal_bias);
+    // octahedral texel offset of N inside a probe's irradiance cell: the same for all eight probes
+    float nox, noy;
+    oct_encode_any(N, nox, noy);
+    const int   is = d.irradiance_probe_side_length, ds = d.depth_probe_side_length;
+    const float ncx = (nox + 1.0f) * 0.5f * (float)is + 1.5f, ncy = (noy + 1.0f) * 0.5f * (float)is + 1.5f;   // + 2 (cell origin) - 0.5 (texel centre)
+    // the cell origins are integers: floor / fract of the in-cell coordinate serve all eight probes (four texel weights)
+    const float nfx0 = __builtin_floorf(ncx), nfy0 = __builtin_floorf(ncy);
+    const float nfx = ncx - nfx0, nfy = ncy - nfy0;
+    const int   nix = clampi((int)nfx0, 1, is + 1), niy = clampi((int)nfy0, 1, is + 1);
+    const float w00 = (1.0f - nfx) * (1.0f - nfy), w10 = nfx * (1.0f - nfy), w01 = (1.0f - nfx) * nfy, w11 = nfx * nfy;
+    const uint32_t irr_row = (uint32_t)a.irr.w * 8u, dep_row = (uint32_t)a.dep.w * 4u;
+    const DivBy    Ddw = div_prepare((float)a.dep.w), Ddh = div_prepare((float)a.dep.h);
+    f3    sum = mk3(0.0f, 0.0f, 0.0f);
+    float sum_w = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
+        const int cx = clampi(bx + ox, 0, nx - 1), cy = clampi(by + oy, 0, ny - 1), cz = clampi(bz + oz, 0, nz - 1);
+        const int col = cx + cy * nx;   // probe p = col + cz * (nx * ny) sits in atlas cell (col, cz)
+        const f3  pp  = mk3(g0.x + gs.x * (float)cx, g0.y + gs.y * (float)cy, g0.z + gs.z * (float)cz);
+        const f3  ptp = mk3(P.x - pp.x + nb.x, P.y - pp.y + nb.y, P.z - pp.z + nb.z);
+        const f3  tri = mk3(ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z);
+        f3 tdp = mk3(pp.x - P.x, pp.y - P.y, pp.z - P.z);
+        const float t = fm::fmax_(0.0001f, (fm::dot(tdp, N) * fm::rsq(fm::dot(tdp, tdp)) + 1.0f) * 0.5f);
+        float weight = t * t + 0.2f;
+        if (d.visibility_test == 1)
+        {
+            float dox, doy;
+            oct_encode_any(ptp, dox, doy);
+            const float l2 = fm::dot(ptp, ptp), dist = l2 * fm::rsq(l2);
+            float ax, ay;
+            fm::atlas_coord_rn(dox, doy, col, cz, ds, (float)a.dep.w, (float)a.dep.h, Ddw, Ddh, ax, ay);
+            const Bilin b = bilin_setup(ax, ay, a.dep.w, a.dep.h);
+            const uint32_t bo = b.o00 * 4u;
+            const uint32_t t00 = fm::ld<uint32_t>(a.dep.p, bo), t10 = fm::ld<uint32_t>(a.dep.p, bo + 4u), t01 = fm::ld<uint32_t>(a.dep.p, bo + dep_row), t11 = fm::ld<uint32_t>(a.dep.p, bo + dep_row + 4u);
+            const float mean = fm::bilerp_rn(fm::lo(t00), fm::lo(t10), fm::lo(t01), fm::lo(t11), b.fx, b.fy);
+            const float m2   = fm::bilerp_rn(fm::hi(t00), fm::hi(t10), fm::hi(t01), fm::hi(t11), b.fx, b.fy);
+            const float variance = fm::cheb_variance_rn(mean, m2);
+            const float dm  = fm::fmax_(dist - mean, 0.0f);
+            float che = variance * fm::rcp(variance + dm * dm);
+            che       = fm::fmax_(che * che * che, 0.0f);
+            weight *= (dist <= mean) ? 1.0f : che;
+        }
+        weight = fm::fmax_(0.000001f, weight);
+        const uint32_t io = (uint32_t)((cz * (is + 2) + niy) * a.irr.w + col * (is + 2) + nix) * 8u;
+        const uint2 q00 = fm::ld<uint2>(a.irr.p, io), q10 = fm::ld<uint2>(a.irr.p, io + 8u), q01 = fm::ld<uint2>(a.irr.p, io + irr_row), q11 = fm::ld<uint2>(a.irr.p, io + irr_row + 8u);
+        const float ir = w00 * fm::lo(q00.x) + w10 * fm::lo(q10.x) + w01 * fm::lo(q01.x) + w11 * fm::lo(q11.x);
+        const float ig = w00 * fm::hi(q00.x) + w10 * fm::hi(q10.x) + w01 * fm::hi(q01.x) + w11 * fm::hi(q11.x);
+        const float ib = w00 * fm::lo(q00.y) + w10 * fm::lo(q10.y) + w01 * fm::lo(q01.y) + w11 * fm::lo(q11.y);
+        if (weight < 0.2f) weight *= weight * weight * 25.0f;   // crush tiny weights (1 / 0.2^2)
+        weight *= tri.x * tri.y * tri.z;
+        sum.x += fm::sqrt1(ir) * weight; sum.y += fm::sqrt1(ig) * weight; sum.z += fm::sqrt1(ib) * weight;   // sqrt-space blending (LINEAR_BLENDING undefined)
+        sum_w += weight;
+    }
+    const float iw = fm::rcp(sum_w);
+    f3 net = mk3(sum.x * iw, sum.y * iw, sum.z * iw);
+    net.x = (net.x != net.x) ? 0.5f : net.x; net.y = (net.y != net.y) ? 0.5f : net.y; net.z = (net.z != net.z) ? 0.5f : net.z;
+    const float k = d.energy_preservation * (0.5f * HR_M_PI) * a.gi_intensity;
+    *outp = make_uint2(fm::pack2(net.x * net.x * k, net.y * net.y * k), fm::pack2(net.z * net.z * k, 1.0f));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// shadows_upsample.comp / ao_upsample.comp / reflections_upsample.comp, tolerance mode
+template <int CH>
+__global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.W || y >= a.H) return;
+    const uint32_t o  = (uint32_t)(y * a.W + x);
+    uint16_t*      op = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * (2u * CH));
+    const float hi_depth = fm::hi(fm::ld<uint32_t>(a.G3, o * 8u + 4u));
+    if (hi_depth == -1.0f)
+    {
+        const uint16_t sv = fm::half_bits(a.sky_value);
+#pragma unroll
+        for (int c = 0; c < CH; c++) op[c] = sv;
+        return;
+    }
+    const f3    hn = fm::oct_unit(fm::ld<uint32_t>(a.G2, o * 8u));
+    const float tu = ((float)x + 0.5f) * fm::rcp((float)a.W), tv = ((float)y + 0.5f) * fm::rcp((float)a.H);
+    const float tsx = fm::rcp((float)a.w), tsy = fm::rcp((float)a.h);
+    float up[CH], total_w = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) up[c] = 0.0f;
+    uint32_t t3[4], t2[4];
+    uint16_t tin[4][CH];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const float kx = (i == 1) ? 1.0f : (i == 2 ? -1.0f : 0.0f), ky = (i == 0) ? 1.0f : (i == 3 ? -1.0f : 0.0f);
+        int sx = (int)__builtin_floorf((tu + kx * tsx) * (float)a.w), sy = (int)__builtin_floorf((tv + ky * tsy) * (float)a.h);
+        sx = clampi(sx, 0, a.w - 1); sy = clampi(sy, 0, a.h - 1);
+        const uint32_t so = (uint32_t)(sy * a.w + sx);
+        t3[i] = fm::ld<uint32_t>(a.g3, so * 8u + 4u); t2[i] = fm::ld<uint32_t>(a.g2, so * 8u);
+        const uint16_t* ip = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.in) + so * (uint32_t)(2 * a.in_channels));
+#pragma unroll
+        for (int c = 0; c < CH; c++) tin[i][c] = ip[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const float cd = fm::hi(t3[i]);
+        // compute_edge_stopping_weight, NORMAL weight only: wL = 1 (edge_stopping.glsl:53-59)
+        const float wZ = fm::exp2f_(-__builtin_fabsf(hi_depth - cd) * 1.44269504088896341f);
+        const float wN = fm::pow32(fm::sat(fm::dot(hn, fm::oct_unit(t2[i]))));
+        const float wt = (cd == -1.0f) ? 0.0f : fm::exp2f_((1.0f + wZ) * -1.44269504088896341f) * wN;
+#pragma unroll
+        for (int c = 0; c < CH; c++) up[c] += (float)__builtin_bit_cast(_Float16, tin[i][c]) * wt;
+        total_w += wt;
+    }
+    const float iw = fm::rcp(fm::fmax_(total_w, 0.00000001f));
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+    {
+        float r = up[c] * iw;
+        if (a.power != 0.0f) r = fm::powf_(r, a.power);
+        op[c] = fm::half_bits(r);
+    }
+}
+
+} // namespace
+
+namespace hr {
+
+void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st)
+{
+    hipLaunchKernelGGL(kf_shadows_temporal, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
+}
+
+void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
+{
+    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
+    const bool n32 = a.phi_normal == 32.0f;
+#define HR_LAUNCH_ATROUS(S) \
+    do { if (n32) hipLaunchKernelGGL((kf_shadows_atrous<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((kf_shadows_atrous<S, false>), grid, dim3(256), 0, st, a); } while (0)
+    if (a.radius == 1 && a.step == 1) HR_LAUNCH_ATROUS(1);
+    else if (a.radius == 1 && a.step == 2) HR_LAUNCH_ATROUS(2);
+    else if (a.radius == 1 && a.step == 4) HR_LAUNCH_ATROUS(4);
+    else if (a.radius == 1 && a.step == 8) HR_LAUNCH_ATROUS(8);
+    else HR_LAUNCH_ATROUS(0);
+#undef HR_LAUNCH_ATROUS
+}
+
+void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st)
+{
+    if (a.spp > 1) hipLaunchKernelGGL(kf_ao_temporal<true>, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(kf_ao_temporal<false>, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
+}
+
+void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
+{
+    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
+    if (a.radius == 4) hipLaunchKernelGGL(kf_ao_blur<4>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(kf_ao_blur_generic, grid, dim3(256), 0, st, a);
+}
+
+void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(kf_refl_temporal, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
+}
+
+void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)
+{
+    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
+    const bool n32 = a.phi_normal == 32.0f;
+#define HR_LAUNCH_RATROUS(S) \
+    do { if (n32) hipLaunchKernelGGL((kf_refl_atrous<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((kf_refl_atrous<S, false>), grid, dim3(256), 0, st, a); } while (0)
+    if (a.radius == 1 && a.step == 1) HR_LAUNCH_RATROUS(1);
+    else if (a.radius == 1 && a.step == 2) HR_LAUNCH_RATROUS(2);
+    else if (a.radius == 1 && a.step == 4) HR_LAUNCH_RATROUS(4);
+    else if (a.radius == 1 && a.step == 8) HR_LAUNCH_RATROUS(8);
+    else HR_LAUNCH_RATROUS(0);
+#undef HR_LAUNCH_RATROUS
+}
+
+void launch_ddgi_sample_fast(const DDGISampleArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(kf_ddgi_sample, dim3(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8)), dim3(256), 0, st, a);
+}
+
+void launch_upsample_fast(const UpsampleArgs& a, hipStream_t st)
+{
+    const dim3 grid(cdiv(a.W, 32), cdiv(a.H, 8));
+    if (a.channels == 4) hipLaunchKernelGGL(kf_upsample<4>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(kf_upsample<1>, grid, dim3(256), 0, st, a);
+}
+
+} // namespace hr

@@ -1,0 +1,122 @@
+// Kernel argument blocks of the denoise / resolve stages, shared by the exact kernels (shadows.hip, ao.hip, reflections.hip,
+// ddgi.hip) and their tolerance-mode counterparts (denoise_fast.hip): both read the same images and write the same outputs.
+#pragma once
+#include "reproject.h"
+#include "shading.h"
+#include "upsample.h"
+
+namespace hr {
+
+struct TemporalArgs
+{
+    float           vpi[16];
+    const uint32_t* mask;
+    int             mw, mh;         // mask image dims (full frame)
+    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
+    ImgR32F         depth, pdepth;
+    ImgRG16F        hist;           // previous à-trous feedback image (vis, var)
+    ImgRGBA16F      hist_moments;
+    uint32_t*       out;            // RG16F
+    uint2*          out_moments;    // RGBA16F
+    uint8_t*        tile_class;
+    float4*         nd;             // decoded normal.xyz + linear z (GB3.w), written for the a-trous iterations
+    int             w, h, y0, y1;
+    int             tiles_x, tiles_y, tile_y0;
+    float           alpha, moments_alpha;
+    int             debug_skip_reproject; // developer ablation switch (HR_DEBUG_SKIP_REPROJECT)
+};
+
+struct AtrousArgs
+{
+    ImgRG16F       in;
+    const float4*  nd;      // decoded normal + linear z of every pixel (k_shadows_temporal)
+    const uint8_t* tile_class;
+    uint32_t*      out;
+    uint32_t*      out2;    // feedback copy (prev_image) or nullptr
+    int            w, h, y0, y1, tiles_x;
+    int            radius, step;
+    float          phi_visibility, phi_normal, sigma_depth, power;
+};
+
+struct AOTemporalArgs
+{
+    float           vpi[16];
+    const uint32_t* mask;
+    int             mw, mh, spp;
+    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
+    ImgR32F         depth, pdepth;
+    ImgR16F         hist, hist_len;
+    uint16_t*       out;
+    uint16_t*       out_len;
+    uint8_t*        tile_class;
+    int             w, h, y0, y1;
+    int             tiles_x, tiles_y, tile_y0;
+    float           alpha;
+};
+
+struct AOBlurArgs
+{
+    ImgR16F        in;
+    ImgR32F        depth;
+    ImgRGBA16F     gb2;
+    const uint8_t* tile_class;
+    uint16_t*      out;
+    float          zbp[4];
+    int            w, h, y0, y1, tiles_x;
+    int            dx, dy, radius;
+};
+
+struct ReflTemporalArgs
+{
+    float       vpi[16], pvp[16];
+    float       cam[3];
+    ImgRGBA16F  in, gb2, gb3, pgb2, pgb3, hist, hist_moments;
+    ImgR32F     depth, pdepth;
+    uint2*      out;
+    uint2*      out_moments;
+    uint8_t*    tile_class;
+    int         w, h, y0, y1, tiles_x;
+    float       alpha, moments_alpha;
+    int         approximate_with_ddgi, moving;
+};
+
+struct ReflAtrousArgs
+{
+    ImgRGBA16F     in, gb2, gb3;
+    ImgR32F        depth;
+    const uint8_t* tile_class;
+    uint2*         out;
+    uint2*         out2;
+    int            w, h, y0, y1, tiles_x, radius, step;
+    float          phi_color, phi_normal, sigma_depth;
+    int            approximate_with_ddgi;
+};
+
+struct DDGISampleArgs
+{
+    DDGIU        d;
+    float        vpi[16];
+    float        cam[3];
+    const float* depth;
+    const uint2* gb2;
+    AtlasRGBA    irr;
+    AtlasRG      dep;
+    uint2*       out;
+    int          w, h, y0, y1;   // rows [y0, y1) of the image are produced (row band)
+    float        gi_intensity;
+};
+
+// ---- tolerance-mode ("fast") launchers, denoise_fast.hip ----------------------------------------------------------------
+// hr_*_params.exact == 0 selects them: same inputs, same outputs, same tile classification rule; fp32 arithmetic through the
+// hardware's v_rcp / v_rsq / v_sqrt / v_exp / v_log, contracted FMAs and re-associated sums.  The visibility
+// masks never pass through them (the trace kernels have one mode).
+void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st);
+void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st);
+void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st);
+void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st);
+void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st);
+void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st);
+void launch_ddgi_sample_fast(const DDGISampleArgs& a, hipStream_t st);
+void launch_upsample_fast(const UpsampleArgs& a, hipStream_t st);
+
+} // namespace hr

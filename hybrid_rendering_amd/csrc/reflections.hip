@@ -10,6 +10,7 @@
 #include "reproject.h"
 #include "shading.h"
 #include "upsample.h"
+#include "pass_args.h"
 
 using namespace hr;
 
@@ -164,19 +165,6 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES) void k_refl_trace(ReflTraceA
 }
 
 // ------------------------------------------------------------------------------------------------
-struct ReflTemporalArgs
-{
-    float       vpi[16], pvp[16];
-    float       cam[3];
-    ImgRGBA16F  in, gb2, gb3, pgb2, pgb3, hist, hist_moments;
-    ImgR32F     depth, pdepth;
-    uint2*      out;
-    uint2*      out_moments;
-    uint8_t*    tile_class;
-    int         w, h, y0, y1, tiles_x;
-    float       alpha, moments_alpha;
-    int         approximate_with_ddgi, moving;
-};
 
 #define RT_TW 32
 #define RT_TH 8
@@ -277,17 +265,6 @@ HR_DEV float pow_phi_normal(float x, float p)
     return det_pow_auto(x, p);
 }
 
-struct ReflAtrousArgs
-{
-    ImgRGBA16F     in, gb2, gb3;
-    ImgR32F        depth;
-    const uint8_t* tile_class;
-    uint2*         out;
-    uint2*         out2;
-    int            w, h, y0, y1, tiles_x, radius, step;
-    float          phi_color, phi_normal, sigma_depth;
-    int            approximate_with_ddgi;
-};
 
 // RADIUS == 1 (the reference default): fully unrolled 3x3 stencil, every load issued up front and the eight tap weights
 // computed unconditionally before the ordered accumulation (see k_shadows_atrous); RADIUS < 0: run-time radius.
@@ -409,7 +386,7 @@ void hr_reflections_default_params(hr_reflections_params* p)
     p->denoise = 1; p->sample_gi = 1; p->approximate_with_ddgi = 1; p->gi_intensity = 0.5f; p->rough_ddgi_intensity = 0.5f;
     p->ibl_indirect_specular_intensity = 0.05f; p->bias = 0.5f; p->trim = 0.8f; p->alpha = 0.01f; p->moments_alpha = 0.2f; p->blur_as_input = 0;
     p->phi_color = 10.0f; p->phi_normal = 32.0f; p->sigma_depth = 1.0f; p->radius = 1; p->filter_iterations = 4; p->feedback_iteration = 1;
-    p->camera_delta[0] = p->camera_delta[1] = p->camera_delta[2] = 0.0f; p->frame_time = 0.0f;
+    p->camera_delta[0] = p->camera_delta[1] = p->camera_delta[2] = 0.0f; p->frame_time = 0.0f; p->exact = 1;
 }
 
 hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_reflections** out)
@@ -532,7 +509,8 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 80);
-    hipLaunchKernelGGL(k_refl_temporal, dim3(cdiv(w, RT_TW), cdiv(y1 - y0, RT_TH)), dim3(256), 0, st, a);
+    if (prm->exact) hipLaunchKernelGGL(k_refl_temporal, dim3(cdiv(w, RT_TW), cdiv(y1 - y0, RT_TH)), dim3(256), 0, st, a);
+    else launch_refl_temporal_fast(a, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -558,7 +536,8 @@ hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inpu
     static const char* names[8] = { "atrous_0", "atrous_1", "atrous_2", "atrous_3", "atrous_4", "atrous_5", "atrous_6", "atrous_7" };
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin(names[i], st, px * 36);
-    if (a.radius == 1) hipLaunchKernelGGL(k_refl_atrous<1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
+    if (!prm->exact) launch_refl_atrous_fast(a, st);
+    else if (a.radius == 1) hipLaunchKernelGGL(k_refl_atrous<1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_refl_atrous<-1>, dim3(cdiv(w, 32), cdiv(y1 - y0, 8)), dim3(256), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
@@ -578,7 +557,8 @@ hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, 
     a.in = p->atrous[p->read_idx].p; a.in_channels = 4; a.channels = 4; a.out = p->upsample.p; a.sky_value = 0.0f; a.power = 0.0f;
     const uint64_t PX = (uint64_t)p->full_w * p->full_h, px = (uint64_t)p->w * p->h;
     int ev = p->prof.begin("upsample", st, PX * 24 + px * 24);
-    launch_upsample(a, st);
+    if (prm->exact) launch_upsample(a, st);
+    else launch_upsample_fast(a, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

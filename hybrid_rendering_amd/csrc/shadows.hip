@@ -10,6 +10,7 @@
 #include "traverse.h"
 #include "shading.h"
 #include "upsample.h"
+#include "pass_args.h"
 
 using namespace hr;
 
@@ -265,24 +266,6 @@ __global__ __launch_bounds__(256) void k_shadows_trace_pw(TraceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-struct TemporalArgs
-{
-    float           vpi[16];
-    const uint32_t* mask;
-    int             mw, mh;         // mask image dims (full frame)
-    ImgRGBA16F      gb2, gb3, pgb2, pgb3;
-    ImgR32F         depth, pdepth;
-    ImgRG16F        hist;           // previous à-trous feedback image (vis, var)
-    ImgRGBA16F      hist_moments;
-    uint32_t*       out;            // RG16F
-    uint2*          out_moments;    // RGBA16F
-    uint8_t*        tile_class;
-    float4*         nd;             // decoded normal.xyz + linear z (GB3.w), written for the a-trous iterations
-    int             w, h, y0, y1;
-    int             tiles_x, tiles_y, tile_y0;
-    float           alpha, moments_alpha;
-    int             debug_skip_reproject; // developer ablation switch (HR_DEBUG_SKIP_REPROJECT)
-};
 
 #ifndef TEMPORAL_WAVES
 #define TEMPORAL_WAVES 4
@@ -384,17 +367,6 @@ __global__ __launch_bounds__(64 * TEMPORAL_WAVES) void k_shadows_temporal(Tempor
 }
 
 // ------------------------------------------------------------------------------------------------
-struct AtrousArgs
-{
-    ImgRG16F       in;
-    const float4*  nd;      // decoded normal + linear z of every pixel (k_shadows_temporal)
-    const uint8_t* tile_class;
-    uint32_t*      out;
-    uint32_t*      out2;    // feedback copy (prev_image) or nullptr
-    int            w, h, y0, y1, tiles_x;
-    int            radius, step;
-    float          phi_visibility, phi_normal, sigma_depth, power;
-};
 
 // edge_stopping.glsl:31-62 with NORMAL + LUMA weights.  FAST = the reference's default parameters
 // (phi_normal == 32, sigma_depth == 1): x / 1.0f == x and pow(x, 32) is five squarings — same bits, fewer ops.
@@ -550,6 +522,7 @@ void hr_shadows_default_params(hr_shadows_params* p)
 {
     p->denoise = 1; p->bias = 0.5f; p->alpha = 0.01f; p->moments_alpha = 0.2f; p->phi_visibility = 10.0f;
     p->phi_normal = 32.0f; p->sigma_depth = 1.0f; p->power = 1.2f; p->radius = 1; p->filter_iterations = 4; p->feedback_iteration = 1;
+    p->exact = 1;
 }
 
 hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_band* band, hr_shadows** out)
@@ -789,7 +762,8 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
-    hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, TEMPORAL_WAVES)), dim3(64 * TEMPORAL_WAVES), 0, st, a);
+    if (prm->exact) hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, TEMPORAL_WAVES)), dim3(64 * TEMPORAL_WAVES), 0, st, a);
+    else launch_shadows_temporal_fast(a, a.tiles_x * a.tiles_y, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;
@@ -821,7 +795,8 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     int ev = p->prof.begin(names[i], st, px * 24 + (a.out2 ? px * 4 : 0));
     const dim3 grid(cdiv(w, 32), cdiv(y1 - y0, 8));
     const bool fast = (prm->phi_normal == 32.0f && prm->sigma_depth == 1.0f);
-    if (prm->radius == 1 && fast) hipLaunchKernelGGL((k_shadows_atrous<1, true>), grid, dim3(256), 0, st, a);
+    if (!prm->exact) launch_shadows_atrous_fast(a, st);
+    else if (prm->radius == 1 && fast) hipLaunchKernelGGL((k_shadows_atrous<1, true>), grid, dim3(256), 0, st, a);
     else if (prm->radius == 1) hipLaunchKernelGGL((k_shadows_atrous<1, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_shadows_atrous<-1, false>), grid, dim3(256), 0, st, a);
     p->prof.end(ev, st);
@@ -844,7 +819,8 @@ hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.out = p->upsample.p; a.sky_value = 0.0f; a.power = 0.0f;
     const uint64_t PX = (uint64_t)p->full_w * p->full_h, px = (uint64_t)p->w * p->h;
     int ev = p->prof.begin("upsample", st, PX * 18 + px * 20);
-    launch_upsample(a, st);
+    if (prm->exact) launch_upsample(a, st);
+    else launch_upsample_fast(a, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -230,6 +230,11 @@ typedef struct
     int32_t radius;             /* ATrous::radius = 1                            */
     int32_t filter_iterations;  /* ATrous::filter_iterations = 4  (1..5)         */
     int32_t feedback_iteration; /* ATrous::feedback_iteration = 1                */
+    int32_t exact;              /* 1 (default): every fp32 operation individually, correctly rounded — stage images equal the oracle
+                                   and the reference's shaders BIT FOR BIT (the parity mode).  0: tolerance mode for production — the
+                                   denoise / resolve kernels use the hardware's rcp / rsq / sqrt / exp / log and fused multiply-adds
+                                   (2-4x faster); fp16 images agree within 2 fp16 ulp (rel-L2 <= 1e-3, tests/test_gpu_tolerance.py);
+                                   visibility masks, ray counts and traversal are identical in both modes */
 } hr_shadows_params;
 
 void      hr_shadows_default_params(hr_shadows_params* p);
@@ -279,6 +284,7 @@ typedef struct
     int32_t blur_radius; /* BilateralBlur::blur_radius = 4      */
     float   power;       /* Upsample::power = 1.2               */
     int32_t spp;         /* EXTENSION (reference = 1): samples per pixel, 1..4 (BASELINE.json configs[2]) */
+    int32_t exact;       /* 1 (default) = bit-for-bit parity arithmetic, 0 = tolerance mode (see hr_shadows_params.exact) */
 } hr_ao_params;
 
 void      hr_ao_default_params(hr_ao_params* p);
@@ -340,6 +346,8 @@ typedef struct
     float   random_orientation[9];     /* column-major 3x3 probe-ray rotation of this frame: the reference draws
                                           it from std::mt19937 seeded by std::random_device (ddgi.cpp:73,788);
                                           here the caller supplies it so frames are reproducible */
+    int32_t exact;                     /* 1 (default) = bit-for-bit parity arithmetic; 0 = tolerance mode for the per-pixel probe-grid
+                                          sample (see hr_shadows_params.exact; the probe trace and atlas updates have one mode) */
 } hr_ddgi_params;
 
 void      hr_ddgi_default_params(hr_ddgi_params* p);
@@ -399,6 +407,7 @@ typedef struct
     int32_t feedback_iteration;              /* 1                                                 */
     float   camera_delta[3];                 /* CommonResources::camera_delta (main.cpp:1077-1079) */
     float   frame_time;                      /* CommonResources::frame_time (pushed, unused by the shader) */
+    int32_t exact;                           /* 1 (default) = bit-for-bit parity arithmetic, 0 = tolerance mode (see hr_shadows_params.exact) */
 } hr_reflections_params;
 
 void      hr_reflections_default_params(hr_reflections_params* p);

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(api.hr_ubo) == 416
     assert C.sizeof(api.hr_gbuffer_level) == 40
     assert C.sizeof(api.hr_frame_inputs) == 3 * 40 + 416 + 8 + 16 + 16
-    assert C.sizeof(api.hr_shadows_params) == 44
+    assert C.sizeof(api.hr_shadows_params) == 48
 
 
 def test_errors_are_status_codes_not_exceptions():

@@ -1,0 +1,266 @@
+"""Tolerance mode (hr_*_params.exact = 0: hardware rcp / rsq / sqrt / exp / log, fused multiply-adds, re-associated sums —
+csrc/denoise_fast.hip) against the CPU oracle.
+
+Stated tolerance (north_star "AO / reflections / GI within a stated fp32 tolerance"):
+  * visibility masks, ray counts: BIT-EXACT (the trace kernels have one mode);
+  * every fp16 output image: <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 error <= 1e-3 over those texels and <= 1e-2 over
+    ALL texels.  The remaining <= 0.1 % are discrete decisions flipped by an fp32 ulp (a reprojection validity threshold, a truncation
+    to a texel index, a tile whose only non-trivial pixel sits on the classification threshold) or 0/0 situations of the reference's
+    own arithmetic (a DDGI pixel all of whose probe weights were crushed to the 1e-6 floor); their energy is bounded by the second
+    L2 figure, not ignored;
+  * tile classes: equal on >= 99.5 % of the tiles;
+  * DDGI atlases are produced by the exact kernels in both modes (bit-exact); the per-pixel probe-grid sample obeys the image rule.
+The runs are several frames long with a moving camera, so the bound holds through the temporal feedback loops."""
+import numpy as np
+import pytest
+
+import helpers
+from hybrid_rendering_amd import synth, synth_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(bits):
+    """fp16 bit patterns -> integers ordered like the values (so that |key_a - key_b| is the distance in fp16 ulp)"""
+    b = bits.astype(np.int32)
+    mag = b & 0x7fff
+    return np.where(b & 0x8000, -mag, mag)
+
+
+def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None):
+    """got / ref: uint16 fp16 bit patterns.  abs_floor: differences below it count as equal (intermediate images whose small
+    values are differences of nearly equal numbers, e.g. variance = m2 - m1^2).  exclude: bool [H, W] of texels left out of the
+    per-texel bound (neighbourhoods of tiles whose classification differs — a discrete decision; they stay in the L2 bound)."""
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    g, r = got.view(np.float16).astype(np.float64), ref.view(np.float16).astype(np.float64)
+    assert np.isfinite(g).all(), f"{what}: non-finite values"
+    num, den = np.sqrt(((g - r) ** 2).sum()), np.sqrt((r ** 2).sum())
+    rl2 = num / den if den > 0 else num
+    ok = (np.abs(_key(got) - _key(ref)) <= ulps) | (np.abs(g - r) <= abs_floor)
+    if exclude is not None:
+        ex = exclude if ok.ndim == 2 else exclude[..., None]
+        ok = ok | ex
+    f = ok.mean()
+    bad = np.argwhere(~ok)
+    where = f"; first offenders (y, x, ...): {bad[:6].tolist()} got {g[tuple(bad[:6].T)].tolist()} ref {r[tuple(bad[:6].T)].tolist()}" if len(bad) else ""
+    sel = ok if exclude is None else (ok & ~(exclude if ok.ndim == 2 else np.broadcast_to(exclude[..., None], ok.shape)))
+    rl2_in = np.sqrt(((g - r)[sel] ** 2).sum()) / max(np.sqrt((r[sel] ** 2).sum()), 1e-30)
+    assert rl2_in <= rel_l2, f"{what}: relative L2 error over the texels inside the ulp bound {rl2_in:.2e} > {rel_l2:.0e}"
+    assert rl2 <= 10 * rel_l2, f"{what}: relative L2 error over all texels {rl2:.2e} > {10 * rel_l2:.0e}"
+    assert f >= frac, f"{what}: only {f * 100:.3f} % of the texels within {ulps} fp16 ulp ({len(bad)} outside, max abs diff {np.abs(g - r).max():.3e}){where}"
+    return rl2, f
+
+
+def tiles_close(got, ref, what, frac=0.995, shape=None, reach=2):
+    """tile classes agree on >= frac of the tiles; returns the per-texel exclusion mask: texels within `reach` tiles of a tile
+    whose class differs (a flipped tile is copied / cleared instead of filtered, and the a-trous taps of its neighbours see it)"""
+    diff = got != ref
+    f = 1.0 - diff.mean()
+    assert f >= frac, f"{what}: tile classes agree on {f * 100:.2f} % of the tiles"
+    if shape is None:
+        return None
+    d = diff.copy()
+    for _ in range(reach):
+        p = np.pad(d, 1)
+        d = p[:-2, :-2] | p[:-2, 1:-1] | p[:-2, 2:] | p[1:-1, :-2] | p[1:-1, 1:-1] | p[1:-1, 2:] | p[2:, :-2] | p[2:, 1:-1] | p[2:, 2:]
+    return np.kron(d, np.ones((8, 8), bool))[:shape[0], :shape[1]]
+
+
+def _tables():
+    import torch
+    sob, sr = synth.blue_noise_tables()
+    return sob, sr, torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+
+
+@pytest.mark.parametrize("name,w,h,dolly,light,params", [
+    ("sponza_small", 320, 184, 1.5, "default", None),
+    ("cornell", 250, 166, 1.0, "soft", None),
+    ("sponza_small", 203, 117, 2.0, "spot", dict(filter_iterations=5, feedback_iteration=0, phi_normal=12.5, power=2.0, alpha=0.05, radius=2, sigma_depth=0.6)),
+])
+def test_shadows_tolerance(oracle, hr, ctx, name, w, h, dolly, light, params):
+    import torch
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    n = 6
+    frames = helpers.make_frames(oracle, osc, name, w, h, n, dolly, light)
+    sob, sr, sob_d, sr_d = _tables()
+    kw = dict(params or {})
+    gp, op = hr.RayTracedShadows(ctx, w, h), oracle.ShadowsPass(w, h, **kw)
+    for k, v in kw.items():
+        setattr(gp.params, k, v)
+    gp.params.exact = 0
+    for f in range(n):
+        cur, prev = frames[f]["gb"], frames[f - 1 if f else 0]["gb"]
+        op.render(osc, frames[f]["ubo"], cur, prev, sob, sr, f)
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), frames[f]["ubo"], f, f & 1, sob_d, sr_d))
+        torch.cuda.synchronize()
+        st = op.stages
+        assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), st["mask"]), f"frame {f}: mask must be bit-exact"
+        assert gp.ray_count() == st["rays"]
+        ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
+        # intermediate images: the variance / second-moment channels are differences of nearly equal numbers
+        compare16(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"], f"frame {f} temporal", abs_floor=1e-3)
+        compare16(helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0))[..., :3], st["moments"][..., :3], f"frame {f} moments", abs_floor=1e-3)
+        out, ref = helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), st["output"]
+        compare16(out[..., 0], ref[..., 0], f"frame {f} denoised visibility", exclude=ex)
+    gp.close(); gsc.close()
+
+
+def test_shadows_half_res_upsample_tolerance(oracle, hr, ctx):
+    import torch
+    name, W, H, scale = "sponza_small", 320, 176, 1
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, W, H, 4, 1.0, scale_mips=scale)
+    sob, sr, sob_d, sr_d = _tables()
+    w, h = W >> scale, H >> scale
+    gp, op = hr.RayTracedShadows(ctx, W, H, scale), oracle.ShadowsPass(w, h)
+    gp.params.exact = 0
+    for f in range(4):
+        cur, prev, full = frames[f]["mips"][scale], frames[f - 1 if f else 0]["mips"][scale], frames[f]["gb"]
+        op.render(osc, frames[f]["ubo"], cur, prev, sob, sr, f)
+        up = oracle.upsample(full, cur, op.stages["output"], channels=1, sky_value=0.0, power=0.0)[..., 0]
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), frames[f]["ubo"], f, f & 1, sob_d, sr_d, cur_full=helpers.to_cuda(full)))
+        torch.cuda.synchronize()
+        assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), op.stages["mask"])
+        ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), op.stages["tiles"], f"frame {f}", shape=(h, w))
+        ex = np.kron(ex, np.ones((2, 2), bool))[:H, :W]
+        compare16(helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE)), up, f"frame {f} upsampled visibility", exclude=ex)
+    gp.close(); gsc.close()
+
+
+@pytest.mark.parametrize("name,W,H,scale,spp,params", [
+    ("sponza_small", 288, 160, 0, 1, None),
+    ("sponza_small", 320, 184, 1, 4, None),
+    ("cornell", 230, 150, 0, 2, dict(blur_radius=6, alpha=0.05, ray_length=40.0)),
+    ("sponza_small", 171, 121, 0, 3, dict(blur_radius=2)),
+])
+def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params):
+    import torch
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    n = 5
+    frames = helpers.make_frames(oracle, osc, name, W, H, n, 1.5, scale_mips=scale)
+    sob, sr, sob_d, sr_d = _tables()
+    zbp = synth.z_buffer_params()
+    w, h = W >> scale, H >> scale
+    kw = dict(params or {})
+    gp, op = hr.RayTracedAO(ctx, W, H, scale), oracle.AOPass(w, h, spp=spp, zbp=zbp, **kw)
+    for k, v in kw.items():
+        setattr(gp.params, k, v)
+    gp.params.spp, gp.params.exact = spp, 0
+    for f in range(n):
+        lvl = (lambda fr: fr["mips"][scale] if scale else fr["gb"])
+        cur, prev, full = lvl(frames[f]), lvl(frames[f - 1 if f else 0]), frames[f]["gb"]
+        op.render(osc, frames[f]["ubo"], cur, prev, sob, sr, f, full=full if scale else None)
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), frames[f]["ubo"], f, f & 1, sob_d, sr_d,
+                                       cur_full=helpers.to_cuda(full) if scale else None, z_buffer_params=zbp))
+        torch.cuda.synchronize()
+        st = op.stages
+        mh = (h + 3) // 4
+        mask = gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32)[:spp * mh].reshape(spp, mh, -1)
+        assert np.array_equal(mask, st["mask"]), f"frame {f}: AO masks must be bit-exact"
+        assert gp.ray_count() == st["rays"]
+        ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
+        compare16(helpers.bits16(gp.image(gp.IMG_AO1 if f & 1 else gp.IMG_AO0)), st["temporal"], f"frame {f} temporal AO")
+        compare16(helpers.bits16(gp.image(gp.IMG_BLUR1)), st["blur1"], f"frame {f} blurred AO", exclude=ex)
+        out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
+        ref = st["output"] if st["output"].ndim == 2 else st["output"][..., 0]
+        if scale:
+            ex = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W]
+        compare16(out, ref, f"frame {f} AO output", exclude=ex)
+    gp.close(); gsc.close()
+
+
+@pytest.mark.parametrize("name,W,H,scale,dolly,params", [
+    ("sponza_small", 288, 160, 1, 2.0, None),
+    ("sponza_small", 224, 128, 0, 1.0, None),
+    ("sponza_small", 160, 96, 0, 1.0, dict(approximate_with_ddgi=0, blur_as_input=1, trim=0.5, filter_iterations=3, phi_color=4.0, gi_intensity=1.0, phi_normal=8.0, radius=2)),
+])
+def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scale, dolly, params):
+    """DDGI (exact atlases, tolerance-mode sample) feeding tolerance-mode reflections.  The reflections TRACE (hit shading) has one
+    mode and is compared bit for bit while it reads the bit-exact atlases; temporal / a-trous / upsample obey the image rule."""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections
+    from oracle import pyoracle_ddgi as od
+    from oracle import pyoracle_reflections as orf
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    lo, hi = sd.bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(5, 3, 4), rays_per_probe=64, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(16)
+    pre, lut = synth_env.prefiltered_chain(sky, 5), synth_env.brdf_lut(16)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=16, pre_levels=5, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 16, 5, f16(lut))
+    n = 5
+    frames = helpers.make_frames(oracle, osc, name, W, H, n, dolly, scale_mips=scale)
+    r01, r003 = np.float16(0.1).view(np.uint16), np.float16(0.03).view(np.uint16)
+    for fr in frames:
+        for g in [fr["gb"]] + fr.get("mips", [])[1:]:
+            ch = g["gb3"][..., 0]
+            ch[ch == r01] = r003
+    sob, sr, sob_d, sr_d = _tables()
+    w, h = W >> scale, H >> scale
+    g_ddgi, o_ddgi = api_gi.DDGI(ctx, W, H, ddgi), od.DDGIPass(ddgi)
+    g_ddgi.params.exact = 0
+    gp = api_reflections.RayTracedReflections(ctx, W, H, scale)
+    kw = dict(params or {})
+    for k, v in kw.items():
+        setattr(gp.params, k, v)
+    gp.params.exact = 0
+    op = orf.ReflectionsPass(w, h, **kw)
+    rng = np.random.RandomState(7)
+    for f in range(n):
+        lvl = (lambda fr: fr["mips"][scale] if scale else fr["gb"])
+        cur, prev, full = lvl(frames[f]), lvl(frames[f - 1 if f else 0]), frames[f]["gb"]
+        orient = synth_env.random_orientation(rng)
+        cam_delta = (0.0, 0.0, 0.0) if f == 0 else (-dolly, 0.0, 0.0)
+        o_ddgi.render(osc, frames[f]["ubo"], full, sky, orient, f)
+        irr, dep = o_ddgi.current_read()
+        op.render(osc, frames[f]["ubo"], ddgi, cur, prev, sob, sr, f, env_np, irr, dep, camera_delta=cam_delta, full=full if scale else None, ping_pong=bool(f & 1))
+        full_d = helpers.to_cuda(full)
+        g_ddgi.render(gsc, hr.frame_inputs(full_d, None, frames[f]["ubo"], f, f & 1, sob_d, sr_d), env, orient)
+        gp.set_camera_delta(cam_delta)
+        gp.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), frames[f]["ubo"], f, f & 1, sob_d, sr_d, cur_full=full_d), env, g_ddgi)
+        torch.cuda.synchronize()
+        gi, gd = g_ddgi.current_read()
+        assert np.array_equal(helpers.bits16(gi), irr) and np.array_equal(helpers.bits16(gd), dep), f"frame {f}: DDGI atlases are exact in both modes"
+        compare16(helpers.bits16(g_ddgi.output())[..., :3], o_ddgi.stages["output"][..., :3], f"frame {f} DDGI probe-grid sample")
+        st = op.stages
+        assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TRACE)), st["trace"]), f"frame {f}: reflection trace has one mode"
+        assert gp.ray_count() == st["rays"]
+        ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
+        tc = helpers.bits16(gp.image(gp.IMG_COLOR1 if f & 1 else gp.IMG_COLOR0))
+        compare16(tc[..., :3], st["temporal"][..., :3], f"frame {f} temporal colour")
+        at = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
+        compare16(at[..., :3], st["atrous"][-1][..., :3], f"frame {f} a-trous colour", exclude=ex)
+        out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
+        if scale:
+            ex = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W]
+        compare16(out[..., :3], st["output"][..., :3], f"frame {f} reflections output", exclude=ex)
+    gp.close(); g_ddgi.close(); gsc.close()
+
+
+def test_1080p_bench_frame_tolerance(oracle, hr, ctx):
+    """the bench workload (BASELINE configs[1], 1920x1080, 278k triangles) in the mode bench.py times: 3 moving frames"""
+    import torch
+    W, H = 1920, 1080
+    sd = helpers.scene_data("sponza")
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(4)]
+    ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(3)]
+    gbs = [gsc.gbuffer(u, W, H) for u in ubos]
+    host = [{n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in g.items()} for g in gbs]
+    sob, sr, sob_d, sr_d = _tables()
+    gp, op = hr.RayTracedShadows(ctx, W, H), oracle.ShadowsPass(W, H)
+    gp.params.exact = 0
+    for k in range(3):
+        op.render(osc, ubos[k], host[k], host[k - 1 if k else 0], sob, sr, k)
+        gp.render(gsc, hr.frame_inputs(gbs[k], gbs[k - 1 if k else 0], ubos[k], k, k & 1, sob_d, sr_d))
+        torch.cuda.synchronize()
+        assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), op.stages["mask"]), f"frame {k}: mask"
+        ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), op.stages["tiles"], f"frame {k}", shape=(H, W))
+        compare16(helpers.bits16(gp.output(hr.OUTPUT_ATROUS))[..., 0], op.stages["output"][..., 0], f"frame {k} denoised visibility", exclude=ex)
+    gp.close(); gsc.close()

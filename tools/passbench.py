@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--refl-scale", type=int, default=1)
     ap.add_argument("--probes", default="16,8,16")
     ap.add_argument("--rays-per-probe", type=int, default=256)
+    ap.add_argument("--exact", type=int, default=0, help="1 = bit-for-bit parity arithmetic, 0 = tolerance mode (the shipping mode)")
     args = ap.parse_args()
     import torch
     from hybrid_rendering_amd import api as hr, api_gi, api_reflections, synth, synth_env
@@ -57,6 +58,7 @@ def main():
 
     def run(name, make_pass, render, scale):
         p = make_pass()
+        p.params.exact = args.exact
         lv = [mip(g, scale) if scale else g for g in gbs]
         fis = [hr.frame_inputs(lv[k % 4], lv[(k - 1) % 4], ubos[k % 4], k, k & 1, sob_d, sr_d, cur_full=gbs[k % 4], z_buffer_params=zbp) for k in range(8)]
         for k in range(8):
@@ -77,7 +79,7 @@ def main():
             rays += p.ray_count()
             for n, t, b in p.stage_times():
                 a = acc.setdefault(n, [0.0, b]); a[0] += t
-        out = dict(pass_=name, res=f"{W >> scale}x{H >> scale}", ms_per_frame=round(ms, 4), rays_per_frame=rays // 10,
+        out = dict(pass_=name, exact=args.exact, res=f"{W >> scale}x{H >> scale}", ms_per_frame=round(ms, 4), rays_per_frame=rays // 10,
                    Mrays_per_s=round(rays / 10 / (ms * 1e-3) / 1e6, 1),
                    stages={n: dict(ms=round(v[0] / 10, 4), GBps=round(v[1] / (v[0] / 10 * 1e-3) / 1e9, 1) if v[0] > 0 else 0) for n, v in acc.items()})
         print(json.dumps(out))
