@@ -38,7 +38,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + sources() + ["-o", LIB + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
+    extra = os.environ.get("HR_CFLAGS", "").split()   # developer A/B builds: HR_CFLAGS="-DFT_SHADOWS_EU=5" python -m hybrid_rendering_amd.build --force
+    cmd = [hipcc()] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", LIB + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

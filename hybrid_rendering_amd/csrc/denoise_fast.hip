@@ -30,166 +30,188 @@ struct HistGeom { int w, h, y0, y1; };   // every history / previous-G-buffer im
 
 struct ReprojOut { float col[3]; float mom[2]; float length; };
 
-// HIST_BPP: bytes per texel of the colour history — 2 (AO, R16F), 4 (shadows, RG16F: .r), 8 (reflections, RGBA16F: .rgb)
+// HIST_BPP: bytes per texel of the colour history — 2 (AO, R16F), 4 (shadows, RG16F: .r), 8 (reflections, RGBA16F: .rgb).
+// Two phases so that a kernel can put independent work (mask popcounts, LDS passes) between them:
+//   issue()    history coordinates + all 21 loads of the 2x2 bilinear footprint and the history-length texel — nothing is waited for;
+//   resolve()  validity tests, weighting, normalisation (+ the rare 3x3 fallback with its own loads).
 template <int HIST_BPP, bool MOMENTS, bool REFL>
-HR_DEV bool reproject_fast(int x, int y, float depth, const float* __restrict__ M, uint32_t c2y, float cur_id, float curvature, f3 cur_n,
-                           f3 cam_pos, const float* __restrict__ prev_vp, float ray_length,
-                           const void* __restrict__ pgb2, const void* __restrict__ pgb3, const void* __restrict__ pdepth,
-                           const void* __restrict__ hist, const void* __restrict__ hist_moments, const void* __restrict__ hist_len,
-                           const HistGeom g, ReprojOut& o)
+struct Reproj
 {
-    constexpr int NC = HIST_BPP == 8 ? 3 : 1;
-    const float fw = (float)g.w, fh = (float)g.h;
-    const float inv_w = fm::rcp(fw), inv_h = fm::rcp(fh);
-    const float tu = ((float)x + 0.5f) * inv_w, tv = ((float)y + 0.5f) * inv_h;
-    const float mvx = fm::lo(c2y), mvy = fm::hi(c2y);
-    const fm::Unproj cb = fm::unproject_base(M, tu, tv);
-    const f3 cur_pos = fm::unproject_at(cb, M, depth);
+    static constexpr int NC = HIST_BPP == 8 ? 3 : 1;
+    const float* __restrict__ M;
+    const void* __restrict__  pgb2;
+    const void* __restrict__  pgb3;
+    const void* __restrict__  pdepth;
+    const void* __restrict__  hist;
+    const void* __restrict__  hist_moments;
+    const void* __restrict__  hist_len;
+    HistGeom   g;
+    f3         cur_pos, cur_n;
+    float      cur_id, hfx, hfy;
+    int        hcx, hcy;
+    bool       inb, lok, tok[4];
+    fm::Unproj hb;
+    uint32_t   g2x[4], g3y[4], mm[4], hx[4], hy[4], lraw;
+    float      td[4];
 
-    float hfx = (float)x + mvx * fw, hfy = (float)y + mvy * fh;   // mv (fp16) * extent (<= 2^12) is exact: same texel as the exact mode
-    int   hcx, hcy;
-    if (REFL)
+    // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel; branch-free
+    HR_DEV bool tap_valid(uint32_t q2x, uint32_t q3y, float d) const
     {
-        if (ray_length > 0.0f && curvature == 0.0f)
-        {
-            // virtual_point_reprojection (reprojection.glsl:71-111): NB current_coord / size without the half-pixel offset
-            const f3    ro  = fm::unproject_at(fm::unproject_base(M, (float)x * inv_w, (float)y * inv_h), M, depth);
-            f3          cr  = sub3(ro, cam_pos);
-            const float l2  = fm::dot(cr, cr);
-            const float il  = fm::rsq(l2), crl = l2 * il;
-            const float k   = (crl + ray_length) * il;
-            const f3    hp  = mk3(cam_pos.x + cr.x * k, cam_pos.y + cr.y * k, cam_pos.z + cr.z * k);
-            const float pw  = prev_vp[3] * hp.x + prev_vp[7] * hp.y + prev_vp[11] * hp.z + prev_vp[15];
-            const float ipw = fm::rcp(pw);
-            const float px  = (prev_vp[0] * hp.x + prev_vp[4] * hp.y + prev_vp[8] * hp.z + prev_vp[12]) * ipw;
-            const float py  = (prev_vp[1] * hp.x + prev_vp[5] * hp.y + prev_vp[9] * hp.z + prev_vp[13]) * ipw;
-            hfx = (px * 0.5f + 0.5f) * fw;
-            hfy = (py * 0.5f + 0.5f) * fh;
-        }
-        hcx = (int)hfx; hcy = (int)hfy;
-    }
-    else
-    {
-        hcx = (int)(hfx + 0.5f);
-        hcy = (int)(hfy + 0.5f);
-    }
-    const bool inb = !(hcx < 0 || hcy < 0 || hcx > g.w - 1 || hcy > g.h - 1);
-    const fm::Unproj hb = fm::unproject_base(M, tu + mvx, tv + mvy);
-
-    // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel
-    auto tap_valid = [&](uint32_t g2x, uint32_t g3y, float d) -> bool {
-        const f3    hn = fm::oct_raw(g2x);
+        const f3    hn = fm::oct_raw(q2x);
         const float dn = fm::dot(cur_n, hn);
         const f3    hp = fm::unproject_at(hb, M, d);
         const float pd = fm::dot(sub3(cur_pos, hp), cur_n);
-        return inb && (cur_id == fm::lo(g3y)) && !(__builtin_fabsf(pd) > 5.0f) && (dn * dn > 0.1f * fm::dot(hn, hn));
-    };
-    auto tap_offset = [&](int px, int py, bool& ok) -> uint32_t {
-        ok = !(px < 0 || py < g.y0 || px >= g.w || py >= g.y1);
+        return inb & (cur_id == fm::lo(q3y)) & !(__builtin_fabsf(pd) > 5.0f) & (dn * dn > 0.1f * fm::dot(hn, hn));
+    }
+    HR_DEV uint32_t tap_offset(int px, int py, bool& ok) const
+    {
+        ok = !((px < 0) | (py < g.y0) | (px >= g.w) | (py >= g.y1));
         return ok ? (uint32_t)(py * g.w + px) : (uint32_t)(g.y0 * g.w);
-    };
-    auto hist_rgb = [&](uint32_t off, bool ok, float* c) {
-        if constexpr (HIST_BPP == 2) c[0] = ok ? (float)__builtin_bit_cast(_Float16, fm::ld<uint16_t>(hist, off * 2u)) : 0.0f;
-        else if constexpr (HIST_BPP == 4) c[0] = ok ? fm::lo(fm::ld<uint32_t>(hist, off * 4u)) : 0.0f;
+    }
+    HR_DEV void hist_decode(uint32_t rx, uint32_t ry, float* c) const
+    {
+        if constexpr (HIST_BPP == 2) c[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)rx);
+        else if constexpr (HIST_BPP == 4) c[0] = fm::lo(rx);
+        else { c[0] = fm::lo(rx); c[1] = fm::hi(rx); c[2] = fm::lo(ry); }
+    }
+    HR_DEV void hist_load(uint32_t off, uint32_t& rx, uint32_t& ry) const
+    {
+        ry = 0u;
+        if constexpr (HIST_BPP == 2) rx = fm::ld<uint16_t>(hist, off * 2u);
+        else if constexpr (HIST_BPP == 4) rx = fm::ld<uint32_t>(hist, off * 4u);
+        else { const uint2 t = fm::ld<uint2>(hist, off * 8u); rx = t.x; ry = t.y; }
+    }
+
+    HR_DEV void issue(int x, int y, float depth, uint32_t c2y, float cur_id_, float curvature, f3 cur_n_, f3 cam_pos, const float* __restrict__ prev_vp, float ray_length)
+    {
+        cur_id = cur_id_; cur_n = cur_n_;
+        const float fw = (float)g.w, fh = (float)g.h;
+        const float inv_w = fm::rcp(fw), inv_h = fm::rcp(fh);
+        const float tu = ((float)x + 0.5f) * inv_w, tv = ((float)y + 0.5f) * inv_h;
+        const float mvx = fm::lo(c2y), mvy = fm::hi(c2y);
+        cur_pos = fm::unproject_at(fm::unproject_base(M, tu, tv), M, depth);
+        hfx = (float)x + mvx * fw; hfy = (float)y + mvy * fh;   // mv (fp16) * extent (<= 2^12) is exact: same texel as the exact mode
+        if (REFL)
+        {
+            if (ray_length > 0.0f && curvature == 0.0f)
+            {
+                // virtual_point_reprojection (reprojection.glsl:71-111): NB current_coord / size without the half-pixel offset
+                const f3    ro  = fm::unproject_at(fm::unproject_base(M, (float)x * inv_w, (float)y * inv_h), M, depth);
+                f3          cr  = sub3(ro, cam_pos);
+                const float l2  = fm::dot(cr, cr);
+                const float il  = fm::rsq(l2), crl = l2 * il;
+                const float k   = (crl + ray_length) * il;
+                const f3    hp  = mk3(cam_pos.x + cr.x * k, cam_pos.y + cr.y * k, cam_pos.z + cr.z * k);
+                const float pw  = prev_vp[3] * hp.x + prev_vp[7] * hp.y + prev_vp[11] * hp.z + prev_vp[15];
+                const float ipw = fm::rcp(pw);
+                const float px  = (prev_vp[0] * hp.x + prev_vp[4] * hp.y + prev_vp[8] * hp.z + prev_vp[12]) * ipw;
+                const float py  = (prev_vp[1] * hp.x + prev_vp[5] * hp.y + prev_vp[9] * hp.z + prev_vp[13]) * ipw;
+                hfx = (px * 0.5f + 0.5f) * fw;
+                hfy = (py * 0.5f + 0.5f) * fh;
+            }
+            hcx = (int)hfx; hcy = (int)hfy;
+        }
         else
         {
-            const uint2 t = fm::ld<uint2>(hist, off * 8u);
-            c[0] = ok ? fm::lo(t.x) : 0.0f; c[1] = ok ? fm::hi(t.x) : 0.0f; c[2] = ok ? fm::lo(t.y) : 0.0f;
+            hcx = (int)(hfx + 0.5f);
+            hcy = (int)(hfy + 0.5f);
         }
-    };
+        inb = !((hcx < 0) | (hcy < 0) | (hcx > g.w - 1) | (hcy > g.h - 1));
+        hb  = fm::unproject_base(M, tu + mvx, tv + mvy);
+        // an outside tap loads a resident address (its value is discarded in resolve()), so no load sits behind a branch
+        const int bx = (int)hfx, by = (int)hfy;
+        uint32_t  off[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) off[s] = tap_offset(bx + (s & 1), by + (s >> 1), tok[s]);
+        const uint32_t loff = tap_offset(hcx, hcy, lok);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+        {
+            g2x[s] = fm::ld<uint32_t>(pgb2, off[s] * 8u);
+            g3y[s] = fm::ld<uint32_t>(pgb3, off[s] * 8u + 4u);
+            td[s]  = fm::ld<float>(pdepth, off[s] * 4u);
+            hist_load(off[s], hx[s], hy[s]);
+            mm[s] = MOMENTS ? fm::ld<uint32_t>(hist_moments, off[s] * 8u) : 0u;
+        }
+        if (MOMENTS) lraw = fm::ld<uint32_t>(hist_moments, loff * 8u + 4u);
+        else lraw = fm::ld<uint16_t>(hist_len, loff * 2u);
+    }
 
-    // 2x2 bilinear footprint: every load first, then the arithmetic (one memory round trip)
-    const int bx = (int)hfx, by = (int)hfy;
-    uint32_t  g2x[4], g3y[4], mm[4];
-    float     td[4], tc[4][NC];
-    bool      tok[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
+    HR_DEV bool resolve(ReprojOut& o) const
     {
-        const uint32_t off = tap_offset(bx + (s & 1), by + (s >> 1), tok[s]);
-        g2x[s] = fm::ld<uint32_t>(pgb2, off * 8u);
-        g3y[s] = fm::ld<uint32_t>(pgb3, off * 8u + 4u);
-        td[s]  = fm::ld<float>(pdepth, off * 4u);
-        hist_rgb(off, tok[s], tc[s]);
-        if (MOMENTS) mm[s] = fm::ld<uint32_t>(hist_moments, off * 8u);
-    }
-    float len_prefetch;
-    {
-        bool           lok;
-        const uint32_t off = tap_offset(hcx, hcy, lok);
-        if (MOMENTS) len_prefetch = lok ? fm::lo(fm::ld<uint32_t>(hist_moments, off * 8u + 4u)) : 0.0f;
-        else len_prefetch = lok ? (float)__builtin_bit_cast(_Float16, fm::ld<uint16_t>(hist_len, off * 2u)) : 0.0f;
-    }
-    const float fx = hfx - __builtin_floorf(hfx), fy = hfy - __builtin_floorf(hfy);
-    const float wgt[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
-    float sumw = 0.0f, col[NC], mom0 = 0.0f, mom1 = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NC; c++) col[c] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-    {
-        // an out-of-image texel reads as zeros (pinned rule) and is validated as such, as in the exact mode
-        const bool  v  = tap_valid(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f);
-        const float ws = v ? wgt[s] : 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; c++) col[c] += ws * tc[s][c];
-        if (MOMENTS) { mom0 += ws * (tok[s] ? fm::lo(mm[s]) : 0.0f); mom1 += ws * (tok[s] ? fm::hi(mm[s]) : 0.0f); }
-        sumw += ws;
-    }
-    // Normalisations are correctly rounded divisions (one shared denominator: device_math.h div_by): a history of all-equal
-    // values must come back EXACTLY (sum(w) * v / sum(w) == v), the tile classification tests `ao < 1` / `visibility > 0`
-    bool valid = sumw >= 0.01f;
-    if (valid)
-    {
-        const DivBy D = div_prepare(sumw);
-#pragma unroll
-        for (int c = 0; c < NC; c++) col[c] = div_by(col[c], D);
-        if (MOMENTS) { mom0 = div_by(mom0, D); mom1 = div_by(mom1, D); }
-    }
-    else
-    {
-        // 3x3 fallback around the nearest history texel (:266-303); rare (disocclusion borders): kept rolled
-        float cnt = 0.0f;
+        const float fx = hfx - __builtin_floorf(hfx), fy = hfy - __builtin_floorf(hfy);
+        const float wgt[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
+        float sumw = 0.0f, col[NC], mom0 = 0.0f, mom1 = 0.0f;
 #pragma unroll
         for (int c = 0; c < NC; c++) col[c] = 0.0f;
-        mom0 = mom1 = 0.0f;
-#pragma unroll 1
-        for (int k = 0; k < 9; k++)
-        {
-            bool           ok;
-            const uint32_t off = tap_offset(hcx + k % 3 - 1, hcy + k / 3 - 1, ok);
-            const uint32_t q2 = fm::ld<uint32_t>(pgb2, off * 8u), q3 = fm::ld<uint32_t>(pgb3, off * 8u + 4u);
-            const float    qd = fm::ld<float>(pdepth, off * 4u);
-            if (tap_valid(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f))
-            {
-                float c3[NC];
-                hist_rgb(off, ok, c3);
 #pragma unroll
-                for (int c = 0; c < NC; c++) col[c] += c3[c];
-                if (MOMENTS)
+        for (int s = 0; s < 4; s++)
+        {
+            // an out-of-image texel reads as zeros (pinned rule) and is validated as such, as in the exact mode: its weight counts
+            // in the normalisation, its (zero) values add nothing
+            const bool  v  = tap_valid(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f);
+            const float ws = v ? wgt[s] : 0.0f, wv = (v & tok[s]) ? wgt[s] : 0.0f;
+            float c3[NC];
+            hist_decode(hx[s], hy[s], c3);
+#pragma unroll
+            for (int c = 0; c < NC; c++) col[c] += wv * c3[c];
+            if (MOMENTS) { mom0 += wv * fm::lo(mm[s]); mom1 += wv * fm::hi(mm[s]); }
+            sumw += ws;
+        }
+        // Normalisations are correctly rounded divisions (one shared denominator: fast_math.h div_by_inrange): a history of
+        // all-equal values must come back EXACTLY (sum(w) v / sum(w) == v) — the tile classification tests `ao < 1`, `visibility > 0`
+        bool valid = sumw >= 0.01f;
+        if (valid)
+        {
+            const DivBy D = div_prepare(sumw);   // 0.01 <= sumw <= 1; numerators are fp16 values times weights <= 1
+#pragma unroll
+            for (int c = 0; c < NC; c++) col[c] = fm::div_by_inrange(col[c], D);
+            if (MOMENTS) { mom0 = fm::div_by_inrange(mom0, D); mom1 = fm::div_by_inrange(mom1, D); }
+        }
+        else
+        {
+            // 3x3 fallback around the nearest history texel (:266-303); rare (disocclusion borders): kept rolled
+            float cnt = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) col[c] = 0.0f;
+            mom0 = mom1 = 0.0f;
+#pragma unroll 1
+            for (int k = 0; k < 9; k++)
+            {
+                bool           ok;
+                const uint32_t qo = tap_offset(hcx + k % 3 - 1, hcy + k / 3 - 1, ok);
+                const uint32_t q2 = fm::ld<uint32_t>(pgb2, qo * 8u), q3 = fm::ld<uint32_t>(pgb3, qo * 8u + 4u);
+                const float    qd = fm::ld<float>(pdepth, qo * 4u);
+                uint32_t       qx, qy;
+                hist_load(qo, qx, qy);
+                const uint32_t qm = MOMENTS ? fm::ld<uint32_t>(hist_moments, qo * 8u) : 0u;
+                if (tap_valid(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f))
                 {
-                    const uint32_t m = ok ? fm::ld<uint32_t>(hist_moments, off * 8u) : 0u;
-                    mom0 += fm::lo(m); mom1 += fm::hi(m);
+                    float c3[NC];
+                    hist_decode(ok ? qx : 0u, ok ? qy : 0u, c3);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) col[c] += c3[c];
+                    if (MOMENTS) { mom0 += fm::lo(ok ? qm : 0u); mom1 += fm::hi(ok ? qm : 0u); }
+                    cnt += 1.0f;
                 }
-                cnt += 1.0f;
+            }
+            if (cnt > 0.0f)
+            {
+                valid = true;
+                const DivBy D = div_prepare(cnt);
+#pragma unroll
+                for (int c = 0; c < NC; c++) col[c] = fm::div_by_inrange(col[c], D);
+                if (MOMENTS) { mom0 = fm::div_by_inrange(mom0, D); mom1 = fm::div_by_inrange(mom1, D); }
             }
         }
-        if (cnt > 0.0f)
-        {
-            valid = true;
-            const DivBy D = div_prepare(cnt);
 #pragma unroll
-            for (int c = 0; c < NC; c++) col[c] = div_by(col[c], D);
-            if (MOMENTS) { mom0 = div_by(mom0, D); mom1 = div_by(mom1, D); }
-        }
+        for (int c = 0; c < NC; c++) o.col[c] = valid ? col[c] : 0.0f;
+        o.mom[0] = valid ? mom0 : 0.0f;
+        o.mom[1] = valid ? mom1 : 0.0f;
+        o.length = (valid & lok) ? fm::lo(lraw) : 0.0f;
+        return valid;
     }
-#pragma unroll
-    for (int c = 0; c < NC; c++) o.col[c] = valid ? col[c] : 0.0f;
-    o.mom[0] = valid ? mom0 : 0.0f;
-    o.mom[1] = valid ? mom1 : 0.0f;
-    o.length = valid ? len_prefetch : 0.0f;
-    return valid;
-}
+};
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 17x17 box sum over packed 8x4 visibility masks (shadows_denoise_reprojection.comp:157-190, ao_...:152-185), 1..4 sample planes.
@@ -235,7 +257,8 @@ template <bool MULTI>
 HR_DEV void mask_window(const MaskRows& R, int lx, int ly, int& sum, int& own)
 {
     uint32_t a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
+    // several planes: rolled in groups so that the 51 row words are not all live at once (102 VGPRs fully unrolled)
+#pragma unroll(MULTI ? 6 : 17)
     for (int yy = 0; yy <= 16; yy++)
     {
         a0 = __builtin_popcount(__builtin_amdgcn_ubfe(R.b0[ly + yy], (uint32_t)lx, 17u)) + a0;
@@ -254,17 +277,22 @@ HR_DEV void mask_window(const MaskRows& R, int lx, int ly, int& sum, int& own)
 // ------------------------------------------------------------------------------------------------------------------------
 // shadows_denoise_reprojection.comp:196-293 (+ reset_args / tile classification), tolerance mode
 #define FT_WAVES 4
-__global__ __launch_bounds__(64 * FT_WAVES) void kf_shadows_temporal(TemporalArgs a)
+#ifndef FT_SHADOWS_EU
+#define FT_SHADOWS_EU 5   // minimum waves per SIMD the register allocator must leave room for.  Measured at 1080p: 5 (83 VGPRs, no
+                          // spill) 49.8 us; 6 (80 VGPRs + 44 B of scratch) 68.8 us; 8 (64 VGPRs, more scratch) 108.6 us — spills cost more than waves buy
+#endif
+__global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
     __shared__ uint32_t s_mask[FT_WAVES][1][18];
     __shared__ MaskRows s_rows[FT_WAVES];
     const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int  tile = blockIdx.x * FT_WAVES + wave;
-    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
-    const int  tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    // grid = (tile columns / FT_WAVES, tile rows): no integer division per wave
+    const int  txr = blockIdx.x * FT_WAVES + wave;
+    const bool tile_ok = txr < a.tiles_x;
+    const int  tx = tile_ok ? txr : 0, ty = (int)blockIdx.y + a.tile_y0;
     const int  lx = lane & 7, ly = lane >> 3;
     const int  x = tx * 8 + lx, y = ty * 8 + ly;
-    // the centre texels do not depend on the masks: request them before the LDS phase
+    // order of the memory round trips: centre texels -> (mask words, LDS) -> history taps -> (popcounts) -> resolve
     const bool in_image = tile_ok && x < a.w && y < a.h && y >= a.y0 && y < a.y1;
     const bool edge     = tile_ok && (x >= a.w || y >= a.h);   // thread without a pixel: votes as the unguarded shader thread does
     const uint32_t pix  = in_image ? (uint32_t)(y * a.w + x) : (uint32_t)(a.y0 * a.w);
@@ -272,23 +300,27 @@ __global__ __launch_bounds__(64 * FT_WAVES) void kf_shadows_temporal(TemporalArg
     const uint2 cg2_raw = fm::ld<uint2>(a.gb2.p, pix * 8u), cg3_raw = fm::ld<uint2>(a.gb3.p, pix * 8u);
     build_mask_rows<false>(s_rows[wave], s_mask[wave], a.mask, 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
     if (!tile_ok) return;
-    int sum, own;
-    mask_window<false>(s_rows[wave], lx, ly, sum, own);
-    const float mean = div_by((float)sum, div_prepare(289.0f));
-
-    float out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
-    bool  flag = false;
     const float d   = edge ? 0.0f : d_raw;
     const uint2 cg2 = edge ? make_uint2(0u, 0u) : cg2_raw, cg3 = edge ? make_uint2(0u, 0u) : cg3_raw;
     const f3    cn  = fm::oct_unit(cg2.x);
-    if ((in_image || edge) && d != 1.0f)
+    const bool  live = (in_image || edge) && d != 1.0f;
+    Reproj<4, true, false> rp;
+    rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
+    rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+    const bool reproj = live && !a.debug_skip_reproject;
+    if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
+    int sum, own;
+    mask_window<false>(s_rows[wave], lx, ly, sum, own);   // 17 bfe + bcnt pairs while the 21 history loads are in flight
+    const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f));
+
+    float out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
+    bool  flag = false;
+    if (live)
     {
         const float visibility = (float)own;
         ReprojOut   r;
         bool        success = false;
-        if (!a.debug_skip_reproject)
-            success = reproject_fast<4, true, false>(x, y, d, a.vpi, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f, a.pgb2.p, a.pgb3.p, a.pdepth.p,
-                                                     a.hist.p, a.hist_moments.p, nullptr, HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+        if (reproj) success = rp.resolve(r);
         else { r.col[0] = 0.0f; r.mom[0] = r.mom[1] = 0.0f; r.length = 0.0f; }
         hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
         float hv = r.col[0];
@@ -309,7 +341,9 @@ __global__ __launch_bounds__(64 * FT_WAVES) void kf_shadows_temporal(TemporalArg
     if (in_image)
     {
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + pix * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hlen, 0.0f));
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.nd) + pix * 16u)       = make_float4(cn.x, cn.y, cn.z, fm::hi(cg3.y));
+        // for the a-trous iterations: the centre's octahedral normal and linear depth, 8 bytes (copies of the G-buffer's fp16 values —
+        // the exact mode keeps 16 bytes of decoded fp32; decoding per tap is cheaper than the extra 8 B x 5 passes of HBM traffic)
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.nd) + pix * 8u)         = make_uint2(cg2.x, cg3.y >> 16);
         *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + pix * 4u)     = fm::pack2(out_v, out_var);
     }
     const unsigned long long any = __ballot(flag);
@@ -353,7 +387,8 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
     const int  reach = step * R > 1 ? step * R : 1;
     const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= (a.y0 > 0 ? a.y0 : 0) && fy0 + 7 + reach < (a.y1 < a.h ? a.y1 : a.h);
     const uint32_t c   = fm::ld<uint32_t>(a.in.p, o * 4u);
-    const float4   cnd = fm::ld<float4>(a.nd, o * 16u);
+    const uint2    cnd = fm::ld<uint2>(a.nd, o * 8u);   // oct normal (fp16 x 2), linear z (fp16)
+    const float    cz  = fm::lo(cnd.y);
     float var = 0.0f;
     // compute_variance_center (:65-88): 3x3 gaussian of the variance channel, unit taps
     if (interior)
@@ -377,9 +412,9 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
         }
     }
     uint32_t result = c;
-    if (!(cnd.w < 0.0f))
+    if (!(cz < 0.0f))
     {
-        const f3    cn = mk3(cnd.x, cnd.y, cnd.z);
+        const f3    cn = fm::oct_unit(cnd.x);
         const float cv = fm::lo(c);
         EdgeK ek;
         ek.kz        = 1.44269504088896341f * fm::rcp(a.sigma_depth);
@@ -390,7 +425,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
         if (STEP > 0)
         {
             uint32_t t_in[8];
-            float4   t_nd[8];
+            uint2    t_nd[8];
             bool     t_ok[8];
             if (interior)
             {
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                     const uint32_t so = (uint32_t)((y + yy * STEP) * a.w + (x + xx * STEP));
                     t_ok[t] = true;
                     t_in[t] = fm::ld<uint32_t>(a.in.p, so * 4u);
-                    t_nd[t] = fm::ld<float4>(a.nd, so * 16u);
+                    t_nd[t] = fm::ld<uint2>(a.nd, so * 8u);
                 }
             }
             else
@@ -411,12 +446,13 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                 {
                     const int k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                     const int px = x + xx * STEP, py = y + yy * STEP;
-                    t_ok[t] = px >= 0 && py >= 0 && px < a.w && py < a.h;
-                    const bool     res = t_ok[t] && py >= a.y0 && py < a.y1;
+                    // a tap outside the image is skipped; one outside the resident rows of a band reads zeros, whose weight is 0 (halo
+                    // rows only): both get weight 0 below
+                    const bool     res = px >= 0 && py >= 0 && px < a.w && py < a.h && py >= a.y0 && py < a.y1;
                     const uint32_t so  = res ? (uint32_t)(py * a.w + px) : o;
+                    t_ok[t] = res;
                     t_in[t] = fm::ld<uint32_t>(a.in.p, so * 4u);
-                    t_nd[t] = fm::ld<float4>(a.nd, so * 16u);
-                    if (!res) { t_in[t] = 0u; t_nd[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                    t_nd[t] = fm::ld<uint2>(a.nd, so * 8u);
                 }
             }
 #pragma unroll
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                 const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                 const float kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
                 const float sv = fm::lo(t_in[t]);
-                float wv = edge_weight_fast(ek, cnd.w, t_nd[t].w, cn, mk3(t_nd[t].x, t_nd[t].y, t_nd[t].z), cv, sv) * kk;
+                float wv = edge_weight_fast(ek, cz, fm::lo(t_nd[t].y), cn, fm::oct_unit(t_nd[t].x), cv, sv) * kk;
                 if (!t_ok[t]) wv = 0.0f;
                 sum_w += wv;
                 sum_v += wv * sv;
@@ -442,13 +478,12 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                     const int   axx = xx < 0 ? -xx : xx, ayy = yy < 0 ? -yy : yy;
                     const float kx = axx == 0 ? 1.0f : (axx == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
                     const float ky = ayy == 0 ? 1.0f : (ayy == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
-                    const bool     res = py >= a.y0 && py < a.y1;
-                    const uint32_t so  = res ? (uint32_t)(py * a.w + px) : o;
-                    uint32_t s  = fm::ld<uint32_t>(a.in.p, so * 4u);
-                    float4   nd = fm::ld<float4>(a.nd, so * 16u);
-                    if (!res) { s = 0u; nd = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+                    if (py < a.y0 || py >= a.y1) continue;   // outside the resident rows of a band: zeros, weight 0
+                    const uint32_t so = (uint32_t)(py * a.w + px);
+                    const uint32_t s  = fm::ld<uint32_t>(a.in.p, so * 4u);
+                    const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
                     const float sv = fm::lo(s);
-                    const float wv = edge_weight_fast(ek, cnd.w, nd.w, cn, mk3(nd.x, nd.y, nd.z), cv, sv) * (kx * ky);
+                    const float wv = edge_weight_fast(ek, cz, fm::lo(nd.y), cn, fm::oct_unit(nd.x), cv, sv) * (kx * ky);
                     sum_w += wv;
                     sum_v += wv * sv;
                     sum_var += (wv * wv) * fm::hi(s);
@@ -468,14 +503,15 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
 // ------------------------------------------------------------------------------------------------------------------------
 // ao_denoise_reprojection.comp:191-260, tolerance mode; spp = 1..4 sample planes (BASELINE configs[2]: 4)
 template <bool MULTI>
-__global__ __launch_bounds__(64 * FT_WAVES) void kf_ao_temporal(AOTemporalArgs a)
+__global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArgs a)
 {
     __shared__ uint32_t s_mask[FT_WAVES][4][18];
     __shared__ MaskRows s_rows[FT_WAVES];
     const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int  tile = blockIdx.x * FT_WAVES + wave;
-    const bool tile_ok = tile < a.tiles_x * a.tiles_y;
-    const int  tx = tile_ok ? tile % a.tiles_x : 0, ty = (tile_ok ? tile / a.tiles_x : 0) + a.tile_y0;
+    // grid = (tile columns / FT_WAVES, tile rows): no integer division per wave
+    const int  txr = blockIdx.x * FT_WAVES + wave;
+    const bool tile_ok = txr < a.tiles_x;
+    const int  tx = tile_ok ? txr : 0, ty = (int)blockIdx.y + a.tile_y0;
     const int  lx = lane & 7, ly = lane >> 3;
     const int  x = tx * 8 + lx, y = ty * 8 + ly;
     const bool in_image = tile_ok && x < a.w && y < a.h && y >= a.y0 && y < a.y1;
@@ -486,22 +522,26 @@ __global__ __launch_bounds__(64 * FT_WAVES) void kf_ao_temporal(AOTemporalArgs a
     const uint32_t cg3y_raw = fm::ld<uint32_t>(a.gb3.p, pix * 8u + 4u);
     build_mask_rows<true>(s_rows[wave], s_mask[wave], a.mask, MULTI ? a.spp : 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
     if (!tile_ok) return;
+    const float    d    = edge ? 0.0f : d_raw;
+    const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_raw;
+    const uint32_t cg3y = edge ? 0u : cg3y_raw;
+    const bool     live = (in_image || edge) && d != 1.0f;
+    Reproj<2, false, false> rp;
+    rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = nullptr; rp.hist_len = a.hist_len.p;
+    rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+    if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
     int sum, own;
-    mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);
-    const float mean = div_by((float)sum, div_prepare(289.0f * (float)a.spp));
+    mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);   // popcounts while the history loads are in flight
+    const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f * (float)a.spp));
     bool flag = false;
     if (in_image || edge)
     {
-        const float d = edge ? 0.0f : d_raw;
         float out = 1.0f, hlen = 0.0f;
-        if (d != 1.0f)
+        if (live)
         {
-            const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_raw;
-            const uint32_t cg3y = edge ? 0u : cg3y_raw;
-            const float    ao   = div_by((float)own, div_prepare((float)a.spp));
-            ReprojOut      r;
-            const bool success = reproject_fast<2, false, false>(x, y, d, a.vpi, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f, a.pgb2.p,
-                                                                 a.pgb3.p, a.pdepth.p, a.hist.p, nullptr, a.hist_len.p, HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+            const float ao = fm::div_by_inrange((float)own, div_prepare((float)a.spp));
+            ReprojOut   r;
+            const bool  success = rp.resolve(r);
             hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
             float hao = r.col[0];
             if (success)
@@ -543,6 +583,13 @@ __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
     __shared__ float  s_gauss[2 * RADIUS + 1];
     const int SW = 32 + 2 * RADIUS * a.dx, SH = 8 + 2 * RADIUS * a.dy;
     const int ox = (int)blockIdx.x * 32 - RADIUS * a.dx, oy = a.y0 + (int)blockIdx.y * 8 - RADIUS * a.dy;
+    // the centre's own reads (tile class, depth) travel with the staging loads: one memory round trip before the barrier
+    const int  lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int  x = (int)blockIdx.x * 32 + lx, y = a.y0 + (int)blockIdx.y * 8 + ly;
+    const bool have = x < a.w && y < a.y1;
+    const uint32_t o = have ? (uint32_t)(y * a.w + x) : (uint32_t)(a.y0 * a.w);
+    const uint8_t  tclass = a.tile_class[have ? (size_t)(y >> 3) * a.tiles_x + (x >> 3) : 0];
+    const float    cdepth = fm::ld<float>(a.depth.p, o * 4u);
     if ((int)threadIdx.x <= 2 * RADIUS) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - RADIUS), (float)RADIUS * (1.0f / 1.5f));
     for (int i = threadIdx.x; i < SW * SH; i += 256)
     {
@@ -559,14 +606,11 @@ __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
         s_ao[i] = (float)__builtin_bit_cast(_Float16, v);
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = (int)blockIdx.x * 32 + lx, y = a.y0 + (int)blockIdx.y * 8 + ly;
-    if (x >= a.w || y >= a.y1) return;
-    const uint32_t o = (uint32_t)(y * a.w + x);
+    if (!have) return;
     uint16_t* outp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * 2u);
     const uint16_t one = 0x3c00u;
-    if (!a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) { *outp = one; return; }   // cleared image (ray_traced_ao.cpp:1048-1055)
-    if (fm::ld<float>(a.depth.p, o * 4u) == 1.0f) { *outp = one; return; }
+    if (!tclass) { *outp = one; return; }   // cleared image (ray_traced_ao.cpp:1048-1055)
+    if (cdepth == 1.0f) { *outp = one; return; }
     const int    ci = (ly + RADIUS * a.dy) * SW + lx + RADIUS * a.dx, stride = a.dy * SW + a.dx;
     const float4 c  = s_nz[ci];
     float total_ao = s_ao[ci], total_w = 1.0f;
@@ -630,7 +674,7 @@ __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 #define FR_TW 32
 #define FR_TH 8
 #define FR_R 8
-__global__ __launch_bounds__(256) void kf_refl_temporal(ReflTemporalArgs a)
+__global__ __launch_bounds__(256, 5) void kf_refl_temporal(ReflTemporalArgs a)
 {
     constexpr int CW = FR_TW + 2 * FR_R, CH = FR_TH + 2 * FR_R;   // 48 x 24
     __shared__ uint2  s_col[CH][CW];        // rgb + ray length, fp16 as stored by the trace
@@ -638,6 +682,14 @@ __global__ __launch_bounds__(256) void kf_refl_temporal(ReflTemporalArgs a)
     __shared__ float2 s_hb[CH][FR_TW];      //                  sum g^2, b^2
     __shared__ int    s_flag[4];
     const int bx0 = blockIdx.x * FR_TW, by0 = a.y0 + blockIdx.y * FR_TH;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = bx0 + lx, y = by0 + ly;
+    const bool have = x < a.w && y < a.y1;
+    // memory round trips in this order: (1) centre texels + the 48x24 colour tile, under which nothing else can run; (2) the history
+    // taps, issued after the horizontal LDS pass and left in flight under the vertical one
+    const uint32_t o = have ? (uint32_t)(y * a.w + x) : (uint32_t)(a.y0 * a.w);
+    const float d   = fm::ld<float>(a.depth.p, o * 4u);
+    const uint2 cg2 = fm::ld<uint2>(a.gb2.p, o * 8u), cg3 = fm::ld<uint2>(a.gb3.p, o * 8u);
     if (threadIdx.x < 4) s_flag[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < CH * CW; i += 256)
     {
@@ -679,37 +731,35 @@ __global__ __launch_bounds__(256) void kf_refl_temporal(ReflTemporalArgs a)
         }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = bx0 + lx, y = by0 + ly;
-    bool flag = false;
-    if (x < a.w && y < a.y1)
+    const bool  live = have && d != 1.0f;
+    const uint2 cq = s_col[ly + FR_R][lx + FR_R];
+    Reproj<8, true, true> rp;
+    rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
+    rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+    if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]), a.pvp, fm::hi(cq.y));
+    // vertical pass of the separable sums (LDS only) while the history taps are in flight
+    float s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
+#pragma unroll 6   // in groups: fully unrolled, the 34 LDS reads are hoisted together and cost 100 VGPRs next to the 25 tap registers
+    for (int dy = 0; dy <= 2 * FR_R; dy++)
     {
-        const uint32_t o = (uint32_t)(y * a.w + x);
-        const float    d = fm::ld<float>(a.depth.p, o * 4u);
-        const uint2    cg3 = fm::ld<uint2>(a.gb3.p, o * 8u);
-        const float    roughness = fm::lo(cg3.x);
+        const float4 ha = s_ha[ly + dy][lx];
+        const float2 hb = s_hb[ly + dy][lx];
+        s1[0] += ha.x; s1[1] += ha.y; s1[2] += ha.z; s2[0] += ha.w; s2[1] += hb.x; s2[2] += hb.y;
+    }
+    bool flag = false;
+    if (have)
+    {
+        const float roughness = fm::lo(cg3.x);
         float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f, m0 = 0.0f, m1 = 0.0f, hl = 0.0f;
-        if (d != 1.0f)
+        if (live)
         {
-            const uint2 cg2 = fm::ld<uint2>(a.gb2.p, o * 8u);
-            const uint2 cq  = s_col[ly + FR_R][lx + FR_R];
-            const f3    color = mk3(fm::lo(cq.x), fm::hi(cq.x), fm::lo(cq.y));
-            ReprojOut   r;
-            const bool  success = reproject_fast<8, true, true>(x, y, d, a.vpi, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]),
-                                                                a.pvp, fm::hi(cq.y), a.pgb2.p, a.pgb3.p, a.pdepth.p, a.hist.p, a.hist_moments.p, nullptr,
-                                                                HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 }, r);
+            const f3  color = mk3(fm::lo(cq.x), fm::hi(cq.x), fm::lo(cq.y));
+            ReprojOut r;
+            const bool success = rp.resolve(r);
             hl = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
             f3 history = mk3(r.col[0], r.col[1], r.col[2]);
             if (success)
             {
-                float s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
-#pragma unroll
-                for (int dy = 0; dy <= 2 * FR_R; dy++)
-                {
-                    const float4 ha = s_ha[ly + dy][lx];
-                    const float2 hb = s_hb[ly + dy][lx];
-                    s1[0] += ha.x; s1[1] += ha.y; s1[2] += ha.z; s2[0] += ha.w; s2[1] += hb.x; s2[2] += hb.y;
-                }
                 float cv[3], ext[3], cen[3], mx = 0.0f;
                 const float hv[3] = { history.x, history.y, history.z };
 #pragma unroll
@@ -1037,7 +1087,7 @@ namespace hr {
 
 void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st)
 {
-    hipLaunchKernelGGL(kf_shadows_temporal, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
+    hipLaunchKernelGGL(kf_shadows_temporal, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
@@ -1056,8 +1106,9 @@ void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
 
 void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st)
 {
-    if (a.spp > 1) hipLaunchKernelGGL(kf_ao_temporal<true>, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
-    else hipLaunchKernelGGL(kf_ao_temporal<false>, dim3(cdiv(n_tiles, FT_WAVES)), dim3(64 * FT_WAVES), 0, st, a);
+    const dim3 grid(cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
+    if (a.spp > 1) hipLaunchKernelGGL(kf_ao_temporal<true>, grid, dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(kf_ao_temporal<false>, grid, dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
