@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X-native ray-trace + denoise hot path.
 
-One "step" = one frame of RayTracedShadows::render (1 spp soft-shadow trace + SVGF temporal +
-4 x a-trous) on synthetic 1080p G-buffers of the procedural Sponza-like scene (~278k triangles),
-inputs resident in HBM (BASELINE.json configs[1]).  Prints ONE JSON line (see the driver contract).
+One "step" = one frame of RayTracedShadows::render (1 spp soft-shadow trace + SVGF temporal + 4 x a-trous) on synthetic 1080p
+G-buffers of the procedural Sponza-like scene (~278k triangles), inputs resident in HBM (BASELINE.json configs[1]), in the
+shipping arithmetic mode (hr_shadows_params.exact = 0: bit-exact masks, fp16 images within the stated tolerance; the bit-for-bit
+parity mode is timed next to it and reported as `exact_mode`).  Prints ONE JSON line (see the driver contract).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): the SAME view is rendered with N times the pixels — 1920*sqrt(N) x 1080*sqrt(N), rounded to
+Besides the headline the line carries (outside the timed region, short runs):
+  passes       N = 1: BASELINE configs[2], [3] and the passes of [4] on one GPU — AO 4 spp, half-res reflections, DDGI 16x8x16x256, the
+               whole hybrid frame at 1080p and at 4K: ms, Mrays/s, frames/s and, per kernel, the HIP-event time and the fraction of the
+               8 TB/s HBM roofline its ALGORITHMIC bytes amount to;
+  hybrid_4k    N > 1: BASELINE configs[4] itself — ONE 3840x2160 hybrid frame row-tiled over the N GPUs (strong scaling), max over ranks;
+  roofline     dominant kernel of the headline; `frac` = algorithmic bytes / time / peak, `dram_frac` = rocprofv3 PMC traffic / time / peak
+               and `bound` = what the committed SQ counters of this build say limits it (profiles/, tools/profile_round.sh);
+  cpu_baseline the SAME ray batch replayed through the oracle's scalar BVH traversal on the host cores (`trace_replay`) and the oracle's
+               denoise chain timed separately (`denoise_ms`), BASELINE.md §3.
+
+N > 1 (weak scaling of the headline): the SAME view is rendered with N times the pixels — 1920*sqrt(N) x 1080*sqrt(N), rounded to
 multiples of 8 — so rays and pixels per frame grow with N while the content statistics stay those of the N = 1 frame.
 The frame is row-tiled, one band per GPU; band boundaries are chosen from a calibration frame so that every band
-carries the same share of the cost model  pixels + 1.25 * rays  (tiling.balanced_bounds: sky rows fire no ray, the
+carries the same share of the cost model  pixels + 1.8 * rays  (tiling.balanced_bounds: sky rows fire no ray, the
 floor fires one per pixel — equal-height bands would leave most GPUs idle).  Every band re-traces / re-filters 24 halo
 rows locally and, once per frame, exchanges the 40 history rows next to each band boundary with its neighbours over
 RCCL (hybrid_rendering_amd/tiling.py), overlapped with the next frame's trace; band rows are bit-identical to the
-single-GPU result (tests/test_gpu_tiling.py).  `value` counts only the rays of band rows (halo work is overhead).
+single-GPU result in exact mode (tests/test_gpu_tiling.py).  `value` counts only the rays of band rows (halo work is overhead).
 """
 from __future__ import annotations
 
@@ -24,6 +35,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -34,6 +46,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 NODE_BYTES, TRI_BYTES = 80, 48
+# stage name of the pass profilers -> kernel name in the rocprofv3 files of profiles/
+KERNEL_OF = {("shadows", "ray_trace"): "k_shadows_trace<false>", ("shadows", "temporal_accumulation"): "kf_shadows_temporal", ("shadows", "atrous"): "kf_shadows_atrous",
+             ("ao", "ray_trace"): "k_ao_trace<false>", ("ao", "temporal_accumulation"): "kf_ao_temporal", ("ao", "blur"): "kf_ao_blur",
+             ("ddgi", "ray_trace"): "k_ddgi_trace", ("ddgi", "sample_probe_grid"): "kf_ddgi_sample", ("ddgi", "irradiance_probe_update"): "k_ddgi_probe_update<false>",
+             ("ddgi", "depth_probe_update"): "k_ddgi_probe_update<true>", ("reflections", "ray_trace"): "k_refl_trace",
+             ("reflections", "temporal_accumulation"): "kf_refl_temporal", ("reflections", "atrous"): "kf_refl_atrous", ("reflections", "upsample"): "kf_upsample"}
 
 
 def parse():
@@ -44,10 +62,79 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~278k triangles)")
+    ap.add_argument("--obj", default=None, help="Wavefront OBJ (+MTL) to render instead of the procedural scene (hybrid_rendering_amd/assets.py)")
     ap.add_argument("--ring", type=int, default=8, help="distinct camera positions cycled through")
+    ap.add_argument("--exact", type=int, default=0, help="1: time the bit-for-bit parity arithmetic as the headline instead of the tolerance mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--no-passes", action="store_true", help="skip the `passes` / `hybrid_4k` blocks (profiling runs)")
+    ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
+
+
+def load_profile():
+    """latest profiles/r*/ directory of this build: per-kernel PMC traffic (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM) and
+    SQ counters -> what bounds each kernel.  PMC cannot be sampled from inside this process: the files are committed with the build."""
+    prof = {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
+    try:
+        pd = os.path.join(ROOT, "profiles")
+        dirs = sorted(d for d in os.listdir(pd) if os.path.exists(os.path.join(pd, d, "pmc_summary.json")))
+        if not dirs:
+            return prof
+        d = os.path.join(pd, dirs[-1])
+        prof["dir"] = "profiles/" + dirs[-1]
+        for k, v in json.load(open(os.path.join(d, "pmc_summary.json"))).items():
+            if "FETCH_SIZE_KB_avg_per_launch" in v and "WRITE_SIZE_KB_avg_per_launch" in v:
+                prof["traffic"][k] = int((2 * v["FETCH_SIZE_KB_avg_per_launch"] + v["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
+        sq = os.path.join(d, "sq_counters.txt")
+        if os.path.exists(sq):
+            cur = None
+            vals = {}
+            for line in open(sq):
+                if line and not line[0].isspace():
+                    cur = line.strip()
+                    vals[cur] = {}
+                else:
+                    m = re.match(r"\s+(\S+)\s+avg\s+([\d.]+)", line)
+                    if m and cur:
+                        vals[cur][m.group(1)] = float(m.group(2))
+            for k, v in vals.items():
+                if "VALUBusy" in v:
+                    prof["valu_busy"][k] = v["VALUBusy"]
+                if v.get("SQ_ACTIVE_INST_VALU"):
+                    prof["lanes"][k] = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * v["SQ_ACTIVE_INST_VALU"])
+    except Exception:
+        pass
+    return prof
+
+
+def lookup(table, kernel):
+    for k, v in table.items():
+        if kernel in k:
+            return v
+    return None
+
+
+def classify(prof, kernel, ms, alg_bytes):
+    """-> dict(frac, dram_frac, bound): `bound` from the measurements — VALU-bound if the SIMDs issue > 70 % of the time, HBM-bound if
+    the counter traffic moves at > 50 % of peak, else latency-bound (dependent fetches / too few bytes in flight)."""
+    out = {"frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 and alg_bytes else None}
+    tr, vb = lookup(prof["traffic"], kernel), lookup(prof["valu_busy"], kernel)
+    out["traffic"] = tr
+    out["dram_frac"] = round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and ms > 0 else None
+    if vb is None and tr is None:
+        out["bound"] = None
+    elif vb is not None and vb > 70.0:
+        out["bound"] = "valu"
+    elif out["dram_frac"] is not None and out["dram_frac"] > 0.5:
+        out["bound"] = "hbm"
+    else:
+        out["bound"] = "latency"
+    if vb is not None:
+        out["valu_busy_pct"] = round(vb, 1)
+    ln = lookup(prof["lanes"], kernel)
+    if ln is not None:
+        out["lane_utilisation"] = round(ln, 2)
+    return out
 
 
 def main():
@@ -69,20 +156,29 @@ def main():
 
     from hybrid_rendering_amd import api as hr
     from hybrid_rendering_amd import synth, tiling
+    from hybrid_rendering_amd.frame import HybridFrame
 
     # N x the pixels of the N = 1 frame, same aspect and view (multiples of 8: tile / band alignment)
     sc = math.sqrt(world)
     W, H = (int(round(args.width * sc / 8)) * 8, int(round(args.height * sc / 8)) * 8) if world > 1 else (args.width, args.height)
-    sd = synth.sponza_like(args.detail)
+    if args.obj:
+        from hybrid_rendering_amd import assets
+        sd = assets.load_obj(args.obj)
+        scene_name = f"{os.path.basename(args.obj)}"
+    else:
+        sd = synth.sponza_like(args.detail)
+        scene_name = "procedural Sponza-like"
     ctx = hr.Context(local_rank)
     scene = hr.Scene(ctx, sd)
     light = synth.sponza_light()
     sob, sr = synth.blue_noise_tables()
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    exact = 1 if args.exact else 0
 
     # ring of camera positions (dolly 0.5 units/frame)
     R = max(2, args.ring)
-    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(R + 1)]
+    cam_of = (lambda f: synth.camera_for_bounds(sd.bounds(), W / H, frame=f, dolly=0.5)) if args.obj else (lambda f: synth.sponza_camera(W / H, frame=f, dolly=0.5))
+    cams = [cam_of(f) for f in range(R + 1)]
     # G-buffers: ring position i rendered with prev = i-1 (forward sweep) and with prev = i+1 (backward sweep)
     gbs = {}
     ubos = {}
@@ -112,66 +208,57 @@ def main():
         cost = tiling.shadow_cost_per_tile_row(gbs[seq[0]]["depth"], cal.tile_ray_counts())
         cal.close()
         bounds = tiling.balanced_bounds(cost, world, H)
-        if world > 1:
-            tb = torch.tensor(bounds, dtype=torch.int64, device="cuda")
-            dist.broadcast(tb, src=0)      # belt and braces: every rank uses rank 0's partition
-            bounds = [int(v) for v in tb.cpu()]
-    tiled = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds)
-    shadows = tiled.pass_
-    b0, b1 = tiled.b0, tiled.b1
-
-    def step(k):
-        fi = cycle[k % len(cycle)]
-        fi.num_frames = k
-        tiled.render(scene, fi)
+        tb = torch.tensor(bounds, dtype=torch.int64, device="cuda")
+        dist.broadcast(tb, src=0)      # belt and braces: every rank uses rank 0's partition
+        bounds = [int(v) for v in tb.cpu()]
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    # Per-kernel HIP events on the launch stream: with HR_BENCH_INLINE_EVENTS=1 they are recorded INSIDE the timed region (a
-    # ring of event pairs per stage in the library, read after the region).  Default: right AFTER it, same stream, same
-    # frames cycle — 12 event records per 0.26 ms frame cost 18% of the throughput (measured: 0.262 -> 0.309 ms/frame), while
-    # the per-kernel averages agree within 1.5% either way (trace 115.7 vs 117.2 us), and rocprofv3 agrees with both.
-    profile_inside = os.environ.get("HR_BENCH_INLINE_EVENTS") is not None
-    if profile_inside:
-        shadows.set_profiling(True)
-        shadows.stage_times()          # start a fresh averaging window
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    acc = {}
-    if profile_inside:
-        tiled.wait_exchange()
-        for name, ms, nbytes in shadows.stage_times():      # averages over the (last <= 512) timed frames
-            acc[name] = [ms, nbytes]
-        shadows.set_profiling(False)
+    def timed_run(tiled, steps, warmup):
+        def step(k):
+            fi = cycle[k % len(cycle)]
+            fi.num_frames = k
+            tiled.render(scene, fi)
+        for k in range(warmup):
+            step(k)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, step
 
-    # ---- ray counts (and, if the inline events were switched off, per-stage timing) outside the timed region ----------
+    # ------------------------------------------------------------------------------------------------ the timed region (headline)
+    tiled = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds)
+    tiled.params.exact = exact
+    shadows = tiled.pass_
+    b0, b1 = tiled.b0, tiled.b1
+    elapsed, step = timed_run(tiled, args.steps, args.warmup)
+
+    # ---- per-kernel HIP events on the launch stream, right AFTER the timed region (same stream, same frame cycle: 12 event records per
+    # ~0.2 ms frame inside it cost 18 % of the throughput; the per-kernel averages agree within 1.5 % either way, and rocprofv3 agrees
+    # with both — DESIGN.md §5), plus ray counts
+    acc = {}
     rays_total, n_prof = 0, min(args.steps, 60)
     k0 = args.warmup + args.steps
-    if not profile_inside:
-        shadows.set_profiling(True)
+    shadows.set_profiling(True)
     for k in range(k0, k0 + n_prof):
         step(k)
         rays_total += shadows.ray_count()
-        if not profile_inside:
-            for name, ms, nbytes in shadows.stage_times():
-                a = acc.setdefault(name, [0.0, nbytes])
-                a[0] += ms / n_prof
+        for name, ms, nbytes in shadows.stage_times():
+            a = acc.setdefault(name, [0.0, nbytes])
+            a[0] += ms / n_prof
     shadows.set_profiling(False)
     rays_per_frame = rays_total / n_prof
     if world > 1:
@@ -183,7 +270,7 @@ def main():
             fi.num_frames = k
             counter.ray_trace(scene, fi)
             tot += counter.ray_count()
-        traced_per_frame, rays_per_frame = rays_per_frame, tot / 8
+        rays_per_frame = tot / 8
         counter.close()
     stages = {n: dict(ms=v[0], bytes=v[1]) for n, v in acc.items()}
     # instrumented trace (node visits / triangle tests) on a few frames of the cycle
@@ -196,9 +283,13 @@ def main():
     trace_bytes = px * 12.125 + rays_per_frame * (nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES)
     if "ray_trace" in stages:
         stages["ray_trace"]["bytes"] = int(trace_bytes)
-    for s in stages.values():
+    prof = load_profile() if (world == 1 and (W, H) == (1920, 1080) and not args.obj) else {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
+    for n, s in stages.items():
+        kern = KERNEL_OF.get(("shadows", re.sub(r"_\d+$", "", n)), n)
+        if exact:
+            kern = kern.replace("kf_", "k_")
+        s.update(classify(prof, kern, s["ms"], s["bytes"]))
         s["GBps"] = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
-        s["frac"] = s["GBps"] / HBM_PEAK_GBS
 
     total_rays = rays_per_frame * args.steps * world
     if world > 1:
@@ -208,80 +299,177 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
     dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this build (separate --pmc runs;
-    # FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md §HBM) — PMC cannot be sampled from inside this process.
-    traffic, traffic_src = None, None
-    try:
-        pdirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
-        if pdirs and world == 1 and (W, args.height) == (1920, 1080):
-            pm = json.load(open(os.path.join(ROOT, "profiles", pdirs[-1], "pmc_summary.json")))
-            kname = {"ray_trace": "k_shadows_trace<false>", "temporal_accumulation": "k_shadows_temporal"}.get(dom[0], "k_shadows_atrous")
-            for k, v in pm.items():
-                if kname in k:
-                    traffic = int((2 * v["FETCH_SIZE_KB_avg_per_launch"] + v["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
-                    traffic_src = f"profiles/{pdirs[-1]}/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE)"
-    except Exception:
-        pass
     out = {
         "metric": "shadow Mrays/s over the fully denoised frame (1 spp trace + SVGF temporal + 4x a-trous)",
         "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} procedural Sponza-like ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise"
+        "config": {"workload": f"{W}x{H} {scene_name} ({sd.n_tris} tris) ray-traced shadows 1spp + SVGF denoise"
                                + (f", same view as 1920x1080 with {world}x the pixels, row-tiled into {world} cost-balanced bands (rows {bounds})" if world > 1 else ""),
+                   "math": ("exact = 1: every fp32 operation correctly rounded, all stage images bit-identical to the oracle" if exact else
+                            "exact = 0 (shipping mode): visibility masks / ray counts bit-exact, fp16 images within 2 fp16 ulp (rel-L2 <= 1e-3) of the oracle — tests/test_gpu_tolerance.py"),
                    "rays_per_frame_per_gpu": int(rays_per_frame), "pixels_per_gpu": px, "bvh_nodes": int(scene.info.n_nodes),
                    "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
         "denoised_frames_per_s": round(args.steps / elapsed, 2),                  # frames of W x H (the whole tiled frame)
         "denoised_1080p_equiv_per_s": round(W * H / (args.width * args.height) * args.steps / elapsed, 2),
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
-        "roofline": {"kernel": dom[0], "bound": "hbm", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom[1]["frac"], 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(dom[1]["bytes"])},
-        "stages": {n: {"ms": round(s["ms"], 4), "GBps": round(s["GBps"], 1), "frac": round(s["frac"], 4), "bytes": s["bytes"]} for n, s in stages.items()},
+        "roofline": {"kernel": dom[0], "bound": dom[1].get("bound") or "latency", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom[1]["frac"], "traffic": dom[1].get("traffic"), "dram_frac": dom[1].get("dram_frac"),
+                     "traffic_source": (prof["dir"] + "/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)") if prof["dir"] else None,
+                     "algorithmic_bytes": int(dom[1]["bytes"]),
+                     "note": "achieved/frac divide the ALGORITHMIC bytes (SURVEY §8d: G-buffer + mask + visited BVH nodes x 80 B + tested triangles x 48 B) by the kernel time; "
+                             "the 15 MB BVH is served by L2 / Infinity Cache, so dram_frac (counter traffic) is the HBM-side figure and `bound` is what the SQ counters show"},
+        "stages": {n: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()} for n, s in stages.items()},
     }
 
-    # ---- CPU baseline: the oracle (a port) on the host cores, bounded sample, rank 0 at N=1 only --------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pyoracle as po
-        osc = po.Scene(sd)
-        op = po.ShadowsPass(W, H)
-        host = {k: {n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in gbs[k].items()} for k in seq[:3]}
-        op.render(osc, ubos[seq[0]], host[seq[0]], host[seq[0]], sob, sr, 0)  # warm (page-in, history)
-        nrays, t0c = 0, time.perf_counter()
-        nf = max(1, args.cpu_frames)
-        for f in range(nf):
-            key, pk = seq[(f + 1) % 3], seq[f % 3]
-            op.render(osc, ubos[key], host[key], host[pk], sob, sr, f + 1)
-            nrays += op.stages["rays"]
-        dt = time.perf_counter() - t0c
-        out["cpu_baseline"] = {"value": round(nrays / dt / 1e6, 3), "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"{nf} full {W}x{H} frames (trace + SVGF denoise) of the same workload through oracle/ (OpenMP, {os.cpu_count()} threads)",
-                               "frames_per_s": round(nf / dt, 3)}
-        # the reference's OWN shaders (oracle/_ref, one host thread): a small frame of the same view, trace + denoise
+    # ---- the other arithmetic mode, same frames, shorter run (reported, never `value`)
+    other = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds)
+    other.params.exact = 1 - exact
+    el2, _ = timed_run(other, max(20, args.steps // 4), 10)
+    n2 = max(20, args.steps // 4)
+    out["tolerance_mode" if exact else "exact_mode"] = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(total_rays / args.steps * n2 / el2 / 1e6, 2), "unit": "Mrays/s",
+                                                        "steps": n2, "note": "hr_shadows_params.exact = %d on the same frames" % (1 - exact)}
+    other.pass_.close()
+
+    # ---- the other BASELINE configurations (outside the timed region) ------------------------------------------------------------
+    if not args.no_passes and not args.obj:
         try:
-            from oracle import pyref, ref_harness as rh
-            if pyref.available():
-                rw, rhh = 240, 136
-                rcams = [synth.sponza_camera(rw / rhh, frame=f, dolly=0.5) for f in range(3)]
-                rubos = [synth.make_ubo(rcams[i + 1], rcams[i], light) for i in range(2)]
-                rgb = [{n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in scene.gbuffer(u, rw, rhh).items()}
-                       for u in rubos]
-                rp, orp = rh.RefShadowsPass(rw, rhh), po.ShadowsPass(rw, rhh)
-                rp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
-                orp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
-                t0r = time.perf_counter()
-                rp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
-                dtr = time.perf_counter() - t0r
-                orp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
-                out["cpu_baseline"]["reference_shaders"] = {
-                    "value": round(orp.stages["rays"] / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                    "sample": f"one {rw}x{rhh} frame of the same view through the reference's shaders compiled for the CPU (oracle/_ref)",
-                    "bit_identical_to_port": bool(np.array_equal(rp.stages["output"], orp.stages["output"]))}
-        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
-            out["cpu_baseline"]["reference_shaders"] = {"error": repr(e)[:200]}
+            if world == 1:
+                out["passes"] = passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact)
+            else:
+                hf = HybridFrame(ctx, scene, sd, 3840, 2160, rank, world, exact=exact)
+                ms = hf.time(20, 4, barrier=barrier)
+                rays = sum(hf.ray_counts().values())
+                t = torch.tensor([ms, float(rays)], dtype=torch.float64, device="cuda")
+                tm = t.clone()
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                out["hybrid_4k"] = {"workload": "ONE 3840x2160 hybrid frame (shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections) row-tiled over the GPUs: strong scaling (BASELINE configs[4])",
+                                    "n_gpus": world, "ms_per_frame": round(float(tm[0]), 4), "frames_per_s": round(1e3 / float(tm[0]), 1),
+                                    "Mrays_per_s": round(float(t[1]) / float(tm[0]) / 1e3, 1), "bands": hf.bounds, "scaling": "strong"}
+                hf.close()
+        except Exception as e:   # a report next to the headline, never a reason to lose the bench line
+            out["passes_error"] = repr(e)[:300]
+
+    # ---- CPU baseline on the host cores, bounded sample, rank 0 at N=1 only -----------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(torch, np, scene, sd, gbs, ubos, seq, sob, sr, W, H, light, synth, args)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
+    """BASELINE configs[2], [3] and [4] on ONE GPU: wall-clock per pass and per hybrid frame, per-kernel event times and roofline fractions"""
+    res = {}
+    hf = HybridFrame(ctx, scene, sd, 1920, 1080, exact=exact)
+    hf.time(6, 2)                                                   # warm every pass (history, atlases)
+    wall = {n: hf.time(30, 4, only=n) for n in ("shadows", "ao", "ddgi", "reflections")}
+    hybrid = hf.time(30, 4)
+    rays = hf.ray_counts()
+    st = hf.stage_times(10)
+    label = {"ao": "AO 4 spp + temporal + 2 blurs, 1920x1080 (configs[2])", "reflections": "reflections 1 spp at half resolution + SVGF + upsample, 1920x1080 frame (configs[3])",
+             "ddgi": "DDGI 16x8x16 probes x 256 rays: trace + probe updates + per-pixel sample, 1920x1080", "shadows": "shadows 1 spp + SVGF, 1920x1080 (inside the hybrid frame)"}
+    for n in ("ao", "reflections", "ddgi", "shadows"):
+        kern = {}
+        for s, (ms, b) in st[n].items():
+            k = KERNEL_OF.get((n, re.sub(r"(_\d+|_x|_y)$", "", s)), s)
+            if exact:
+                k = k.replace("kf_", "k_")
+            e = {"ms": round(ms, 4), "kernel": k}
+            c = classify(prof, k, ms, b if "ray_trace" not in s else 0)
+            e.update({kk: vv for kk, vv in c.items() if vv is not None})
+            kern[s] = e
+        res[n] = {"workload": label[n], "ms_per_frame": round(wall[n], 4), "frames_per_s": round(1e3 / wall[n], 1), "rays_per_frame": rays[n],
+                  "Mrays_per_s": round(rays[n] / wall[n] / 1e3, 1), "kernels": kern}
+    res["hybrid_1080p"] = {"workload": "whole hybrid frame 1920x1080 on one GPU: shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, one stream",
+                           "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1)}
+    hf.close()
+    hf4 = HybridFrame(ctx, scene, sd, 3840, 2160, exact=exact)
+    ms4 = hf4.time(15, 4)
+    r4 = hf4.ray_counts()
+    res["hybrid_4k_one_gpu"] = {"workload": "whole hybrid frame 3840x2160 on ONE GPU (BASELINE configs[4] names 8)", "ms_per_frame": round(ms4, 4), "frames_per_s": round(1e3 / ms4, 1),
+                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1)}
+    hf4.close()
+    res["note"] = ("kernel `frac` = algorithmic bytes (SURVEY §8d) / HIP-event time / 8 TB/s; `dram_frac`, `bound`, `valu_busy_pct`, `lane_utilisation` from the rocprofv3 "
+                   "counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + "; trace kernels carry no `frac` here (their BVH bytes need the "
+                   "instrumented build: see the headline's roofline)")
+    return res
+
+
+def cpu_baseline(torch, np, scene, sd, gbs, ubos, seq, sob, sr, W, H, light, synth, args):
+    """BASELINE.md §3 / SURVEY §8d: the identical BVH (binary form) and the identical ray batch of a bench frame replayed through the
+    oracle's scalar any-hit traversal (OpenMP over rays, all host threads), and the oracle's denoise chain timed on its own."""
+    from oracle import pyoracle as po
+    ncpu = po.set_threads()          # min(affinity, cgroup quota): the box shows 256 hardware threads and grants 16
+    host = {k: {n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in gbs[k].items()} for k in seq[:3]}
+    osc = po.Scene(sd)
+    res = {"unit": "Mrays/s", "cores": ncpu, "kind": "port"}
+    # (1) trace replay: the rays the GPU kernel fires for this frame, generated once, traversed repeatedly for ~10 s
+    key = seq[1]
+    rays = po.shadows_gen_rays(ubos[key], host[key]["depth"], host[key]["gb2"], sob, sr, 0.5, 1)
+    rays = np.ascontiguousarray(rays[rays[:, 7] > 0.0])
+    rays[:, 7] = 0.01                                                 # t_min of the shadow query (ray_query.glsl:13-27)
+    _, st = osc.any_hit(rays[::16], stats=True)                       # instrumented (serial) pass on a sample: nodes / triangles per ray
+    st = [float(v) * 16 for v in st]
+    osc.any_hit(rays)                                                 # warm
+    n_rep, t0 = 0, time.perf_counter()
+    while True:
+        occ = osc.any_hit(rays)
+        n_rep += 1
+        if time.perf_counter() - t0 > 8.0 or n_rep >= 400:
+            break
+    dt = time.perf_counter() - t0
+    res["value"] = round(len(rays) * n_rep / dt / 1e6, 3)
+    res["trace_replay"] = {"value": res["value"], "unit": "Mrays/s", "rays_per_batch": int(len(rays)), "batches": n_rep, "seconds": round(dt, 2),
+                           "nodes_per_ray_bvh2": round(float(st[0]) / len(rays), 2), "tris_per_ray_bvh2": round(float(st[1]) / len(rays), 2),
+                           "occluded_fraction": round(float(occ.mean()), 4)}
+    res["sample"] = (f"the {len(rays)} shadow rays of one {W}x{H} bench frame (identical origins / directions / t_max) through the oracle's scalar BVH2 any-hit "
+                     f"traversal, OpenMP over rays on {ncpu} host threads (the box's cgroup CPU quota; {os.cpu_count()} hardware threads are visible), {n_rep} repetitions")
+    # (2) the denoise chain of the oracle (temporal + 4 a-trous), one warm frame, for context
+    op = po.ShadowsPass(W, H)
+    op.render(osc, ubos[seq[0]], host[seq[0]], host[seq[0]], sob, sr, 0)
+    mask, _ = po.shadows_ray_trace(osc, ubos[key], host[key]["depth"], host[key]["gb2"], sob, sr, 0.5, 1)
+    t0 = time.perf_counter()
+    tv, mom, tiles = po.shadows_temporal(ubos[key], mask, host[key], host[seq[0]], op.prev_image, op.moments)
+    t1 = time.perf_counter()
+    img = tv
+    for i in range(4):
+        img = po.shadows_atrous(img, host[key]["gb2"], host[key]["gb3"], tiles, 1 << i, power=1.2 if i == 3 else 0.0)
+    t2 = time.perf_counter()
+    res["denoise_ms"] = {"temporal": round((t1 - t0) * 1e3, 2), "atrous_x4": round((t2 - t1) * 1e3, 2), "threads": ncpu,
+                         "note": "oracle restatement of shadows_denoise_reprojection.comp + 4 x shadows_denoise_atrous.comp on one 1920x1080 frame (OpenMP over rows)"}
+    # (3) whole oracle frames (trace + denoise through the ctypes boundary), the figure round 1 reported
+    nrays, nf = 0, max(1, args.cpu_frames)
+    t0 = time.perf_counter()
+    for f in range(nf):
+        k1, k0 = seq[(f + 1) % 3], seq[f % 3]
+        op.render(osc, ubos[k1], host[k1], host[k0], sob, sr, f + 1)
+        nrays += op.stages["rays"]
+    dt = time.perf_counter() - t0
+    res["whole_frames"] = {"frames_per_s": round(nf / dt, 3), "Mrays_per_s": round(nrays / dt / 1e6, 3), "frames": nf}
+    # (4) the reference's OWN shaders (oracle/_ref, one host thread): a small frame of the same view, trace + denoise
+    try:
+        from oracle import pyref, ref_harness as rh
+        if pyref.available():
+            rw, rhh = 240, 136
+            rcams = [synth.sponza_camera(rw / rhh, frame=f, dolly=0.5) for f in range(3)]
+            rubos = [synth.make_ubo(rcams[i + 1], rcams[i], light) for i in range(2)]
+            rgb = [{n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in scene.gbuffer(u, rw, rhh).items()} for u in rubos]
+            rp, orp = rh.RefShadowsPass(rw, rhh), po.ShadowsPass(rw, rhh)
+            rp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
+            orp.render(osc, rubos[0], rgb[0], rgb[0], sob, sr, 0)
+            t0r = time.perf_counter()
+            rp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
+            dtr = time.perf_counter() - t0r
+            orp.render(osc, rubos[1], rgb[1], rgb[0], sob, sr, 1)
+            res["reference_shaders"] = {"value": round(orp.stages["rays"] / dtr / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                                        "sample": f"one {rw}x{rhh} frame of the same view through the reference's shaders compiled for the CPU (oracle/_ref)",
+                                        "bit_identical_to_port": bool(np.array_equal(rp.stages["output"], orp.stages["output"]))}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        res["reference_shaders"] = {"error": repr(e)[:200]}
+    return res
 
 
 if __name__ == "__main__":

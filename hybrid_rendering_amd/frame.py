@@ -1,0 +1,132 @@
+"""The whole hybrid frame of the reference's render loop (main.cpp:80-83: shadows, AO, DDGI, reflections) on 1..N GPUs —
+BASELINE.json configs[4].  Shared by bench.py (the `passes` block and the N > 1 `hybrid_4k` figure) and tools/frame_bench.py.
+
+Every rank renders its cost-balanced row band of the SAME frame with tiling.TiledShadows / TiledAO / TiledReflections and its
+probe slab with tiling.ShardedDDGI (RCCL: one neighbour exchange per tiled pass + one all-gather per DDGI atlas per frame)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+
+class HybridFrame:
+    def __init__(self, ctx, scene, sd, W, H, rank=0, world=1, exact=0, ao_spp=4, probes=(16, 8, 16), rays_per_probe=256, refl_scale=1, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import api as hr, api_gi, synth, synth_env, tiling
+        self.ctx, self.scene, self.W, self.H, self.rank, self.world = ctx, scene, W, H, rank, world
+        self.hr = hr
+        light = synth.sponza_light()
+        sob, sr = synth.blue_noise_tables()
+        self.sob_d, self.sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+        cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(3)]
+        self.ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(2)]
+        self.gbs = [scene.gbuffer(u, W, H) for u in self.ubos]
+        self.low = [hr.gbuffer_mip(g, refl_scale) for g in self.gbs] if refl_scale else self.gbs
+        self.zbp = synth.z_buffer_params()
+        lo, hi = sd.bounds()
+        self.ddgi_u = synth_env.ddgi_uniforms(lo, hi, probe_counts=tuple(probes), rays_per_probe=rays_per_probe, normal_bias=0.1)
+        sky = synth_env.sky_cubemap(32)
+        f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+        self.env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 32, 5, f16(synth_env.brdf_lut(32)))
+        # cost-balanced bands from a calibration trace of the shadow pass (full-resolution rows; the low-resolution reflections
+        # band is the same band in low-resolution rows, which needs 16-row alignment of the full-res cuts)
+        bounds = None
+        if world > 1:
+            cal = hr.RayTracedShadows(ctx, W, H)
+            cal.ray_trace(scene, hr.frame_inputs(self.gbs[0], self.gbs[0], self.ubos[0], 0, 0, self.sob_d, self.sr_d))
+            cost = tiling.shadow_cost_per_tile_row(self.gbs[0]["depth"], cal.tile_ray_counts())
+            cal.close()
+            cost16 = np.add.reduceat(cost, np.arange(0, len(cost), 2))
+            bounds = tiling.balanced_bounds(cost16, world, H, min_tiles=4, align=16)
+            tb = torch.tensor(bounds, dtype=torch.int64, device="cuda")
+            dist.broadcast(tb, src=0, group=group)
+            bounds = [int(v) for v in tb.cpu()]
+        self.bounds = bounds
+        lb = [b >> refl_scale for b in bounds] if bounds else None
+        if lb:
+            lb[-1] = H >> refl_scale
+        self.shadows = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds, group=group)
+        self.ao = tiling.TiledAO(ctx, W, H, rank, world, scale=0, bounds=bounds, group=group)
+        self.ao.params.spp = ao_spp
+        self.gi = tiling.ShardedDDGI(ctx, W, H, self.ddgi_u, rank, world, group=group)
+        if world > 1 and bounds:
+            self.gi.pass_.set_shard(self.gi.z0, self.gi.z1, bounds[rank], bounds[rank + 1])
+            self.gi.b0, self.gi.b1 = bounds[rank], bounds[rank + 1]
+        self.refl = tiling.TiledReflections(ctx, W, H, rank, world, scale=refl_scale, bounds=lb, group=group)
+        for p in (self.shadows, self.ao, self.gi, self.refl):
+            p.params.exact = int(exact)
+        self.rng = np.random.RandomState(1)
+        # host-side cost matters once the GPU frame is ~1.5 ms: the two parities' input blocks and a ring of probe rotations are built once
+        self._inputs = [self._make_inputs(0), self._make_inputs(1)]
+        self._orients = [synth_env.random_orientation(self.rng) for _ in range(16)]
+        self.ao_spp, self.probes, self.rays_per_probe, self.refl_scale = ao_spp, tuple(probes), rays_per_probe, refl_scale
+
+    def passes(self):
+        return dict(shadows=self.shadows.pass_, ao=self.ao.pass_, ddgi=self.gi.pass_, reflections=self.refl.pass_)
+
+    def _make_inputs(self, k):
+        hr = self.hr
+        a, b = k & 1, (k + 1) & 1
+        fi = hr.frame_inputs(self.gbs[a], self.gbs[b], self.ubos[a], k, a, self.sob_d, self.sr_d, cur_full=self.gbs[a], z_buffer_params=self.zbp)
+        fl = hr.frame_inputs(self.low[a], self.low[b], self.ubos[a], k, a, self.sob_d, self.sr_d, cur_full=self.gbs[a], z_buffer_params=self.zbp)
+        return fi, fl
+
+    def inputs(self, k):
+        fi, fl = self._inputs[k & 1]
+        fi.num_frames = fl.num_frames = k
+        return fi, fl
+
+    def render(self, k, only=None):
+        """frame k in the reference's order (main.cpp:80-83); `only`: one pass name (DDGI still runs before reflections once)"""
+        fi, fl = self.inputs(k)
+        if only in (None, "shadows"):
+            self.shadows.render(self.scene, fi)
+        if only in (None, "ao"):
+            self.ao.render(self.scene, fi)
+        if only in (None, "ddgi"):
+            self.gi.render(self.scene, fi, self.env, self._orients[k & 15])
+        if only in (None, "reflections"):
+            self.refl.render(self.scene, fl, self.env, self.gi.pass_)
+
+    def ray_counts(self):
+        return {n: int(p.ray_count()) for n, p in self.passes().items()}
+
+    def time(self, frames, warmup=4, only=None, barrier=None):
+        """wall-clock ms per frame between device synchronisations (+ `barrier()` across ranks)"""
+        import torch
+        for k in range(warmup):
+            self.render(k, only)
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + frames):
+            self.render(k, only)
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        return (time.perf_counter() - t0) / frames * 1e3
+
+    def stage_times(self, frames=10):
+        """per-kernel HIP-event averages of every pass: {pass: {stage: (ms, algorithmic bytes)}}"""
+        import torch
+        ps = self.passes()
+        for p in ps.values():
+            p.set_profiling(True)
+            p.stage_times()
+        for k in range(100, 100 + frames):
+            self.render(k)
+        torch.cuda.synchronize()
+        for t in (self.shadows, self.ao, self.refl):
+            t.wait_exchange()
+        out = {}
+        for n, p in ps.items():
+            out[n] = {s: (ms, b) for s, ms, b in p.stage_times()}
+            p.set_profiling(False)
+        return out
+
+    def close(self):
+        for p in self.passes().values():
+            p.close()

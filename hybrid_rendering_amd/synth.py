@@ -430,6 +430,19 @@ def sponza_camera(aspect=16 / 9, frame: int = 0, dolly: float = 0.0) -> Camera:
     return Camera(tuple(eye), tuple(eye + np.array([-1.0, 0.12, 0.08])), aspect=aspect)
 
 
+def camera_for_bounds(bounds, aspect=16 / 9, frame: int = 0, dolly: float = 0.0) -> Camera:
+    """A camera for an arbitrary scene (bench.py --obj): inside the box at 80 % of its length and 35 % of its height, looking down the
+    long horizontal axis as the Sponza preset does, dollying `dolly` scene-relative units per frame (1 unit = 1/1100 of the length)."""
+    lo, hi = (np.asarray(b, np.float64) for b in bounds)
+    ext = hi - lo
+    ax = 0 if ext[0] >= ext[2] else 2
+    fwd = np.zeros(3); fwd[ax] = -1.0
+    eye = lo + ext * np.array([0.5, 0.35, 0.5])
+    eye[ax] = lo[ax] + 0.8 * ext[ax]
+    eye = eye + fwd * dolly * frame * (ext[ax] / 1100.0)
+    return Camera(tuple(eye), tuple(eye + fwd + np.array([0.0, 0.12, 0.0]) + np.roll(np.array([0.0, 0.0, 0.08]), 0 if ax == 0 else 1)), aspect=aspect)
+
+
 def sponza_light() -> np.ndarray:
     """Directional sun of the Sponza preset (main.cpp:869-874): radius 0.08, intensity 10,
     transform = rotZ(30deg) * rotX(-10deg); direction = mat3(T) * (0,-1,0); UBO stores -direction."""

@@ -34,12 +34,45 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def effective_cpus() -> int:
+    """Host threads this process can actually run at once: the smaller of the affinity mask and the cgroup CPU quota.  The GPU box
+    shows 256 hardware threads but grants a quota of 16 (cpu.max = 1600000 100000): 256 OpenMP threads on it run SLOWER than 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
+
+
+def set_threads(n: int = None) -> int:
+    """OpenMP team size of the oracle library (default: effective_cpus(), unless OMP_NUM_THREADS is set)."""
+    if n is None:
+        if os.environ.get("OMP_NUM_THREADS"):
+            return int(os.environ["OMP_NUM_THREADS"])
+        n = effective_cpus()
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(int(n)))
+    except OSError:
+        pass
+    return int(n)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
         _lib = C.CDLL(_LIB_PATH)
+        set_threads()
         _lib.orc_scene_create.restype = C.c_void_p
         _lib.orc_scene_num_nodes.restype = C.c_int
         _lib.orc_f32_to_f16.restype = C.c_uint16

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--probes", default="16,8,16")
     ap.add_argument("--rays-per-probe", type=int, default=256)
     ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--exact", type=int, default=0, help="1 = bit-for-bit parity arithmetic, 0 = tolerance mode (the shipping mode)")
     ap.add_argument("--check", action="store_true", help="compare every band with an un-tiled render on this rank (slow)")
     args = ap.parse_args()
     import torch
@@ -82,6 +83,8 @@ def main():
         gi.pass_.set_shard(gi.z0, gi.z1, bounds[rank], bounds[rank + 1])
         gi.b0, gi.b1 = bounds[rank], bounds[rank + 1]
     refl = tiling.TiledReflections(ctx, W, H, rank, world, scale=1, bounds=hb)
+    for p_ in (shadows, ao, gi, refl):
+        p_.params.exact = 1 if args.check else args.exact       # --check compares band rows bit for bit: parity arithmetic
     rng = np.random.RandomState(1)
     orients = [synth_env.random_orientation(rng) for _ in range(args.warmup + args.frames)]
 
