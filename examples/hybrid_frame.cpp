@@ -161,14 +161,19 @@ int main(int argc, char** argv)
         g.irradiance_texture_width = 10 * 25 + 2; g.irradiance_texture_height = 10 * 5 + 2;
         g.depth_texture_width = 18 * 25 + 2; g.depth_texture_height = 18 * 5 + 2;
 
-        // ---- passes, created like main.cpp:1150-1159 ---------------------------------------------------------------------
-        hr::RayTracedShadows      shadows(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::RayTracedAO           ao(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::DDGI                  ddgi(ctx, W, H, g);
-        hr::RayTracedReflections  reflections(ctx, W, H, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::DeferredShading       deferred(ctx, W, H);
+        // ---- passes, created like main.cpp:1150-1159: every pass keeps non-owning pointers to the application's CommonResources
+        // and GBuffer (ray_traced_shadows.h:127-129) and reads them at render() --------------------------------------------------
+        hr::CommonResources common;
+        hr::GBuffer         g_buffer;
+        common.scene = &scene; common.environment = &env;
+        g_buffer.current[0].width = W; g_buffer.current[0].height = H;   // the extent is read at construction, the images every frame
+        hr::RayTracedShadows      shadows(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::RayTracedAO           ao(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DDGI                  ddgi(ctx, &common, &g_buffer, g);
+        hr::RayTracedReflections  reflections(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DeferredShading       deferred(ctx, &common, &g_buffer);
         hr::TemporalAA            taa(ctx, W, H);
-        hr::GroundTruthPathTracer ground_truth(ctx, W, H);
+        hr::GroundTruthPathTracer ground_truth(ctx, &common, &g_buffer);
 
         // ---- G-buffers (two, ping-pong) + blue-noise tables ---------------------------------------------------------------
         void *gb1[2], *gb2[2], *gb3[2], *depth[2];
@@ -189,10 +194,8 @@ int main(int argc, char** argv)
         for (uint32_t f = 0; f < 3; f++)
         {
             const int pp = (int)(f & 1);
-            hr::Frame frame;
-            std::memset(&frame.inputs, 0, sizeof(frame.inputs));
-            frame.scene = &scene; frame.environment = &env;
-            hr_ubo& u = frame.inputs.ubo;
+            hr_ubo& u = common.ubo;            // main.cpp:951-966 fills the per-frame UBO of CommonResources
+            std::memset(&u, 0, sizeof(u));
             // TemporalAA::update() first: the jitter goes into the projection and the UBO (main.cpp:941-957, :1025)
             taa.update(f);
             const float eye[3] = { 50.0f + 1.5f * f, 50.0f, 235.0f - 2.0f * f };
@@ -215,22 +218,23 @@ int main(int argc, char** argv)
             hr::check(hr_gbuffer_raycast(scene.handle(), &u, W, H, gb1[pp], gb2[pp], gb3[pp], (float*)depth[pp], nullptr), "hr_gbuffer_raycast");
             hr_gbuffer_level cur { gb1[pp], gb2[pp], gb3[pp], (const float*)depth[pp], W, H };
             hr_gbuffer_level prv = f ? hr_gbuffer_level { gb1[!pp], gb2[!pp], gb3[!pp], (const float*)depth[!pp], W, H } : cur;
-            frame.inputs.cur = cur; frame.inputs.prev = prv; frame.inputs.cur_full = cur;
-            frame.inputs.num_frames = f; frame.inputs.ping_pong = pp;
-            frame.inputs.sobol = sob_d; frame.inputs.scrambling_ranking = sr_d;
-            frame.inputs.z_buffer_params[0] = 1.0f - fa / n; frame.inputs.z_buffer_params[1] = fa / n;
-            frame.inputs.z_buffer_params[2] = frame.inputs.z_buffer_params[0] / fa; frame.inputs.z_buffer_params[3] = frame.inputs.z_buffer_params[1] / fa;
+            g_buffer.current[0] = cur; g_buffer.history[0] = prv;           // GBuffer::output_ds() / history_ds()
+            common.num_frames = f; common.ping_pong = pp != 0;              // main.cpp:123-128
+            common.sobol = sob_d; common.scrambling_ranking = sr_d;
+            common.z_buffer_params[0] = 1.0f - fa / n; common.z_buffer_params[1] = fa / n;
+            common.z_buffer_params[2] = common.z_buffer_params[0] / fa; common.z_buffer_params[3] = common.z_buffer_params[1] / fa;
 
-            // main.cpp:80-99
-            shadows.render(nullptr, frame);
-            ao.render(nullptr, frame);
-            ddgi.render(nullptr, frame);
-            reflections.render(nullptr, frame, &ddgi);
+            // main.cpp:80-99, call for call
+            hr::Stream cmd_buf = nullptr;
+            shadows.render(cmd_buf);
+            ao.render(cmd_buf);
+            ddgi.render(cmd_buf);
+            reflections.render(cmd_buf, &ddgi);
+            deferred.render(cmd_buf, &ao, &shadows, &reflections, &ddgi);
             hr::ImageView s_v = shadows.output_ds(), a_v = ao.output_ds(), r_v = reflections.output_ds(), g_v = ddgi.output_ds();
-            deferred.render(nullptr, frame, &a_v, &s_v, &r_v, &g_v);
             hr::ImageView color = deferred.output_ds();
-            taa.render(nullptr, color, cur, pp != 0);
-            ground_truth.render(nullptr, frame);
+            taa.render(cmd_buf, color, cur, pp != 0);
+            ground_truth.render(cmd_buf);
             HIP_OK(hipDeviceSynchronize());
             m_shadow = mean_of(s_v, s_v.format == HR_FORMAT_R16F ? 1 : 2, 0);
             m_ao = mean_of(a_v, 1, 0); m_gi = mean_of(g_v, 4, 1); m_refl = mean_of(r_v, 4, 1);

@@ -4,15 +4,19 @@
 //
 //   reference                                                     this header
 //   ------------------------------------------------------------  ---------------------------------------------
-//   RayTracedShadows(backend, common, g_buffer, scale)            hr::RayTracedShadows(ctx, width, height, scale)
-//   void render(dw::vk::CommandBuffer::Ptr cmd_buf)               void render(hr::Stream, const hr::Frame&)
+//   RayTracedShadows(backend, common, g_buffer, scale)            hr::RayTracedShadows(ctx, common, g_buffer, scale)
+//   void render(dw::vk::CommandBuffer::Ptr cmd_buf)               void render(hr::Stream cmd_buf)          ray_traced_shadows.h:26
+//   void render(cmd_buf, DDGI* ddgi)                              void render(hr::Stream cmd_buf, DDGI*)   ray_traced_reflections.h:27
 //   dw::vk::DescriptorSet::Ptr output_ds()                        hr::ImageView output_ds()
 //   width()/height()/scale()/current_output()/set_current_output  same names
 //   DDGI::current_read_ds(), restart_accumulation(), setters      same names
 //
-// dw::vk::CommandBuffer::Ptr -> hr::Stream (a hipStream_t), dw::vk::DescriptorSet::Ptr -> hr::ImageView
-// (device pointer + extent + format), CommonResources/GBuffer -> hr::Frame (hr_frame_inputs + scene + env).
-// render() returns void like the reference; failures throw hr::Error on THIS side of the ABI only.
+// dw::vk::CommandBuffer::Ptr -> hr::Stream (a hipStream_t), dw::vk::DescriptorSet::Ptr -> hr::ImageView (device pointer + extent +
+// format).  As in the reference (ray_traced_shadows.h:127-129) a pass keeps NON-OWNING pointers to the application's
+// hr::CommonResources (per-frame UBO, frame counters, blue-noise tables, scene, environment) and hr::GBuffer (current / history mip
+// chain), given at construction; the application updates both every frame (main.cpp:123-128, :951-966) and then calls render(cmd_buf)
+// in the order of main.cpp:80-83 — the call sites do not change.  A second form, render(cmd_buf, const hr::Frame&), takes the inputs
+// explicitly (tests, tools).  render() returns void like the reference; failures throw hr::Error on THIS side of the ABI only.
 #pragma once
 #include "../hr_api.h"
 #include <stdexcept>
@@ -60,13 +64,51 @@ private:
     hr_scene* m_scene = nullptr;
 };
 
-// What CommonResources + GBuffer hand to every pass each frame.
+// What CommonResources + GBuffer hand to every pass each frame, spelled out (the explicit-inputs form of render()).
 struct Frame
 {
     const Scene*          scene = nullptr;
     hr_frame_inputs       inputs {};
     const hr_environment* environment = nullptr; // reflections / DDGI
 };
+
+// src/common.h CommonResources — the per-frame state the application owns and every pass reads: the per-frame UBO contents
+// (main.cpp:951-966), frame counters toggled by the app (main.cpp:123-128), the blue-noise tables (blue_noise.cpp:5-19), the
+// ray-traced scene and the current environment maps.  Passes hold a pointer to it; nothing here is owned by a pass.
+struct CommonResources
+{
+    const Scene*          scene = nullptr;                 // dw::RayTracedScene
+    hr_ubo                ubo {};                          // per_frame_ubo
+    uint32_t              num_frames = 0;                  // CommonResources::num_frames
+    bool                  ping_pong = false;               // CommonResources::ping_pong
+    const uint8_t*        sobol = nullptr;                 // device, blue_noise_image_1 / 2
+    const uint8_t*        scrambling_ranking = nullptr;
+    const hr_environment* environment = nullptr;           // current_skybox + prefiltered chain + BRDF LUT
+    float                 z_buffer_params[4] = { 0, 0, 0, 0 }; // main.cpp:253-254
+    float                 camera_delta[3] = { 0, 0, 0 };   // main.cpp:1077-1079
+    float                 frame_time = 0.0f;
+};
+
+// src/g_buffer.h GBuffer — the images every pass samples: mip chain (g_buffer.cpp:240-243) of the current frame (output_ds()) and of
+// the previous one (history_ds()); level `scale` is read by a pass created with that RayTraceScale, level 0 by its upsample stage.
+struct GBuffer
+{
+    hr_gbuffer_level current[3] {};   // mip 0 (full resolution), 1 (half), 2 (quarter)
+    hr_gbuffer_level history[3] {};
+    uint32_t width() const { return (uint32_t)current[0].width; }
+    uint32_t height() const { return (uint32_t)current[0].height; }
+};
+
+inline Frame make_frame(const CommonResources& c, const GBuffer& g, int scale)
+{
+    Frame f;
+    f.scene = c.scene; f.environment = c.environment;
+    f.inputs.cur = g.current[scale]; f.inputs.prev = g.history[scale].depth ? g.history[scale] : g.current[scale]; f.inputs.cur_full = g.current[0];
+    f.inputs.ubo = c.ubo; f.inputs.num_frames = c.num_frames; f.inputs.ping_pong = c.ping_pong ? 1 : 0;
+    f.inputs.sobol = c.sobol; f.inputs.scrambling_ranking = c.scrambling_ranking;
+    for (int i = 0; i < 4; i++) f.inputs.z_buffer_params[i] = c.z_buffer_params[i];
+    return f;
+}
 
 class RayTracedShadows
 {
@@ -79,10 +121,17 @@ public:
         hr_shadows_default_params(&params);
         check(hr_shadows_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_shadows_create");
     }
+    // the reference's constructor shape: RayTracedShadows(backend, common_resources, g_buffer, scale) — non-owning pointers, read at render()
+    RayTracedShadows(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES, const hr_band* band = nullptr) :
+        RayTracedShadows(ctx, g_buffer->width(), g_buffer->height(), scale, band)
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~RayTracedShadows() { hr_shadows_destroy(m_pass); }
     RayTracedShadows(const RayTracedShadows&) = delete;
     RayTracedShadows& operator=(const RayTracedShadows&) = delete;
 
+    void render(Stream cmd_buf) { render(cmd_buf, make_frame(*providers(), *m_g_buffer, (int)m_scale)); }   // ray_traced_shadows.h:26
     void render(Stream cmd_buf, const Frame& frame) { check(hr_shadows_render(m_pass, frame.scene->handle(), &frame.inputs, &params, cmd_buf), "RayTracedShadows::render"); }
     ImageView output_ds()
     {
@@ -101,6 +150,13 @@ public:
     hr_shadows_params params; // the members the reference exposes through gui() (ray_traced_shadows.cpp:120-131)
 
 private:
+    const CommonResources* providers() const
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "RayTracedShadows::render(cmd_buf): constructed without CommonResources / GBuffer");
+        return m_common_resources;
+    }
+    CommonResources* m_common_resources = nullptr;   // non-owning, like the reference's raw pointers
+    GBuffer*         m_g_buffer = nullptr;
     hr_shadows*   m_pass = nullptr;
     RayTraceScale m_scale;
     OutputType    m_current_output = OUTPUT_UPSAMPLE;
@@ -118,10 +174,17 @@ public:
         hr_ao_default_params(&params);
         check(hr_ao_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_ao_create");
     }
+    // the reference's constructor shape: RayTracedAO(backend, common_resources, g_buffer, scale) — non-owning pointers, read at render()
+    RayTracedAO(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES, const hr_band* band = nullptr) :
+        RayTracedAO(ctx, g_buffer->width(), g_buffer->height(), scale, band)
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~RayTracedAO() { hr_ao_destroy(m_pass); }
     RayTracedAO(const RayTracedAO&) = delete;
     RayTracedAO& operator=(const RayTracedAO&) = delete;
 
+    void render(Stream cmd_buf) { render(cmd_buf, make_frame(*providers(), *m_g_buffer, (int)m_scale)); }   // ray_traced_ao.h:26
     void render(Stream cmd_buf, const Frame& frame) { check(hr_ao_render(m_pass, frame.scene->handle(), &frame.inputs, &params, cmd_buf), "RayTracedAO::render"); }
     ImageView output_ds()
     {
@@ -139,6 +202,13 @@ public:
     hr_ao_params params;
 
 private:
+    const CommonResources* providers() const
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "RayTracedAO::render(cmd_buf): constructed without CommonResources / GBuffer");
+        return m_common_resources;
+    }
+    CommonResources* m_common_resources = nullptr;   // non-owning, like the reference's raw pointers
+    GBuffer*         m_g_buffer = nullptr;
     hr_ao*        m_pass = nullptr;
     RayTraceScale m_scale;
     OutputType    m_current_output = OUTPUT_UPSAMPLE;
@@ -154,10 +224,17 @@ public:
         hr_ddgi_default_params(&params);
         check(hr_ddgi_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, &grid, &m_pass), "hr_ddgi_create");
     }
+    // the reference's constructor shape: DDGI(backend, common_resources, g_buffer, scale) — non-owning pointers, read at render()
+    DDGI(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, const hr_ddgi_uniforms& grid, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
+        DDGI(ctx, g_buffer->width(), g_buffer->height(), grid, scale)
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~DDGI() { hr_ddgi_destroy(m_pass); }
     DDGI(const DDGI&) = delete;
     DDGI& operator=(const DDGI&) = delete;
 
+    void render(Stream cmd_buf) { render(cmd_buf, make_frame(*providers(), *m_g_buffer, (int)m_scale)); }   // ddgi.h:15
     void render(Stream cmd_buf, const Frame& frame)
     {
         check(hr_ddgi_render(m_pass, frame.scene->handle(), &frame.inputs, frame.environment, &params, cmd_buf), "DDGI::render");
@@ -183,6 +260,13 @@ public:
     hr_ddgi_params params; // incl. this frame's probe-ray rotation (std::mt19937 in the reference, ddgi.cpp:788)
 
 private:
+    const CommonResources* providers() const
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "DDGI::render(cmd_buf): constructed without CommonResources / GBuffer");
+        return m_common_resources;
+    }
+    CommonResources* m_common_resources = nullptr;   // non-owning, like the reference's raw pointers
+    GBuffer*         m_g_buffer = nullptr;
     hr_ddgi*      m_pass = nullptr;
     RayTraceScale m_scale;
     uint32_t      m_width, m_height;
@@ -199,11 +283,24 @@ public:
         hr_reflections_default_params(&params);
         check(hr_reflections_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, band, &m_pass), "hr_reflections_create");
     }
+    // the reference's constructor shape: RayTracedReflections(backend, common_resources, g_buffer, scale) — non-owning pointers, read at render()
+    RayTracedReflections(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES, const hr_band* band = nullptr) :
+        RayTracedReflections(ctx, g_buffer->width(), g_buffer->height(), scale, band)
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~RayTracedReflections() { hr_reflections_destroy(m_pass); }
     RayTracedReflections(const RayTracedReflections&) = delete;
     RayTracedReflections& operator=(const RayTracedReflections&) = delete;
 
     // RayTracedReflections::render(cmd_buf, ddgi) — ray_traced_reflections.h:27
+    void render(Stream cmd_buf, DDGI* ddgi)
+    {
+        const CommonResources* c = providers();
+        for (int i = 0; i < 3; i++) params.camera_delta[i] = c->camera_delta[i];   // pushed with the temporal pass (ray_traced_reflections.cpp:1124-1135)
+        params.frame_time = c->frame_time;
+        render(cmd_buf, make_frame(*c, *m_g_buffer, (int)m_scale), ddgi);
+    }
     void render(Stream cmd_buf, const Frame& frame, DDGI* ddgi)
     {
         check(hr_reflections_render(m_pass, frame.scene->handle(), &frame.inputs, frame.environment, ddgi->handle(), &params, cmd_buf), "RayTracedReflections::render");
@@ -224,6 +321,13 @@ public:
     hr_reflections_params params;
 
 private:
+    const CommonResources* providers() const
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "RayTracedReflections::render(cmd_buf): constructed without CommonResources / GBuffer");
+        return m_common_resources;
+    }
+    CommonResources* m_common_resources = nullptr;   // non-owning, like the reference's raw pointers
+    GBuffer*         m_g_buffer = nullptr;
     hr_reflections* m_pass = nullptr;
     RayTraceScale   m_scale;
     OutputType      m_current_output = OUTPUT_UPSAMPLE;
@@ -239,12 +343,22 @@ public:
         hr_deferred_default_params(&params);
         check(hr_deferred_create(ctx.handle(), (int32_t)width, (int32_t)height, &m_pass), "hr_deferred_create");
     }
+    DeferredShading(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer) : DeferredShading(ctx, g_buffer->width(), g_buffer->height())
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~DeferredShading() { hr_deferred_destroy(m_pass); }
     DeferredShading(const DeferredShading&) = delete;
     DeferredShading& operator=(const DeferredShading&) = delete;
 
-    // DeferredShading::render(cmd_buf, ao, shadows, reflections, ddgi) (deferred_shading.cpp:715-723): the pass outputs
-    // are the views returned by their output_ds()
+    // DeferredShading::render(cmd_buf, ao, shadows, reflections, ddgi) (deferred_shading.cpp:715-723), literally: the passes' output_ds()
+    void render(Stream cmd_buf, RayTracedAO* ao, RayTracedShadows* shadows, RayTracedReflections* reflections, DDGI* ddgi)
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "DeferredShading::render(cmd_buf, ...): constructed without CommonResources / GBuffer");
+        const ImageView a = ao->output_ds(), s = shadows->output_ds(), r = reflections->output_ds(), g = ddgi->output_ds();
+        render(cmd_buf, make_frame(*m_common_resources, *m_g_buffer, 0), &a, &s, &r, &g);
+    }
+    // explicit-inputs form: the pass outputs are the views returned by their output_ds()
     void render(Stream cmd_buf, const Frame& frame, const ImageView* ao, const ImageView* shadows, const ImageView* reflections, const ImageView* gi)
     {
         check(hr_deferred_render(m_pass, &frame.inputs, frame.environment, shadows, ao, reflections, gi, &params, cmd_buf), "DeferredShading::render");
@@ -260,6 +374,8 @@ public:
     hr_deferred_params params;
 
 private:
+    CommonResources* m_common_resources = nullptr;
+    GBuffer*         m_g_buffer = nullptr;
     hr_deferred* m_pass = nullptr;
 };
 
@@ -272,11 +388,20 @@ public:
         hr_ground_truth_default_params(&params);
         check(hr_ground_truth_create(ctx.handle(), (int32_t)width, (int32_t)height, nullptr, &m_pass), "hr_ground_truth_create");
     }
+    GroundTruthPathTracer(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer) : GroundTruthPathTracer(ctx, g_buffer->width(), g_buffer->height())
+    {
+        m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
     ~GroundTruthPathTracer() { hr_ground_truth_destroy(m_pass); }
     GroundTruthPathTracer(const GroundTruthPathTracer&) = delete;
     GroundTruthPathTracer& operator=(const GroundTruthPathTracer&) = delete;
 
-    // the reference reads the camera / light UBO and the sky cubemap from CommonResources
+    // the reference reads the camera / light UBO and the sky cubemap from CommonResources (ground_truth_path_tracer.h:16)
+    void render(Stream cmd_buf)
+    {
+        if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "GroundTruthPathTracer::render(cmd_buf): constructed without CommonResources / GBuffer");
+        render(cmd_buf, make_frame(*m_common_resources, *m_g_buffer, 0));
+    }
     void render(Stream cmd_buf, const Frame& frame)
     {
         check(hr_ground_truth_render(m_pass, frame.scene->handle(), &frame.inputs.ubo, frame.environment, &params, cmd_buf), "GroundTruthPathTracer::render");
@@ -295,6 +420,8 @@ public:
     hr_ground_truth_params params;
 
 private:
+    CommonResources* m_common_resources = nullptr;
+    GBuffer*         m_g_buffer = nullptr;
     hr_ground_truth* m_pass = nullptr;
     uint32_t         m_width, m_height;
 };
