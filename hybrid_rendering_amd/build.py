@@ -27,6 +27,23 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, s) for s in OPTIONAL if os.path.exists(os.path.join(CSRC, s))]
 
 
+COMM_LIB = os.path.join(HERE, "libhr_comm.so")   # include/hr_comm.h: RCCL / loopback transport of the row-tiled frame (host code only)
+
+
+def build_comm(force: bool = False, verbose: bool = False) -> str:
+    src = os.path.join(CSRC, "comm.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "hr_comm.h"), os.path.join(HERE, "..", "include", "hr_api.h"), LIB]
+    if not force and os.path.exists(COMM_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(COMM_LIB) for d in deps):
+        return COMM_LIB
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "hip", "--offload-arch=gfx950", src, "-o", COMM_LIB + ".tmp",
+           "-L", HERE, "-lhybrid_rendering_amd", "-ldl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(COMM_LIB + ".tmp", COMM_LIB)
+    return COMM_LIB
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -37,6 +54,7 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
+        build_comm(False, verbose)
         return LIB
     extra = os.environ.get("HR_CFLAGS", "").split()   # developer A/B builds: HR_CFLAGS="-DFT_SHADOWS_EU=5" python -m hybrid_rendering_amd.build --force
     cmd = [hipcc()] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", LIB + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
@@ -44,6 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    build_comm(True, verbose)
     return LIB
 
 

@@ -252,6 +252,8 @@ hr_status hr_ctx_destroy(hr_ctx* ctx)
     return HR_OK;
 }
 
+int32_t hr_ctx_device(const hr_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out);
 
 // Host-only: build the 8-wide BVH of a triangle soup and report its shape (no device, no upload).  What hr_scene_create

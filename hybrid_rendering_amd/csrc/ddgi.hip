@@ -67,6 +67,10 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceA
         float hit_distance = 10000.0f;
         rays++;
         const HitRec h = trace_closest(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane);
+#ifdef HR_ABL_DDGI_PRIMARY_ONLY   // developer ablation (tools/ablate.sh): what does each part of the kernel cost?
+        if (true) { L = mk3(h.t, h.u, h.v); hit_distance = h.t; }
+        else
+#endif
         if (h.prim < 0) L = a.sky.fetch(dir);
         else
         {
@@ -77,7 +81,11 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceA
             const float r2x = next_float(rng), r2y = next_float(rng);
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
             f3 Lo = direct_lighting(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
+#ifndef HR_ABL_DDGI_NO_IRRADIANCE
             if (a.infinite_bounces == 1)
+#else
+            if (false)
+#endif
             {
                 const f3 F   = fresnel_schlick_roughness(max2(dot3(s.N, Wo), 0.0f), F0, s.roughness);
                 const f3 kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);

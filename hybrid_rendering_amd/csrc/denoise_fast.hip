@@ -61,11 +61,11 @@ struct Reproj
         const float dn = fm::dot(cur_n, hn);
         const f3    hp = fm::unproject_at(hb, M, d);
         const float pd = fm::dot(sub3(cur_pos, hp), cur_n);
-        return inb & (cur_id == fm::lo(q3y)) & !(__builtin_fabsf(pd) > 5.0f) & (dn * dn > 0.1f * fm::dot(hn, hn));
+        return ((int)inb & (int)(cur_id == fm::lo(q3y)) & (int)!(__builtin_fabsf(pd) > 5.0f) & (int)(dn * dn > 0.1f * fm::dot(hn, hn))) != 0;
     }
     HR_DEV uint32_t tap_offset(int px, int py, bool& ok) const
     {
-        ok = !((px < 0) | (py < g.y0) | (px >= g.w) | (py >= g.y1));
+        ok = ((int)(px < 0) | (int)(py < g.y0) | (int)(px >= g.w) | (int)(py >= g.y1)) == 0;
         return ok ? (uint32_t)(py * g.w + px) : (uint32_t)(g.y0 * g.w);
     }
     HR_DEV void hist_decode(uint32_t rx, uint32_t ry, float* c) const
@@ -116,7 +116,7 @@ struct Reproj
             hcx = (int)(hfx + 0.5f);
             hcy = (int)(hfy + 0.5f);
         }
-        inb = !((hcx < 0) | (hcy < 0) | (hcx > g.w - 1) | (hcy > g.h - 1));
+        inb = ((int)(hcx < 0) | (int)(hcy < 0) | (int)(hcx > g.w - 1) | (int)(hcy > g.h - 1)) == 0;
         hb  = fm::unproject_base(M, tu + mvx, tv + mvy);
         // an outside tap loads a resident address (its value is discarded in resolve()), so no load sits behind a branch
         const int bx = (int)hfx, by = (int)hfy;
@@ -150,7 +150,7 @@ struct Reproj
             // an out-of-image texel reads as zeros (pinned rule) and is validated as such, as in the exact mode: its weight counts
             // in the normalisation, its (zero) values add nothing
             const bool  v  = tap_valid(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f);
-            const float ws = v ? wgt[s] : 0.0f, wv = (v & tok[s]) ? wgt[s] : 0.0f;
+            const float ws = v ? wgt[s] : 0.0f, wv = ((int)v & (int)tok[s]) ? wgt[s] : 0.0f;
             float c3[NC];
             hist_decode(hx[s], hy[s], c3);
 #pragma unroll
@@ -208,7 +208,7 @@ struct Reproj
         for (int c = 0; c < NC; c++) o.col[c] = valid ? col[c] : 0.0f;
         o.mom[0] = valid ? mom0 : 0.0f;
         o.mom[1] = valid ? mom1 : 0.0f;
-        o.length = (valid & lok) ? fm::lo(lraw) : 0.0f;
+        o.length = ((int)valid & (int)lok) ? fm::lo(lraw) : 0.0f;
         return valid;
     }
 };
@@ -258,7 +258,7 @@ HR_DEV void mask_window(const MaskRows& R, int lx, int ly, int& sum, int& own)
 {
     uint32_t a0 = 0, a1 = 0, a2 = 0;
     // several planes: rolled in groups so that the 51 row words are not all live at once (102 VGPRs fully unrolled)
-#pragma unroll(MULTI ? 6 : 17)
+#pragma clang loop unroll_count(MULTI ? 6 : 17)
     for (int yy = 0; yy <= 16; yy++)
     {
         a0 = __builtin_popcount(__builtin_amdgcn_ubfe(R.b0[ly + yy], (uint32_t)lx, 17u)) + a0;

@@ -466,11 +466,13 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         f3    Li, Wi, Wh;
         float t_max, attenuation;
         fetch_light_hard(light, Wo, P, N, Li, Wi, Wh, t_max, attenuation);
+#ifndef HR_ABL_NO_SECONDARY   // developer ablation (tools/ablate.sh)
         if (attenuation > 0.0f)
         {
             rays++;
             attenuation = attenuation * (trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
         }
+#endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
         Lo = add3(Lo, mul3(scale3(mul3(T, brdf), attenuation), Li));
     }
@@ -479,8 +481,10 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         const f3 Wi = sample_cosine_lobe_n(N, r2x, r2y);
         f3       Li = sky.fetch(Wi);
         const f3 Wh = normalize3(add3(Wo, Wi));
+#ifndef HR_ABL_NO_SECONDARY
         rays++;
         Li = scale3(Li, trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
+#endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
         Lo = add3(Lo, mul3(mul3(T, brdf), Li));
     }

@@ -1,0 +1,176 @@
+// C++ shims of the row-tiled (multi-GPU) frame over include/hr_comm.h + include/hr/passes.hpp — the native counterpart of
+// hybrid_rendering_amd/tiling.py.  One hr::Tiled* object per GPU and pass: it owns the pass of ONE row band and the
+// per-frame neighbour exchange of the history rows the NEXT frame's reprojection reads.  render() keeps the reference's arity.
+//
+//   hr::Comm comm(ctx, world, rank, id);                         // RCCL (or hr::Comm::loopback for several ranks in one process)
+//   hr::TiledShadows shadows(ctx, comm, &common, &g_buffer, bounds);
+//   shadows.render(cmd_buf);                                     // trace -> [wait last exchange] -> temporal -> a-trous -> post exchange
+//
+// Redundant compute instead of per-iteration halo traffic: every band traces / filters `halo` = 24 rows beyond its own (8 mask rows of
+// the 17x17 statistics + 1 + 2 + 4 + 8 a-trous rows), and ONE grouped neighbour exchange per frame refreshes the `history_halo` rows of
+// the images the next frame reprojects from.  The alternative SURVEY §8e names — exchanging 2^i + 1 rows of every a-trous iteration —
+// needs five dependent exchanges per frame for a 4 us saving of redundant work per band at 4K / 8 GPUs.
+#pragma once
+#include "../hr_comm.h"
+#include "passes.hpp"
+#include <vector>
+
+namespace hr {
+
+constexpr int kHalo = 24, kHistoryHalo = 40;
+
+class Comm
+{
+public:
+    Comm(Context& ctx, int world, int rank, const uint8_t id[HR_COMM_ID_BYTES]) { check(hr_comm_create_rccl(ctx.handle(), world, rank, id, &m_comm), "hr_comm_create_rccl"); }
+    static Comm loopback(Context& ctx, int world, int rank, const char* name)
+    {
+        Comm c;
+        check(hr_comm_create_loopback(ctx.handle(), world, rank, name, &c.m_comm), "hr_comm_create_loopback");
+        return c;
+    }
+    Comm(Comm&& o) noexcept : m_comm(o.m_comm) { o.m_comm = nullptr; }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    ~Comm() { hr_comm_destroy(m_comm); }
+    int      rank() const { return hr_comm_rank(m_comm); }
+    int      world() const { return hr_comm_world(m_comm); }
+    void     wait(Stream s) { check(hr_comm_wait(m_comm, s), "hr_comm_wait"); }
+    hr_comm* handle() const { return m_comm; }
+    static void unique_id(uint8_t id[HR_COMM_ID_BYTES]) { check(hr_comm_get_unique_id(id), "hr_comm_get_unique_id"); }
+private:
+    Comm() = default;
+    hr_comm* m_comm = nullptr;
+};
+
+// uniform band boundaries on the 8-row tile grid (tiling.band_rows); cost-balanced boundaries come from the application
+inline std::vector<int32_t> uniform_bounds(int height, int world, int align = 8)
+{
+    std::vector<int32_t> b(world + 1);
+    const int tiles = (height + align - 1) / align;
+    for (int r = 0; r <= world; r++) b[r] = (int32_t)((long long)tiles * r / world) * align;
+    b[world] = height;
+    return b;
+}
+inline hr_band band_of(const std::vector<int32_t>& bounds, int rank, int halo, int history_halo)
+{
+    hr_band b;
+    b.band_y0 = bounds[rank]; b.band_y1 = bounds[rank + 1]; b.halo = halo; b.history_halo = history_halo;
+    return b;
+}
+
+class TiledShadows
+{
+public:
+    TiledShadows(Context& ctx, Comm& comm, CommonResources* common, GBuffer* g_buffer, std::vector<int32_t> bounds, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
+        m_comm(comm), m_bounds(std::move(bounds)), m_band(band_of(m_bounds, comm.rank(), kHalo, kHistoryHalo)),
+        m_pass(ctx, common, g_buffer, scale, comm.world() > 1 ? &m_band : nullptr), m_common(common), m_g_buffer(g_buffer)
+    {
+    }
+    // RayTracedShadows::render stage by stage (ray_traced_shadows.cpp:100-116): the trace reads no history, so it is enqueued BEFORE
+    // the compute stream is made to wait for last frame's halo rows; the exchange of this frame's rows is posted at the end and
+    // overlaps whatever the application enqueues next
+    void render(Stream cmd_buf)
+    {
+        const Frame f = make_frame(*m_common, *m_g_buffer, (int)m_pass.scale());
+        hr_shadows* p = m_pass.handle();
+        check(hr_shadows_ray_trace(p, f.scene->handle(), &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::ray_trace");
+        m_comm.wait(cmd_buf);
+        if (m_pass.params.denoise)
+        {
+            check(hr_shadows_temporal(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::temporal");
+            for (int i = 0; i < m_pass.params.filter_iterations; i++) check(hr_shadows_atrous_iteration(p, &f.inputs, &m_pass.params, i, cmd_buf), "TiledShadows::atrous");
+            if (m_pass.scale() != RAY_TRACE_SCALE_FULL_RES) check(hr_shadows_upsample(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::upsample");
+            check(hr_shadows_exchange_history(p, m_comm.handle(), m_bounds.data(), f.inputs.ping_pong, kHistoryHalo, cmd_buf), "TiledShadows::exchange");
+        }
+    }
+    RayTracedShadows& pass() { return m_pass; }
+    int band_y0() const { return m_bounds[m_comm.rank()]; }
+    int band_y1() const { return m_bounds[m_comm.rank() + 1]; }
+private:
+    Comm&                m_comm;
+    std::vector<int32_t> m_bounds;
+    hr_band              m_band;
+    RayTracedShadows     m_pass;
+    CommonResources*     m_common;
+    GBuffer*             m_g_buffer;
+};
+
+class TiledAO
+{
+public:
+    TiledAO(Context& ctx, Comm& comm, CommonResources* common, GBuffer* g_buffer, std::vector<int32_t> bounds, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES) :
+        m_comm(comm), m_bounds(std::move(bounds)), m_band(band_of(m_bounds, comm.rank(), kHalo, kHalo)),
+        m_pass(ctx, common, g_buffer, scale, comm.world() > 1 ? &m_band : nullptr), m_common(common)
+    {
+    }
+    void render(Stream cmd_buf)
+    {
+        m_comm.wait(cmd_buf);
+        m_pass.render(cmd_buf);
+        if (m_pass.params.denoise) check(hr_ao_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledAO::exchange");
+    }
+    RayTracedAO& pass() { return m_pass; }
+private:
+    Comm&                m_comm;
+    std::vector<int32_t> m_bounds;
+    hr_band              m_band;
+    RayTracedAO          m_pass;
+    CommonResources*     m_common;
+};
+
+// DDGI: probes partitioned by grid z-slab for the ray trace and both probe updates, atlas rows all-gathered, every rank samples the
+// full atlases for its own row band (tiling.ShardedDDGI)
+class ShardedDDGI
+{
+public:
+    ShardedDDGI(Context& ctx, Comm& comm, CommonResources* common, GBuffer* g_buffer, const hr_ddgi_uniforms& grid, std::vector<int32_t> bounds) :
+        m_comm(comm), m_pass(ctx, common, g_buffer, grid), m_common(common), m_g_buffer(g_buffer)
+    {
+        const int cz = grid.probe_counts[2], w = comm.world(), r = comm.rank();
+        if (w > 1) check(hr_ddgi_set_shard(m_pass.handle(), (int)((long long)cz * r / w), (int)((long long)cz * (r + 1) / w), bounds[r], bounds[r + 1]), "hr_ddgi_set_shard");
+    }
+    void render(Stream cmd_buf)
+    {
+        const Frame f = make_frame(*m_common, *m_g_buffer, 0);
+        hr_ddgi* p = m_pass.handle();
+        check(hr_ddgi_ray_trace(p, f.scene->handle(), &f.inputs, f.environment, &m_pass.params, cmd_buf), "ShardedDDGI::ray_trace");
+        check(hr_ddgi_probe_update(p, cmd_buf), "ShardedDDGI::probe_update");
+        check(hr_ddgi_allgather_atlases(p, m_comm.handle(), cmd_buf), "ShardedDDGI::allgather");
+        m_comm.wait(cmd_buf);   // loopback: the copies may sit on another rank's stream; RCCL: already ordered (no-op)
+        check(hr_ddgi_sample_probe_grid(p, &f.inputs, &m_pass.params, cmd_buf), "ShardedDDGI::sample_probe_grid");
+        check(hr_ddgi_end_frame(p), "ShardedDDGI::end_frame");
+    }
+    DDGI& pass() { return m_pass; }
+private:
+    Comm&            m_comm;
+    DDGI             m_pass;
+    CommonResources* m_common;
+    GBuffer*         m_g_buffer;
+};
+
+class TiledReflections
+{
+public:
+    TiledReflections(Context& ctx, Comm& comm, CommonResources* common, GBuffer* g_buffer, std::vector<int32_t> bounds, RayTraceScale scale = RAY_TRACE_SCALE_HALF_RES) :
+        m_comm(comm), m_bounds(std::move(bounds)), m_band(band_of(m_bounds, comm.rank(), kHalo, kHalo)),
+        m_pass(ctx, common, g_buffer, scale, comm.world() > 1 ? &m_band : nullptr), m_common(common)
+    {
+    }
+    void render(Stream cmd_buf, DDGI* ddgi)
+    {
+        m_comm.wait(cmd_buf);
+        m_pass.render(cmd_buf, ddgi);
+        if (m_pass.params.denoise)
+            check(hr_reflections_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledReflections::exchange");
+    }
+    RayTracedReflections& pass() { return m_pass; }
+private:
+    Comm&                m_comm;
+    std::vector<int32_t> m_bounds;     // in rows of the PASS image (full height >> scale)
+    hr_band              m_band;
+    RayTracedReflections m_pass;
+    CommonResources*     m_common;
+};
+
+} // namespace hr

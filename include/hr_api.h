@@ -115,6 +115,7 @@ typedef struct hr_scene hr_scene;
 
 hr_status hr_ctx_create(int device_ordinal, hr_ctx** out);
 hr_status hr_ctx_destroy(hr_ctx* ctx);
+int32_t   hr_ctx_device(const hr_ctx* ctx);   /* HIP device ordinal the context was created on (-1: NULL) */
 
 /* Replaces dw::RayTracedScene (BLAS/TLAS build, main.cpp:74 build_tlas, common.cpp:355-521
  * initialize_for_ray_tracing): flattens instances to world space, builds the compressed 8-wide BVH

@@ -1,0 +1,75 @@
+/* hr_comm.h — native multi-GPU transport of the row-tiled frame, C ABI.
+ *
+ * The reference is a single-GPU application; this is the surface a maintainer binds to run its passes on the GPUs of one node:
+ * one process (or thread) per GPU, each owning ONE row band of every pass (hr_band in hr_api.h) and one z-slab of the DDGI probes.
+ * Two collectives exist, both between direct neighbours or small and latency-bound (no all-reduce anywhere):
+ *   - hr_comm_exchange_rows      the history rows next to a band boundary (a-trous feedback image + moments, AO value + history
+ *                                length, ...) go to the neighbour above / below: grouped ncclSend / ncclRecv pairs on a dedicated
+ *                                communication stream, ordered against the caller's compute stream with events;
+ *   - hr_comm_allgather_rows     every rank contributes the atlas rows of its probe slab, all ranks end up with the whole atlas.
+ * The python mirror hybrid_rendering_amd/tiling.py drives the same plan through torch.distributed (the driver's bench.py launch);
+ * this library is what a C++ host links (examples/tiled_frame.cpp).
+ *
+ * Back ends:  RCCL over xGMI (librccl is dlopen'ed on first use — a single-GPU integration never loads it), and an in-process
+ * LOOPBACK where all ranks live in one process on one device (device-to-device copies): the functional test of the plan on a one-GPU
+ * box (tests/test_gpu_comm.py).  RCCL refuses two ranks on one GPU, so on such a box only the loopback can run.
+ *
+ * Library: hybrid_rendering_amd/libhr_comm.so (links libhybrid_rendering_amd.so).  Calls on one hr_comm are externally serialised.
+ */
+#ifndef HR_COMM_H
+#define HR_COMM_H
+
+#include "hr_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hr_comm hr_comm;
+
+#define HR_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* RCCL: rank 0 draws an id (ncclGetUniqueId) and hands it to the other ranks by whatever the host has (MPI, a file, a socket);
+ * every rank then joins with ncclCommInitRank.  HR_ERR_UNSUPPORTED when librccl cannot be loaded. */
+hr_status hr_comm_get_unique_id(uint8_t id[HR_COMM_ID_BYTES]);
+hr_status hr_comm_create_rccl(hr_ctx* ctx, int32_t world, int32_t rank, const uint8_t id[HR_COMM_ID_BYTES], hr_comm** out);
+/* Loopback: `world` ranks of the group `name` inside this process, all on ctx's device. */
+hr_status hr_comm_create_loopback(hr_ctx* ctx, int32_t world, int32_t rank, const char* name, hr_comm** out);
+hr_status hr_comm_destroy(hr_comm* comm);
+int32_t   hr_comm_rank(const hr_comm* comm);
+int32_t   hr_comm_world(const hr_comm* comm);
+
+/* A row-major image addressed by ABSOLUTE frame row (the pass images of hr_api.h are): data = address of row 0. */
+typedef struct
+{
+    void*   data;
+    int64_t row_pitch_bytes;
+} hr_comm_image;
+
+/* Neighbour exchange.  bounds[0 .. world] are the band boundaries in rows of these images (bounds[r] .. bounds[r + 1] = rank r's
+ * band; 0 and the image height at the ends).  For every image: my `rows` band rows next to each boundary go to that neighbour, the
+ * neighbour's `rows` rows next to it arrive in my copy (min(rows, band height) when a band is shorter).
+ * Ordering: the transfer starts after everything already enqueued on `compute_stream`; nothing later on `compute_stream` waits for
+ * it until hr_comm_wait(comm, compute_stream) — so the next frame's ray trace (which reads no history) overlaps the exchange. */
+hr_status hr_comm_exchange_rows(hr_comm* comm, const hr_comm_image* images, int32_t n_images, const int32_t* bounds, int32_t rows, void* compute_stream);
+hr_status hr_comm_wait(hr_comm* comm, void* compute_stream);
+
+/* All-gather of row slabs: rank r owns rows row_bounds[r] .. row_bounds[r + 1] of `image` (slabs may be ragged or empty); afterwards
+ * every rank holds all rows.  `compute_stream` continues only when the gather is complete (the sample / reflections passes read it). */
+hr_status hr_comm_allgather_rows(hr_comm* comm, hr_comm_image image, const int32_t* row_bounds, void* compute_stream);
+
+/* Per-pass conveniences over the calls above: they pick the images the NEXT frame's reprojection reads —
+ *   shadows      feedback image (RG16F) + the moments written this frame (ping_pong)          hr_band.history_halo rows
+ *   AO           temporal output + history length written this frame
+ *   reflections  feedback image + moments
+ *   DDGI         irradiance + depth atlas rows of this rank's probe z-slabs [z0, z1) of `cz` slabs (hr_ddgi_set_shard)
+ * bounds are in rows of the PASS image (full height >> scale). */
+hr_status hr_shadows_exchange_history(hr_shadows* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
+hr_status hr_ao_exchange_history(hr_ao* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
+hr_status hr_reflections_exchange_history(hr_reflections* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
+hr_status hr_ddgi_allgather_atlases(hr_ddgi* p, hr_comm* comm, void* compute_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -32,6 +32,23 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert sorted(set(api.ABI_SYMBOLS)) == decl, set(api.ABI_SYMBOLS) ^ set(decl)
 
 
+def test_comm_library_exports_every_declared_symbol():
+    """include/hr_comm.h (native RCCL / loopback transport of the row-tiled frame): libhr_comm.so loads without a GPU and without
+    librccl (dlopen'ed on first use) and exports what the header declares"""
+    from hybrid_rendering_amd import build as hb, comm
+    hb.build()
+    src = open(os.path.join(ROOT, "include", "hr_comm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decl = sorted(set(re.findall(r"\b(hr_[a-z0-9_]+)\s*\(", src)))
+    L = comm.lib()
+    assert not [s for s in decl if not hasattr(L, s)]
+    assert sorted(comm.ABI_SYMBOLS) == decl, set(comm.ABI_SYMBOLS) ^ set(decl)
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.hr_comm_create_loopback(None, 2, 0, b"x", C.byref(h)) == 1      # HR_ERR_INVALID_ARG, never an exception
+    assert L.hr_comm_wait(None, None) == 1
+
+
 def test_struct_layouts_match_header():
     from hybrid_rendering_amd import api
     assert C.sizeof(api.hr_ubo) == 416
@@ -68,7 +85,7 @@ def test_cpp_shims_compile():
     """include/hr/passes.hpp (the C++ mirror of the reference's pass classes) is valid C++14 against hr_api.h."""
     import subprocess
     import tempfile
-    src = '#include <hr/passes.hpp>\nint main() { hr_shadows_params p; hr_shadows_default_params(&p); return sizeof(hr::RayTracedShadows) + sizeof(hr::DDGI) > 0 ? 0 : 1; }\n'
+    src = '#include <hr/passes.hpp>\n#include <hr/tiled.hpp>\nint main() { hr_shadows_params p; hr_shadows_default_params(&p); return sizeof(hr::RayTracedShadows) + sizeof(hr::DDGI) + sizeof(hr::TiledShadows) > 0 ? 0 : 1; }\n'
     with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
         f.write(src)
     subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])

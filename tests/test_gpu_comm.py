@@ -1,0 +1,121 @@
+"""The native transport (include/hr_comm.h, libhr_comm.so) through its LOOPBACK back end: all ranks of the row-tiled frame in one
+process on the one GPU of the test box (RCCL refuses two ranks on one device).  The plan, the row ranges, the event ordering and the
+per-pass conveniences are the code the RCCL back end runs; only the wire differs (hipMemcpyAsync instead of ncclSend / ncclRecv)."""
+import numpy as np
+import pytest
+
+import helpers
+from hybrid_rendering_amd import synth, synth_env, tiling
+
+pytestmark = pytest.mark.gpu
+
+
+def test_exchange_rows_and_allgather_loopback(hr, ctx):
+    import torch
+    from hybrid_rendering_amd import comm
+    H, W, world, rows = 96, 40, 3, 16
+    bounds = [0, 24, 64, 96]
+    comms = [comm.NativeComm(ctx, world, r, loopback_name="t1") for r in range(world)]
+    # every rank's copy holds its own band rows = rank + 1, everything else = -1
+    imgs = [[torch.full((H, W, 2), -1.0, dtype=torch.float16, device="cuda"), torch.full((H, W), -1, dtype=torch.int32, device="cuda")] for _ in range(world)]
+    for r in range(world):
+        for t in imgs[r]:
+            t[bounds[r]:bounds[r + 1]] = r + 1
+    # rank 2 posts first, then 0, then 1: any interleaving must work; nothing is waited for until wait()
+    for r in (2, 0, 1):
+        comms[r].exchange_rows(imgs[r], bounds, rows)
+    for r in range(world):
+        comms[r].wait()
+    torch.cuda.synchronize()
+    for r in range(world):
+        for t in imgs[r]:
+            v = t[..., 0] if t.dim() == 3 else t
+            exp = np.full(H, -1.0)
+            exp[bounds[r]:bounds[r + 1]] = r + 1
+            if r > 0:
+                exp[max(bounds[r] - rows, bounds[r - 1]):bounds[r]] = r          # the upper neighbour's last rows
+            if r < world - 1:
+                exp[bounds[r + 1]:min(bounds[r + 1] + rows, bounds[r + 2])] = r + 2
+            assert np.array_equal(v[:, 0].float().cpu().numpy(), exp), f"rank {r}"
+    # ragged all-gather (one empty slab)
+    rb = [1, 1, 30, 50]
+    atl = [torch.zeros((52, 8), dtype=torch.float32, device="cuda") for _ in range(world)]
+    for r in range(world):
+        atl[r][rb[r]:rb[r + 1]] = r + 1
+    for r in range(world):
+        comms[r].allgather_rows(atl[r], rb)
+    for r in range(world):
+        comms[r].wait()
+    torch.cuda.synchronize()
+    exp = np.zeros(52); exp[1:30] = 2; exp[30:50] = 3
+    for r in range(world):
+        assert np.array_equal(atl[r][:, 0].cpu().numpy(), exp)
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world):
+    """shadows + AO + DDGI + reflections on `world` bands through the C-ABI exchange / all-gather calls: every band row equals the
+    un-tiled render bit for bit (exact mode) over 4 frames with camera motion."""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections, comm
+    name, W, H, n_frames = "sponza_small", 192, 264, 4
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, W, H, n_frames, 2.0)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    zbp = synth.z_buffer_params()
+    lo, hi = sd.bounds()
+    ddgi_u = synth_env.ddgi_uniforms(lo, hi, probe_counts=(4, 3, 6), rays_per_probe=32, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(16)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 16, 5, f16(synth_env.brdf_lut(16)))
+    bounds = [tiling.band_rows(H, world, r)[0] for r in range(world)] + [H]
+    comms = [comm.NativeComm(ctx, world, r, loopback_name=f"frame{world}") for r in range(world)]
+    band = lambda r: (bounds[r], bounds[r + 1], tiling.HALO, tiling.HISTORY_HALO)
+    w_sh, w_ao, w_gi, w_rf = hr.RayTracedShadows(ctx, W, H), hr.RayTracedAO(ctx, W, H, 0), api_gi.DDGI(ctx, W, H, ddgi_u), api_reflections.RayTracedReflections(ctx, W, H, 0)
+    t_sh = [hr.RayTracedShadows(ctx, W, H, 0, band=band(r)) for r in range(world)]
+    t_ao = [hr.RayTracedAO(ctx, W, H, 0, band=(bounds[r], bounds[r + 1], tiling.HALO, tiling.HALO)) for r in range(world)]
+    t_rf = [api_reflections.RayTracedReflections(ctx, W, H, 0, band=(bounds[r], bounds[r + 1], tiling.HALO, tiling.HALO)) for r in range(world)]
+    t_gi = [api_gi.DDGI(ctx, W, H, ddgi_u) for _ in range(world)]
+    for r, g in enumerate(t_gi):
+        z0, z1 = tiling.probe_slabs(6, world, r)
+        g.set_shard(z0, z1, bounds[r], bounds[r + 1])
+    rng = np.random.RandomState(3)
+    for f in range(n_frames):
+        cur, prev = helpers.to_cuda(frames[f]["gb"]), helpers.to_cuda(frames[f - 1 if f else 0]["gb"])
+        fi = hr.frame_inputs(cur, prev, frames[f]["ubo"], f, f & 1, sob_d, sr_d, cur_full=cur, z_buffer_params=zbp)
+        orient = synth_env.random_orientation(rng)
+        w_sh.render(gsc, fi); w_ao.render(gsc, fi); w_gi.render(gsc, fi, env, orient); w_rf.render(gsc, fi, env, w_gi)
+        # one rank after the other, each doing its whole frame (the loopback queues the posts until the neighbour arrives)
+        for r in range(world):
+            c = comms[r]
+            c.wait()                                            # last frame's history rows have landed
+            t_sh[r].render(gsc, fi)
+            c.exchange_shadows(t_sh[r], bounds, f & 1, tiling.HISTORY_HALO)
+            t_ao[r].render(gsc, fi)
+            c.exchange_ao(t_ao[r], bounds, f & 1, tiling.HALO)
+            g = t_gi[r]
+            g.set_orientation(orient)
+            g.ray_trace(gsc, fi, env); g.probe_update()
+            c.allgather_ddgi(g)
+        for r in range(world):                                  # the gather completes when the last rank has posted
+            comms[r].wait()
+            g = t_gi[r]
+            g.sample_probe_grid(fi); g.end_frame()
+            t_rf[r].render(gsc, fi, env, g)
+            comms[r].exchange_reflections(t_rf[r], bounds, f & 1, tiling.HALO)
+        torch.cuda.synchronize()
+        for r in range(world):
+            b0, b1 = bounds[r], bounds[r + 1]
+            assert torch.equal(t_sh[r].output(hr.OUTPUT_ATROUS)[b0:b1], w_sh.output(hr.OUTPUT_ATROUS)[b0:b1]), f"frame {f} rank {r}: shadows"
+            assert torch.equal(t_ao[r].output(hr.OUTPUT_UPSAMPLE)[b0:b1], w_ao.output(hr.OUTPUT_UPSAMPLE)[b0:b1]), f"frame {f} rank {r}: AO"
+            gi_r, gd_r = t_gi[r].current_read()
+            wi, wd = w_gi.current_read()
+            assert torch.equal(gi_r, wi) and torch.equal(gd_r, wd), f"frame {f} rank {r}: gathered atlases"
+            assert torch.equal(t_gi[r].output()[b0:b1], w_gi.output()[b0:b1]), f"frame {f} rank {r}: DDGI sample"
+            assert torch.equal(t_rf[r].output(hr.OUTPUT_UPSAMPLE)[b0:b1], w_rf.output(hr.OUTPUT_UPSAMPLE)[b0:b1]), f"frame {f} rank {r}: reflections"
+    for c in comms:
+        c.close()

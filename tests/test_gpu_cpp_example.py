@@ -35,3 +35,18 @@ def test_cpp_hybrid_frame_example_runs(hr):
     out = _run_example("hybrid_frame")
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all passes ran" in out.stdout and out.stdout.count("frame ") == 3 and "tone-mapped frame" in out.stdout
+
+
+def test_cpp_tiled_frame_example_runs(hr):
+    """the native multi-GPU path from C++ (hr_comm.h + hr/tiled.hpp): two ranks on their own host threads, shadows + AO bands equal
+    the un-tiled render bit for bit (RCCL with >= 2 GPUs visible, the in-process loopback on a one-GPU box)"""
+    exe = os.path.join(ROOT, "examples", "_build", "tiled_frame")
+    if not os.path.exists(exe):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "tiled_frame.cpp"),
+                               "-L", os.path.join(ROOT, "hybrid_rendering_amd"), "-lhr_comm", "-lhybrid_rendering_amd", "-lpthread",
+                               "-Wl,-rpath," + os.path.join(ROOT, "hybrid_rendering_amd"), "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "hybrid_rendering_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "every band row equals the un-tiled render" in out.stdout and out.stdout.count("shadows ==") == 6
