@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "hr_status_string", "hr_last_error", "hr_version", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info",
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
-    "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
+    "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
     "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
@@ -308,6 +308,12 @@ class _Pass:
         _check(getattr(lib(), self._prefix + "_output")(self.h, C.c_int(kind), C.byref(v)), self._prefix + "_output")
         return view_to_tensor(v)
 
+    def history_apron_exceeded(self) -> bool:
+        """row bands: a history tap fell on an image row this GPU does not hold since the last call (motion beyond history_halo)"""
+        v = C.c_int32(0)
+        _check(getattr(lib(), self._prefix + "_history_apron_exceeded")(self.h, C.byref(v)), self._prefix + "_history_apron_exceeded")
+        return bool(v.value)
+
     def reset_history(self):
         _check(getattr(lib(), self._prefix + "_reset_history")(self.h), self._prefix + "_reset_history")
 
@@ -410,5 +416,5 @@ class RayTracedAO(_Pass):
 
 
 ABI_SYMBOLS += ["hr_ao_default_params", "hr_ao_create", "hr_ao_render", "hr_ao_output", "hr_ao_reset_history", "hr_ao_destroy", "hr_ao_ray_trace",
-                "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
+                "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_history_apron_exceeded", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
                 "hr_ao_trace_stats"]

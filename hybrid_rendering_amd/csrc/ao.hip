@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
     const float mean = __fdiv_rn((float)sum, 289.0f * (float)a.spp);
     const bool  in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
     const bool  edge = x >= a.w || y >= a.h;   // no pixel, but the unguarded shader thread (:191-260) still votes (see k_shadows_temporal)
-    bool        flag = false;
+    bool        flag = false, apron_miss = false;
     if (in_image || edge)
     {
         const float d = edge ? 0.0f : a.depth.p[(size_t)y * a.w + x];
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
             float hao, dummy[2];
             ImgRGBA16F none { nullptr, 0, 0, 0 };
             const bool success = reproject<true, false, false, ImgR16F>(in, a.hist, none, a.hist_len, &hao, dummy, hlen);
+            apron_miss = in.apron_miss && in_image && y >= a.band_y0 && y < a.band_y1;
             hlen = min2(32.0f, success ? hlen + 1.0f : 1.0f);
             if (success)
             {
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
         }
         flag = out < 1.0f;
     }
+    if (a.apron_flag && __ballot(apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
     const unsigned long long any = __ballot(flag);
     if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
 }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void k_ao_blur(AOBlurArgs a)
 struct hr_ao
 {
     hr_ctx* ctx = nullptr;
-    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0;
+    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, band_y0 = 0, band_y1 = 0;
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0, max_spp = 4;
     DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true, want_stats = false;
@@ -314,6 +316,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
+        p->band_y0 = band->band_y0; p->band_y1 = band->band_y1;
         p->y0 = band->band_y0 - band->halo < 0 ? 0 : band->band_y0 - band->halo;
         p->y1 = band->band_y1 + band->halo > p->h ? p->h : band->band_y1 + band->halo;
         if ((p->y0 & 7) || ((p->y1 & 7) && p->y1 != p->h)) { set_last_error("band rows must be multiples of 8"); delete p; return HR_ERR_INVALID_ARG; }
@@ -346,6 +349,17 @@ hr_status hr_ao_destroy(hr_ao* p)
     return HR_OK;
 }
 hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
+{
+    HR_CHECK_ARG(p && exceeded);
+    uint32_t v = 0;
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(&v, (char*)p->counters.p + 48, 4, hipMemcpyDeviceToHost));
+    if (v) HR_HIP(hipMemset((char*)p->counters.p + 48, 0, 4));
+    *exceeded = v ? 1 : 0;
+    return HR_OK;
+}
+
 hr_status hr_ao_set_profiling(hr_ao* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
 hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
 hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays)
@@ -432,6 +446,8 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     a.hist = ImgR16F { (const uint16_t*)p->color[!pp].p, w, y0, y1 };
     a.hist_len = ImgR16F { (const uint16_t*)p->length[!pp].p, w, y0, y1 };
     a.out = (uint16_t*)p->color[pp].p; a.out_len = (uint16_t*)p->length[pp].p; a.tile_class = (uint8_t*)p->tile_class.p;
+    a.apron_flag = (y0 > 0 || y1 < p->h) ? (uint32_t*)((char*)p->counters.p + 48) : nullptr;   // row bands only
+    a.band_y0 = p->band_y0; a.band_y1 = p->band_y1;
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha;

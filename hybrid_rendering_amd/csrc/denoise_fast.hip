@@ -49,7 +49,7 @@ struct Reproj
     f3         cur_pos, cur_n;
     float      cur_id, hfx, hfy;
     int        hcx, hcy;
-    bool       inb, lok, tok[4];
+    bool       inb, lok, tok[4], apron_miss;   // apron_miss: the footprint touched an image row that is not resident (row bands)
     fm::Unproj hb;
     uint32_t   g2x[4], g3y[4], mm[4], hx[4], hy[4], lraw;
     float      td[4];
@@ -120,6 +120,7 @@ struct Reproj
         hb  = fm::unproject_base(M, tu + mvx, tv + mvy);
         // an outside tap loads a resident address (its value is discarded in resolve()), so no load sits behind a branch
         const int bx = (int)hfx, by = (int)hfy;
+        apron_miss = ((unsigned)by < (unsigned)g.h && (by < g.y0 || by >= g.y1)) || ((unsigned)(by + 1) < (unsigned)g.h && (by + 1 < g.y0 || by + 1 >= g.y1));
         uint32_t  off[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) off[s] = tap_offset(bx + (s & 1), by + (s >> 1), tok[s]);
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_tempo
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     const bool reproj = live && !a.debug_skip_reproject;
     if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
+    if (a.apron_flag && __ballot(reproj && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
     int sum, own;
     mask_window<false>(s_rows[wave], lx, ly, sum, own);   // 17 bfe + bcnt pairs while the 21 history loads are in flight
     const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f));
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArg
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = nullptr; rp.hist_len = a.hist_len.p;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
+    if (a.apron_flag && __ballot(live && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
     int sum, own;
     mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);   // popcounts while the history loads are in flight
     const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f * (float)a.spp));
@@ -737,6 +740,7 @@ __global__ __launch_bounds__(256, 5) void kf_refl_temporal(ReflTemporalArgs a)
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]), a.pvp, fm::hi(cq.y));
+    if (a.apron_flag && live && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) atomicOr(a.apron_flag, 1u);   // rare
     // vertical pass of the separable sums (LDS only) while the history taps are in flight
     float s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
 #pragma unroll 6   // in groups: fully unrolled, the 34 LDS reads are hoisted together and cost 100 VGPRs next to the 25 tap registers

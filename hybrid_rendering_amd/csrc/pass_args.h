@@ -24,6 +24,10 @@ struct TemporalArgs
     int             tiles_x, tiles_y, tile_y0;
     float           alpha, moments_alpha;
     int             debug_skip_reproject; // developer ablation switch (HR_DEBUG_SKIP_REPROJECT)
+    uint32_t*       apron_flag;     // row bands only (else nullptr): set to 1 when a history tap of a pixel of the band proper [band_y0,
+                                    // band_y1) fell on a row of the image that is not resident on this GPU — the motion exceeded
+                                    // hr_band.history_halo (the tap read as disoccluded).  Halo rows are the neighbour's to get right.
+    int             band_y0, band_y1;
 };
 
 struct AtrousArgs
@@ -52,6 +56,8 @@ struct AOTemporalArgs
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha;
+    uint32_t*       apron_flag;     // see TemporalArgs
+    int             band_y0, band_y1;
 };
 
 struct AOBlurArgs
@@ -78,6 +84,8 @@ struct ReflTemporalArgs
     int         w, h, y0, y1, tiles_x;
     float       alpha, moments_alpha;
     int         approximate_with_ddgi, moving;
+    uint32_t*   apron_flag;         // see TemporalArgs
+    int         band_y0, band_y1;
 };
 
 struct ReflAtrousArgs

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void k_refl_temporal(ReflTemporalArgs a)
             float hc[3], hm[2];
             ImgR16F none { nullptr, 0, 0, 0 };
             const bool success = reproject<false, true, true, ImgRGBA16F>(in, a.hist, a.hist_moments, none, hc, hm, hl);
+            if (a.apron_flag && in.apron_miss && y >= a.band_y0 && y < a.band_y1) atomicOr(a.apron_flag, 1u);   // rare (motion beyond the history apron of a row band)
             hl = min2(32.0f, success ? hl + 1.0f : 1.0f);
             f3 history = mk3(hc[0], hc[1], hc[2]);
             if (success)
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void k_refl_atrous(ReflAtrousArgs a)
 struct hr_reflections
 {
     hr_ctx* ctx = nullptr;
-    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, tiles_x = 0, tiles_y = 0;
+    int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, band_y0 = 0, band_y1 = 0, tiles_x = 0, tiles_y = 0;
     DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true;
     int     read_idx = 0, last_pp = 0;
@@ -398,6 +399,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
+        p->band_y0 = band->band_y0; p->band_y1 = band->band_y1;
         p->y0 = band->band_y0 - band->halo < 0 ? 0 : band->band_y0 - band->halo;
         p->y1 = band->band_y1 + band->halo > p->h ? p->h : band->band_y1 + band->halo;
         if ((p->y0 & 7) || ((p->y1 & 7) && p->y1 != p->h)) { set_last_error("band rows must be multiples of 8"); delete p; return HR_ERR_INVALID_ARG; }
@@ -424,6 +426,17 @@ hr_status hr_reflections_destroy(hr_reflections* p)
     return HR_OK;
 }
 hr_status hr_reflections_reset_history(hr_reflections* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
+{
+    HR_CHECK_ARG(p && exceeded);
+    uint32_t v = 0;
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(&v, (char*)p->counters.p + 48, 4, hipMemcpyDeviceToHost));
+    if (v) HR_HIP(hipMemset((char*)p->counters.p + 48, 0, 4));
+    *exceeded = v ? 1 : 0;
+    return HR_OK;
+}
+
 hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
 hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
 hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays)
@@ -503,6 +516,8 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     a.depth = ImgR32F { in->cur.depth, w, y0, y1 }; a.pdepth = ImgR32F { in->prev.depth, w, y0, y1 };
     a.out = (uint2*)p->color[pp].p; a.out_moments = (uint2*)p->moments[pp].p; a.tile_class = (uint8_t*)p->tile_class.p;
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x;
+    a.apron_flag = (y0 > 0 || y1 < p->h) ? (uint32_t*)((char*)p->counters.p + 48) : nullptr;   // row bands only
+    a.band_y0 = p->band_y0; a.band_y1 = p->band_y1;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha; a.approximate_with_ddgi = prm->approximate_with_ddgi ? 1 : 0;
     const float* cd = prm->camera_delta;
     a.moving = (sqrtf((cd[0] * cd[0] + cd[1] * cd[1]) + cd[2] * cd[2]) > 0.0f) ? 1 : 0; // compute_max_accumulated_frame :162-168

@@ -83,6 +83,8 @@ struct ReprojIn
     ImgRGBA16F   gb2, gb3, pgb2, pgb3;
     ImgR32F      pdepth;
     int          w, h;
+    // out: the bilinear footprint touched a row of the image that is not resident (row band: motion beyond the history apron)
+    bool         apron_miss = false;
     // optional: the caller has already fetched / decoded the centre pixel (shadows: it also stores the decoded normal)
     bool         has_center = false;
     uint2        c2, c3;
@@ -91,7 +93,7 @@ struct ReprojIn
 
 // HistT: ImgRG16F (shadows: r = visibility), ImgR16F (AO), ImgRGBA16F (reflections rgb)
 template <bool SINGLE, bool MOMENTS, bool REFL, typename HistT>
-HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& hist_moments, const ImgR16F& hist_length, float* hcol, float* hmom, float& history_length)
+HR_DEV bool reproject(ReprojIn& in, const HistT& hist, const ImgRGBA16F& hist_moments, const ImgR16F& hist_length, float* hcol, float* hmom, float& history_length)
 {
     const int   w = in.w, h = in.h;
     const float fw = (float)w, fh = (float)h;
@@ -140,6 +142,7 @@ HR_DEV bool reproject(const ReprojIn& in, const HistT& hist, const ImgRGBA16F& h
     if (MOMENTS) { hmom[0] = 0.0f; hmom[1] = 0.0f; }
 
     const int bx = (int)hfx, by = (int)hfy;
+    in.apron_miss = (by >= 0 && by < h && (by < in.pgb2.y0 || by >= in.pgb2.y1)) || (by + 1 >= 0 && by + 1 < h && (by + 1 < in.pgb2.y0 || by + 1 >= in.pgb2.y1));
     // Issue EVERY load of the 2x2 bilinear footprint (previous G-buffer, history colour, history moments) and the
     // history-length texel before the first use: one memory round trip instead of three dependent ones
     // (validity -> history -> length).  Texels of invalid taps are fetched but never used.

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * TEMPORAL_WAVES) void k_shadows_temporal(Tempor
     // g_should_denoise — e.g. with the mask bit its twin in the ray-trace dispatch produced (device_math.h trace_lane_kind).
     const bool edge = x >= a.w || y >= a.h;
     float      out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
-    bool       flag = false;
+    bool       flag = false, apron_miss = false;
     if (in_image || edge)
     {
         const size_t pix = in_image ? (size_t)y * a.w + x : (size_t)a.y0 * a.w;
@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64 * TEMPORAL_WAVES) void k_shadows_temporal(Tempor
             bool success = false;
             if (!a.debug_skip_reproject) success = reproject<true, true, false, ImgRG16F>(in, a.hist, a.hist_moments, none, &hv, hm, hlen);
             else { hv = 0.0f; hm[0] = hm[1] = 0.0f; hlen = 0.0f; }
+            apron_miss = in.apron_miss && in_image && y >= a.band_y0 && y < a.band_y1;
             hlen = min2(32.0f, success ? hlen + 1.0f : 1.0f);
             if (success)
             {
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(64 * TEMPORAL_WAVES) void k_shadows_temporal(Tempor
             a.out[pix] = pack_h2(out_v, out_var);
         }
     }
+    if (a.apron_flag && __ballot(apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
     // tile classification (:275-291): any lit pixel => the tile needs the à-trous filter
     const unsigned long long any = __ballot(flag);
     if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
@@ -597,6 +599,20 @@ hr_status hr_shadows_reset_history(hr_shadows* p)
     return HR_OK;
 }
 
+// Row bands: did any history tap of the frames rendered since the last call fall on an image row this GPU does not hold (per-frame
+// motion beyond hr_band.history_halo)?  Such taps were treated as disoccluded — the image stays valid but is no longer identical to
+// the single-GPU one; the integrator widens history_halo (or re-creates the band) when this fires.  Synchronises the stream.
+hr_status hr_shadows_history_apron_exceeded(hr_shadows* p, int32_t* exceeded)
+{
+    HR_CHECK_ARG(p && exceeded);
+    uint32_t v = 0;
+    HR_HIP(hipStreamSynchronize(p->last_stream));
+    HR_HIP(hipMemcpy(&v, (char*)p->counters.p + 48, 4, hipMemcpyDeviceToHost));
+    if (v) HR_HIP(hipMemset((char*)p->counters.p + 48, 0, 4));
+    *exceeded = v ? 1 : 0;
+    return HR_OK;
+}
+
 hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable)
 {
     HR_CHECK_ARG(p);
@@ -759,6 +775,8 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
     a.debug_skip_reproject = p->dbg_skip_reproject ? 1 : 0;
+    a.apron_flag = (p->y0 > 0 || p->y1 < p->h) ? (uint32_t*)((char*)p->counters.p + 48) : nullptr;   // row bands only
+    a.band_y0 = p->band_y0; a.band_y1 = p->band_y1;
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);

@@ -163,6 +163,12 @@ class _TiledPass:
         self.wait_exchange()
         self.pass_.render(scene, inputs, *extra, stream=stream)
 
+    def history_apron_exceeded(self) -> bool:
+        """Runtime guard of the history apron: True if, since the last call, a history tap of this band fell on an image row this GPU
+        does not hold (per-frame motion beyond ``history_rows`` minus the halo).  Such taps read as disoccluded, so the band is still a
+        valid image but no longer identical to the single-GPU one; the caller widens the apron.  Synchronises the device."""
+        return self.pass_.history_apron_exceeded()
+
     def wait_exchange(self):
         """Orders everything enqueued afterwards behind the previous frame's halo exchange.  With RCCL req.wait() only
         makes the current stream wait for the communication stream (no host synchronisation); with gloo it blocks."""

@@ -84,6 +84,8 @@ public:
             check(hr_shadows_exchange_history(p, m_comm.handle(), m_bounds.data(), f.inputs.ping_pong, kHistoryHalo, cmd_buf), "TiledShadows::exchange");
         }
     }
+    // a history tap fell on an image row this GPU does not hold (motion beyond the history apron): it read as disoccluded
+    bool history_apron_exceeded() { int32_t v = 0; check(hr_shadows_history_apron_exceeded(m_pass.handle(), &v), "history_apron_exceeded"); return v != 0; }
     RayTracedShadows& pass() { return m_pass; }
     int band_y0() const { return m_bounds[m_comm.rank()]; }
     int band_y1() const { return m_bounds[m_comm.rank() + 1]; }
@@ -110,6 +112,7 @@ public:
         m_pass.render(cmd_buf);
         if (m_pass.params.denoise) check(hr_ao_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledAO::exchange");
     }
+    bool history_apron_exceeded() { int32_t v = 0; check(hr_ao_history_apron_exceeded(m_pass.handle(), &v), "history_apron_exceeded"); return v != 0; }
     RayTracedAO& pass() { return m_pass; }
 private:
     Comm&                m_comm;
@@ -164,6 +167,7 @@ public:
         if (m_pass.params.denoise)
             check(hr_reflections_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledReflections::exchange");
     }
+    bool history_apron_exceeded() { int32_t v = 0; check(hr_reflections_history_apron_exceeded(m_pass.handle(), &v), "history_apron_exceeded"); return v != 0; }
     RayTracedReflections& pass() { return m_pass; }
 private:
     Comm&                m_comm;

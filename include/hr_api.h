@@ -257,6 +257,10 @@ hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr
  * 4 prev (feedback) image, 5/6 à-trous ping/pong, 7 upsample, 8 tile classes (uint8 as R8 in an R32 view is not
  * representable: width/height are in tiles, format HR_FORMAT_R32_UINT is NOT implied — 1 byte per tile). */
 hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* view);
+/* Row bands: did a history tap of the frames rendered since the last call fall on an image row this GPU does not hold (per-frame
+ * motion beyond hr_band.history_halo)?  Such taps read as disoccluded: the band stays a valid image but stops being identical to the
+ * single-GPU one; widen history_halo when this fires.  Synchronises the pass's stream; clears the flag. */
+hr_status hr_shadows_history_apron_exceeded(hr_shadows* p, int32_t* exceeded);
 hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable);
 hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out); /* synchronises the recorded events */
 /* rays fired by the last ray_trace (lit, non-sky pixels); synchronises the stream it ran on */
@@ -304,6 +308,7 @@ hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* pa
 hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
 /* 0 mask planes, 1/2 AO[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes (1 byte per tile) */
 hr_status hr_ao_image(hr_ao* p, int32_t which, hr_image_view* view);
+hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
 hr_status hr_ao_set_profiling(hr_ao* p, int32_t enable);
 hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out);
 hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays);
@@ -428,6 +433,7 @@ hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inpu
 hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 /* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes */
 hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* view);
+hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
 hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);
 hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out);
 hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);

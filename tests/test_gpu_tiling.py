@@ -182,3 +182,43 @@ def test_two_processes_hybrid_frame_bit_identical():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["bit_identical_to_untiled"] is True, line + out.stderr[-2000:]
     assert len(j["bands"]) == 3 and j["rays_per_frame"] > 100_000
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_history_apron_guard(oracle, hr, ctx, exact):
+    """a row band whose per-frame motion stays inside hr_band.history_halo never raises the flag; a vertical jump of the camera that
+    reprojects pixels beyond the apron raises it (those taps read as disoccluded), in both arithmetic modes, and reading clears it"""
+    import torch
+    name, W, H = "sponza_small", 192, 264
+    sd = helpers.scene_data(name)
+    gsc = hr.Scene(ctx, sd)
+    light = synth.sponza_light()
+    base = synth.sponza_camera(W / H)
+    def cam(dy):
+        e = np.array(base.eye) + np.array([0.0, dy, 0.0])
+        return synth.Camera(tuple(e), tuple(np.array(base.target) + np.array([0.0, dy, 0.0])), fov=base.fov, aspect=W / H)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    b0, b1 = tiling.band_rows(H, 3, 1)
+    gp = hr.RayTracedShadows(ctx, W, H, 0, band=(b0, b1, tiling.HALO, tiling.HISTORY_HALO))
+    gp.params.exact = exact
+    ao = hr.RayTracedAO(ctx, W, H, 0, band=(b0, b1, tiling.HALO, tiling.HALO))
+    ao.params.exact = exact
+    cams = [cam(0.0), cam(0.3), cam(120.0)]         # small step, then a jump of many rows
+    prev_gb = None
+    flags = []
+    for f in range(3):
+        ubo = synth.make_ubo(cams[f], cams[f - 1] if f else None, light)
+        gb = gsc.gbuffer(ubo, W, H)
+        fi = hr.frame_inputs(gb, prev_gb if prev_gb is not None else gb, ubo, f, f & 1, sob_d, sr_d, z_buffer_params=synth.z_buffer_params())
+        gp.render(gsc, fi); ao.render(gsc, fi)
+        flags.append((gp.history_apron_exceeded(), ao.history_apron_exceeded()))
+        prev_gb = gb
+    assert flags[0] == (False, False) and flags[1] == (False, False), flags
+    assert flags[2] == (True, True), flags
+    assert gp.history_apron_exceeded() is False      # reading cleared it
+    whole = hr.RayTracedShadows(ctx, W, H)
+    assert whole.history_apron_exceeded() is False   # un-tiled passes have no apron
+    for p in (gp, ao, whole):
+        p.close()
+    gsc.close()
