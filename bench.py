@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0, help="scene tessellation (1.0 = ~278k triangles)")
+    ap.add_argument("--tier", default="standard", choices=["standard", "hard"], help="hard: the ~2.5 M triangle scene with layered fabric, foliage cards and a grazing sun as the headline workload")
     ap.add_argument("--obj", default=None, help="Wavefront OBJ (+MTL) to render instead of the procedural scene (hybrid_rendering_amd/assets.py)")
     ap.add_argument("--ring", type=int, default=8, help="distinct camera positions cycled through")
     ap.add_argument("--exact", type=int, default=0, help="1: time the bit-for-bit parity arithmetic as the headline instead of the tolerance mode")
@@ -166,11 +167,11 @@ def main():
         sd = assets.load_obj(args.obj)
         scene_name = f"{os.path.basename(args.obj)}"
     else:
-        sd = synth.sponza_like(args.detail)
-        scene_name = "procedural Sponza-like"
+        sd = synth.sponza_like(args.detail, tier=args.tier)
+        scene_name = "procedural Sponza-like" + (" (hard tier: layered fabric, foliage cards, grazing sun)" if args.tier == "hard" else "")
     ctx = hr.Context(local_rank)
     scene = hr.Scene(ctx, sd)
-    light = synth.sponza_light()
+    light = synth.sponza_hard_light() if args.tier == "hard" else synth.sponza_light()
     sob, sr = synth.blue_noise_tables()
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
     exact = 1 if args.exact else 0
@@ -283,7 +284,7 @@ def main():
     trace_bytes = px * 12.125 + rays_per_frame * (nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES)
     if "ray_trace" in stages:
         stages["ray_trace"]["bytes"] = int(trace_bytes)
-    prof = load_profile() if (world == 1 and (W, H) == (1920, 1080) and not args.obj) else {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
+    prof = load_profile() if (world == 1 and (W, H) == (1920, 1080) and not args.obj and args.tier == "standard") else {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
     for n, s in stages.items():
         kern = KERNEL_OF.get(("shadows", re.sub(r"_\d+$", "", n)), n)
         if exact:
@@ -332,10 +333,11 @@ def main():
     other.pass_.close()
 
     # ---- the other BASELINE configurations (outside the timed region) ------------------------------------------------------------
-    if not args.no_passes and not args.obj:
+    if not args.no_passes and not args.obj and args.tier == "standard":
         try:
             if world == 1:
                 out["passes"] = passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact)
+                out["passes"]["hard_tier"] = hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact)
             else:
                 hf = HybridFrame(ctx, scene, sd, 3840, 2160, rank, world, exact=exact)
                 ms = hf.time(20, 4, barrier=barrier)
@@ -396,6 +398,47 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
                    "counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + "; trace kernels carry no `frac` here (their BVH bytes need the "
                    "instrumented build: see the headline's roofline)")
     return res
+
+
+def hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact):
+    """the headline pass on the harder workload tier: ~2.5 M triangles, layered fabric + foliage cards, sun 20 degrees
+    above the horizon — what a deep, thin-geometry BVH costs per ray"""
+    W, H = 1920, 1080
+    sd = synth.sponza_like(1.0, tier="hard")
+    scene = hr.Scene(ctx, sd)
+    light = synth.sponza_hard_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(3)]
+    ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(2)]
+    gbs = [scene.gbuffer(u, W, H) for u in ubos]
+    fis = [hr.frame_inputs(gbs[k & 1], gbs[(k + 1) & 1], ubos[k & 1], k, k & 1, sob_d, sr_d) for k in range(2)]
+    p = hr.RayTracedShadows(ctx, W, H)
+    p.params.exact = exact
+    for k in range(6):
+        fis[k & 1].num_frames = k
+        p.render(scene, fis[k & 1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 60
+    for k in range(6, 6 + n):
+        fis[k & 1].num_frames = k
+        p.render(scene, fis[k & 1])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    p.set_profiling(True)
+    acc = {}
+    for k in range(70, 80):
+        fis[k & 1].num_frames = k
+        p.render(scene, fis[k & 1])
+        for nme, t, b in p.stage_times():
+            acc[nme] = acc.get(nme, 0.0) + t / 10
+    rays = p.ray_count()
+    r, nn, nt = p.trace_stats(scene, fis[0])
+    out = {"workload": f"1920x1080 hard tier ({sd.n_tris} tris, {int(scene.info.n_nodes)} BVH nodes, depth {int(scene.info.max_depth)}): shadows 1 spp + SVGF",
+           "ms_per_frame": round(ms, 4), "rays_per_frame": int(rays), "Mrays_per_s": round(rays / ms / 1e3, 1), "nodes_per_ray": round(nn / max(r, 1), 2),
+           "tris_per_ray": round(nt / max(r, 1), 2), "trace_only_Mrays_per_s": round(rays / acc.get("ray_trace", 1e9) / 1e3, 1),
+           "stage_ms": {k: round(v, 4) for k, v in acc.items()}}
+    p.close(); scene.close()
+    return out
 
 
 def cpu_baseline(torch, np, scene, sd, gbs, ubos, seq, sob, sr, W, H, light, synth, args):

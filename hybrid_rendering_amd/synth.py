@@ -170,6 +170,22 @@ class _Builder:
         N /= np.maximum(np.linalg.norm(N, axis=-1, keepdims=True), 1e-20)
         return self.grid(P.astype(np.float32), N.astype(np.float32), material, mesh_id)
 
+    def cards(self, center, radius, count, size, material, rng, mesh_id=None):
+        """`count` randomly oriented quads (two triangles each) scattered in a ball: foliage cards — thin, overlapping, incoherent"""
+        c = np.asarray(center, np.float32)
+        d = rng.normal(size=(count, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pos = c + d * (radius * rng.uniform(0.2, 1.0, size=(count, 1)) ** (1 / 3)).astype(np.float32)
+        a = rng.normal(size=(count, 3)).astype(np.float32)
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = np.cross(a, rng.normal(size=(count, 3)).astype(np.float32))
+        b /= np.maximum(np.linalg.norm(b, axis=1, keepdims=True), 1e-6)
+        su = (size * rng.uniform(0.5, 1.5, size=(count, 1))).astype(np.float32)
+        sv = (size * 0.45 * rng.uniform(0.5, 1.5, size=(count, 1))).astype(np.float32)
+        p0, p1, p2, p3 = pos - a * su - b * sv, pos + a * su - b * sv, pos + a * su + b * sv, pos - a * su + b * sv
+        V = np.concatenate([np.stack([p0, p1, p2], 1), np.stack([p0, p2, p3], 1)])
+        return self.add(V, None, material, mesh_id)
+
     def finish(self, materials, name, **meta) -> SceneData:
         return SceneData(np.concatenate(self.v), np.concatenate(self.n), np.concatenate(self.mat), np.concatenate(self.mid),
                          np.asarray(materials, np.float32), name, dict(meta))
@@ -246,11 +262,16 @@ def cornell32() -> SceneData:
     return sc
 
 
-def sponza_like(detail: float = 1.0, seed: int = 1234) -> SceneData:
+def sponza_like(detail: float = 1.0, seed: int = 1234, tier: str = "standard") -> SceneData:
     """Colonnaded two-storey atrium, open roof; ~262k triangles at detail=1.
 
     Extents ~1100 x 450 x 700 (x: length, y: up, z: width) like the reference's Sponza
-    instance (common.cpp:528).  ``detail`` scales tessellation (0.25 -> ~20k tris)."""
+    instance (common.cpp:528).  ``detail`` scales tessellation (0.25 -> ~20k tris).
+
+    ``tier="hard"`` (the standard scene costs only ~6 BVH nodes per shadow ray): the same building plus what makes
+    real Sponza deep to traverse — three layers of finely folded fabric per curtain bay, foliage (thousands of randomly oriented thin
+    cards in plant-sized clusters on the floor and the galleries), hanging chains of thin links, denser clutter: ~2.5 M triangles at
+    detail=1 (1.0 M at detail=0.62), thin overlapping geometry that no split plane separates."""
     rng = np.random.RandomState(seed)
     mats = [
         [0.70, 0.66, 0.58, 0.0, 0.85, 0, 0, 0],  # 0 stone wall
@@ -324,7 +345,46 @@ def sponza_like(detail: float = 1.0, seed: int = 1234) -> SceneData:
         z = rng.choice([-1.0, 1.0]) * rng.uniform(200, 330)
         s = rng.uniform(8, 25)
         b.box((x - s, 215, z - s), (x + s, 215 + 2 * s, z + s), 8 if k % 2 else 10)
-    return b.finish(mats, "sponza_like", detail=detail, seed=seed)
+    if tier == "hard":
+        mats.append([0.12, 0.35, 0.10, 0.0, 0.70, 0, 0, 0])   # 11 leaf
+        mats.append([0.25, 0.22, 0.20, 1.0, 0.40, 0, 0, 0])   # 12 iron
+        # fabric: two more layers behind every curtain, finer folds, slightly different phase (overlapping thin sheets)
+        for sgn in (-1, 1):
+            for i in range(0, ncol - 1):
+                x0, x1 = xs[i] + 14, xs[i + 1] - 14
+                for layer in range(3):
+                    z = sgn * (zc - 10 - 5 * layer)
+                    b.curtain((x0, 345 - 2 * layer, z), (x1 - x0, 0, 0), (0, -125 - 60 * (layer == 2), 0), 3 + (i + layer) % 3, nu=t(120, 8), nv=t(96, 8),
+                              amp=4.0 + 2.0 * layer, waves=6.0 + 2.5 * layer)
+        for x in np.linspace(-420, 420, 8):
+            for layer in range(2):
+                b.curtain((x + 6 * layer, 405, -150), (0, 0, 300), (0, -170, 0), 3 + int(x > 0) + layer, nu=t(140, 8), nv=t(90, 8), amp=6.0 + 3 * layer, waves=5.0 + layer)
+        # foliage: plant-sized clusters of thin cards along the floor edges and on the galleries
+        for k in range(140):
+            on_gallery = k % 3 == 0
+            x = rng.uniform(-520, 520)
+            z = rng.choice([-1.0, 1.0]) * (rng.uniform(200, 330) if on_gallery else rng.uniform(100, 150))
+            y = (215.0 if on_gallery else 0.0) + rng.uniform(20, 45)
+            b.cards((x, y, z), rng.uniform(18, 34), t(900, 40), rng.uniform(3.0, 6.0), 11, rng)
+        # hanging chains: thin vertical links from the roof slabs
+        for k in range(60):
+            x, z = rng.uniform(-520, 520), rng.choice([-1.0, 1.0]) * rng.uniform(175, 340)
+            for j in range(t(24, 4)):
+                y = 405 - 7.5 * j
+                b.cylinder((x + (j % 2) * 0.8, y - 6, z), 0.7, 6.0, 12, seg=t(10, 4), stacks=1)
+        for k in range(160):
+            x = rng.uniform(-500, 500)
+            z = rng.choice([-1.0, 1.0]) * rng.uniform(200, 330)
+            sz = rng.uniform(4, 14)
+            b.box((x - sz, 215, z - sz), (x + sz, 215 + 2 * sz, z + sz), 8 if k % 2 else 10)
+    return b.finish(mats, "sponza_like" + ("_hard" if tier == "hard" else ""), detail=detail, seed=seed, tier=tier)
+
+
+def sponza_hard_light() -> np.ndarray:
+    """a low sun (about 20 degrees above the horizon, along the atrium): grazing shadow rays that run the length of the building
+    through the fabric and the foliage"""
+    d = np.array([0.82, 0.36, 0.44])
+    return make_light(LIGHT_DIRECTIONAL, direction_to_light=d / np.linalg.norm(d), radius=0.08, intensity=10.0)
 
 
 # --------------------------------------------------------------------------- camera / UBO
