@@ -51,17 +51,17 @@ int orc_closest_hit_one(void* scene, const float* o, const float* d, float t_min
 void orc_any_hit_batch(const void* scene, int n, const float* rays, uint8_t* out, int brute_force, uint64_t* stats)
 {
     const Scene& s = *(const Scene*)scene;
-    s.stat_nodes = s.stat_tris = 0;
     if (stats)
     {
+        traversal_stats() = TraversalStats();
         // serial, instrumented
         for (int i = 0; i < n; i++)
         {
             const float* r = rays + (size_t)i * 8;
             out[i] = s.any_hit(v3(r[0], r[1], r[2]), v3(r[4], r[5], r[6]), r[7], r[3]) ? 1 : 0;
         }
-        stats[0] = s.stat_nodes;
-        stats[1] = s.stat_tris;
+        stats[0] = traversal_stats().nodes;
+        stats[1] = traversal_stats().tris;
         return;
     }
 #pragma omp parallel for schedule(dynamic, 256)

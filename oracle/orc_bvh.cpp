@@ -5,6 +5,9 @@
 
 namespace orc {
 
+static thread_local TraversalStats tl_stats;
+TraversalStats& traversal_stats() { return tl_stats; }
+
 namespace {
 struct AABB
 {
@@ -180,13 +183,13 @@ bool Scene::any_hit(vec3 o, vec3 d, float t_min, float t_max) const
     {
         const BVH2Node& n = nodes[stk[--sp]];
         float           tn;
-        stat_nodes++;
+        tl_stats.nodes++;
         if (!slab(n, o, id, t_min, t_max, &tn)) continue;
         if (n.count)
         {
             for (int i = 0; i < n.count; i++)
             {
-                stat_tris++;
+                tl_stats.tris++;
                 if (ray_tri(r, tris[order[n.left + i]], t_min, t_max, nullptr, nullptr, nullptr)) return true;
             }
         }
@@ -221,7 +224,7 @@ Hit Scene::closest_hit(vec3 o, vec3 d, float t_min, float t_max) const
     {
         const BVH2Node& n = nodes[stk[--sp]];
         float           tn;
-        stat_nodes++;
+        tl_stats.nodes++;
         // cull against the current best (inclusive, so equal-t candidates are still visited)
         if (!slab(n, o, id, t_min, best.prim < 0 ? t_max : best.t * 1.0000004f, &tn)) continue;
         if (n.count)
@@ -230,7 +233,7 @@ Hit Scene::closest_hit(vec3 o, vec3 d, float t_min, float t_max) const
             {
                 int   p = order[n.left + i];
                 float t, u, v;
-                stat_tris++;
+                tl_stats.tris++;
                 if (ray_tri(r, tris[p], t_min, t_max, &t, &u, &v))
                 {
                     if (best.prim < 0 || t < best.t || (t == best.t && p < best.prim)) best = Hit { t, u, v, p };

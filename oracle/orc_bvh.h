@@ -118,8 +118,11 @@ struct Scene
     bool any_hit_brute(vec3 o, vec3 d, float t_min, float t_max) const;
     Hit  closest_hit(vec3 o, vec3 d, float t_min, float t_max) const;
     Hit  closest_hit_brute(vec3 o, vec3 d, float t_min, float t_max) const;
-    // instrumentation for the CPU replay
-    mutable uint64_t stat_nodes = 0, stat_tris = 0;
 };
+
+// instrumentation for the CPU replay: node visits / triangle tests of the calling THREAD (a counter shared by the OpenMP team put
+// every traversal step of every thread on one cache line: the "parallel" replay of round 1 ran no faster than one core)
+struct TraversalStats { uint64_t nodes = 0, tris = 0; };
+TraversalStats& traversal_stats();
 
 } // namespace orc
