@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhybrid_rendering_amd.so")
+# HR_LIBRARY: developer A/B builds (python -m hybrid_rendering_amd.build --variant NAME with HR_CFLAGS=...) — a HIP library either way
+LIB_PATH = os.environ.get("HR_LIBRARY") or os.path.join(_HERE, "libhybrid_rendering_amd.so")
 
 # ------------------------------------------------------------------------------ ctypes structs
 

@@ -52,19 +52,27 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, variant: str = None) -> str:
+    """variant: a developer A/B build (HR_CFLAGS="-DFT_SHADOWS_EU=5" python -m hybrid_rendering_amd.build --variant eu5) written next to
+    the product library as variants/libhybrid_rendering_amd.<variant>.so; HR_LIBRARY=<that path> selects it (api.py)."""
+    out = LIB
+    if variant:
+        os.makedirs(os.path.join(HERE, "variants"), exist_ok=True)
+        out = os.path.join(HERE, "variants", f"libhybrid_rendering_amd.{variant}.so")
+    elif not force and not needs_build():
         build_comm(False, verbose)
         return LIB
-    extra = os.environ.get("HR_CFLAGS", "").split()   # developer A/B builds: HR_CFLAGS="-DFT_SHADOWS_EU=5" python -m hybrid_rendering_amd.build --force
-    cmd = [hipcc()] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", LIB + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
+    extra = os.environ.get("HR_CFLAGS", "").split()
+    cmd = [hipcc()] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", out + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    build_comm(True, verbose)
-    return LIB
+    os.replace(out + ".tmp", out)
+    if not variant:
+        build_comm(True, verbose)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose=True, variant=v))

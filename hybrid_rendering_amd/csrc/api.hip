@@ -17,16 +17,21 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 __global__ __launch_bounds__(256) void k_any_hit_batch(const Node8* nodes, const TriGPU* tris, long long n, const float* rays, uint8_t* out, unsigned long long* stats)
 {
     __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ CoopWave s_coop[4];
     const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i    = (long long)blockIdx.x * 256 + threadIdx.x;
     uint32_t        nn = 0, nt = 0;
-    if (i < n)
+    // the counting query walks per lane (trace_any); the plain one is the wave-cooperative walk the AO pass uses (trace_coop)
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (i < n) { a = ((const float4*)rays)[i * 2]; b = ((const float4*)rays)[i * 2 + 1]; }
+    if (stats)
     {
-        const float4 a = ((const float4*)rays)[i * 2], b = ((const float4*)rays)[i * 2 + 1];
-        bool         occ;
-        if (stats) occ = trace_any<true>(nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], lane, nn, nt);
-        else occ = trace_any<false>(nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], lane, nn, nt);
-        out[i] = occ ? 1 : 0;
+        if (i < n) out[i] = trace_any<true>(nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], lane, nn, nt) ? 1 : 0;
+    }
+    else
+    {
+        const bool occ = trace_coop<true>(i < n, nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], s_coop[wave], lane).prim == 0;
+        if (i < n) out[i] = occ ? 1 : 0;
     }
     if (stats)
     {
@@ -42,11 +47,14 @@ __global__ __launch_bounds__(256) void k_any_hit_batch(const Node8* nodes, const
 __global__ __launch_bounds__(256) void k_closest_hit_batch(const Node8* nodes, const TriGPU* tris, long long n, const float* rays, float* out_tuv, int32_t* out_prim)
 {
     __shared__ uint32_t s_stack[4][HR_STACK_ENTRIES * 64];
+    __shared__ CoopWave s_coop[4];
     const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i    = (long long)blockIdx.x * 256 + threadIdx.x;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (i < n) { a = ((const float4*)rays)[i * 2]; b = ((const float4*)rays)[i * 2 + 1]; }
+    // the walk the DDGI and reflection passes use (trace_coop); lanes past the end of the batch only serve as triangle-test lanes
+    const HitRec h = trace_coop<false>(i < n, nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], s_coop[wave], lane);
     if (i >= n) return;
-    const float4 a = ((const float4*)rays)[i * 2], b = ((const float4*)rays)[i * 2 + 1];
-    HitRec       h = trace_closest(nodes, tris, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), b.w, a.w, s_stack[wave], lane);
     out_tuv[i * 3 + 0] = h.t;
     out_tuv[i * 3 + 1] = h.u;
     out_tuv[i * 3 + 2] = h.v;
@@ -322,6 +330,11 @@ static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene
     if (b.nodes.size() >= (1u << 23))   // traversal stack entries hold child_base in 23 bits
     {
         set_last_error("hr_scene_create: more than 2^23 BVH nodes");
+        return HR_ERR_UNSUPPORTED;
+    }
+    if (b.tris.size() >= kCoopMaxTriangles)   // cooperative triangle jobs hold the triangle reference in 26 bits (traverse.h CoopWave)
+    {
+        set_last_error("hr_scene_create: more than 2^26 triangle references");
         return HR_ERR_UNSUPPORTED;
     }
     if (b.max_depth >= kMaxTraversalDepth)   // one stack entry per level (traverse.h); the builder's depth cap keeps real input below it

@@ -6,6 +6,7 @@
 #include "hr_internal.h"
 #include "shading.h"
 #include "pass_args.h"
+#include "trace_queue.h"
 
 using namespace hr;
 
@@ -45,28 +46,55 @@ struct DDGITraceArgs
 
 // one thread per (probe, ray); a wave covers 64 consecutive rays of one probe (same origin: the rays share the nodes around
 // it — the transposed mapping, one direction from 64 probes per wave, measured 0.40 -> 0.45 ms)
+#ifdef HR_TRACE_DIVERGENCE
+static __device__ unsigned long long g_div_ddgi[16];   // 0-7 primary rays, 8-15 secondary rays
+extern "C" int hr_debug_divergence_ddgi(uint64_t* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_div_ddgi), sizeof(g_div_ddgi)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_div_ddgi), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 #ifndef DDGI_TRACE_WAVES
 #define DDGI_TRACE_WAVES 1
+#endif
+#ifndef DDGI_COOP
+#define DDGI_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop); 0 = the per-lane loops
 #endif
 __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceArgs a)
 {
     __shared__ uint32_t s_stack[DDGI_TRACE_WAVES][HR_STACK_ENTRIES * 64];
+#if DDGI_COOP
+    __shared__ CoopWave s_coop[DDGI_TRACE_WAVES];
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = a.d.rays_per_probe;
     const long long gid = (long long)blockIdx.x * (64 * DDGI_TRACE_WAVES) + threadIdx.x;
     const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
     uint32_t  rays = 0;
-    if (probe < a.n_probes)
+    HR_DIV(DivCounters dvp = {}, dvs = {};)
+    const bool valid = probe < a.n_probes;
+    f3 origin = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 1.0f);
+    if (valid)
     {
-        const f3 origin = probe_location(a.d, probe);
+        origin = probe_location(a.d, probe);
         const f3 f      = spherical_fibonacci((float)ray, (float)R);
         const float* M  = a.orientation;
-        const f3 dir = normalize3(mk3((M[0] * f.x + M[3] * f.y) + M[6] * f.z, (M[1] * f.x + M[4] * f.y) + M[7] * f.z, (M[2] * f.x + M[5] * f.y) + M[8] * f.z));
+        dir = normalize3(mk3((M[0] * f.x + M[3] * f.y) + M[6] * f.z, (M[1] * f.x + M[4] * f.y) + M[7] * f.z, (M[2] * f.x + M[5] * f.y) + M[8] * f.z));
+        rays++;
+    }
+#if DDGI_COOP
+    const HitRec h = trace_coop<false>(valid, a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+#else
+    HitRec h;
+    h.prim = -1;
+    if (valid) h = trace_closest(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp));
+#endif
+    if (valid)
+    {
         Rng   rng = rng_init((uint32_t)ray, (uint32_t)probe, a.num_frames);
         f3    L;
         float hit_distance = 10000.0f;
-        rays++;
-        const HitRec h = trace_closest(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane);
 #ifdef HR_ABL_DDGI_PRIMARY_ONLY   // developer ablation (tools/ablate.sh): what does each part of the kernel cost?
         if (true) { L = mk3(h.t, h.u, h.v); hit_distance = h.t; }
         else
@@ -80,6 +108,7 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceA
             const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
             const float r2x = next_float(rng), r2y = next_float(rng);
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
+            HR_DIV(tc.dv = &dvs;)
             f3 Lo = direct_lighting(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
 #ifndef HR_ABL_DDGI_NO_IRRADIANCE
             if (a.infinite_bounces == 1)
@@ -99,8 +128,137 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceA
         a.radiance[o] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, 0.0f));
         a.dirdist[o]  = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
     }
+    HR_DIV(div_flush(dvp, g_div_ddgi); div_flush(dvs, g_div_ddgi + 8);)
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
     if (lane == 0) a.ray_slots[blockIdx.x * DDGI_TRACE_WAVES + wave] = rays;
+}
+
+// ---- wavefront form of ray_trace() (trace_queue.h): gen -> closest-hit queue -> shade + secondary queue -> any-hit queue -> combine
+struct DDGIWaveArgs
+{
+    DDGITraceArgs  t;
+    RayRec*        rays;        // primary rays, index = (probe - probe_begin) * R + ray
+    const float4*  hits;
+    RayRec*        sec_rays;    // secondary queue (light rays and sky rays of the hit points)
+    uint32_t*      sec_count;
+    const uint8_t* sec_occluded;
+    uint4*         part;        // 3 x uint4 per primary ray: P1.xyz, P2.x | P2.yz, I.xy | I.z, slot1, slot2, flags
+};
+#define DDGI_NO_SLOT 0xffffffffu
+
+__global__ __launch_bounds__(256) void k_ddgi_gen(DDGIWaveArgs w)
+{
+    const DDGITraceArgs& a = w.t;
+    const int R = a.d.rays_per_probe;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
+    if (probe >= a.n_probes) return;
+    const f3 origin = probe_location(a.d, probe);
+    const f3 f      = spherical_fibonacci((float)ray, (float)R);
+    const float* M  = a.orientation;
+    const f3 dir = normalize3(mk3((M[0] * f.x + M[3] * f.y) + M[6] * f.z, (M[1] * f.x + M[4] * f.y) + M[7] * f.z, (M[2] * f.x + M[5] * f.y) + M[8] * f.z));
+    float4* q = reinterpret_cast<float4*>(w.rays + gid);
+    q[0] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+    q[1] = make_float4(dir.x, dir.y, dir.z, 10000.0f);
+}
+
+// append one ray per flagged lane to the secondary queue: one atomic per wave
+HR_DEV uint32_t queue_append(bool want, uint32_t* count, RayRec* q, f3 o, f3 d, float t_min, float t_max)
+{
+    const unsigned long long b = __ballot(want);
+    if (b == 0ull) return DDGI_NO_SLOT;
+    const int first = __ffsll((long long)b) - 1;
+    uint32_t  base  = 0u;
+    if ((int)(threadIdx.x & 63) == first) base = atomicAdd(count, (uint32_t)__popcll(b));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    if (!want) return DDGI_NO_SLOT;
+    const uint32_t slot = base + lanes_below(b);
+    float4* p = reinterpret_cast<float4*>(q + slot);
+    p[0] = make_float4(o.x, o.y, o.z, t_min);
+    p[1] = make_float4(d.x, d.y, d.z, t_max);
+    return slot;
+}
+
+// gi_ray_trace.rchit:95-128 / .rmiss:24-27 without the two visibility queries: one thread per primary ray
+__global__ __launch_bounds__(64) void k_ddgi_shade(DDGIWaveArgs w)
+{
+    const DDGITraceArgs& a = w.t;
+    const int lane = threadIdx.x & 63;
+    const int R = a.d.rays_per_probe;
+    const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
+    const bool valid = probe < a.n_probes;
+    uint32_t rays = valid ? 1u : 0u;
+    bool     want1 = false, want2 = false;
+    f3       so = mk3(0.0f, 0.0f, 0.0f), d1 = mk3(0.0f, 0.0f, 1.0f), d2 = mk3(0.0f, 0.0f, 1.0f);
+    float    tmax1 = 0.0f;
+    f3       P1 = mk3(0.0f, 0.0f, 0.0f), P2 = P1, I = P1;
+    uint32_t flags = 0u;   // 1: add P2 when the sky ray is unoccluded, 2: add I
+    if (valid)
+    {
+        const float4 q1  = reinterpret_cast<const float4*>(w.rays + gid)[1];
+        const f3     dir = mk3(q1.x, q1.y, q1.z);
+        const float4 hq  = w.hits[gid];
+        HitRec h;
+        h.t = hq.x; h.u = hq.y; h.v = hq.z; h.prim = (int32_t)__float_as_uint(hq.w);
+        float hit_distance = 10000.0f;
+        if (h.prim < 0) P1 = a.sky.fetch(dir);
+        else
+        {
+            Rng rng = rng_init((uint32_t)ray, (uint32_t)probe, a.num_frames);
+            const SurfaceHit s = surface_at(a.sh, h);
+            const f3 Wo = neg3(dir);
+            const f3 F0 = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
+            const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
+            const float r2x = next_float(rng), r2y = next_float(rng);
+            const DirectSplit ds = direct_lighting_split(a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky);
+            so = ds.origin; d1 = ds.Wi1; d2 = ds.Wi2; tmax1 = ds.t_max1; want1 = ds.ray1; want2 = true;
+            P1 = ds.P1; P2 = ds.P2; flags = 1u;
+            if (a.infinite_bounces == 1)
+            {
+                const f3 F   = fresnel_schlick_roughness(max2(dot3(s.N, Wo), 0.0f), F0, s.roughness);
+                const f3 kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);
+                const f3 irr = sample_irradiance(a.d, s.P, s.N, Wo, a.prev_irr, a.prev_depth);
+                I = mul3(mul3(scale3(kD, a.gi_intensity), c_diffuse), irr);
+                flags |= 2u;
+            }
+            hit_distance = 0.001f + h.t;
+        }
+        a.dirdist[(size_t)probe * R + ray] = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
+    }
+    const uint32_t slot1 = queue_append(want1, w.sec_count, w.sec_rays, so, d1, 0.01f, tmax1);
+    const uint32_t slot2 = queue_append(want2, w.sec_count, w.sec_rays, so, d2, 0.01f, 10000.0f);
+    if (valid)
+    {
+        uint4* o = w.part + (size_t)gid * 3;
+        o[0] = make_uint4(__float_as_uint(P1.x), __float_as_uint(P1.y), __float_as_uint(P1.z), __float_as_uint(P2.x));
+        o[1] = make_uint4(__float_as_uint(P2.y), __float_as_uint(P2.z), __float_as_uint(I.x), __float_as_uint(I.y));
+        o[2] = make_uint4(__float_as_uint(I.z), slot1, slot2, flags);
+    }
+    rays += (want1 ? 1u : 0u) + (want2 ? 1u : 0u);
+    for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
+    if (lane == 0) a.ray_slots[blockIdx.x] = rays;
+}
+
+// lighting.glsl:117-196 with the two visibilities known (shading.h DirectSplit) + the irradiance term of gi_ray_trace.rchit:119-126
+__global__ __launch_bounds__(256) void k_ddgi_combine(DDGIWaveArgs w)
+{
+    const DDGITraceArgs& a = w.t;
+    const int R = a.d.rays_per_probe;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int probe = a.probe_begin + (int)(gid / R), ray = (int)(gid % R);
+    if (probe >= a.n_probes) return;
+    const uint4* p = w.part + (size_t)gid * 3;
+    const uint4  p0 = p[0], p1 = p[1], p2 = p[2];
+    const f3 P1 = mk3(__uint_as_float(p0.x), __uint_as_float(p0.y), __uint_as_float(p0.z));
+    const f3 P2 = mk3(__uint_as_float(p0.w), __uint_as_float(p1.x), __uint_as_float(p1.y));
+    const f3 I  = mk3(__uint_as_float(p1.z), __uint_as_float(p1.w), __uint_as_float(p2.x));
+    const bool o1 = p2.y != DDGI_NO_SLOT && w.sec_occluded[p2.y] != 0;
+    const bool o2 = p2.z != DDGI_NO_SLOT && w.sec_occluded[p2.z] != 0;
+    f3 L = o1 ? mk3(0.0f, 0.0f, 0.0f) : P1;
+    if ((p2.w & 1u) && !o2) L = add3(L, P2);
+    if (p2.w & 2u) L = add3(L, I);
+    a.radiance[(size_t)probe * R + ray] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, 0.0f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,6 +405,8 @@ struct hr_ddgi
     DDGIU   d;
     int     n_probes = 0;
     DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters, ray_slots;
+    DevBuf  wf_rays, wf_hits, wf_sec_rays, wf_occluded, wf_part;   // wavefront ray_trace (trace_queue.h); counters + 32: queue words
+    bool    wavefront = false;  // developer A/B (HR_DDGI_WAVEFRONT=1): measured slower than the single kernel, DESIGN.md §4
     bool    first_frame = true, ping_pong = false;
     int     z0 = 0, z1 = 0;     // probe z-slabs this instance traces and updates
     int     sy0 = 0, sy1 = 0;   // image rows this instance samples
@@ -290,6 +450,11 @@ hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, h
     A(sample, (size_t)p->w * p->h * 8)
     A(counters, 64)
     A(ray_slots, ((nr + 255) / 256) * 4 * 4)
+    if (const char* e = getenv("HR_DDGI_WAVEFRONT")) p->wavefront = atoi(e) != 0;   // developer A/B switch, read once
+    if (p->wavefront)
+    {
+        A(wf_rays, nr * sizeof(RayRec)) A(wf_hits, nr * 16) A(wf_sec_rays, 2 * nr * sizeof(RayRec)) A(wf_occluded, 2 * nr) A(wf_part, nr * 48)
+    }
 #undef A
     for (int i = 0; i < 2; i++) { HR_HIP(hipMemset(p->irr[i].p, 0, ib)); HR_HIP(hipMemset(p->dep[i].p, 0, db)); }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -359,8 +524,31 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     a.probe_begin = p->z0 * slab; a.n_probes = p->z1 * slab;
     const long long n = (long long)(a.n_probes - a.probe_begin) * p->d.rays_per_probe;
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
-    const int tb = 64 * DDGI_TRACE_WAVES;
-    hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
+    if (p->wavefront)
+    {
+        // queue words (counters + 32): 0 primary fetch counter, 1 secondary queue length, 2 secondary fetch counter
+        uint32_t* qw = (uint32_t*)((char*)p->counters.p + 32);
+        HR_HIP(hipMemsetAsync(qw, 0, 16, st));
+        DDGIWaveArgs w;
+        w.t = a;
+        w.rays = (RayRec*)p->wf_rays.p; w.hits = (const float4*)p->wf_hits.p; w.sec_rays = (RayRec*)p->wf_sec_rays.p;
+        w.sec_count = qw + 1; w.sec_occluded = (const uint8_t*)p->wf_occluded.p; w.part = (uint4*)p->wf_part.p;
+        const int persistent = trace_queue_grid(p->ctx->props.multiProcessorCount);
+        hipLaunchKernelGGL(k_ddgi_gen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w);
+        TraceQueueArgs q;
+        q.nodes = a.nodes; q.tris = a.tris;
+        q.rays = w.rays; q.n_rays_dev = nullptr; q.n_rays = (uint32_t)n; q.fetch_counter = qw + 0; q.hits = (float4*)p->wf_hits.p; q.occluded = nullptr;
+        hipLaunchKernelGGL(k_trace_queue<false>, dim3(persistent), dim3(64), 0, st, q);
+        hipLaunchKernelGGL(k_ddgi_shade, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, w);
+        q.rays = w.sec_rays; q.n_rays_dev = qw + 1; q.n_rays = 0; q.fetch_counter = qw + 2; q.hits = nullptr; q.occluded = (uint8_t*)p->wf_occluded.p;
+        hipLaunchKernelGGL(k_trace_queue<true>, dim3(persistent), dim3(64), 0, st, q);
+        hipLaunchKernelGGL(k_ddgi_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w);
+    }
+    else
+    {
+        const int tb = 64 * DDGI_TRACE_WAVES;
+        hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
+    }
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

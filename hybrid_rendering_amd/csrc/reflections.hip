@@ -84,34 +84,52 @@ struct ReflTraceArgs
     float          gi_intensity, rough_ddgi_intensity, ibl_intensity;
 };
 
+#ifdef HR_TRACE_DIVERGENCE
+static __device__ unsigned long long g_div_refl[16];   // 0-7 reflection rays, 8-15 secondary rays
+extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_div_refl), sizeof(g_div_refl)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_div_refl), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 #ifndef REFL_TRACE_WAVES
 #define REFL_TRACE_WAVES 1
+#endif
+#ifndef REFL_COOP
+#define REFL_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop); 0 = the per-lane loops
 #endif
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES) void k_refl_trace(ReflTraceArgs a)
 {
     __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
+#if REFL_COOP
+    __shared__ CoopWave s_coop[REFL_TRACE_WAVES];
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * REFL_TRACE_WAVES + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;
+    if (tile >= a.tiles_x * a.tiles_y) return;   // wave-uniform
     const int x = (tile % a.tiles_x) * 8 + (lane & 7), y = (tile / a.tiles_x + a.tile_y0) * 8 + (lane >> 3);
     uint32_t  rays = 0;
+    HR_DIV(DivCounters dvp = {}, dvs = {};)
+    // per pixel: the reflection ray (or none); the wave stays converged around the traversal
+    const size_t o = (size_t)y * a.w + x;
+    bool  geom = false, trace = false;
+    f3    color = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 1.0f), ray_origin = mk3(0.0f, 0.0f, 0.0f);
+    float ray_length = -1.0f;
     if (x < a.w && y >= a.y0 && y < a.y1)
     {
-        const size_t o  = (size_t)y * a.w + x;
         const float  dp = a.depth[o];
         if (dp == 1.0f) a.out[o] = make_uint2(0u, pack_h2(0.0f, -1.0f));
         else
         {
+            geom = true;
             const uint2 g2 = a.gb2[o], g3 = a.gb3[o];
             const float roughness = h2f_lo(g3.x);
             const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
             const f3 P  = world_pos_from_depth(tu, tv, dp, a.vpi);
             const f3 N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
             const f3 Wo = normalize3(sub3(mk3(a.cam[0], a.cam[1], a.cam[2]), P));
-            const f3 ray_origin = add3(P, scale3(N, a.bias));
-            f3    color = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 0.0f);
-            float ray_length = -1.0f;
-            bool  trace = false;
+            ray_origin  = add3(P, scale3(N, a.bias));
             if (roughness < 0.05f) { dir = reflect3(neg3(Wo), N); trace = true; }
             else if (roughness > 0.75f && a.approximate_with_ddgi == 1)
             {
@@ -126,41 +144,49 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES) void k_refl_trace(ReflTraceA
                 dir   = reflect3(neg3(Wo), Wh);
                 trace = true;
             }
-            if (trace)
-            {
-                rays++;
-                const HitRec hit = trace_closest(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane);
-                if (hit.prim < 0) { color = a.env.sky.fetch(dir); ray_length = -1.0f; }
-                else
-                {
-                    const SurfaceHit s = surface_at(a.sh, hit);
-                    const f3 hWo = neg3(dir);
-                    const f3 F0  = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
-                    const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
-                    TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
-                    CubeMap  none { nullptr, 0 };
-                    f3 Lo = direct_lighting(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
-                    if (a.sample_gi == 1)
-                    {
-                        const f3    R   = reflect3(neg3(hWo), s.N);
-                        const float ndv = max2(dot3(s.N, hWo), 0.0f);
-                        const f3    F   = fresnel_schlick_roughness(ndv, F0, s.roughness);
-                        const f3    kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);
-                        const f3    pre = a.env.prefiltered_fetch(R, s.roughness * 4.0f);
-                        float bx, by;
-                        a.env.lut_fetch(ndv, s.roughness, bx, by);
-                        const f3 specular = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), a.ibl_intensity);
-                        const f3 diffuse  = mul3(scale3(c_diffuse, a.gi_intensity), sample_irradiance(a.d, s.P, s.N, hWo, a.irr, a.dep));
-                        Lo = add3(Lo, add3(mul3(kD, diffuse), specular));
-                    }
-                    color      = Lo;
-                    ray_length = 0.001f + hit.t;
-                }
-            }
-            a.out[o] = make_uint2(pack_h2(min2(color.x, 0.7f), min2(color.y, 0.7f)), pack_h2(min2(color.z, 0.7f), ray_length));
         }
     }
-    for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
+    if (trace) rays++;
+#if REFL_COOP
+    const HitRec hit = trace_coop<false>(trace, a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+#else
+    HitRec hit;
+    hit.prim = -1;
+    if (trace) hit = trace_closest(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp));
+#endif
+    if (trace)
+    {
+        if (hit.prim < 0) { color = a.env.sky.fetch(dir); ray_length = -1.0f; }
+        else
+        {
+            const SurfaceHit s = surface_at(a.sh, hit);
+            const f3 hWo = neg3(dir);
+            const f3 F0  = mix3(mk3(0.04f, 0.04f, 0.04f), s.albedo, s.metallic);
+            const f3 c_diffuse = mix3(mul3(s.albedo, sub3(one3(), F0)), mk3(0.0f, 0.0f, 0.0f), s.metallic);
+            TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
+            HR_DIV(tc.dv = &dvs;)
+            CubeMap  none { nullptr, 0 };
+            f3 Lo = direct_lighting(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
+            if (a.sample_gi == 1)
+            {
+                const f3    R   = reflect3(neg3(hWo), s.N);
+                const float ndv = max2(dot3(s.N, hWo), 0.0f);
+                const f3    F   = fresnel_schlick_roughness(ndv, F0, s.roughness);
+                const f3    kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);
+                const f3    pre = a.env.prefiltered_fetch(R, s.roughness * 4.0f);
+                float bx, by;
+                a.env.lut_fetch(ndv, s.roughness, bx, by);
+                const f3 specular = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), a.ibl_intensity);
+                const f3 diffuse  = mul3(scale3(c_diffuse, a.gi_intensity), sample_irradiance(a.d, s.P, s.N, hWo, a.irr, a.dep));
+                Lo = add3(Lo, add3(mul3(kD, diffuse), specular));
+            }
+            color      = Lo;
+            ray_length = 0.001f + hit.t;
+        }
+    }
+    if (geom) a.out[o] = make_uint2(pack_h2(min2(color.x, 0.7f), min2(color.y, 0.7f)), pack_h2(min2(color.z, 0.7f), ray_length));
+    HR_DIV(div_flush(dvp, g_div_refl); div_flush(dvs, g_div_refl + 8);)
+    for (int o2 = 32; o2 > 0; o2 >>= 1) rays += __shfl_down(rays, o2);
     if (lane == 0) a.ray_slots[tile] = rays;
 }
 

@@ -453,6 +453,7 @@ struct TraceCtx
     const TriGPU* tris;
     uint32_t*     wave_stack;
     int           lane;
+    DivCounters*  dv = nullptr;   // developer instrumentation (traverse.h)
 };
 
 // direct_lighting (lighting.glsl:117-196)
@@ -470,7 +471,7 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         if (attenuation > 0.0f)
         {
             rays++;
-            attenuation = attenuation * (trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
+            attenuation = attenuation * (trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
         }
 #endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
@@ -483,12 +484,52 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         const f3 Wh = normalize3(add3(Wo, Wi));
 #ifndef HR_ABL_NO_SECONDARY
         rays++;
-        Li = scale3(Li, trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt) ? 0.0f : 1.0f);
+        Li = scale3(Li, trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
 #endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
         Lo = add3(Lo, mul3(mul3(T, brdf), Li));
     }
     return Lo;
+}
+
+// direct_lighting split for the wavefront path (trace_queue.h): everything but the two visibility rays.  With occlusion o1 / o2 of
+// the light ray and the sky ray known, direct_lighting's result is, operation for operation,
+//     Lo = (ray1 && o1) ? 0 : P1;   if (sky && !o2) Lo = Lo + P2;
+// (a factor 0 turns the term into a signed zero, and x + (+-0) == x for every x the first line can produce).
+struct DirectSplit
+{
+    f3    origin;        // of both rays
+    f3    Wi1, Wi2;
+    float t_max1;
+    bool  ray1;          // the light ray is traced (attenuation > 0)
+    f3    P1, P2;
+};
+HR_DEV DirectSplit direct_lighting_split(const hr_light& light, f3 Wo, f3 N, f3 P, f3 F0, f3 diffuse_color, float roughness, f3 T, bool sample_sky,
+                                         float r2x, float r2y, const CubeMap& sky)
+{
+    DirectSplit s;
+    s.origin = add3(P, scale3(N, 0.1f));
+    {
+        f3    Li, Wi, Wh;
+        float t_max, attenuation;
+        fetch_light_hard(light, Wo, P, N, Li, Wi, Wh, t_max, attenuation);
+        s.ray1 = attenuation > 0.0f;
+        s.Wi1 = Wi; s.t_max1 = t_max;
+        if (s.ray1) attenuation = attenuation * 1.0f;
+        const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
+        s.P1 = add3(mk3(0.0f, 0.0f, 0.0f), mul3(scale3(mul3(T, brdf), attenuation), Li));
+    }
+    s.Wi2 = mk3(0.0f, 0.0f, 1.0f); s.P2 = mk3(0.0f, 0.0f, 0.0f);
+    if (sample_sky)
+    {
+        const f3 Wi = sample_cosine_lobe_n(N, r2x, r2y);
+        const f3 Li = scale3(sky.fetch(Wi), 1.0f);
+        const f3 Wh = normalize3(add3(Wo, Wi));
+        const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
+        s.Wi2 = Wi;
+        s.P2  = mul3(mul3(T, brdf), Li);
+    }
+    return s;
 }
 
 } // namespace hr

@@ -21,6 +21,37 @@ namespace hr {
 #define HR_SPILL_ENTRIES 48
 static_assert(HR_STACK_ENTRIES + HR_SPILL_ENTRIES >= hr::kMaxTraversalDepth, "traversal stack shallower than the deepest BVH hr_scene_create accepts");
 
+// Developer instrumentation (tools/divergence.py builds with -DHR_TRACE_DIVERGENCE): what a wave executes against what its lanes
+// need.  lane_*: loop iterations THIS lane ran; wave_*: counted by one lane of every iteration the wave executed.
+struct DivCounters { uint32_t lane_nodes, lane_pairs, wave_nodes, wave_pairs; };
+#ifdef HR_TRACE_DIVERGENCE
+#define HR_DIV(...) __VA_ARGS__
+HR_DEV void div_count(uint32_t& lane_ctr, uint32_t& wave_ctr)
+{
+    lane_ctr++;
+    const unsigned long long b = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) wave_ctr++;
+}
+// slots: 0 sum lane_nodes, 1 sum lane_pairs, 2 wave_nodes, 3 wave_pairs, 4 max-lane nodes, 5 max-lane pairs, 6 waves, 7 lanes that traced
+HR_DEV void div_flush(const DivCounters& c, unsigned long long* g)
+{
+    uint32_t ln = c.lane_nodes, lp = c.lane_pairs, wn = c.wave_nodes, wp = c.wave_pairs, mn = c.lane_nodes, mp = c.lane_pairs, act = c.lane_nodes ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ln += __shfl_xor(ln, o); lp += __shfl_xor(lp, o); wn += __shfl_xor(wn, o); wp += __shfl_xor(wp, o); act += __shfl_xor(act, o);
+        const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mp, o);
+        mn = a > mn ? a : mn; mp = b > mp ? b : mp;
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicAdd(g + 0, (unsigned long long)ln); atomicAdd(g + 1, (unsigned long long)lp); atomicAdd(g + 2, (unsigned long long)wn); atomicAdd(g + 3, (unsigned long long)wp);
+        atomicAdd(g + 4, (unsigned long long)mn); atomicAdd(g + 5, (unsigned long long)mp); atomicAdd(g + 6, 1ull); atomicAdd(g + 7, (unsigned long long)act);
+    }
+}
+#else
+#define HR_DIV(...)
+#endif
+
 struct RayPre
 {
     f3    o;
@@ -293,7 +324,7 @@ HR_DEV uint32_t entry_node_for_box(const Node8* __restrict__ nodes, f3 lo, f3 hi
 
 template <bool STATS>
 HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u)
+                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u, DivCounters* dv = nullptr)
 {
     if (entry == HR_NO_ENTRY) return false;
     RayPre    r = ray_prepare(o, d);
@@ -306,9 +337,11 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     {
         const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
         if (STATS) n_nodes++;
+        HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
         {
+            HR_DIV(if (dv) div_count(dv->lane_pairs, dv->wave_pairs);)
             // two triangles per iteration: both fetches in flight together, both tests back to back (AO trace -2.5%)
             const uint32_t i0 = (uint32_t)__builtin_ctz(trimask);
             trimask &= trimask - 1u;
@@ -378,7 +411,7 @@ struct HitRec
 // Closest hit: smallest t, ties broken by the smallest original triangle index (so the answer
 // does not depend on traversal order).
 HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                            uint32_t* wave_stack, int lane)
+                            uint32_t* wave_stack, int lane, DivCounters* dv = nullptr)
 {
     RayPre    r = ray_prepare(o, d);
     uint32_t  spill_array[HR_SPILL_ENTRIES];
@@ -391,9 +424,11 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
     {
         const float    tfar = best.prim < 0 ? t_max : best.t * 1.0000005f;
         const NodeHits h    = test_node<true>(load_node(nodes, ni), r, t_min, tfar);
+        HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
         {
+            HR_DIV(if (dv) div_count(dv->lane_pairs, dv->wave_pairs);)
             const uint32_t i = (uint32_t)__builtin_ctz(trimask);
             trimask &= trimask - 1u;
             const TriRaw tri = load_tri_raw(tris, h.tri_base + i);
@@ -405,6 +440,148 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
             }
         }
     }
+    return best;
+}
+
+// ---- wave-cooperative traversal: deferred, redistributed triangle tests -----------------------------------------------------
+// tools/divergence.py on the hit-shading passes: the node loop of a wave runs at 25-50 % lane utilisation, the triangle loop
+// nested in it at 5-7 % (a handful of lanes have leaf hits in any one step, the other lanes wait) — and it was half of the
+// instructions a wave issued.  Here a lane does not test its own triangles: it appends (lane, triangle) jobs to a ring in LDS and
+// keeps walking; whenever the ring holds a job for every lane of the wave, ALL lanes — including those whose ray has finished or
+// that never had one — each take one job, fetch the owner's ray through ds_bpermute, run the same watertight test (bit-identical
+// decisions: same code, same operands), and hand the result back through LDS (closest hit: 64-bit ds_min of (t, prim), the
+// reference's tie rule).  The far limit a lane culls nodes with lags by at most one flush; that only costs node visits, never a hit.
+// The caller keeps the wave converged around the call (inactive lanes pass active = false and serve as job lanes).
+#define HR_COOP_RING 256   // jobs; > 63 queued + HR_COOP_PUSH per lane per step
+#ifndef HR_COOP_PUSH
+#define HR_COOP_PUSH 2     // jobs a lane may append per step (a lane with more pending leaf triangles skips node steps until drained)
+#endif
+struct CoopWave
+{
+    uint32_t           jobs[HR_COOP_RING];   // owner lane << 26 | triangle index (hr_scene_create bounds the triangle count)
+    unsigned long long key[64];              // closest: ordered(t) << 32 | prim, ~0 = miss;  any-hit: 0 = occluded
+    float2             uv[64];
+};
+constexpr uint32_t kCoopMaxTriangles = 1u << 26;
+
+HR_DEV uint32_t float_ordered(float f) { const uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+HR_DEV float    ordered_float(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+HR_DEV void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+HR_DEV uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+template <bool ANY>
+HR_DEV void coop_flush(CoopWave& cw, const TriGPU* __restrict__ tris, const RayPre& r, float t_min, float t_max, uint32_t rank, uint32_t head, uint32_t n, int lane)
+{
+    const bool     mine  = rank < n;
+    const uint32_t job   = mine ? cw.jobs[(head + rank) & (HR_COOP_RING - 1)] : ((uint32_t)lane << 26);
+    const int      owner = (int)(job >> 26);
+    RayPre q;
+    q.o.x = __shfl(r.o.x, owner); q.o.y = __shfl(r.o.y, owner); q.o.z = __shfl(r.o.z, owner);
+    q.Sx  = __shfl(r.Sx, owner);  q.Sy  = __shfl(r.Sy, owner);  q.Sz  = __shfl(r.Sz, owner);
+    const int kp = __shfl(r.kx | (r.ky << 2) | (r.kz << 4), owner);
+    q.kx = kp & 3; q.ky = (kp >> 2) & 3; q.kz = kp >> 4;
+    const float q_min = __shfl(t_min, owner), q_max = __shfl(t_max, owner);
+    bool     hit = false;
+    float    t = 0.0f, u = 0.0f, v = 0.0f;
+    uint32_t prim = 0u;
+    if (mine)
+    {
+        const TriRaw tr = load_tri_raw(tris, job & (kCoopMaxTriangles - 1u));
+        hit  = ray_tri_raw<!ANY>(q, tr, q_min, q_max, t, u, v);
+        prim = tr.a.w;
+    }
+    if (ANY)
+    {
+        if (hit) cw.key[owner] = 0ull;
+    }
+    else
+    {
+        const unsigned long long k = ((unsigned long long)float_ordered(t) << 32) | prim;
+        if (hit) atomicMin(&cw.key[owner], k);
+        wave_fence();
+        if (hit && cw.key[owner] == k) cw.uv[owner] = make_float2(u, v);
+    }
+    wave_fence();
+}
+
+// Closest hit (ANY = false: smallest t, ties to the smallest original triangle index — trace_closest's answer bit for bit) or
+// any-hit (ANY = true: HitRec.prim = 0 if occluded, -1 if not; t, u, v unset).
+template <bool ANY>
+HR_DEV HitRec trace_coop(bool active, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
+                         uint32_t* wave_stack, CoopWave& cw, int lane, uint32_t entry = 0u, DivCounters* dv = nullptr)
+{
+    const unsigned long long exec  = __ballot(1);
+    const uint32_t           nproc = (uint32_t)__popcll(exec), rank = lanes_below(exec);
+    RayPre    r = ray_prepare(o, d);
+    uint32_t  spill_array[HR_SPILL_ENTRIES];
+    LaneStack st;
+    st.init(wave_stack, lane, spill_array);
+    bool     alive = active && entry != HR_NO_ENTRY;
+    uint32_t cur   = alive ? ((entry << 9) | 1u) : 0u, pend = 0u, pend_base = 0u;
+    uint32_t head = 0u, count = 0u;   // wave-uniform
+    float    tfar = t_max;
+    cw.key[lane] = ~0ull;
+    wave_fence();
+    for (;;)
+    {
+        if (alive && pend == 0u)
+        {
+            uint32_t ni;
+            if (walk_next<!ANY>(cur, st, ni))
+            {
+                const NodeHits h = test_node<!ANY>(load_node(nodes, ni), r, t_min, tfar);
+                HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
+                pend      = walk_expand(h, cur, st);
+                pend_base = h.tri_base;
+            }
+            else
+                alive = false;
+        }
+        uint32_t left = (uint32_t)__popc(pend);
+        uint32_t pos  = head + count;
+#pragma unroll
+        for (int k = 0; k < HR_COOP_PUSH; k++)
+        {
+            const bool               has = left > (uint32_t)k;
+            const unsigned long long b   = __ballot(has);
+            if (has)
+            {
+                const uint32_t i = (uint32_t)__builtin_ctz(pend);
+                pend &= pend - 1u;
+                cw.jobs[(pos + lanes_below(b)) & (HR_COOP_RING - 1)] = ((uint32_t)lane << 26) | (pend_base + i);
+            }
+            pos += (uint32_t)__popcll(b);
+        }
+        count = pos - head;
+        const bool walking = __ballot(alive) != 0ull;
+        bool       flushed = false;
+        while (count >= nproc || (!walking && count > 0u))
+        {
+            const uint32_t n = count < nproc ? count : nproc;
+            wave_fence();
+            HR_DIV(if (dv) div_count(dv->lane_pairs, dv->wave_pairs);)
+            coop_flush<ANY>(cw, tris, r, t_min, t_max, rank, head, n, lane);
+            head += n; count -= n;
+            flushed = true;
+        }
+        if (flushed)
+        {
+            const unsigned long long k = cw.key[lane];
+            if (ANY) { if (k == 0ull) { alive = false; pend = 0u; } }
+            else if (k != ~0ull) tfar = ordered_float((uint32_t)(k >> 32)) * 1.0000005f;
+        }
+        if (!walking && count == 0u) break;
+    }
+    HitRec best;
+    best.t = t_max; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
+    const unsigned long long k = cw.key[lane];
+    if (ANY) { if (k == 0ull) best.prim = 0; }
+    else if (k != ~0ull)
+    {
+        const float2 uv = cw.uv[lane];
+        best.t = ordered_float((uint32_t)(k >> 32)); best.u = uv.x; best.v = uv.y; best.prim = (int32_t)(uint32_t)k;
+    }
+    wave_fence();   // the next call re-initialises key[]
     return best;
 }
 
