@@ -502,6 +502,104 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
 }
 
 
+// The same filter with its taps staged through LDS (radius 1, tap distance STEP = 1 / 2 / 4 / 8: the reference's four iterations).
+// The 32x8 tile and its STEP-wide apron are fetched ONCE per workgroup — (32+2S)x(8+2S) texels instead of 27 loads per pixel, which
+// had the kernel bound by the L1 data path, not by HBM or the VALU (SQ counters: 38 % VALU busy, counter traffic 27-40 MB) — and
+// each texel's octahedral normal is decoded once instead of once per tap that reads it.  A texel that is not resident (outside the
+// image or the band's rows) is staged as (value 0, normal 0): its edge weight is exactly 0 (pow(dot(n, 0), phi) = 0).
+#ifndef FT_ATROUS_LDS
+#define FT_ATROUS_LDS 1
+#endif
+#ifndef FT_ATROUS_VOTE
+#define FT_ATROUS_VOTE 1   // 0: stage unconditionally — 14.4 -> 17.8 µs (step 1): the shadow-tile workgroups are a large share of the launch
+#endif
+template <int STEP, bool N32>
+__global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
+{
+    constexpr int TW = 32 + 2 * STEP, TH = 8 + 2 * STEP;
+    __shared__ uint32_t s_in[TH * TW];
+    __shared__ float4   s_nz[TH * TW];   // unit normal, linear z
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * 8;
+    const int x = bx0 + lx, y = by0 + ly;
+    const bool inside = x < a.w && y < a.y1;
+    const uint32_t cls = inside ? a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] : 0u;
+#if FT_ATROUS_VOTE
+    if (__syncthreads_or((int)cls))   // a workgroup of shadow tiles only stages nothing
+#endif
+    {
+        const int ry0 = a.y0 > 0 ? a.y0 : 0, ry1 = a.y1 < a.h ? a.y1 : a.h;
+        for (int i = threadIdx.x; i < TH * TW; i += 256)
+        {
+            const int  cy = i / TW, cx = i - cy * TW;
+            const int  gx = bx0 - STEP + cx, gy = by0 - STEP + cy;
+            const bool res = gx >= 0 && gx < a.w && gy >= ry0 && gy < ry1;
+            const uint32_t so = res ? (uint32_t)(gy * a.w + gx) : (uint32_t)(ry0 * a.w);
+            const uint32_t v  = fm::ld<uint32_t>(a.in.p, so * 4u);
+            const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
+            const f3       n  = fm::oct_unit(nd.x);
+            s_in[i] = res ? v : 0u;
+            s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::lo(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+    }
+    if (!inside) return;
+    const uint32_t o = (uint32_t)(y * a.w + x);
+    uint32_t* outp  = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + o * 4u);
+    uint32_t* out2p = a.out2 ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out2) + o * 4u) : nullptr;
+    if (!cls)
+    {
+        *outp = 0u; // shadows_denoise_copy_shadow_tiles.comp:35
+        if (out2p) *out2p = 0u;
+        return;
+    }
+    const int      ci  = (ly + STEP) * TW + (lx + STEP);
+    const uint32_t c   = s_in[ci];
+    const float4   cnz = s_nz[ci];
+    // compute_variance_center (:65-88): 3x3 gaussian of the variance channel, unit taps
+    float var = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+    {
+        const int   xx = k % 3 - 1, yy = k / 3 - 1;
+        const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+        var += fm::hi(s_in[ci + yy * TW + xx]) * kw;
+    }
+    uint32_t result = c;
+    if (!(cnz.w < 0.0f))
+    {
+        const f3    cn = mk3(cnz.x, cnz.y, cnz.z);
+        const float cv = fm::lo(c);
+        EdgeK ek;
+        ek.kz        = 1.44269504088896341f * fm::rcp(a.sigma_depth);
+        ek.phi_n     = a.phi_normal;
+        ek.n32       = N32;
+        ek.inv_phi_l = fm::rcp(a.phi_visibility * fm::sqrt1(fm::fmax_(0.0f, 1e-10f + var)));
+        float sum_w = 1.0f, sum_v = cv, sum_var = fm::hi(c);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            const int      k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+            const float    kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
+            const int      ti = ci + yy * STEP * TW + xx * STEP;
+            const uint32_t tv = s_in[ti];
+            const float4   tn = s_nz[ti];
+            const float    sv = fm::lo(tv);
+            const float    wv = edge_weight_fast(ek, cnz.w, tn.w, cn, mk3(tn.x, tn.y, tn.z), cv, sv) * kk;
+            sum_w += wv;
+            sum_v += wv * sv;
+            sum_var += (wv * wv) * fm::hi(tv);
+        }
+        const float iw = fm::rcp(sum_w);
+        float ov = sum_v * iw;
+        const float ovar = sum_var * (iw * iw);
+        if (a.power != 0.0f) ov = fm::powf_(fm::fmax_(ov, 0.0f), a.power);
+        result = fm::pack2(ov, ovar);
+    }
+    *outp = result;
+    if (out2p) *out2p = result;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // ao_denoise_reprojection.comp:191-260, tolerance mode; spp = 1..4 sample planes (BASELINE configs[2]: 4)
 template <bool MULTI>
@@ -1098,13 +1196,17 @@ void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
 {
     const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
     const bool n32 = a.phi_normal == 32.0f;
-#define HR_LAUNCH_ATROUS(S) \
-    do { if (n32) hipLaunchKernelGGL((kf_shadows_atrous<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((kf_shadows_atrous<S, false>), grid, dim3(256), 0, st, a); } while (0)
-    if (a.radius == 1 && a.step == 1) HR_LAUNCH_ATROUS(1);
-    else if (a.radius == 1 && a.step == 2) HR_LAUNCH_ATROUS(2);
-    else if (a.radius == 1 && a.step == 4) HR_LAUNCH_ATROUS(4);
-    else if (a.radius == 1 && a.step == 8) HR_LAUNCH_ATROUS(8);
-    else HR_LAUNCH_ATROUS(0);
+#define HR_LAUNCH_ATROUS(K, S) \
+    do { if (n32) hipLaunchKernelGGL((K<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((K<S, false>), grid, dim3(256), 0, st, a); } while (0)
+    // tap distances 1 and 2 through LDS (apron 1-2 texels: 14.4 / 14.6 µs against 15.8 / 15.9 for per-pixel gathers at 1080p, event
+    // times); at 4 and 8 the apron is as large as the tile and the gathers win (15.7 / 18.7 against 16.1 / 15.9)
+    if (a.radius == 1 && a.step == 1 && FT_ATROUS_LDS) HR_LAUNCH_ATROUS(kf_shadows_atrous_lds, 1);
+    else if (a.radius == 1 && a.step == 2 && FT_ATROUS_LDS) HR_LAUNCH_ATROUS(kf_shadows_atrous_lds, 2);
+    else if (a.radius == 1 && a.step == 1) HR_LAUNCH_ATROUS(kf_shadows_atrous, 1);
+    else if (a.radius == 1 && a.step == 2) HR_LAUNCH_ATROUS(kf_shadows_atrous, 2);
+    else if (a.radius == 1 && a.step == 4) HR_LAUNCH_ATROUS(kf_shadows_atrous, 4);
+    else if (a.radius == 1 && a.step == 8) HR_LAUNCH_ATROUS(kf_shadows_atrous, 8);
+    else HR_LAUNCH_ATROUS(kf_shadows_atrous, 0);
 #undef HR_LAUNCH_ATROUS
 }
 
