@@ -222,14 +222,28 @@ def main():
             fi = cycle[k % len(cycle)]
             fi.num_frames = k
             tiled.render(scene, fi)
-        for k in range(warmup):
+        # frames in flight: the host enqueues a step in ~40 us, the GPU needs 200; left alone it runs a thousand launches ahead, and
+        # past some depth the HIP queue makes the host wait in coarse steps (seen on the hybrid frame: sporadic +1 ms per frame in a
+        # 30-frame run).  A renderer keeps a few frames in flight; so does this loop: before step k the host waits for step k - 32,
+        # which the GPU finished long ago — the GPU never idles.
+        fences = [torch.cuda.Event() for _ in range(4)]
+
+        def paced(k):
+            if k % 8:                       # a fence every 8th step (an event record costs the stream ~2 us): <= 32 steps in flight
+                return step(k)
+            f = fences[(k // 8) % len(fences)]
+            if k >= 8 * len(fences):
+                f.synchronize()
             step(k)
+            f.record()
+        for k in range(warmup):
+            paced(k)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(warmup, warmup + steps):
-            step(k)
+            paced(k)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -340,7 +354,7 @@ def main():
                 out["passes"]["hard_tier"] = hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact)
             else:
                 hf = HybridFrame(ctx, scene, sd, 3840, 2160, rank, world, exact=exact)
-                ms = hf.time(20, 4, barrier=barrier)
+                ms = hf.time(12, 4, barrier=barrier, repeats=2)
                 rays = sum(hf.ray_counts().values())
                 t = torch.tensor([ms, float(rays)], dtype=torch.float64, device="cuda")
                 tm = t.clone()
@@ -367,8 +381,11 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     res = {}
     hf = HybridFrame(ctx, scene, sd, 1920, 1080, exact=exact)
     hf.time(6, 2)                                                   # warm every pass (history, atlases)
-    wall = {n: hf.time(30, 4, only=n) for n in ("shadows", "ao", "ddgi", "reflections")}
-    hybrid = hf.time(30, 4)
+    wall = {n: hf.time(12, 4, only=n, repeats=3) for n in ("shadows", "ao", "ddgi", "reflections")}
+    hybrid = hf.time(12, 4, repeats=3)
+    hf.concurrent_streams(True)
+    hybrid3 = hf.time(12, 6, repeats=3)
+    hf.concurrent_streams(False)
     rays = hf.ray_counts()
     st = hf.stage_times(10)
     label = {"ao": "AO 4 spp + temporal + 2 blurs, 1920x1080 (configs[2])", "reflections": "reflections 1 spp at half resolution + SVGF + upsample, 1920x1080 frame (configs[3])",
@@ -386,13 +403,17 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
         res[n] = {"workload": label[n], "ms_per_frame": round(wall[n], 4), "frames_per_s": round(1e3 / wall[n], 1), "rays_per_frame": rays[n],
                   "Mrays_per_s": round(rays[n] / wall[n] / 1e3, 1), "kernels": kern}
     res["hybrid_1080p"] = {"workload": "whole hybrid frame 1920x1080 on one GPU: shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, one stream",
-                           "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1)}
+                           "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1),
+                           "three_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
+                                             "note": "shadows | AO | DDGI -> reflections on three HIP streams, joined at the end of the frame (the chains are independent; same images)"}}
     hf.close()
     hf4 = HybridFrame(ctx, scene, sd, 3840, 2160, exact=exact)
-    ms4 = hf4.time(15, 4)
+    ms4 = hf4.time(8, 4, repeats=3)
     r4 = hf4.ray_counts()
+    hf4.concurrent_streams(True)
+    ms43 = hf4.time(8, 4, repeats=3)
     res["hybrid_4k_one_gpu"] = {"workload": "whole hybrid frame 3840x2160 on ONE GPU (BASELINE configs[4] names 8)", "ms_per_frame": round(ms4, 4), "frames_per_s": round(1e3 / ms4, 1),
-                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1)}
+                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "three_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)}}
     hf4.close()
     res["note"] = ("kernel `frac` = algorithmic bytes (SURVEY §8d) / HIP-event time / 8 TB/s; `dram_frac`, `bound`, `valu_busy_pct`, `lane_utilisation` from the rocprofv3 "
                    "counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + "; trace kernels carry no `frac` here (their BVH bytes need the "

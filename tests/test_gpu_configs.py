@@ -285,3 +285,25 @@ def test_fuzz_seed(oracle, hr, ctx, seed):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     fz.run_seed(seed, oracle, hr, ctx)
+
+
+def test_hybrid_frame_on_three_streams_gives_the_same_images(hr, ctx):
+    """frame.HybridFrame(concurrent=True): shadows | AO | DDGI -> reflections on three HIP streams, joined at the end of the frame.
+    The chains share no image, so every pass output must equal the one-stream frame's, bit for bit (both arithmetic modes' kernels
+    are deterministic)."""
+    import torch
+    from hybrid_rendering_amd import synth
+    from hybrid_rendering_amd.frame import HybridFrame
+    sd = synth.sponza_like(0.25)
+    scene = hr.Scene(ctx, sd)
+    outs = []
+    for conc in (False, True):
+        f = HybridFrame(ctx, scene, sd, 480, 272, probes=(6, 3, 5), rays_per_probe=64, concurrent=conc)
+        for k in range(4):
+            f.render(k)
+        torch.cuda.synchronize()
+        outs.append({n: p.output().clone() for n, p in f.passes().items()})
+        f.close()
+    for n in outs[0]:
+        assert torch.equal(outs[0][n].view(torch.int16), outs[1][n].view(torch.int16)), f"{n}: three-stream frame differs from the one-stream frame"
+    scene.close()
