@@ -298,7 +298,11 @@ def main():
     trace_bytes = px * 12.125 + rays_per_frame * (nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES)
     if "ray_trace" in stages:
         stages["ray_trace"]["bytes"] = int(trace_bytes)
-    prof = load_profile() if (world == 1 and (W, H) == (1920, 1080) and not args.obj and args.tier == "standard") else {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
+    prof = load_profile()
+    if not (world == 1 and (W, H) == (1920, 1080) and not args.obj and args.tier == "standard"):
+        # another frame size / scene than the profiled one: the per-launch counter traffic does not carry over; what the SQ counters say
+        # about the SAME kernels (VALU busy, lane utilisation -> `bound`) is kept as the best available classification
+        prof = dict(prof, traffic={})
     for n, s in stages.items():
         kern = KERNEL_OF.get(("shadows", re.sub(r"_\d+$", "", n)), n)
         if exact:
@@ -330,7 +334,8 @@ def main():
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
         "roofline": {"kernel": dom[0], "bound": dom[1].get("bound") or "latency", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom[1]["frac"], "traffic": dom[1].get("traffic"), "dram_frac": dom[1].get("dram_frac"),
-                     "traffic_source": (prof["dir"] + "/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)") if prof["dir"] else None,
+                     "traffic_source": (prof["dir"] + "/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)") if (prof["dir"] and dom[1].get("traffic")) else None,
+                     "bound_source": (prof["dir"] + "/sq_counters.txt (1080p bench frame)") if prof["dir"] else None,
                      "algorithmic_bytes": int(dom[1]["bytes"]),
                      "note": "achieved/frac divide the ALGORITHMIC bytes (SURVEY §8d: G-buffer + mask + visited BVH nodes x 80 B + tested triangles x 48 B) by the kernel time; "
                              "the 15 MB BVH is served by L2 / Infinity Cache, so dram_frac (counter traffic) is the HBM-side figure and `bound` is what the SQ counters show"},
