@@ -409,8 +409,8 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
                   "Mrays_per_s": round(rays[n] / wall[n] / 1e3, 1), "kernels": kern}
     res["hybrid_1080p"] = {"workload": "whole hybrid frame 1920x1080 on one GPU: shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, one stream",
                            "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1),
-                           "three_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
-                                             "note": "shadows | AO | DDGI -> reflections on three HIP streams, joined at the end of the frame (the chains are independent; same images)"}}
+                           "concurrent_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
+                                                  "note": "shadows | AO | DDGI trace + update -> reflections | DDGI sample on four HIP streams, joined at the end of the frame (independent chains; same images)"}}
     hf.close()
     hf4 = HybridFrame(ctx, scene, sd, 3840, 2160, exact=exact)
     ms4 = hf4.time(8, 4, repeats=3)
@@ -418,7 +418,7 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     hf4.concurrent_streams(True)
     ms43 = hf4.time(8, 4, repeats=3)
     res["hybrid_4k_one_gpu"] = {"workload": "whole hybrid frame 3840x2160 on ONE GPU (BASELINE configs[4] names 8)", "ms_per_frame": round(ms4, 4), "frames_per_s": round(1e3 / ms4, 1),
-                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "three_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)}}
+                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "concurrent_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)}}
     hf4.close()
     res["note"] = ("kernel `frac` = algorithmic bytes (SURVEY §8d) / HIP-event time / 8 TB/s; `dram_frac`, `bound`, `valu_busy_pct`, `lane_utilisation` from the rocprofv3 "
                    "counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + "; trace kernels carry no `frac` here (their BVH bytes need the "

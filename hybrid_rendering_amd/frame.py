@@ -64,7 +64,7 @@ class HybridFrame:
         self._orients = [synth_env.random_orientation(self.rng) for _ in range(16)]
         self.ao_spp, self.probes, self.rays_per_probe, self.refl_scale = ao_spp, tuple(probes), rays_per_probe, refl_scale
         # concurrent: shadows, AO and DDGI -> reflections are independent chains inside a frame (the reference records them into one
-        # command buffer with per-resource barriers only); on three HIP streams the latency-bound denoise kernels of one chain fill
+        # command buffer with per-resource barriers only); on separate HIP streams (+ one for the DDGI probe-grid sample, which only the composite reads) the latency-bound denoise kernels of one chain fill
         # the SIMD slots the VALU-bound trace kernels of another leave idle.  Joined on the caller's stream at the end of the frame.
         self.concurrent = False
         self.concurrent_streams(concurrent)
@@ -72,9 +72,9 @@ class HybridFrame:
     def concurrent_streams(self, on):
         import torch
         if on and not hasattr(self, "_side"):
-            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
-            self._ev_in = torch.cuda.Event()
-            self._ev_out = [torch.cuda.Event(), torch.cuda.Event()]
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            self._ev_in, self._ev_atlas = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_out = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]
         torch.cuda.synchronize()
         self.concurrent = bool(on) and self.world == 1   # the tiled (N > 1) frame keeps its exchanges on one compute stream
 
@@ -100,11 +100,20 @@ class HybridFrame:
             import torch
             main = torch.cuda.current_stream()
             self._ev_in.record(main)
-            for s_, work in zip(self._side, ((lambda st: self.shadows.render(self.scene, fi, stream=st)), (lambda st: self.ao.render(self.scene, fi, stream=st)))):
+            for s_, work in zip(self._side[:2], ((lambda st: self.shadows.render(self.scene, fi, stream=st)), (lambda st: self.ao.render(self.scene, fi, stream=st)))):
                 s_.wait_event(self._ev_in)
                 work(s_)
-            self.gi.render(self.scene, fi, self.env, self._orients[k & 15])
-            self.refl.render(self.scene, fl, self.env, self.gi.pass_)
+            # DDGI: the reflections' hit shading reads the ATLASES (ready after the probe update); the per-pixel probe-grid sample
+            # only feeds the composite, so it leaves the critical chain for a stream of its own
+            gp = self.gi.pass_
+            gp.set_orientation(self._orients[k & 15])
+            gp.ray_trace(self.scene, fi, self.env, None)
+            gp.probe_update(None)
+            self._ev_atlas.record(main)
+            self._side[2].wait_event(self._ev_atlas)
+            gp.sample_probe_grid(fi, self._side[2])
+            gp.end_frame()
+            self.refl.render(self.scene, fl, self.env, gp)
             for s_, ev in zip(self._side, self._ev_out):
                 ev.record(s_)
                 main.wait_event(ev)

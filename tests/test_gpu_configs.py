@@ -287,8 +287,8 @@ def test_fuzz_seed(oracle, hr, ctx, seed):
     fz.run_seed(seed, oracle, hr, ctx)
 
 
-def test_hybrid_frame_on_three_streams_gives_the_same_images(hr, ctx):
-    """frame.HybridFrame(concurrent=True): shadows | AO | DDGI -> reflections on three HIP streams, joined at the end of the frame.
+def test_hybrid_frame_on_concurrent_streams_gives_the_same_images(hr, ctx):
+    """frame.HybridFrame(concurrent=True): shadows | AO | DDGI trace + update -> reflections | DDGI sample on four HIP streams, joined at the end of the frame.
     The chains share no image, so every pass output must equal the one-stream frame's, bit for bit (both arithmetic modes' kernels
     are deterministic)."""
     import torch
