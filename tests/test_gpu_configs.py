@@ -8,7 +8,8 @@
      of all four passes vs the oracle's rows of the whole frame;
  (d) the random-parameter / ragged-size seeds of tools/fuzz_gpu.py as a parametrised test, so the driver's run sees them.
 
-Everything is compared bit for bit (exact mode)."""
+Everything is compared bit for bit (exact mode); the 1080p reflections test also runs the tolerance mode (exact = 0,
+DESIGN.md §3.6) on the same frames against the same oracle images."""
 import numpy as np
 import pytest
 
@@ -116,6 +117,11 @@ def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
     w, h = W >> scale, H >> scale
     g_ddgi, o_ddgi = api_gi.DDGI(ctx, W, H, ddgi), od.DDGIPass(ddgi)
     gp, op = api_reflections.RayTracedReflections(ctx, W, H, scale), orf.ReflectionsPass(w, h)
+    # the tolerance mode (exact = 0: what bench.py times) on the same frames: reflections denoise + upsample, and the DDGI probe-grid sample
+    import test_gpu_tolerance as tol
+    gf, gf_ddgi = api_reflections.RayTracedReflections(ctx, W, H, scale), api_gi.DDGI(ctx, W, H, ddgi)
+    gf.params.exact = 0
+    gf_ddgi.params.exact = 0
     rng = np.random.RandomState(3)
     fulls = []
     for f in range(2):
@@ -147,6 +153,18 @@ def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
         assert np.array_equal(at, st["atrous"][-1]), f"frame {f}: a-trous differs in {(at != st['atrous'][-1]).sum()} halfs"
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         assert np.array_equal(out, st["output"]), f"frame {f}: output differs in {(out != st['output']).sum()} halfs"
+        gf_ddgi.render(gsc, hr.frame_inputs(full_d, None, ubos[f], f, f & 1, sob_d, sr_d), env, orient)
+        gf.set_camera_delta(cam_delta)
+        gf.render(gsc, hr.frame_inputs(helpers.to_cuda(cur), helpers.to_cuda(prev), ubos[f], f, f & 1, sob_d, sr_d, cur_full=full_d), env, gf_ddgi)
+        torch.cuda.synchronize()
+        tol.compare16(helpers.bits16(gf_ddgi.output())[..., :3], o_ddgi.stages["output"][..., :3], f"frame {f} DDGI probe-grid sample at 1080p (exact = 0)")
+        assert np.array_equal(helpers.bits16(gf.image(gf.IMG_TRACE)), st["trace"]) and gf.ray_count() == st["rays"], f"frame {f}: the trace has one mode"
+        ex = tol.tiles_close(gf.image(gf.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f} (exact = 0)", shape=(h, w))
+        tol.compare16(helpers.bits16(gf.image(gf.IMG_COLOR1 if f & 1 else gf.IMG_COLOR0))[..., :3], st["temporal"][..., :3], f"frame {f} temporal colour (exact = 0)", abs_floor=1e-3)   # intermediate image, as for the shadows
+        tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_ATROUS))[..., :3], st["atrous"][-1][..., :3], f"frame {f} a-trous colour (exact = 0)", exclude=ex)
+        exu = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W] if scale else ex
+        tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE))[..., :3], st["output"][..., :3], f"frame {f} reflections output (exact = 0)", exclude=exu)
+    gf.close(); gf_ddgi.close()
     rough = oracle.f16(lows[-1]["gb3"][..., 0])
     geo = lows[-1]["depth"] != 1.0
     assert ((rough < 0.05) & geo).any() and ((rough > 0.75) & geo).any() and ((rough > 0.1) & (rough < 0.7) & geo).any()

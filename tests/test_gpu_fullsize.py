@@ -35,7 +35,8 @@ def _fi(hr, full, k):
 
 
 def test_shadows_1080p_matches_oracle(oracle, hr, ctx, full):
-    """the bench workload itself, two frames (trace + temporal + 4 a-trous), every image bit for bit"""
+    """the bench workload itself, two frames (trace + temporal + 4 a-trous), every image bit for bit (the tolerance mode on the same
+    workload: test_gpu_tolerance.py::test_1080p_bench_frame_tolerance)"""
     import torch
     osc = oracle.Scene(full["sd"])
     op, gp = oracle.ShadowsPass(W, H), hr.RayTracedShadows(ctx, W, H)
@@ -135,6 +136,17 @@ def test_ao_4spp_1080p_matches_oracle(oracle, hr, ctx, full):
     ref = st["output"] if st["output"].ndim == 2 else st["output"][..., 0]
     assert np.array_equal(out, ref)
     gp.close()
+    # the tolerance mode on the same frame (what bench.py's `passes` block times)
+    import test_gpu_tolerance as tol
+    gf = hr.RayTracedAO(ctx, W, H, 0)
+    gf.params.spp = 4
+    gf.params.exact = 0
+    gf.render(full["scene"], hr.frame_inputs(full["gbs"][0], full["gbs"][0], full["ubos"][0], 0, 0, full["sob_d"], full["sr_d"], z_buffer_params=zbp))
+    torch.cuda.synchronize()
+    assert np.array_equal(gf.image(gf.IMG_MASK).cpu().numpy().view(np.uint32)[:4 * mh].reshape(4, mh, -1), st["mask"]) and gf.ray_count() == st["rays"]
+    ex = tol.tiles_close(gf.image(gf.IMG_TILES).cpu().numpy(), st["tiles"], "AO 1080p (exact = 0)", shape=(H, W))
+    tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE)), ref, "AO 1080p output (exact = 0)", exclude=ex)
+    gf.close()
 
 
 def test_ddgi_full_grid_shards_equal_unsharded(hr, ctx, full):
