@@ -10,8 +10,9 @@ from hybrid_rendering_amd import synth, tiling
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("exact", [1, 0])   # both arithmetic modes: the kernels of either are deterministic, so bands == whole frame bit for bit
 @pytest.mark.parametrize("world,bounds", [(2, None), (3, None), (3, [0, 64, 176, 264])])
-def test_bands_match_single_pass(oracle, hr, ctx, world, bounds):
+def test_bands_match_single_pass(oracle, hr, ctx, world, bounds, exact):
     import torch
     name, W, H, n_frames = "sponza_small", 192, 264, 5
     sd = helpers.scene_data(name)
@@ -21,8 +22,10 @@ def test_bands_match_single_pass(oracle, hr, ctx, world, bounds):
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
     whole = hr.RayTracedShadows(ctx, W, H)
     bands = [tiling.TiledShadows(ctx, W, H, r, world, bounds=bounds) for r in range(world)]   # uniform or cost-balanced heights
+    whole.params.exact = exact
     for b in bands:
         b.world = 1  # exchange is emulated below with device copies
+        b.params.exact = exact
     ping = False
     for f in range(n_frames):
         cur_d = helpers.to_cuda(frames[f]["gb"])
@@ -56,8 +59,9 @@ def _emulate_exchange(bands, H, ping):
                 mine[r0:r1].copy_(theirs[r0:r1])
 
 
+@pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("world", [2, 3])
-def test_ao_bands_match_single_pass(oracle, hr, ctx, world):
+def test_ao_bands_match_single_pass(oracle, hr, ctx, world, exact):
     import torch
     name, W, H, n_frames = "sponza_small", 192, 264, 4
     sd = helpers.scene_data(name)
@@ -67,10 +71,12 @@ def test_ao_bands_match_single_pass(oracle, hr, ctx, world):
     sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
     whole = hr.RayTracedAO(ctx, W, H, 0)
     whole.params.spp = 2
+    whole.params.exact = exact
     bands = [tiling.TiledAO(ctx, W, H, r, world, scale=0) for r in range(world)]
     for b in bands:
         b.world = 1
         b.params.spp = 2
+        b.params.exact = exact
     ping = False
     for f in range(n_frames):
         cur_d = helpers.to_cuda(frames[f]["gb"])
@@ -91,8 +97,9 @@ def test_ao_bands_match_single_pass(oracle, hr, ctx, world):
         ping = not ping
 
 
+@pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("world", [2])
-def test_reflections_bands_and_ddgi_shards_match_single_gpu(oracle, hr, ctx, world):
+def test_reflections_bands_and_ddgi_shards_match_single_gpu(oracle, hr, ctx, world, exact):
     """DDGI sharded by probe z-slab (+ emulated all-gather of the atlas rows) feeding band-tiled reflections:
     every band row of every rank equals the single-GPU frame bit for bit."""
     import torch
@@ -114,8 +121,12 @@ def test_reflections_bands_and_ddgi_shards_match_single_gpu(oracle, hr, ctx, wor
     for r, g in enumerate(gis):
         g.pass_.set_shard(*tiling.probe_slabs(4, world, r), *tiling.band_rows(H, world, r))
     bands = [tiling.TiledReflections(ctx, W, H, r, world, scale=0) for r in range(world)]
+    whole.params.exact = whole_gi.params.exact = exact
+    for g in gis:
+        g.params.exact = exact
     for b in bands:
         b.world = 1
+        b.params.exact = exact
     rng = np.random.RandomState(3)
     ping = False
     for f in range(n_frames):
