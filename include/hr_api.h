@@ -155,7 +155,7 @@ typedef struct
 } hr_scene_info;
 
 /* HR_ERR_INVALID_ARG: a tri_material entry >= n_materials or a texture index >= n_textures (both are dereferenced by the hit
- * shading); HR_ERR_UNSUPPORTED: >= 2^23 BVH nodes, or a BVH deeper than the traversal stack (64 levels — the builder caps its
+ * shading); HR_ERR_UNSUPPORTED: >= 2^23 BVH nodes, >= 2^26 triangle references, or a BVH deeper than the traversal stack (64 levels — the builder caps its
  * depth, so no triangle soup reaches it); HR_ERR_OUT_OF_MEMORY: host or device allocation failed.  Never throws. */
 hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* desc, hr_scene** out);
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info);
