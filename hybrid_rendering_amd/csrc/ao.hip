@@ -64,7 +64,10 @@ extern "C" int hr_debug_divergence_ao(uint64_t* out, int reset)
 #define AO_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop) for the AO rays: 0.418 -> 0.399 ms at 1080p, 4 spp
 #endif
 template <bool STATS>
-__global__ __launch_bounds__(64 * AO_TRACE_WAVES) void k_ao_trace(AOTraceArgs a)
+#ifndef AO_TRACE_EU
+#define AO_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 8 -> 393 / 389 / 396 us (noise level)
+#endif
+__global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(AOTraceArgs a)
 {
     __shared__ uint32_t s_stack[AO_TRACE_WAVES][HR_STACK_ENTRIES * 64];
 #if AO_COOP

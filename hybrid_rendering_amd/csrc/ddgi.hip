@@ -61,7 +61,10 @@ extern "C" int hr_debug_divergence_ddgi(uint64_t* out, int reset)
 #ifndef DDGI_COOP
 #define DDGI_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop); 0 = the per-lane loops
 #endif
-__global__ __launch_bounds__(64 * DDGI_TRACE_WAVES) void k_ddgi_trace(DDGITraceArgs a)
+#ifndef DDGI_TRACE_EU
+#define DDGI_TRACE_EU 6   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 325 / 318 / 338 us
+#endif
+__global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_trace(DDGITraceArgs a)
 {
     __shared__ uint32_t s_stack[DDGI_TRACE_WAVES][HR_STACK_ENTRIES * 64];
 #if DDGI_COOP

@@ -99,7 +99,10 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 #ifndef REFL_COOP
 #define REFL_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop); 0 = the per-lane loops
 #endif
-__global__ __launch_bounds__(64 * REFL_TRACE_WAVES) void k_refl_trace(ReflTraceArgs a)
+#ifndef REFL_TRACE_EU
+#define REFL_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 216 / 226 / 235 us
+#endif
+__global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)
 {
     __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
 #if REFL_COOP
