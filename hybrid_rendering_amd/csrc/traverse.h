@@ -92,14 +92,16 @@ HR_DEV RayPre ray_prepare(f3 o, f3 d)
 }
 
 // Watertight ray/triangle test.  true iff t_min < t < t_max.  Optionally returns t,u,v.
+// kx, ky, kz: the ray's axis permutation — r.kx / r.ky / r.kz, or the same values as compile-time constants when a whole wave shares
+// them (ray_tri_uniform below): the 18 v_cndmask of the component picks then fold away; the arithmetic is the same either way.
 template <bool WANT_TUV>
-HR_DEV bool ray_tri(const RayPre& r, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float& t_out, float& u_out, float& v_out)
+HR_DEV bool ray_tri_perm(const RayPre& r, const int kx, const int ky, const int kz, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float& t_out, float& u_out, float& v_out)
 {
     f3 A = sub3(v0, r.o), B = sub3(v1, r.o), C = sub3(v2, r.o);
-    float Akz = pick(A, r.kz), Bkz = pick(B, r.kz), Ckz = pick(C, r.kz);
-    float Ax = pick(A, r.kx) - r.Sx * Akz, Ay = pick(A, r.ky) - r.Sy * Akz;
-    float Bx = pick(B, r.kx) - r.Sx * Bkz, By = pick(B, r.ky) - r.Sy * Bkz;
-    float Cx = pick(C, r.kx) - r.Sx * Ckz, Cy = pick(C, r.ky) - r.Sy * Ckz;
+    float Akz = pick(A, kz), Bkz = pick(B, kz), Ckz = pick(C, kz);
+    float Ax = pick(A, kx) - r.Sx * Akz, Ay = pick(A, ky) - r.Sy * Akz;
+    float Bx = pick(B, kx) - r.Sx * Bkz, By = pick(B, ky) - r.Sy * Bkz;
+    float Cx = pick(C, kx) - r.Sx * Ckz, Cy = pick(C, ky) - r.Sy * Ckz;
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -119,6 +121,18 @@ HR_DEV bool ray_tri(const RayPre& r, f3 v0, f3 v1, f3 v2, float t_min, float t_m
         v_out = W * inv;
     }
     return true;
+}
+template <bool WANT_TUV>
+HR_DEV bool ray_tri(const RayPre& r, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float& t_out, float& u_out, float& v_out)
+{
+    return ray_tri_perm<WANT_TUV>(r, r.kx, r.ky, r.kz, v0, v1, v2, t_min, t_max, t_out, u_out, v_out);
+}
+// permutation code of a ray: kz * 2 + (kx, ky swapped); -1 from wave_perm_code when the lanes of the wave disagree
+HR_DEV int perm_code(const RayPre& r) { return r.kz * 2 + ((r.kx != (r.kz == 2 ? 0 : r.kz + 1)) ? 1 : 0); }
+HR_DEV int wave_perm_code(const RayPre& r)
+{
+    const int c = perm_code(r), c0 = __builtin_amdgcn_readfirstlane(c);
+    return __all(c == c0) ? c0 : -1;
 }
 
 HR_DEV float ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
@@ -236,6 +250,24 @@ HR_DEV TriRaw load_tri_raw(const TriGPU* __restrict__ tris, uint32_t i)
     t.a = p[0]; t.b = p[1]; t.c = p[2];
     return t;
 }
+// `code`: wave_perm_code() of the rays being traced (wave-uniform, so the switch is a scalar branch).  Shadow rays towards a
+// directional light and the hit shaders' light rays share one permutation per wave almost always.
+template <bool WANT_TUV>
+HR_DEV bool ray_tri_raw_uniform(const RayPre& r, int code, const TriRaw& q, float t_min, float t_max, float& t, float& u, float& v)
+{
+    const f3 v0 = mk3(__uint_as_float(q.a.x), __uint_as_float(q.a.y), __uint_as_float(q.a.z)), v1 = mk3(__uint_as_float(q.b.x), __uint_as_float(q.b.y), __uint_as_float(q.b.z)),
+             v2 = mk3(__uint_as_float(q.c.x), __uint_as_float(q.c.y), __uint_as_float(q.c.z));
+    switch (code)
+    {
+    case 0: return ray_tri_perm<WANT_TUV>(r, 1, 2, 0, v0, v1, v2, t_min, t_max, t, u, v);
+    case 1: return ray_tri_perm<WANT_TUV>(r, 2, 1, 0, v0, v1, v2, t_min, t_max, t, u, v);
+    case 2: return ray_tri_perm<WANT_TUV>(r, 2, 0, 1, v0, v1, v2, t_min, t_max, t, u, v);
+    case 3: return ray_tri_perm<WANT_TUV>(r, 0, 2, 1, v0, v1, v2, t_min, t_max, t, u, v);
+    case 4: return ray_tri_perm<WANT_TUV>(r, 0, 1, 2, v0, v1, v2, t_min, t_max, t, u, v);
+    case 5: return ray_tri_perm<WANT_TUV>(r, 1, 0, 2, v0, v1, v2, t_min, t_max, t, u, v);
+    default: return ray_tri_perm<WANT_TUV>(r, r.kx, r.ky, r.kz, v0, v1, v2, t_min, t_max, t, u, v);
+    }
+}
 template <bool WANT_TUV>
 HR_DEV bool ray_tri_raw(const RayPre& r, const TriRaw& q, float t_min, float t_max, float& t, float& u, float& v)
 {
@@ -333,6 +365,7 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     st.init(wave_stack, lane, spill_array);
     uint32_t cur = (entry << 9) | 1u, ni;   // the entry node (root = 0) = "child 0 of child_base entry"
     bool     hit = false;
+    const int pcode = wave_perm_code(r);
     while (walk_next<false>(cur, st, ni))
     {
         const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
@@ -351,8 +384,8 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
             const TriRaw ta = load_tri_raw(tris, h.tri_base + i0), tb = load_tri_raw(tris, h.tri_base + i1);
             if (STATS) n_tris += two ? 2u : 1u;
             float t, u, v;
-            const bool ha = ray_tri_raw<false>(r, ta, t_min, t_max, t, u, v);
-            const bool hb = ray_tri_raw<false>(r, tb, t_min, t_max, t, u, v);
+            const bool ha = ray_tri_raw_uniform<false>(r, pcode, ta, t_min, t_max, t, u, v);
+            const bool hb = ray_tri_raw_uniform<false>(r, pcode, tb, t_min, t_max, t, u, v);
             if (ha || hb) { hit = true; break; }
         }
         if (hit) break;
