@@ -529,7 +529,7 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
     if (p->wavefront)
     {
-        // queue words (counters + 32): 0 primary fetch counter, 1 secondary queue length, 2 secondary fetch counter
+        // queue words (counters + 32): word 1 = length of the secondary queue (appended by k_ddgi_shade, read by the any-hit queue kernel)
         uint32_t* qw = (uint32_t*)((char*)p->counters.p + 32);
         HR_HIP(hipMemsetAsync(qw, 0, 16, st));
         DDGIWaveArgs w;
@@ -540,10 +540,10 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
         hipLaunchKernelGGL(k_ddgi_gen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w);
         TraceQueueArgs q;
         q.nodes = a.nodes; q.tris = a.tris;
-        q.rays = w.rays; q.n_rays_dev = nullptr; q.n_rays = (uint32_t)n; q.fetch_counter = qw + 0; q.hits = (float4*)p->wf_hits.p; q.occluded = nullptr;
+        q.rays = w.rays; q.n_rays_dev = nullptr; q.n_rays = (uint32_t)n; q.hits = (float4*)p->wf_hits.p; q.occluded = nullptr;
         hipLaunchKernelGGL(k_trace_queue<false>, dim3(persistent), dim3(64), 0, st, q);
         hipLaunchKernelGGL(k_ddgi_shade, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, w);
-        q.rays = w.sec_rays; q.n_rays_dev = qw + 1; q.n_rays = 0; q.fetch_counter = qw + 2; q.hits = nullptr; q.occluded = (uint8_t*)p->wf_occluded.p;
+        q.rays = w.sec_rays; q.n_rays_dev = qw + 1; q.n_rays = 0; q.hits = nullptr; q.occluded = (uint8_t*)p->wf_occluded.p;
         hipLaunchKernelGGL(k_trace_queue<true>, dim3(persistent), dim3(64), 0, st, q);
         hipLaunchKernelGGL(k_ddgi_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w);
     }

@@ -1,15 +1,16 @@
-// Wavefront ray queues for the hit-shading passes (DDGI, reflections): the traversal of a ray batch as its own kernel.
+// Wavefront ray queues for the DDGI hit-shading pass: the traversal of a ray batch as its own kernel — a developer A/B path
+// (HR_DDGI_WAVEFRONT=1), NOT the default: measured slower than the single kernel.
 //
-// The reference traces these rays from ray-generation shaders whose closest-hit shader traces further rays (gi_ray_trace.rgen:96 ->
-// gi_ray_trace.rchit:95-128 -> ray_query.glsl; reflections_ray_trace.rgen:150,165 -> .rchit:117-150): on RT cores the driver's
-// scheduler regroups that work.  One HIP kernel doing the same per lane runs its loops at 25-50 % (node steps) and 5-7 % (triangle
-// tests) lane utilisation (tools/divergence.py), so the hot path here is split the way a wavefront path tracer is:
+// The reference traces these rays from a ray-generation shader whose closest-hit shader traces further rays (gi_ray_trace.rgen:96 ->
+// gi_ray_trace.rchit:95-128 -> ray_query.glsl): on RT cores the driver's scheduler regroups that work.  One HIP kernel doing the same
+// per lane runs its loops at 25-50 % (node steps) and 5-7 % (triangle tests) lane utilisation (tools/divergence.py); this path splits
+// it the way a wavefront path tracer does:
 //     generate rays -> k_trace_queue<closest> -> shade densely, append secondary rays -> k_trace_queue<any-hit> -> combine.
-// k_trace_queue is a persistent kernel: a lane whose ray is finished fetches the next ray of the queue (one atomic per refill of a
-// wave), so a wave issues node steps for (sum of its rays' steps) / 64 rather than for its longest ray, and the triangle tests are
-// the cooperative, redistributed ones of traverse.h (trace_coop).  Results are keyed by ray id: nothing depends on the order in which
+// k_trace_queue is a persistent kernel: a lane whose ray is finished fetches the next ray of its wave's share of the queue, so a
+// wave issues node steps for (sum of its rays' steps) / 64 rather than for its longest ray, and the triangle tests are the
+// cooperative, redistributed ones of traverse.h (trace_coop).  Results are keyed by ray id: nothing depends on the order in which
 // rays are fetched or queues are filled, and every hit decision is the same watertight test on the same operands — images are
-// identical to the single-kernel path (tests/test_gpu_ddgi.py, test_gpu_reflections.py compare both with the oracle).
+// identical to the single-kernel path (tests/test_gpu_ddgi.py::test_ddgi_wavefront_variant compares both with the oracle).
 #pragma once
 #include "traverse.h"
 
@@ -28,7 +29,6 @@ struct TraceQueueArgs
     const RayRec*   rays;
     const uint32_t* n_rays_dev;   // ray count in device memory (a queue filled by an earlier kernel), or nullptr: n_rays
     uint32_t        n_rays;
-    uint32_t*       fetch_counter; // zeroed before the launch
     float4*         hits;          // closest: (t, u, v, prim as bits; prim = -1: miss) per ray
     uint8_t*        occluded;      // any-hit: 1 / 0 per ray
 };
