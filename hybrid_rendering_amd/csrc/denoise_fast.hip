@@ -1142,8 +1142,8 @@ __global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
         return;
     }
     const f3    hn = fm::oct_unit(fm::ld<uint32_t>(a.G2, o * 8u));
-    const float tu = ((float)x + 0.5f) * fm::rcp((float)a.W), tv = ((float)y + 0.5f) * fm::rcp((float)a.H);
-    const float tsx = fm::rcp((float)a.w), tsy = fm::rcp((float)a.h);
+    const float tu = fm::div_rn((float)x + 0.5f, (float)a.W), tv = fm::div_rn((float)y + 0.5f, (float)a.H);
+    const float tsx = fm::div_rn(1.0f, (float)a.w), tsy = fm::div_rn(1.0f, (float)a.h);
     float up[CH], total_w = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH; c++) up[c] = 0.0f;
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
     for (int i = 0; i < 4; i++)
     {
         const float kx = (i == 1) ? 1.0f : (i == 2 ? -1.0f : 0.0f), ky = (i == 0) ? 1.0f : (i == 3 ? -1.0f : 0.0f);
-        int sx = (int)__builtin_floorf((tu + kx * tsx) * (float)a.w), sy = (int)__builtin_floorf((tv + ky * tsy) * (float)a.h);
+        int sx = fm::tap_texel(tu, kx, tsx, (float)a.w), sy = fm::tap_texel(tv, ky, tsy, (float)a.h);   // fast_math.h: the reference's rounding
         sx = clampi(sx, 0, a.w - 1); sy = clampi(sy, 0, a.h - 1);
         const uint32_t so = (uint32_t)(sy * a.w + sx);
         t3[i] = fm::ld<uint32_t>(a.g3, so * 8u + 4u); t2[i] = fm::ld<uint32_t>(a.g2, so * 8u);

@@ -128,5 +128,11 @@ HR_DEV void atlas_coord_rn(float ox, float oy, int col, int row, int side, float
 HR_DEV float bilerp_rn(float t00, float t10, float t01, float t11, float fx, float fy) { return mix_rn(mix_rn(t00, t10, fx), mix_rn(t01, t11, fx), fy); }
 HR_DEV float cheb_variance_rn(float mean, float m2) { return __builtin_fabsf(mean * mean - m2); }
 
+// Texel addressing of the upsample kernels (*_upsample.comp:70-84): uv = (pixel + 0.5) / size and the tap's texel
+// floor((uv + k / size_low) * size_low) are DISCRETE decisions that hit integers exactly for whole columns / rows of an odd-sized
+// image ((96 + 0.5) / 193 = 0.5): they keep the reference's operations — correctly rounded divisions, separate multiply and add.
+HR_DEV float div_rn(float n, float d) { return __fdiv_rn(n, d); }
+HR_DEV int   tap_texel(float uv, float k, float texel_size, float extent) { return (int)__builtin_floorf((uv + k * texel_size) * extent); }
+
 } // namespace fm
 } // namespace hr

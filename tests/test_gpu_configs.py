@@ -162,7 +162,7 @@ def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
         ex = tol.tiles_close(gf.image(gf.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f} (exact = 0)", shape=(h, w))
         tol.compare16(helpers.bits16(gf.image(gf.IMG_COLOR1 if f & 1 else gf.IMG_COLOR0))[..., :3], st["temporal"][..., :3], f"frame {f} temporal colour (exact = 0)", abs_floor=1e-3)   # intermediate image, as for the shadows
         tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_ATROUS))[..., :3], st["atrous"][-1][..., :3], f"frame {f} a-trous colour (exact = 0)", exclude=ex)
-        exu = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W] if scale else ex
+        exu = tol.upscale_mask(ex, scale, H, W) if scale else ex
         tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE))[..., :3], st["output"][..., :3], f"frame {f} reflections output (exact = 0)", exclude=exu)
     gf.close(); gf_ddgi.close()
     rough = oracle.f16(lows[-1]["gb3"][..., 0])

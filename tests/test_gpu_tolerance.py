@@ -66,6 +66,12 @@ def tiles_close(got, ref, what, frac=0.995, shape=None, reach=2):
     return np.kron(d, np.ones((8, 8), bool))[:shape[0], :shape[1]]
 
 
+def upscale_mask(ex, scale, H, W):
+    """low-resolution exclusion mask -> full resolution (odd sizes: the last row / column repeats)"""
+    up = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W]
+    return np.pad(up, ((0, H - up.shape[0]), (0, W - up.shape[1])), mode="edge")
+
+
 def _tables():
     import torch
     sob, sr = synth.blue_noise_tables()
@@ -124,7 +130,7 @@ def test_shadows_half_res_upsample_tolerance(oracle, hr, ctx):
         torch.cuda.synchronize()
         assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), op.stages["mask"])
         ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), op.stages["tiles"], f"frame {f}", shape=(h, w))
-        ex = np.kron(ex, np.ones((2, 2), bool))[:H, :W]
+        ex = upscale_mask(ex, 1, H, W)
         compare16(helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE)), up, f"frame {f} upsampled visibility", exclude=ex)
     gp.close(); gsc.close()
 
@@ -134,6 +140,10 @@ def test_shadows_half_res_upsample_tolerance(oracle, hr, ctx):
     ("sponza_small", 320, 184, 1, 4, None),
     ("cornell", 230, 150, 0, 2, dict(blur_radius=6, alpha=0.05, ray_length=40.0)),
     ("sponza_small", 171, 121, 0, 3, dict(blur_radius=2)),
+    # odd frame size at half resolution: (96 + 0.5) / 193 == 0.5 exactly — a whole column of upsample taps sits on a texel boundary, where
+    # an approximate reciprocal picks the other texel (found by tools/fuzz_tolerance.py; the tap addressing keeps the reference's rounding)
+    ("sponza_small", 193, 148, 1, 2, None),
+    ("cornell", 230, 141, 1, 1, None),
 ])
 def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params):
     import torch
@@ -167,7 +177,7 @@ def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params):
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         ref = st["output"] if st["output"].ndim == 2 else st["output"][..., 0]
         if scale:
-            ex = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W]
+            ex = upscale_mask(ex, scale, H, W)
         compare16(out, ref, f"frame {f} AO output", exclude=ex)
     gp.close(); gsc.close()
 
@@ -237,7 +247,7 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
         compare16(at[..., :3], st["atrous"][-1][..., :3], f"frame {f} a-trous colour", exclude=ex)
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         if scale:
-            ex = np.kron(ex, np.ones((1 << scale, 1 << scale), bool))[:H, :W]
+            ex = upscale_mask(ex, scale, H, W)
         compare16(out[..., :3], st["output"][..., :3], f"frame {f} reflections output", exclude=ex)
     gp.close(); g_ddgi.close(); gsc.close()
 
