@@ -83,11 +83,11 @@ def _tables():
     ("cornell", 250, 166, 1.0, "soft", None),
     ("sponza_small", 203, 117, 2.0, "spot", dict(filter_iterations=5, feedback_iteration=0, phi_normal=12.5, power=2.0, alpha=0.05, radius=2, sigma_depth=0.6)),
 ])
-def test_shadows_tolerance(oracle, hr, ctx, name, w, h, dolly, light, params):
+def test_shadows_tolerance(oracle, hr, ctx, name, w, h, dolly, light, params, n_frames=6):
     import torch
     sd = helpers.scene_data(name)
     osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
-    n = 6
+    n = n_frames
     frames = helpers.make_frames(oracle, osc, name, w, h, n, dolly, light)
     sob, sr, sob_d, sr_d = _tables()
     kw = dict(params or {})
@@ -145,11 +145,11 @@ def test_shadows_half_res_upsample_tolerance(oracle, hr, ctx):
     ("sponza_small", 193, 148, 1, 2, None),
     ("cornell", 230, 141, 1, 1, None),
 ])
-def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params):
+def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params, n_frames=5):
     import torch
     sd = helpers.scene_data(name)
     osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
-    n = 5
+    n = n_frames
     frames = helpers.make_frames(oracle, osc, name, W, H, n, 1.5, scale_mips=scale)
     sob, sr, sob_d, sr_d = _tables()
     zbp = synth.z_buffer_params()
@@ -187,7 +187,7 @@ def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params):
     ("sponza_small", 224, 128, 0, 1.0, None),
     ("sponza_small", 160, 96, 0, 1.0, dict(approximate_with_ddgi=0, blur_as_input=1, trim=0.5, filter_iterations=3, phi_color=4.0, gi_intensity=1.0, phi_normal=8.0, radius=2)),
 ])
-def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scale, dolly, params):
+def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scale, dolly, params, n_frames=5):
     """DDGI (exact atlases, tolerance-mode sample) feeding tolerance-mode reflections.  The reflections TRACE (hit shading) has one
     mode and is compared bit for bit while it reads the bit-exact atlases; temporal / a-trous / upsample obey the image rule."""
     import torch
@@ -203,7 +203,7 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
     env_np = dict(sky=sky, prefiltered=pre, pre_size=16, pre_levels=5, lut=lut)
     f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
     env = api_gi.environment(f16(sky), f16(pre), 16, 5, f16(lut))
-    n = 5
+    n = n_frames
     frames = helpers.make_frames(oracle, osc, name, W, H, n, dolly, scale_mips=scale)
     r01, r003 = np.float16(0.1).view(np.uint16), np.float16(0.03).view(np.uint16)
     for fr in frames:

@@ -1,6 +1,7 @@
 """GPU developer tool: the tolerance-mode runners of tests/test_gpu_tolerance.py (exact = 0 against the oracle within the stated
 tolerance — masks bit-exact, >= 99.9 % of the texels within 2 fp16 ulp, rel-L2 <= 1e-3) on random image sizes,
-scenes, lights, camera speeds, resolution scales and pass parameters.   python tools/fuzz_tolerance.py [seed] [n_configs]"""
+scenes, lights, camera speeds, resolution scales (full / half / quarter) and pass parameters; `frames` > the tests' 5-6 checks that the
+bound holds once the temporal feedback has run to its steady state.   python tools/fuzz_tolerance.py [seed] [n_configs] [frames]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,8 @@ import test_gpu_tolerance as tol
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+kw = dict(n_frames=n_frames) if n_frames else {}
 rng = np.random.RandomState(seed)
 ctx = hr.Context(0)
 bad = 0
@@ -20,7 +23,7 @@ for trial in range(n):
     W, H = int(rng.randint(160, 360)), int(rng.randint(120, 220))
     light = str(rng.choice(["default", "point", "spot"]) if name != "cornell" else rng.choice(["default", "soft"]))
     dolly = float(rng.uniform(0.2, 2.5))
-    scale = int(rng.choice([0, 1]))
+    scale = int(rng.choice([0, 1, 1, 2]))
     sp = ap = rp = None
     if trial % 2:
         sp = dict(alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)), phi_visibility=float(rng.uniform(1, 20)),
@@ -31,9 +34,9 @@ for trial in range(n):
                   phi_normal=float(rng.choice([32.0, 8.0, 12.5])), sigma_depth=float(rng.uniform(0.3, 3)), radius=int(rng.choice([1, 2])),
                   filter_iterations=int(rng.choice([1, 3, 5])), feedback_iteration=int(rng.choice([0, 1])))
     res = []
-    for label, fn in (("shadows", lambda: tol.test_shadows_tolerance(oracle, hr, ctx, name, W, H, dolly, light, sp)),
-                      ("ao", lambda: tol.test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, int(rng.randint(1, 5)), ap)),
-                      ("reflections+ddgi", lambda: tol.test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scale, dolly, rp))):
+    for label, fn in (("shadows", lambda: tol.test_shadows_tolerance(oracle, hr, ctx, name, W, H, dolly, light, sp, **kw)),
+                      ("ao", lambda: tol.test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, int(rng.randint(1, 5)), ap, **kw)),
+                      ("reflections+ddgi", lambda: tol.test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, min(scale, 1), dolly, rp, **kw))):
         try:
             fn()
             res.append(label + " ok")
