@@ -235,3 +235,32 @@ def test_scene_create_rejects_bad_indices(hr, ctx):
     bad.tri_material[5] = len(sd.materials)
     with pytest.raises(hr.HRError, match="HR_ERR_INVALID_ARG"):
         hr.Scene(ctx, bad)
+
+
+def test_hard_tier_queries_and_shadow_mask_match_oracle(oracle, hr, ctx):
+    """the harder workload tier of bench.py (`--tier hard`: 2.48 M triangles of layered fabric, foliage cards and chains; 11.5 nodes +
+    4.3 triangles per shadow ray): raw any-hit / closest-hit queries and the 1080p shadow mask under the grazing sun, bit for bit"""
+    import torch
+    from hybrid_rendering_amd import synth
+    sd = synth.sponza_like(1.0, tier="hard")
+    assert sd.n_tris > 2_000_000
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    rays = _random_rays(sd, 600_000, 11)
+    assert int((osc.any_hit(rays) != gsc.any_hit(torch.from_numpy(rays).cuda()).cpu().numpy()).sum()) == 0
+    rays2 = _random_rays(sd, 300_000, 12, tmax_mode="far")
+    tuv, prim = osc.closest_hit(rays2)
+    gt, gp = gsc.closest_hit(torch.from_numpy(rays2).cuda())
+    gt, gp = gt.cpu().numpy(), gp.cpu().numpy()
+    assert (prim >= 0).mean() > 0.3 and np.array_equal(prim, gp)
+    assert np.array_equal(tuv[prim >= 0].view(np.uint32), gt[prim >= 0].view(np.uint32))
+    W, H = 1920, 1080
+    ubo = synth.make_ubo(synth.sponza_camera(W / H, frame=1, dolly=0.5), synth.sponza_camera(W / H, frame=0, dolly=0.5), synth.sponza_hard_light())
+    gb = gsc.gbuffer(ubo, W, H)
+    host = {n: (t.cpu().numpy().view(np.uint16) if t.dtype == torch.float16 else t.cpu().numpy()) for n, t in gb.items()}
+    sob, sr = synth.blue_noise_tables()
+    mask, nrays = oracle.shadows_ray_trace(osc, ubo, host["depth"], host["gb2"], sob, sr)
+    gp_ = hr.RayTracedShadows(ctx, W, H)
+    gp_.ray_trace(gsc, hr.frame_inputs(gb, gb, ubo, 0, 0, torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()))
+    torch.cuda.synchronize()
+    assert np.array_equal(gp_.image(gp_.IMG_MASK).cpu().numpy().view(np.uint32), mask) and gp_.ray_count() == nrays and nrays > 1_000_000
+    gp_.close(); gsc.close()
