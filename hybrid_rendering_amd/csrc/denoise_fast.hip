@@ -1142,8 +1142,9 @@ __global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
         return;
     }
     const f3    hn = fm::oct_unit(fm::ld<uint32_t>(a.G2, o * 8u));
-    const float tu = fm::div_rn((float)x + 0.5f, (float)a.W), tv = fm::div_rn((float)y + 0.5f, (float)a.H);
-    const float tsx = fm::div_rn(1.0f, (float)a.w), tsy = fm::div_rn(1.0f, (float)a.h);
+    // correctly rounded quotients (the texel addressing below is a discrete decision); the divisors are launch constants
+    const float tu = fm::div_by_inrange((float)x + 0.5f, div_prepare((float)a.W)), tv = fm::div_by_inrange((float)y + 0.5f, div_prepare((float)a.H));
+    const float tsx = fm::div_by_inrange(1.0f, div_prepare((float)a.w)), tsy = fm::div_by_inrange(1.0f, div_prepare((float)a.h));
     float up[CH], total_w = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH; c++) up[c] = 0.0f;
