@@ -412,6 +412,14 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
                            "concurrent_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
                                                   "note": "shadows | AO | DDGI trace + update -> reflections | DDGI sample on four HIP streams, joined at the end of the frame (independent chains; same images)"}}
     hf.close()
+    # configs[3] read as FULL-resolution reflections (the reference's default, timed above, is half resolution)
+    hfr = HybridFrame(ctx, scene, sd, 1920, 1080, exact=exact, refl_scale=0)
+    hfr.time(4, 2)
+    ms_r = hfr.time(12, 4, only="reflections", repeats=3)
+    rays_r = hfr.ray_counts()["reflections"]
+    res["reflections_full_res"] = {"workload": "reflections 1 spp at FULL resolution + SVGF, 1920x1080 (configs[3] without the reference's half-resolution default)",
+                                   "ms_per_frame": round(ms_r, 4), "frames_per_s": round(1e3 / ms_r, 1), "rays_per_frame": rays_r, "Mrays_per_s": round(rays_r / ms_r / 1e3, 1)}
+    hfr.close()
     hf4 = HybridFrame(ctx, scene, sd, 3840, 2160, exact=exact)
     ms4 = hf4.time(8, 4, repeats=3)
     r4 = hf4.ray_counts()
