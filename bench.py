@@ -49,8 +49,8 @@ NODE_BYTES, TRI_BYTES = 80, 48
 # stage name of the pass profilers -> kernel name in the rocprofv3 files of profiles/
 KERNEL_OF = {("shadows", "ray_trace"): "k_shadows_trace<false>", ("shadows", "temporal_accumulation"): "kf_shadows_temporal", ("shadows", "atrous"): "kf_shadows_atrous",
              ("ao", "ray_trace"): "k_ao_trace<false>", ("ao", "temporal_accumulation"): "kf_ao_temporal", ("ao", "blur"): "kf_ao_blur",
-             ("ddgi", "ray_trace"): "k_ddgi_trace", ("ddgi", "sample_probe_grid"): "kf_ddgi_sample", ("ddgi", "irradiance_probe_update"): "k_ddgi_probe_update<false>",
-             ("ddgi", "depth_probe_update"): "k_ddgi_probe_update<true>", ("reflections", "ray_trace"): "k_refl_trace",
+             ("ddgi", "ray_trace"): "k_ddgi_trace", ("ddgi", "sample_probe_grid"): "kf_ddgi_sample", ("ddgi", "irradiance_probe_update"): "k_ddgi_probe_update<false",
+             ("ddgi", "depth_probe_update"): "k_ddgi_probe_update<true", ("reflections", "ray_trace"): "k_refl_trace",
              ("reflections", "temporal_accumulation"): "kf_refl_temporal", ("reflections", "atrous"): "kf_refl_atrous", ("reflections", "upsample"): "kf_upsample"}
 
 
