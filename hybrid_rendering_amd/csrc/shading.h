@@ -167,18 +167,25 @@ HR_DEV f3 probe_location(const DDGIU& d, int index)
     const int cz = index / (d.probe_counts[0] * d.probe_counts[1]);
     return grid_coord_to_position(d, cx, cy, cz);
 }
-HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
+// (col, row) = the probe's cell in the atlas = (probe_index % per_row, probe_index / per_row) with per_row = (tw - 2) / (side + 2)
+// (gi_common.glsl:164-184).  The atlas is probe_counts.x * probe_counts.y cells wide by construction (ddgi.cpp:197-201, checked in
+// hr_ddgi_create), so for probe (cx, cy, cz) the cell is (cx + cy * nx, cz): the same integers without two per-lane divisions.
+HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, int tw, int th, int side, float& u, float& v)
 {
     float ox, oy;
     gi_oct_encode(normalize3(dir), ox, oy);
     const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;
     const float pwb = (float)side + 2.0f;
     const float cx = __fdiv_rn(zx * (float)side, (float)tw), cy = __fdiv_rn(zy * (float)side, (float)th);
-    const int   per_row = (tw - 2) / (side + 2);
-    const float tlx = (float)(probe_index % per_row) * pwb + 2.0f; // mod() of small integers is exact
-    const float tly = (float)(probe_index / per_row) * pwb + 2.0f;
+    const float tlx = (float)col * pwb + 2.0f;
+    const float tly = (float)row * pwb + 2.0f;
     u = __fdiv_rn(tlx, (float)tw) + cx;
     v = __fdiv_rn(tly, (float)th) + cy;
+}
+HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
+{
+    const int per_row = (tw - 2) / (side + 2);
+    texture_coord_from_cell(dir, probe_index % per_row, probe_index / per_row, tw, th, side, u, v);   // mod() of small integers is exact
 }
 HR_DEV int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
@@ -231,7 +238,7 @@ HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& 
     {
         const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
         const int cx = clampi(bx + ox, 0, d.probe_counts[0] - 1), cy = clampi(by + oy, 0, d.probe_counts[1] - 1), cz = clampi(bz + oz, 0, d.probe_counts[2] - 1);
-        const int p  = cx + cy * d.probe_counts[0] + cz * d.probe_counts[0] * d.probe_counts[1];
+        const int col = cx + cy * d.probe_counts[0];   // probe cx + cy * nx + cz * nx * ny sits in atlas cell (col, cz)
         const f3 probe_pos      = grid_coord_to_position(d, cx, cy, cz);
         const f3 probe_to_point = add3(sub3(P, probe_pos), scale3(add3(N, scale3(Wo, 3.0f)), d.normal_bias));
         const f3 dir            = normalize3(neg3(probe_to_point));
@@ -245,7 +252,7 @@ HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& 
         if (d.visibility_test == 1)
         {
             float u, v, mean, m2;
-            texture_coord_from_direction(neg3(dir), p, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
+            texture_coord_from_cell(neg3(dir), col, cz, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
             const float dist = len3(probe_to_point);
             atlas_bilinear_rg(depth, u, v, mean, m2);
             const float variance = fabsf(mean * mean - m2);
@@ -256,7 +263,7 @@ HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& 
         }
         weight = max2(0.000001f, weight);
         float u, v;
-        texture_coord_from_direction(normalize3(N), p, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
+        texture_coord_from_cell(normalize3(N), col, cz, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
         f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
         const float crush = 0.2f;
         if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
