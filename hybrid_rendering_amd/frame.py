@@ -12,7 +12,7 @@ import numpy as np
 
 class HybridFrame:
     def __init__(self, ctx, scene, sd, W, H, rank=0, world=1, exact=0, ao_spp=4, probes=(16, 8, 16), rays_per_probe=256, refl_scale=1, group=None,
-                 concurrent=False):
+                 concurrent=False, bounds=None):
         import torch
         import torch.distributed as dist
         from . import api as hr, api_gi, synth, synth_env, tiling
@@ -33,8 +33,7 @@ class HybridFrame:
         self.env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 32, 5, f16(synth_env.brdf_lut(32)))
         # cost-balanced bands from a calibration trace of the shadow pass (full-resolution rows; the low-resolution reflections
         # band is the same band in low-resolution rows, which needs 16-row alignment of the full-res cuts)
-        bounds = None
-        if world > 1:
+        if world > 1 and bounds is None:
             cal = hr.RayTracedShadows(ctx, W, H)
             cal.ray_trace(scene, hr.frame_inputs(self.gbs[0], self.gbs[0], self.ubos[0], 0, 0, self.sob_d, self.sr_d))
             cost = tiling.shadow_cost_per_tile_row(self.gbs[0]["depth"], cal.tile_ray_counts())
@@ -44,20 +43,8 @@ class HybridFrame:
             tb = torch.tensor(bounds, dtype=torch.int64, device="cuda")
             dist.broadcast(tb, src=0, group=group)
             bounds = [int(v) for v in tb.cpu()]
-        self.bounds = bounds
-        lb = [b >> refl_scale for b in bounds] if bounds else None
-        if lb:
-            lb[-1] = H >> refl_scale
-        self.shadows = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds, group=group)
-        self.ao = tiling.TiledAO(ctx, W, H, rank, world, scale=0, bounds=bounds, group=group)
-        self.ao.params.spp = ao_spp
-        self.gi = tiling.ShardedDDGI(ctx, W, H, self.ddgi_u, rank, world, group=group)
-        if world > 1 and bounds:
-            self.gi.pass_.set_shard(self.gi.z0, self.gi.z1, bounds[rank], bounds[rank + 1])
-            self.gi.b0, self.gi.b1 = bounds[rank], bounds[rank + 1]
-        self.refl = tiling.TiledReflections(ctx, W, H, rank, world, scale=refl_scale, bounds=lb, group=group)
-        for p in (self.shadows, self.ao, self.gi, self.refl):
-            p.params.exact = int(exact)
+        self.group, self.exact, self.ao_spp, self.refl_scale = group, int(exact), ao_spp, refl_scale
+        self._build_passes(bounds)
         self.rng = np.random.RandomState(1)
         # host-side cost matters once the GPU frame is ~1.5 ms: the two parities' input blocks and a ring of probe rotations are built once
         self._inputs = [self._make_inputs(0), self._make_inputs(1)]
@@ -68,6 +55,48 @@ class HybridFrame:
         # the SIMD slots the VALU-bound trace kernels of another leave idle.  Joined on the caller's stream at the end of the frame.
         self.concurrent = False
         self.concurrent_streams(concurrent)
+
+    def _build_passes(self, bounds):
+        """(re)creates the tiled passes of this rank for the band boundaries `bounds` (full-resolution rows; None: one GPU)"""
+        from . import tiling
+        ctx, W, H, rank, world, group, refl_scale = self.ctx, self.W, self.H, self.rank, self.world, self.group, self.refl_scale
+        for p in getattr(self, "_passes", []):
+            p.pass_.close()
+        self.bounds = bounds
+        lb = [b >> refl_scale for b in bounds] if bounds else None
+        if lb:
+            lb[-1] = H >> refl_scale
+        self.shadows = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds, group=group)
+        self.ao = tiling.TiledAO(ctx, W, H, rank, world, scale=0, bounds=bounds, group=group)
+        self.ao.params.spp = self.ao_spp
+        self.gi = tiling.ShardedDDGI(ctx, W, H, self.ddgi_u, rank, world, group=group)
+        if world > 1 and bounds:
+            self.gi.pass_.set_shard(self.gi.z0, self.gi.z1, bounds[rank], bounds[rank + 1])
+            self.gi.b0, self.gi.b1 = bounds[rank], bounds[rank + 1]
+        self.refl = tiling.TiledReflections(ctx, W, H, rank, world, scale=refl_scale, bounds=lb, group=group)
+        self._passes = [self.shadows, self.ao, self.gi, self.refl]
+        for p in self._passes:
+            p.params.exact = self.exact
+
+    def rebalance(self, rounds=1, barrier=None):
+        """N > 1: re-cut the bands from MEASURED per-rank frame times (tiling.rebalanced_bounds).  The first cut balances the
+        shadow pass's cost model only; the hybrid frame's cost (AO rays, glossy pixels, each rank's fixed launch floors) shifts it."""
+        import torch
+        import torch.distributed as dist
+        from . import tiling
+        if self.world == 1:
+            return self.bounds
+        for _ in range(rounds):
+            ms = self.time(6, 3, barrier=barrier)
+            t = torch.zeros(self.world, dtype=torch.float64, device="cuda")
+            t[self.rank] = ms
+            dist.all_reduce(t, group=self.group)
+            new = tiling.rebalanced_bounds(self.bounds, [float(v) for v in t.cpu()], self.H)
+            if new == list(self.bounds):
+                break
+            torch.cuda.synchronize()
+            self._build_passes(new)
+        return self.bounds
 
     def concurrent_streams(self, on):
         import torch

@@ -67,6 +67,25 @@ def balanced_bounds(cost_per_tile_row: Sequence[float], world: int, height: int,
     return [c_ * align for c_ in cuts] + [height]
 
 
+
+def rebalanced_bounds(bounds: Sequence[int], times: Sequence[float], height: int, align: int = 16, min_rows: int = 64, fixed_fraction: float = 0.35) -> List[int]:
+    """New band boundaries from MEASURED per-rank frame times (one per band of ``bounds``).  A rank's time is modelled as a fixed
+    part (launch floors, its probe slab: ``fixed_fraction`` of the mean time) plus a cost density, constant over its rows; the new
+    cuts give every band the same share of the integrated density.  Deterministic, so every rank computes the same answer from
+    the all-gathered times.  Cuts are multiples of ``align`` rows and every band keeps ``min_rows``."""
+    world = len(times)
+    assert len(bounds) == world + 1
+    mean = sum(times) / world
+    fixed = fixed_fraction * mean
+    dens = [max(times[r] - fixed, 0.05 * mean) / max(bounds[r + 1] - bounds[r], 1) for r in range(world)]   # cost per row of each old band
+    n = (height + align - 1) // align
+    cost = []
+    for i in range(n):
+        y = min(i * align + align // 2, height - 1)
+        r = max(k for k in range(world) if bounds[k] <= y)
+        cost.append(dens[min(r, world - 1)] * align)
+    return balanced_bounds(cost, world, height, min_tiles=max(1, min_rows // align), align=align)
+
 RAY_WEIGHT = 1.8    # cost of one shadow ray in units of one geometry pixel of denoising.  The 1080p stage times give 1.25 (trace
                     # 0.131 ns/ray, temporal + a-trous 0.105 ns/pixel); 1.8 balances the measured band times of the 4- and 8-band
                     # frames best (tools/band_balance.py: slowest/mean band 1.04 instead of 1.10) — ray-dense rows are also the deep ones

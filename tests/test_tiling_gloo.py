@@ -131,3 +131,21 @@ def test_ddgi_slab_allgather_gloo(world, cz):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def test_rebalanced_bounds_from_measured_times():
+    """tiling.rebalanced_bounds: bands re-cut from per-rank frame times — slow ranks give rows away, cuts stay 16-row aligned,
+    every band keeps its minimum height, equal times leave the cuts (nearly) alone; deterministic (every rank computes it)."""
+    from hybrid_rendering_amd import tiling
+    H = 2160
+    b = [0, 368, 704, 1024, 1344, 1616, 1808, 1984, 2160]
+    t = [1.074, 1.102, 1.08, 1.14, 1.038, 0.917, 0.864, 0.816]
+    nb = tiling.rebalanced_bounds(b, t, H)
+    assert nb == tiling.rebalanced_bounds(b, t, H) and nb[0] == 0 and nb[-1] == H and len(nb) == 9
+    assert all(c % 16 == 0 for c in nb[:-1]) and all(y - x >= 64 for x, y in zip(nb, nb[1:]))
+    assert nb[1] < b[1] and (nb[-1] - nb[-2]) > (b[-1] - b[-2])          # the slow first band shrinks, the fast last band grows
+    even = tiling.rebalanced_bounds([0, 544, 1088, 1632, 2160], [1.0, 1.0, 1.0, 1.0], H)
+    assert all(abs(x - y) <= 16 for x, y in zip(even, [0, 544, 1088, 1632, 2160]))
+    # a degenerate measurement (one rank 10x slower) still yields legal bands
+    wild = tiling.rebalanced_bounds([0, 720, 1440, 2160], [10.0, 1.0, 1.0], H)
+    assert wild[0] == 0 and wild[-1] == H and all(y - x >= 64 for x, y in zip(wild, wild[1:]))
