@@ -45,6 +45,7 @@ def main():
         for r in range(world):
             t = tiling.TiledShadows(ctx, W, H, r, world, bounds=bounds)
             t.world = 1   # no exchange: timing of the band's own work (band + halo)
+            t.params.exact = int(os.environ.get("EXACT", "0"))   # the mode bench.py times by default
             fis = [hr.frame_inputs(gbs[k & 1], gbs[(k + 1) & 1], ubos[k & 1], k, k & 1, sob_d, sr_d) for k in range(2)]
             for k in range(6):
                 fis[k & 1].num_frames = k
