@@ -61,6 +61,8 @@ class HybridFrame:
         from . import tiling
         ctx, W, H, rank, world, group, refl_scale = self.ctx, self.W, self.H, self.rank, self.world, self.group, self.refl_scale
         for p in getattr(self, "_passes", []):
+            if hasattr(p, "wait_exchange"):
+                p.wait_exchange()      # no history rows in flight into images that are about to be freed
             p.pass_.close()
         self.bounds = bounds
         lb = [b >> refl_scale for b in bounds] if bounds else None
@@ -204,5 +206,8 @@ class HybridFrame:
         return out
 
     def close(self):
+        for t in getattr(self, "_passes", []):
+            if hasattr(t, "wait_exchange"):
+                t.wait_exchange()
         for p in self.passes().values():
             p.close()
