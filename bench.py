@@ -349,6 +349,8 @@ def main():
     n2 = max(20, args.steps // 4)
     out["tolerance_mode" if exact else "exact_mode"] = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(total_rays / args.steps * n2 / el2 / 1e6, 2), "unit": "Mrays/s",
                                                         "steps": n2, "note": "hr_shadows_params.exact = %d on the same frames" % (1 - exact)}
+    other.wait_exchange()
+    torch.cuda.synchronize()
     other.pass_.close()
 
     # ---- the other BASELINE configurations (outside the timed region) ------------------------------------------------------------
