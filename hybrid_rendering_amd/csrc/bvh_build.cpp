@@ -304,7 +304,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     }
     // references: one per triangle, or several tight pieces for triangles longer than diag * split_fraction
     // Off by default: the bench scene is finely tessellated and splitting at diag/16 .. diag/100 changed nodes/ray by
-    // < 2% and the trace time by < 1.5% (tools/stagebench.py).  HR_BVH_SPLIT=<fraction of the scene diagonal> enables it
+    // < 2% and the trace time by < 1.5% (tools/passbench.py).  HR_BVH_SPLIT=<fraction of the scene diagonal> enables it
     // for scenes with wall-sized triangles (original Sponza: two triangles per wall).
     double split_fraction = 0.0;
     if (const char* e = getenv("HR_BVH_SPLIT")) split_fraction = atof(e);
