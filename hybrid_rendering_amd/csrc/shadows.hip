@@ -510,7 +510,7 @@ struct hr_shadows
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
     bool          persistent_waves = false; // HR_TRACE_KERNEL=queue selects the persistent-wave ray-queue kernel (A/B measurements)
-    // developer switches (tools/timeline.py, tools/stagebench.py), read from the environment ONCE in hr_shadows_create — the
+    // developer switches (tools/timeline.py, tools/passbench.py), read from the environment ONCE in hr_shadows_create — the
     // render path never calls getenv
     int           dbg_only_tx = -1, dbg_only_ty = -1;
     bool          dbg_skip_traversal = false, dbg_skip_reproject = false, dbg_timeline_stats = false;
