@@ -131,15 +131,15 @@ class HybridFrame:
             import torch
             main = torch.cuda.current_stream()
             self._ev_in.record(main)
-            for s_, work in zip(self._side[:2], ((lambda st: self.shadows.render(self.scene, fi, stream=st)), (lambda st: self.ao.render(self.scene, fi, stream=st)))):
-                s_.wait_event(self._ev_in)
-                work(s_)
             # DDGI: the reflections' hit shading reads the ATLASES (ready after the probe update); the per-pixel probe-grid sample
             # only feeds the composite, so it leaves the critical chain for a stream of its own
             gp = self.gi.pass_
             gp.set_orientation(self._orients[k & 15])
             gp.ray_trace(self.scene, fi, self.env, None)
             gp.probe_update(None)
+            for s_, work in zip(self._side[:2], ((lambda st: self.shadows.render(self.scene, fi, stream=st)), (lambda st: self.ao.render(self.scene, fi, stream=st)))):
+                s_.wait_event(self._ev_in)
+                work(s_)
             self._ev_atlas.record(main)
             self._side[2].wait_event(self._ev_atlas)
             gp.sample_probe_grid(fi, self._side[2])
