@@ -20,6 +20,9 @@ from hybrid_rendering_amd import synth, synth_env
 pytestmark = pytest.mark.gpu
 
 
+VARIANCE_FLOOR = 1e-4     # absolute slack of the variance channels (see compare16)
+
+
 def _key(bits):
     """fp16 bit patterns -> integers ordered like the values (so that |key_a - key_b| is the distance in fp16 ulp)"""
     b = bits.astype(np.int32)
@@ -27,16 +30,22 @@ def _key(bits):
     return np.where(b & 0x8000, -mag, mag)
 
 
-def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None):
-    """got / ref: uint16 fp16 bit patterns.  abs_floor: differences below it count as equal (intermediate images whose small
-    values are differences of nearly equal numbers, e.g. variance = m2 - m1^2).  exclude: bool [H, W] of texels left out of the
-    per-texel bound (neighbourhoods of tiles whose classification differs — a discrete decision; they stay in the L2 bound)."""
+def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None, variance_channels=(), variance_floor=VARIANCE_FLOOR):
+    """got / ref: uint16 fp16 bit patterns, ALL channels of the image.  abs_floor: differences below it count as equal (intermediate
+    images whose small values are differences of nearly equal numbers, e.g. variance = m2 - m1^2).  exclude: bool [H, W] of texels
+    left out of the per-texel bound (neighbourhoods of tiles whose classification differs — a discrete decision; they stay in the L2
+    bound).  variance_channels: channels that carry a variance estimate (shadows .y, reflections .a): they descend from
+    `m2 - m1^2` / `E[x^2] - E[x]^2`, a difference of nearly equal numbers, so their rule is "2 fp16 ulp OR |diff| <= variance_floor"
+    — the quantity the next a-trous iteration reads them for is phi * sqrt(variance) (shadows_denoise_atrous.comp:65-88), on which
+    a 1e-4 absolute slip is far below the 2-ulp bound of the filtered channel; the L2 bounds cover them like every other channel."""
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     g, r = got.view(np.float16).astype(np.float64), ref.view(np.float16).astype(np.float64)
     assert np.isfinite(g).all(), f"{what}: non-finite values"
     num, den = np.sqrt(((g - r) ** 2).sum()), np.sqrt((r ** 2).sum())
     rl2 = num / den if den > 0 else num
     ok = (np.abs(_key(got) - _key(ref)) <= ulps) | (np.abs(g - r) <= abs_floor)
+    for c in variance_channels:
+        ok[..., c] |= np.abs(g - r)[..., c] <= variance_floor
     if exclude is not None:
         ex = exclude if ok.ndim == 2 else exclude[..., None]
         ok = ok | ex
@@ -106,9 +115,10 @@ def test_shadows_tolerance(oracle, hr, ctx, name, w, h, dolly, light, params, n_
         ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
         # intermediate images: the variance / second-moment channels are differences of nearly equal numbers
         compare16(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"], f"frame {f} temporal", abs_floor=1e-3)
-        compare16(helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0))[..., :3], st["moments"][..., :3], f"frame {f} moments", abs_floor=1e-3)
+        compare16(helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0)), st["moments"], f"frame {f} moments (m1, m2, history length, 0)", abs_floor=1e-3)
         out, ref = helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), st["output"]
-        compare16(out[..., 0], ref[..., 0], f"frame {f} denoised visibility", exclude=ex)
+        compare16(out, ref, f"frame {f} denoised visibility + filtered variance", exclude=ex, variance_channels=(1,))
+        compare16(helpers.bits16(gp.image(gp.IMG_PREV)), op.prev_image, f"frame {f} feedback image (next frame's history)", exclude=ex, variance_channels=(1,))
     gp.close(); gsc.close()
 
 
@@ -236,19 +246,21 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
         torch.cuda.synchronize()
         gi, gd = g_ddgi.current_read()
         assert np.array_equal(helpers.bits16(gi), irr) and np.array_equal(helpers.bits16(gd), dep), f"frame {f}: DDGI atlases are exact in both modes"
-        compare16(helpers.bits16(g_ddgi.output())[..., :3], o_ddgi.stages["output"][..., :3], f"frame {f} DDGI probe-grid sample")
+        compare16(helpers.bits16(g_ddgi.output()), o_ddgi.stages["output"], f"frame {f} DDGI probe-grid sample")
         st = op.stages
         assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TRACE)), st["trace"]), f"frame {f}: reflection trace has one mode"
         assert gp.ray_count() == st["rays"]
         ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
         tc = helpers.bits16(gp.image(gp.IMG_COLOR1 if f & 1 else gp.IMG_COLOR0))
-        compare16(tc[..., :3], st["temporal"][..., :3], f"frame {f} temporal colour")
+        compare16(tc, st["temporal"], f"frame {f} temporal colour + variance", variance_channels=(3,))
+        mo = helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0))
+        compare16(mo, st["moments"], f"frame {f} moments (m1, m2, history length, 0)")
         at = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
-        compare16(at[..., :3], st["atrous"][-1][..., :3], f"frame {f} a-trous colour", exclude=ex)
+        compare16(at, st["atrous"][-1], f"frame {f} a-trous colour + variance", exclude=ex, variance_channels=(3,))
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         if scale:
             ex = upscale_mask(ex, scale, H, W)
-        compare16(out[..., :3], st["output"][..., :3], f"frame {f} reflections output", exclude=ex)
+        compare16(out, st["output"], f"frame {f} reflections output", exclude=ex, variance_channels=(3,))
     gp.close(); g_ddgi.close(); gsc.close()
 
 
@@ -272,5 +284,5 @@ def test_1080p_bench_frame_tolerance(oracle, hr, ctx):
         torch.cuda.synchronize()
         assert np.array_equal(gp.image(gp.IMG_MASK).cpu().numpy().view(np.uint32), op.stages["mask"]), f"frame {k}: mask"
         ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), op.stages["tiles"], f"frame {k}", shape=(H, W))
-        compare16(helpers.bits16(gp.output(hr.OUTPUT_ATROUS))[..., 0], op.stages["output"][..., 0], f"frame {k} denoised visibility", exclude=ex)
+        compare16(helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), op.stages["output"], f"frame {k} denoised visibility + filtered variance", exclude=ex, variance_channels=(1,))
     gp.close(); gsc.close()

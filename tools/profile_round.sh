@@ -7,6 +7,7 @@
 #   sq_counters.txt          SQ instruction / busy counters per kernel (tools/pmc_sets.sh) over the passbench run
 # --pmc passes never carry a trace domain (gpurun refuses the combination).
 # usage: tools/profile_round.sh r2_a [exact]
+#   PASS_ARGS="--width 3840 --height 2160" SKIP_BENCH=1 tools/profile_round.sh r3_4k    the hybrid frame's kernels at 4K only
 NAME=${1:-round}
 EXACT=${2:-0}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,10 +15,12 @@ OUT=$R/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH=(python $R/bench.py --steps 100 --warmup 20 --exact $EXACT)
-PASSES=(python $R/tools/passbench.py --exact $EXACT --frames 6)
+PASSES=(python $R/tools/passbench.py --exact $EXACT --frames 6 $PASS_ARGS)
+if [ -z "$SKIP_BENCH" ]; then
 python $R/bench.py --exact $EXACT 2>/dev/null | tail -1 > $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- "${BENCH[@]}" --no-cpu-baseline --no-passes > /dev/null 2> $OUT/kt.err
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktf -- "${PASSES[@]}" > $OUT/passbench.json 2> $OUT/ktf.err
 cp $(find $OUT/ktf -name '*kernel_stats.csv' | head -1) $OUT/frame_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
