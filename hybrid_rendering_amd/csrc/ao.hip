@@ -328,6 +328,7 @@ struct hr_ao
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0, max_spp = 4;
     DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true, want_stats = false;
+    bool    fuse = true;   // tolerance mode: both blur passes in one launch (developer A/B switch HR_FUSE=0, read once at create)
     int     last_pp = 0;
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
@@ -346,6 +347,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     HR_HIP(hipSetDevice(ctx->device));
     hr_ao* p = new hr_ao();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
@@ -520,6 +522,29 @@ hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* pr
     return HR_OK;
 }
 
+// tolerance mode, radius 4: X and Y pass in one launch, the X image stays in LDS (kf_ao_blur_xy); IMG_BLUR0 is not written
+static hr_status ao_blur_xy(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream_, bool* done)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    AOBlurArgs a;
+    a.in = ImgR16F { (const uint16_t*)p->color[p->last_pp].p, w, y0, y1 };
+    a.depth = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.gb2 = ImgRGBA16F { (const uint2*)in->cur.gb2, w, y0, y1 };
+    a.tile_class = (const uint8_t*)p->tile_class.p;
+    a.out = (uint16_t*)p->blur[1].p;
+    for (int i = 0; i < 4; i++) a.zbp[i] = in->z_buffer_params[i];
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x;
+    a.dx = 1; a.dy = 1; a.radius = prm->blur_radius;
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    int ev = p->prof.begin("blur_xy", st, px * 16);
+    *done = launch_ao_blur_xy_fast(a, st);
+    p->prof.end(ev, st);
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream_)
 {
     HR_CHECK_ARG(p && in && prm);
@@ -553,8 +578,13 @@ hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* i
     if (prm->denoise)
     {
         if ((s = hr_ao_temporal(p, in, prm, stream)) != HR_OK) return s;
-        if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
-        if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->blur_radius == 4 && (s = ao_blur_xy(p, in, prm, stream, &fused)) != HR_OK) return s;
+        if (!fused)
+        {
+            if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
+            if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+        }
         if (p->scale != 0 && (s = hr_ao_upsample(p, in, prm, stream)) != HR_OK) return s;
     }
     return HR_OK;

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                 const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                 const float kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
                 const float sv = fm::lo(t_in[t]);
-                float wv = edge_weight_fast(ek, cz, fm::lo(t_nd[t].y), cn, fm::oct_unit(t_nd[t].x), cv, sv) * kk;
+                float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::lo(t_nd[t].y), cn, fm::oct_unit(t_nd[t].x), cv, sv), kk);
                 if (!t_ok[t]) wv = 0.0f;
                 sum_w += wv;
                 sum_v += wv * sv;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                     const uint32_t s  = fm::ld<uint32_t>(a.in.p, so * 4u);
                     const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
                     const float sv = fm::lo(s);
-                    const float wv = edge_weight_fast(ek, cz, fm::lo(nd.y), cn, fm::oct_unit(nd.x), cv, sv) * (kx * ky);
+                    const float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::lo(nd.y), cn, fm::oct_unit(nd.x), cv, sv), kx * ky);
                     sum_w += wv;
                     sum_v += wv * sv;
                     sum_var += (wv * wv) * fm::hi(s);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
             const uint32_t tv = s_in[ti];
             const float4   tn = s_nz[ti];
             const float    sv = fm::lo(tv);
-            const float    wv = edge_weight_fast(ek, cnz.w, tn.w, cn, mk3(tn.x, tn.y, tn.z), cv, sv) * kk;
+            const float    wv = fm::mul_rn(edge_weight_fast(ek, cnz.w, tn.w, cn, mk3(tn.x, tn.y, tn.z), cv, sv), kk);
             sum_w += wv;
             sum_v += wv * sv;
             sum_var += (wv * wv) * fm::hi(tv);
@@ -598,6 +598,125 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
     }
     *outp = result;
     if (out2p) *out2p = result;
+}
+
+// A-trous iterations 0 and 1 (tap distances 1 and 2, radius 1) in ONE launch: iteration 0's image never leaves LDS.
+// Per 32 x TH output tile: region A = the tile + 4 texels all round is staged once (value/variance + decoded normal + linear z);
+// iteration 0 runs on region B = the tile + 3 (iteration 1 reads B at distance 2 and its 3x3 variance prefilter at distance 1) and
+// is rounded to RG16F exactly as the stored image would be; iteration 1 runs on the tile.  Saves one launch, one 4 B/px image write
+// and the second pass's re-fetch of the 8 B/px normal/depth image at the cost of (B + tile) / (2 tile) filter evaluations.
+// Texel rules are those of kf_shadows_atrous_lds: a texel outside the image / the band's resident rows is (0, normal 0) in BOTH
+// images (weight exactly 0), a texel of a shadow tile is 0 after iteration 0 (copy_shadow_tiles.comp), so the result is
+// bit-identical to the two launches (tests/test_gpu_fused.py).  a.out2 = feedback copy of iteration 1, a.out_first2 = of iteration 0.
+template <int TH, bool N32>
+__global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_t* out_first2, float power1)
+{
+    constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
+    __shared__ uint32_t s_in[AH * AW];
+    __shared__ float4   s_nz[AH * AW];   // unit normal, linear z
+    __shared__ uint32_t s_mid[BH * BW];  // iteration 0, as the RG16F image would hold it
+    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    const int ry0 = a.y0 > 0 ? a.y0 : 0, ry1 = a.y1 < a.h ? a.y1 : a.h;
+    // tile classes of this workgroup's own tiles: all shadow => every output is 0 and nothing is staged
+    int any_cls = 0;
+    if ((int)threadIdx.x < 4 * (TH / 8))
+    {
+        const int tx = (bx0 >> 3) + ((int)threadIdx.x & 3), ty = (by0 >> 3) + ((int)threadIdx.x >> 2);
+        if (tx < a.tiles_x && ty * 8 < a.y1) any_cls = a.tile_class[(size_t)ty * a.tiles_x + tx];
+    }
+    if (!__syncthreads_or(any_cls))
+    {
+        for (int j = threadIdx.x; j < TH * 32; j += 256)
+        {
+            const int x = bx0 + (j & 31), y = by0 + (j >> 5);
+            if (x >= a.w || y >= a.y1) continue;
+            const uint32_t o = (uint32_t)(y * a.w + x);
+            a.out[o] = 0u;
+            if (a.out2) a.out2[o] = 0u;
+            if (out_first2) out_first2[o] = 0u;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < AH * AW; i += 256)
+    {
+        const int  cy = i / AW, cx = i - cy * AW;
+        const int  gx = bx0 - 4 + cx, gy = by0 - 4 + cy;
+        const bool res = gx >= 0 && gx < a.w && gy >= ry0 && gy < ry1;
+        const uint32_t so = res ? (uint32_t)(gy * a.w + gx) : (uint32_t)(ry0 * a.w);
+        const uint32_t v  = fm::ld<uint32_t>(a.in.p, so * 4u);
+        const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
+        const f3       n  = fm::oct_unit(nd.x);
+        s_in[i] = res ? v : 0u;
+        s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::lo(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    EdgeK ek;
+    ek.kz    = 1.44269504088896341f * fm::rcp(a.sigma_depth);
+    ek.phi_n = a.phi_normal;
+    ek.n32   = N32;
+    // one filter evaluation: centre index ci in the A grid, values from `img` (stride IW, centre index vi), taps at distance D
+    auto filter = [&](const uint32_t* img, int IW, int vi, int ci, int D, float power) -> uint32_t {
+        const uint32_t c   = img[vi];
+        const float4   cnz = s_nz[ci];
+        float var = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const int   xx = k % 3 - 1, yy = k / 3 - 1;
+            const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            var += fm::hi(img[vi + yy * IW + xx]) * kw;
+        }
+        if (cnz.w < 0.0f) return c;
+        const f3    cn = mk3(cnz.x, cnz.y, cnz.z);
+        const float cv = fm::lo(c);
+        ek.inv_phi_l = fm::rcp(a.phi_visibility * fm::sqrt1(fm::fmax_(0.0f, 1e-10f + var)));
+        float sum_w = 1.0f, sum_v = cv, sum_var = fm::hi(c);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            const int      k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+            const float    kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
+            const uint32_t tv = img[vi + yy * D * IW + xx * D];
+            const float4   tn = s_nz[ci + yy * D * AW + xx * D];
+            const float    sv = fm::lo(tv);
+            const float    wv = fm::mul_rn(edge_weight_fast(ek, cnz.w, tn.w, cn, mk3(tn.x, tn.y, tn.z), cv, sv), kk);
+            sum_w += wv;
+            sum_v += wv * sv;
+            sum_var += (wv * wv) * fm::hi(tv);
+        }
+        const float iw = fm::rcp(sum_w);
+        float ov = sum_v * iw;
+        const float ovar = sum_var * (iw * iw);
+        if (power != 0.0f) ov = fm::powf_(fm::fmax_(ov, 0.0f), power);
+        return fm::pack2(ov, ovar);
+    };
+    // iteration 0 on region B
+    for (int j = threadIdx.x; j < BH * BW; j += 256)
+    {
+        const int  cy = j / BW, cx = j - cy * BW;
+        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
+        const bool res = gx >= 0 && gx < a.w && gy >= ry0 && gy < ry1;
+        uint32_t   r = 0u;
+        if (res && a.tile_class[(size_t)(gy >> 3) * a.tiles_x + (gx >> 3)])
+        {
+            const int ci = (cy + 1) * AW + cx + 1;
+            r = filter(s_in, AW, ci, ci, 1, 0.0f);
+        }
+        s_mid[j] = r;
+        if (out_first2 && res && cx >= 3 && cx < 35 && cy >= 3 && cy < 3 + TH && gy < a.y1) out_first2[(uint32_t)(gy * a.w + gx)] = r;
+    }
+    __syncthreads();
+    // iteration 1 on the tile
+    for (int j = threadIdx.x; j < TH * 32; j += 256)
+    {
+        const int lx = j & 31, ly = j >> 5, x = bx0 + lx, y = by0 + ly;
+        if (x >= a.w || y >= a.y1) continue;
+        const uint32_t o = (uint32_t)(y * a.w + x);
+        uint32_t r = 0u;
+        if (a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) r = filter(s_mid, BW, (ly + 3) * BW + lx + 3, (ly + 4) * AW + lx + 4, 2, power1);
+        a.out[o] = r;
+        if (a.out2) a.out2[o] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -727,6 +846,92 @@ __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
         total_w += w;
     }
     *outp = fm::half_bits(total_ao * fm::rcp(fm::fmax_(total_w, 0.0001f)));
+}
+
+// Both passes of the separable blur in ONE launch: the X result of the tile's rows + a RADIUS-row apron above
+// and below never leaves LDS.  Per 32 x TH output tile: (32 + 2R) x (TH + 2R) input texels are fetched and decoded once (the
+// two-launch form fetched the tile + apron twice and wrote / re-read the X image: 2 x 74 MB of counter traffic at 1080p for 33 MB of
+// algorithmic bytes), the X pass runs on 32 x (TH + 2R) texels, the Y pass on 32 x TH.  The X result is rounded to fp16 exactly as
+// the R16F blur image stored it, tile classes / sky texels / out-of-band rows follow the same rules texel by texel, so the output
+// is BIT-IDENTICAL to kf_ao_blur run twice (tests/test_gpu_fused.py); IMG_BLUR0 is not written in this form.
+template <int RADIUS, int TH>
+__global__ __launch_bounds__(256) void kf_ao_blur_xy(AOBlurArgs a)
+{
+    constexpr int SW = 32 + 2 * RADIUS, SH = TH + 2 * RADIUS;
+    __shared__ float4  s_nz[SH * SW];      // unit normal, linear eye depth
+    __shared__ float   s_ao[SH * SW];
+    __shared__ uint8_t s_kind[SH * SW];    // 0: not resident (reads as zeros), 1: cleared tile or sky (1.0), 2: filtered
+    __shared__ float   s_x[SH * 32];       // X pass, as the R16F image would hold it
+    __shared__ float   s_gauss[2 * RADIUS + 1];
+    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    const int ox = bx0 - RADIUS, oy = by0 - RADIUS;
+    if ((int)threadIdx.x <= 2 * RADIUS) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - RADIUS), (float)RADIUS * (1.0f / 1.5f));
+    for (int i = threadIdx.x; i < SW * SH; i += 256)
+    {
+        const int  sy = i / SW, sx = i - sy * SW;
+        const int  px = ox + sx, py = oy + sy;
+        const bool ok = !(px < 0 || py < a.y0 || px >= a.w || py >= a.y1);
+        const uint32_t off = ok ? (uint32_t)(py * a.w + px) : (uint32_t)(a.y0 * a.w);
+        float    z  = fm::ld<float>(a.depth.p, off * 4u);
+        uint32_t g2 = fm::ld<uint32_t>(a.gb2.p, off * 8u);
+        uint16_t v  = fm::ld<uint16_t>(a.in.p, off * 2u);
+        const uint8_t tc = a.tile_class[ok ? (size_t)(py >> 3) * a.tiles_x + (px >> 3) : 0];
+        s_kind[i] = !ok ? 0 : ((!tc || z == 1.0f) ? 1 : 2);
+        if (!ok) { z = 0.0f; g2 = 0u; v = 0; }          // texel fetches outside the image read 0 (pinned rule), then decode as usual
+        const f3 n = fm::oct_unit(g2);
+        s_nz[i] = make_float4(n.x, n.y, n.z, fm::rcp_nr(fm::mad_rn(a.zbp[2], z, a.zbp[3])));
+        s_ao[i] = (float)__builtin_bit_cast(_Float16, v);
+    }
+    __syncthreads();
+    // X pass over the tile's columns and SH rows
+    for (int j = threadIdx.x; j < SH * 32; j += 256)
+    {
+        const int sy = j >> 5, sx = j & 31, ci = sy * SW + sx + RADIUS;
+        const uint8_t kind = s_kind[ci];
+        float r = kind == 1 ? 1.0f : 0.0f;
+        if (kind == 2)
+        {
+            const float4 c = s_nz[ci];
+            float total_ao = s_ao[ci], total_w = 1.0f;
+#pragma unroll
+            for (int i = -RADIUS; i <= RADIUS; i++)
+            {
+                if (i == 0) continue;
+                const float4 t  = s_nz[ci + i];
+                const float  wZ = fm::exp2f_(-__builtin_fabsf(c.w - t.w) * 1.44269504088896341f);
+                const float  wN = fm::pow32(fm::sat(c.x * t.x + c.y * t.y + c.z * t.z));
+                const float  w  = s_gauss[i + RADIUS] * (fm::exp2f_((1.0f + wZ) * -1.44269504088896341f) * wN);
+                total_ao += w * s_ao[ci + i];
+                total_w += w;
+            }
+            r = (float)__builtin_bit_cast(_Float16, fm::half_bits(total_ao * fm::rcp(fm::fmax_(total_w, 0.0001f))));
+        }
+        s_x[j] = r;
+    }
+    __syncthreads();
+    // Y pass over the tile
+    for (int j = threadIdx.x; j < TH * 32; j += 256)
+    {
+        const int ly = j >> 5, lx = j & 31, x = bx0 + lx, y = by0 + ly;
+        if (x >= a.w || y >= a.y1) continue;
+        uint16_t* outp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + (uint32_t)(y * a.w + x) * 2u);
+        const int ci = (ly + RADIUS) * SW + lx + RADIUS, xi = (ly + RADIUS) * 32 + lx;
+        if (s_kind[ci] != 2) { *outp = 0x3c00u; continue; }   // cleared image (ray_traced_ao.cpp:1048-1055) / sky
+        const float4 c = s_nz[ci];
+        float total_ao = s_x[xi], total_w = 1.0f;
+#pragma unroll
+        for (int i = -RADIUS; i <= RADIUS; i++)
+        {
+            if (i == 0) continue;
+            const float4 t  = s_nz[ci + i * SW];
+            const float  wZ = fm::exp2f_(-__builtin_fabsf(c.w - t.w) * 1.44269504088896341f);
+            const float  wN = fm::pow32(fm::sat(c.x * t.x + c.y * t.y + c.z * t.z));
+            const float  w  = s_gauss[i + RADIUS] * (fm::exp2f_((1.0f + wZ) * -1.44269504088896341f) * wN);
+            total_ao += w * s_x[xi + i * 32];
+            total_w += w;
+        }
+        *outp = fm::half_bits(total_ao * fm::rcp(fm::fmax_(total_w, 0.0001f)));
+    }
 }
 
 // run-time radius: plain gathers
@@ -946,7 +1151,7 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
             auto tap = [&](uint2 q, uint32_t q2x, uint32_t q3y, float kk, bool ok) {
                 const f3    sc = mk3(fm::lo(q.x), fm::hi(q.x), fm::lo(q.y));
                 const float sl = fm::fmax_(0.299f * sc.x + 0.587f * sc.y + 0.114f * sc.z, 0.0001f);
-                float wc = edge_weight_fast(ek, center_depth, fm::hi(q3y), cn, fm::oct_unit(q2x), center_luma, sl) * kk;
+                float wc = fm::mul_rn(edge_weight_fast(ek, center_depth, fm::hi(q3y), cn, fm::oct_unit(q2x), center_luma, sl), kk);
                 if (!ok) wc = 0.0f;
                 sum_w += wc;
                 s0 += wc * sc.x; s1 += wc * sc.y; s2 += wc * sc.z;
@@ -1007,6 +1212,102 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
     if (a.out2) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out2) + o * 8u) = result;
 }
 
+
+// Reflections a-trous iterations 0 and 1 in ONE launch (the scheme of kf_shadows_atrous01: A = tile + 4 staged once, iteration 0
+// on B = tile + 3 rounded to RGBA16F as stored, iteration 1 on the tile).  Texel rules of kf_refl_atrous, texel by texel: outside
+// the image -> weight 0 (staged with a zero normal); inside the image but outside the band's resident rows -> zeros that DO enter
+// the sums (halo rows only), in both images; sky -> 0; copy tiles and mirror / DDGI-rough texels pass through.  Bit-identical to the
+// two launches (tests/test_gpu_fused.py).
+template <int TH, bool N32>
+__global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2* out_first2)
+{
+    constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
+    __shared__ uint2  s_in[AH * AW];
+    __shared__ float4 s_nz[AH * AW];    // unit normal (0 outside the image), linear z
+    __shared__ float  s_r[AH * AW];     // roughness; -1: sky texel
+    __shared__ uint2  s_mid[BH * BW];
+    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    for (int i = threadIdx.x; i < AH * AW; i += 256)
+    {
+        const int  cy = i / AW, cx = i - cy * AW;
+        const int  gx = bx0 - 4 + cx, gy = by0 - 4 + cy;
+        const bool img = gx >= 0 && gx < a.w && gy >= 0 && gy < a.h;
+        const bool res = img && gy >= a.in.y0 && gy < a.in.y1;
+        const uint32_t so = res ? (uint32_t)(gy * a.w + gx) : (uint32_t)(a.in.y0 * a.w);
+        uint2    c  = fm::ld<uint2>(a.in.p, so * 8u);
+        uint32_t g2 = fm::ld<uint32_t>(a.gb2.p, so * 8u);
+        uint2    g3 = fm::ld<uint2>(a.gb3.p, so * 8u);
+        float    d  = fm::ld<float>(a.depth.p, so * 4u);
+        if (!res) { c = make_uint2(0u, 0u); g2 = 0u; g3 = make_uint2(0u, 0u); d = 0.0f; }
+        const f3 n = fm::oct_unit(g2);
+        s_in[i] = c;
+        s_nz[i] = img ? make_float4(n.x, n.y, n.z, fm::hi(g3.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_r[i]  = d == 1.0f ? -1.0f : fm::lo(g3.x);
+    }
+    __syncthreads();
+    EdgeK ek;
+    ek.kz    = 1.44269504088896341f * fm::rcp(a.sigma_depth);
+    ek.phi_n = a.phi_normal;
+    ek.n32   = N32;
+    auto filter = [&](const uint2* img, int IW, int vi, int ci, int D) -> uint2 {
+        const uint2 c = img[vi];
+        const float roughness = s_r[ci];
+        if (roughness == -1.0f) return make_uint2(0u, 0u);
+        if (roughness < 0.05f || (a.approximate_with_ddgi == 1 && roughness > 0.75f)) return c;
+        float var = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const int   xx = k % 3 - 1, yy = k / 3 - 1;
+            const float kw = (xx == 0 ? (yy == 0 ? 0.25f : 0.125f) : (yy == 0 ? 0.125f : 0.0625f));
+            var += fm::hi(img[vi + yy * IW + xx].y) * kw;
+        }
+        const float4 cnz = s_nz[ci];
+        const f3     cn  = mk3(cnz.x, cnz.y, cnz.z);
+        const f3     cc  = mk3(fm::lo(c.x), fm::hi(c.x), fm::lo(c.y));
+        const float  center_luma = fm::fmax_(0.299f * cc.x + 0.587f * cc.y + 0.114f * cc.z, 0.0001f);
+        ek.inv_phi_l = fm::rcp(a.phi_color * fm::sqrt1(fm::fmax_(0.0f, 1e-10f + var)));
+        float sum_w = 1.0f, s0 = cc.x, s1 = cc.y, s2 = cc.z, s3 = fm::hi(c.y);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            const int    k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
+            const float  kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
+            const uint2  q  = img[vi + yy * D * IW + xx * D];
+            const float4 tn = s_nz[ci + yy * D * AW + xx * D];
+            const f3     sc = mk3(fm::lo(q.x), fm::hi(q.x), fm::lo(q.y));
+            const float  sl = fm::fmax_(0.299f * sc.x + 0.587f * sc.y + 0.114f * sc.z, 0.0001f);
+            const float  wc = fm::mul_rn(edge_weight_fast(ek, cnz.w, tn.w, cn, mk3(tn.x, tn.y, tn.z), center_luma, sl), kk);
+            sum_w += wc;
+            s0 += wc * sc.x; s1 += wc * sc.y; s2 += wc * sc.z;
+            s3 += (wc * wc) * fm::hi(q.y);
+        }
+        const float iw = fm::rcp(sum_w);
+        return make_uint2(fm::pack2(s0 * iw, s1 * iw), fm::pack2(s2 * iw, s3 * (iw * iw)));
+    };
+    for (int j = threadIdx.x; j < BH * BW; j += 256)
+    {
+        const int  cy = j / BW, cx = j - cy * BW;
+        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
+        const bool res = gx >= 0 && gx < a.w && gy >= (a.y0 > 0 ? a.y0 : 0) && gy < (a.y1 < a.h ? a.y1 : a.h);
+        const int  ci = (cy + 1) * AW + cx + 1;
+        uint2      r = make_uint2(0u, 0u);
+        if (res) r = a.tile_class[(size_t)(gy >> 3) * a.tiles_x + (gx >> 3)] ? filter(s_in, AW, ci, ci, 1) : s_in[ci];
+        s_mid[j] = r;
+        if (out_first2 && res && cx >= 3 && cx < 35 && cy >= 3 && cy < 3 + TH) out_first2[(uint32_t)(gy * a.w + gx)] = r;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TH * 32; j += 256)
+    {
+        const int lx = j & 31, ly = j >> 5, x = bx0 + lx, y = by0 + ly;
+        if (x >= a.w || y >= a.y1) continue;
+        const uint32_t o = (uint32_t)(y * a.w + x);
+        const int vi = (ly + 3) * BW + lx + 3;
+        const uint2 r = a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] ? filter(s_mid, BW, vi, (ly + 4) * AW + lx + 4, 2) : s_mid[vi];
+        a.out[o] = r;
+        if (a.out2) a.out2[o] = r;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // gi_sample_probe_grid.comp:75-99 + sample_irradiance (gi_common.glsl:188-320), tolerance mode.  Hoisted out of the 8-probe
@@ -1211,6 +1512,20 @@ void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
 #undef HR_LAUNCH_ATROUS
 }
 
+#ifndef FT_ATROUS01_TH
+#define FT_ATROUS01_TH 16
+#endif
+// iterations 0 + 1 in one launch; `a` describes iteration 0 (a.in = temporal output, a.step == 1), a.out = the image iteration 1
+// writes, a.out2 / out_first2 = the feedback copy of iteration 1 / 0, power1 = iteration 1's power.  false: not available
+bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, float power1, hipStream_t st)
+{
+    if (a.radius != 1 || a.step != 1) return false;
+    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_ATROUS01_TH));
+    if (a.phi_normal == 32.0f) hipLaunchKernelGGL((kf_shadows_atrous01<FT_ATROUS01_TH, true>), grid, dim3(256), 0, st, a, out_first2, power1);
+    else hipLaunchKernelGGL((kf_shadows_atrous01<FT_ATROUS01_TH, false>), grid, dim3(256), 0, st, a, out_first2, power1);
+    return true;
+}
+
 void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st)
 {
     const dim3 grid(cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
@@ -1223,6 +1538,16 @@ void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
     const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
     if (a.radius == 4) hipLaunchKernelGGL(kf_ao_blur<4>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(kf_ao_blur_generic, grid, dim3(256), 0, st, a);
+}
+
+#ifndef FT_AO_BLUR_TH
+#define FT_AO_BLUR_TH 16
+#endif
+bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
+{
+    if (a.radius != 4) return false;   // other radii keep the two-launch form
+    hipLaunchKernelGGL((kf_ao_blur_xy<4, FT_AO_BLUR_TH>), dim3(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_AO_BLUR_TH)), dim3(256), 0, st, a);
+    return true;
 }
 
 void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st)
@@ -1242,6 +1567,18 @@ void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)
     else if (a.radius == 1 && a.step == 8) HR_LAUNCH_RATROUS(8);
     else HR_LAUNCH_RATROUS(0);
 #undef HR_LAUNCH_RATROUS
+}
+
+#ifndef FT_RATROUS01_TH
+#define FT_RATROUS01_TH 16
+#endif
+bool launch_refl_atrous01_fast(const ReflAtrousArgs& a, uint2* out_first2, hipStream_t st)
+{
+    if (a.radius != 1 || a.step != 1) return false;
+    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_RATROUS01_TH));
+    if (a.phi_normal == 32.0f) hipLaunchKernelGGL((kf_refl_atrous01<FT_RATROUS01_TH, true>), grid, dim3(256), 0, st, a, out_first2);
+    else hipLaunchKernelGGL((kf_refl_atrous01<FT_RATROUS01_TH, false>), grid, dim3(256), 0, st, a, out_first2);
+    return true;
 }
 
 void launch_ddgi_sample_fast(const DDGISampleArgs& a, hipStream_t st)

@@ -35,6 +35,9 @@ HR_DEV float mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1
 // a * b + c with TWO roundings (this header is compiled with fp-contract off; only __builtin_fmaf fuses): for denominators the
 // oracle forms that way and whose reciprocals are then subtracted from one another
 HR_DEV float mad_rn(float a, float b, float c) { return a * b + c; }
+// a * b that never fuses with a following add (a tap weight that is summed AND multiplied further: the fused and unfused forms of
+// a filter must round it alike to stay bit-identical to each other)
+HR_DEV float mul_rn(float a, float b) { return a * b; }
 // reciprocal refined by one Newton step (~0.5 ulp): for quantities whose DIFFERENCES are used (linear eye depth of neighbouring
 // texels cancels 3-4 digits in the bilateral depth weight)
 HR_DEV float rcp_nr(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }

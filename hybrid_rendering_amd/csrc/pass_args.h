@@ -120,10 +120,13 @@ struct DDGISampleArgs
 // masks never pass through them (the trace kernels have one mode).
 void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st);
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st);
+bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, float power1, hipStream_t st);   // iterations 0 + 1 in one launch
 void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st);
 void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st);
+bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st);   // X + Y in one launch (radius 4); false: not available for these arguments
 void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st);
 void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st);
+bool launch_refl_atrous01_fast(const ReflAtrousArgs& a, uint2* out_first2, hipStream_t st);   // iterations 0 + 1 in one launch
 void launch_ddgi_sample_fast(const DDGISampleArgs& a, hipStream_t st);
 void launch_upsample_fast(const UpsampleArgs& a, hipStream_t st);
 

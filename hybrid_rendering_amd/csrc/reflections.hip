@@ -405,6 +405,7 @@ struct hr_reflections
     DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true;
     int     read_idx = 0, last_pp = 0;
+    bool    fuse = true;   // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0, read once at create)
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
 };
@@ -425,6 +426,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     HR_HIP(hipSetDevice(ctx->device));
     hr_reflections* p = new hr_reflections();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+    if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
@@ -588,6 +590,33 @@ hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inpu
     return HR_OK;
 }
 
+// tolerance mode, radius 1: iterations 0 and 1 in one launch (kf_refl_atrous01; iteration 0's image stays in LDS)
+static hr_status reflections_atrous01(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* prm, void* stream_, bool* done)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    ReflAtrousArgs a;
+    auto img = [&](const void* ptr) { return ImgRGBA16F { (const uint2*)ptr, w, y0, y1 }; };
+    a.in = img(p->color[p->last_pp].p);
+    a.gb2 = img(in->cur.gb2); a.gb3 = img(in->cur.gb3); a.depth = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.tile_class = (const uint8_t*)p->tile_class.p;
+    a.out = (uint2*)p->atrous[0].p;
+    a.out2 = (prm->feedback_iteration == 1 && prm->blur_as_input) ? (uint2*)p->prev_image.p : nullptr;
+    uint2* first2 = (prm->feedback_iteration == 0 && prm->blur_as_input) ? (uint2*)p->prev_image.p : nullptr;
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x; a.radius = prm->radius; a.step = 1;
+    a.phi_color = prm->phi_color; a.phi_normal = prm->phi_normal; a.sigma_depth = prm->sigma_depth;
+    a.approximate_with_ddgi = prm->approximate_with_ddgi ? 1 : 0;
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    // algorithmic bytes: in 8 + GB2 8 + GB3 8 + depth 4 + out 8 — the G-buffer counts once for the two iterations
+    int ev = p->prof.begin("atrous_01", st, px * 36);
+    *done = launch_refl_atrous01_fast(a, first2, st);
+    p->prof.end(ev, st);
+    if (*done) p->read_idx = 0;
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* prm, void* stream_)
 {
     HR_CHECK_ARG(p && in && prm);
@@ -620,7 +649,10 @@ hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const 
     if (prm->denoise)
     {
         if ((s = hr_reflections_temporal(p, in, prm, stream)) != HR_OK) return s;
-        for (int i = 0; i < prm->filter_iterations; i++)
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+            (s = reflections_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
             if ((s = hr_reflections_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
         if (p->scale != 0 && (s = hr_reflections_upsample(p, in, prm, stream)) != HR_OK) return s;
     }

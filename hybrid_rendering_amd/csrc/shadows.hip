@@ -509,6 +509,7 @@ struct hr_shadows
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
+    bool          fuse = true;              // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0)
     bool          persistent_waves = false; // HR_TRACE_KERNEL=queue selects the persistent-wave ray-queue kernel (A/B measurements)
     // developer switches (tools/timeline.py, tools/passbench.py), read from the environment ONCE in hr_shadows_create — the
     // render path never calls getenv
@@ -535,6 +536,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     { const char* e = getenv("HR_TRACE_KERNEL"); p->persistent_waves = (e && std::string(e) == "queue"); }
     if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &p->dbg_only_tx, &p->dbg_only_ty);
+    if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
     p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
     p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
@@ -822,6 +824,35 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     return HR_OK;
 }
 
+// tolerance mode, radius 1: iterations 0 and 1 in one launch (kf_shadows_atrous01; iteration 0's image stays in LDS)
+static hr_status shadows_atrous01(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_, bool* done)
+{
+    hr_status s = check_inputs(p, in, false);
+    if (s != HR_OK) return s;
+    hipStream_t st = (hipStream_t)stream_;
+    p->last_stream = st;
+    AtrousArgs a;
+    const int w = p->w, y0 = p->y0, y1 = p->y1;
+    a.in  = ImgRG16F { (const uint32_t*)p->temporal_out.p, w, y0, y1 };
+    a.nd = (const float4*)p->nd.p;
+    a.tile_class = (const uint8_t*)p->tile_class.p;
+    a.out  = (uint32_t*)p->atrous[0].p;   // iteration 1 writes atrous[0] (ping-pong of a_trous_filter(), :1101-1107)
+    a.out2 = (prm->feedback_iteration == 1) ? (uint32_t*)p->prev_image.p : nullptr;
+    uint32_t* first2 = (prm->feedback_iteration == 0) ? (uint32_t*)p->prev_image.p : nullptr;
+    a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1; a.tiles_x = p->tiles_x;
+    a.radius = prm->radius; a.step = 1;
+    a.phi_visibility = prm->phi_visibility; a.phi_normal = prm->phi_normal; a.sigma_depth = prm->sigma_depth;
+    a.power = 0.0f;
+    const uint64_t px = (uint64_t)w * (y1 - y0);
+    // algorithmic bytes: in 4 + normal/depth 8 + out 4 (+ 4 feedback); the G-buffer side image counts once
+    int ev = p->prof.begin("atrous_01", st, px * 16 + ((a.out2 || first2) ? px * 4 : 0));
+    *done = launch_shadows_atrous01_fast(a, first2, prm->filter_iterations == 2 ? prm->power : 0.0f, st);
+    p->prof.end(ev, st);
+    if (*done) p->read_idx = 0;
+    HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
 hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_)
 {
     HR_CHECK_ARG(p && in && prm);
@@ -855,7 +886,10 @@ hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame
     if (prm->denoise)
     {
         if ((s = hr_shadows_temporal(p, in, prm, stream)) != HR_OK) return s;
-        for (int i = 0; i < prm->filter_iterations; i++)
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+            (s = shadows_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
             if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
         if (p->scale != 0 && (s = hr_shadows_upsample(p, in, prm, stream)) != HR_OK) return s;
     }
