@@ -50,12 +50,42 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 NODE_BYTES, TRI_BYTES = 80, 48
-# stage name of the pass profilers -> kernel name in the rocprofv3 files of profiles/
-KERNEL_OF = {("shadows", "ray_trace"): "k_shadows_trace<false>", ("shadows", "temporal_accumulation"): "kf_shadows_temporal", ("shadows", "atrous"): "kf_shadows_atrous",
-             ("ao", "ray_trace"): "k_ao_trace<false>", ("ao", "temporal_accumulation"): "kf_ao_temporal", ("ao", "blur"): "kf_ao_blur",
-             ("ddgi", "ray_trace"): "k_ddgi_trace", ("ddgi", "sample_probe_grid"): "kf_ddgi_sample", ("ddgi", "irradiance_probe_update"): "k_ddgi_probe_update<false",
-             ("ddgi", "depth_probe_update"): "k_ddgi_probe_update<true", ("reflections", "ray_trace"): "k_refl_trace",
-             ("reflections", "temporal_accumulation"): "kf_refl_temporal", ("reflections", "atrous"): "kf_refl_atrous", ("reflections", "upsample"): "kf_upsample"}
+# stage name of a pass profiler -> EXACT kernel instance (normalised rocprofv3 name: no "void", namespaces or argument list), so that
+# every a-trous step / template instance carries its own counters (a substring match gave steps 1..8 step 1's traffic)
+def kernel_of(pass_, stage, exact):
+    step = {"atrous_0": 1, "atrous_1": 2, "atrous_2": 4, "atrous_3": 8}
+    if pass_ == "shadows":
+        if stage == "ray_trace": return "k_shadows_trace<false>"
+        if stage == "temporal_accumulation": return "k_shadows_temporal" if exact else "kf_shadows_temporal"
+        if stage == "atrous_01": return "kf_shadows_atrous01<16, true>"
+        if stage in step:
+            if exact: return "k_shadows_atrous<1, true>"       # one instance serves the four iterations in the parity mode
+            return ("kf_shadows_atrous_lds<%d, true>" if step[stage] <= 2 else "kf_shadows_atrous<%d, true>") % step[stage]
+    if pass_ == "ao":
+        if stage == "ray_trace": return "k_ao_trace<false>"
+        if stage == "temporal_accumulation": return "k_ao_temporal" if exact else "kf_ao_temporal<true>"
+        if stage == "blur_xy": return "kf_ao_blur_xy<4, 16>"
+        if stage in ("blur_x", "blur_y"): return "k_ao_blur<4>" if exact else "kf_ao_blur<4>"   # two launches of one instance: the counters average X and Y
+    if pass_ == "ddgi":
+        return {"ray_trace": "k_ddgi_trace", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
+                "sample_probe_grid": "k_ddgi_sample" if exact else "kf_ddgi_sample"}.get(stage)
+    if pass_ == "reflections":
+        if stage == "ray_trace": return "k_refl_trace"
+        if stage == "temporal_accumulation": return "k_refl_temporal" if exact else "kf_refl_temporal"
+        if stage == "atrous_01": return "kf_refl_atrous01<16, true>"
+        if stage in step: return "k_refl_atrous<1>" if exact else "kf_refl_atrous<%d, true>" % step[stage]
+        if stage == "upsample": return "k_upsample<4>" if exact else "kf_upsample<4>"
+    return None
+
+
+def norm_kernel(name):
+    n = re.sub(r"^void\s+", "", name.strip())
+    n = n.replace("(anonymous namespace)::", "").replace("hr::", "")
+    return n.split("(")[0].strip()
+
+
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+N_XCD = 8                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
 
 
 def parse():
@@ -76,69 +106,82 @@ def parse():
     return ap.parse_args()
 
 
-def load_profile():
-    """latest profiles/r*/ directory of this build: per-kernel PMC traffic (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md §HBM) and
-    SQ counters -> what bounds each kernel.  PMC cannot be sampled from inside this process: the files are committed with the build."""
-    prof = {"dir": None, "traffic": {}, "valu_busy": {}, "lanes": {}}
+def load_profile(suffix=""):
+    """latest profiles/r*/ directory of this build that holds the counters for this frame size (suffix "" = 1080p, "_4k" = 3840x2160;
+    tools/profile_round.sh): per-kernel PMC traffic, raw SQ counters and rocprofv3's average duration, keyed by the EXACT normalised
+    kernel name.  PMC cannot be sampled from inside this process: the files are committed with the build, and every number taken
+    from them is marked stale when the kernel's live HIP-event time is more than 10 % off the profiled duration.
+      traffic     = 2 * FETCH_SIZE + WRITE_SIZE   FETCH_SIZE tallies every L2 -> fabric read request at 64 B; a streaming read's requests
+                                                  are 128 B (profiles/r3_calib: streams read back exactly 1/2 of their bytes, writes 1/1)
+      traffic_lo  = FETCH_SIZE + WRITE_SIZE       a sparse gather's requests are 64 B (r3_calib: 4 B gathers, one per line, tally 64 B per
+                                                  lane; two lanes on the two halves of a line tally 64 B per pair): BVH-walking kernels lie
+                                                  between the two
+      valu_issue_frac  = 4 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   share of the SIMD cycles a VALU instruction issues in
+      lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)             active lanes per issued VALU instruction
+    (the derived VALUBusy of this rocprofv3 falls back to gfx94x formulas and exceeds 100 %: not used)"""
+    prof = {"dir": None, "traffic": {}, "traffic_lo": {}, "sq": {}, "avg_us": {}, "suffix": suffix}
     try:
         pd = os.path.join(ROOT, "profiles")
-        dirs = sorted(d for d in os.listdir(pd) if os.path.exists(os.path.join(pd, d, "pmc_summary.json")))
+        dirs = sorted(d for d in os.listdir(pd) if os.path.exists(os.path.join(pd, d, f"pmc_summary{suffix}.json")))
         if not dirs:
             return prof
         d = os.path.join(pd, dirs[-1])
         prof["dir"] = "profiles/" + dirs[-1]
-        for k, v in json.load(open(os.path.join(d, "pmc_summary.json"))).items():
+        for k, v in json.load(open(os.path.join(d, f"pmc_summary{suffix}.json"))).items():
             if "FETCH_SIZE_KB_avg_per_launch" in v and "WRITE_SIZE_KB_avg_per_launch" in v:
-                prof["traffic"][k] = int((2 * v["FETCH_SIZE_KB_avg_per_launch"] + v["WRITE_SIZE_KB_avg_per_launch"]) * 1024)
-        sq = os.path.join(d, "sq_counters.txt")
+                f_, w_ = v["FETCH_SIZE_KB_avg_per_launch"] * 1024, v["WRITE_SIZE_KB_avg_per_launch"] * 1024
+                prof["traffic"][norm_kernel(k)] = int(2 * f_ + w_)
+                prof["traffic_lo"][norm_kernel(k)] = int(f_ + w_)
+        sq = os.path.join(d, f"sq_counters{suffix}.json")
         if os.path.exists(sq):
-            cur = None
-            vals = {}
-            for line in open(sq):
-                if line and not line[0].isspace():
-                    cur = line.strip()
-                    vals[cur] = {}
-                else:
-                    m = re.match(r"\s+(\S+)\s+avg\s+([\d.]+)", line)
-                    if m and cur:
-                        vals[cur][m.group(1)] = float(m.group(2))
-            for k, v in vals.items():
-                if "VALUBusy" in v:
-                    prof["valu_busy"][k] = v["VALUBusy"]
-                if v.get("SQ_ACTIVE_INST_VALU"):
-                    prof["lanes"][k] = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * v["SQ_ACTIVE_INST_VALU"])
-    except Exception:
-        pass
+            prof["sq"] = {norm_kernel(k): v for k, v in json.load(open(sq)).items()}
+        import csv
+        for fn in (f"kernel_stats{suffix}.csv", f"frame_kernel_stats{suffix}.csv"):   # the frame file wins: same command as the counters
+            fp = os.path.join(d, fn)
+            if os.path.exists(fp):
+                for row in csv.DictReader(open(fp)):
+                    prof["avg_us"][norm_kernel(row["Name"])] = float(row["AverageNs"]) / 1e3
+    except Exception as e:
+        prof["error"] = repr(e)[:200]
     return prof
 
 
-def lookup(table, kernel):
-    for k, v in table.items():
-        if kernel in k:
-            return v
-    return None
-
-
-def classify(prof, kernel, ms, alg_bytes):
-    """-> dict(frac, dram_frac, bound): `bound` from the measurements — VALU-bound if the SIMDs issue > 70 % of the time, HBM-bound if
-    the counter traffic moves at > 50 % of peak, else latency-bound (dependent fetches / too few bytes in flight)."""
-    out = {"frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 and alg_bytes else None}
-    tr, vb = lookup(prof["traffic"], kernel), lookup(prof["valu_busy"], kernel)
-    out["traffic"] = tr
-    out["dram_frac"] = round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and ms > 0 else None
-    if vb is None and tr is None:
+def classify(prof, kernel, ms, alg_bytes, gather=False):
+    """-> dict(frac, traffic, dram_frac, valu_issue_frac, lane_utilisation, valu_frac, bound, ...) for ONE kernel instance (exact name).
+    bound: `valu` if VALU instructions issue in > 70 % of the SIMD cycles, `hbm` if the counter traffic moves at > 50 % of peak, else
+    `latency` (dependent fetches / too little in flight).  valu_frac = issue share x lane utilisation = the part of the VALU roof that does
+    useful work; it is the operative roofline figure of a `valu` kernel (an HBM fraction says little about it)."""
+    out = {"kernel": kernel, "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 and alg_bytes else None}
+    tr, sq, avg = prof["traffic"].get(kernel), prof["sq"].get(kernel), prof["avg_us"].get(kernel)
+    state = None
+    if avg is not None and ms > 0:
+        out["profile_avg_us"] = round(avg, 2)
+        state = "fresh" if abs(ms * 1e3 - avg) <= 0.10 * avg + 3.0 else "stale"   # + 3 us: the HIP-event pair includes the launch gap
+        out["profile_state"] = state
+    if tr is not None:
+        out["traffic"] = tr
+        out["dram_frac"] = round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None
+        if gather:
+            out["traffic_lo"] = prof["traffic_lo"].get(kernel)
+    if sq and sq.get("SQ_INSTS_VALU") and sq.get("GRBM_GUI_ACTIVE"):
+        raw = 4.0 * sq["SQ_INSTS_VALU"] / (N_SIMD * sq["GRBM_GUI_ACTIVE"] / N_XCD)
+        # the 4-cycles-per-wave64-instruction model over-counts kernels with long EXEC-masked stretches (a fully masked VALU instruction
+        # retires faster): raw values of 1.0-1.4 were measured on the trace and probe-update kernels; they mean "saturated"
+        out["valu_issue_frac"] = round(min(raw, 1.0), 3)
+        if raw > 1.0:
+            out["valu_issue_raw"] = round(raw, 3)
+    if sq and sq.get("SQ_ACTIVE_INST_VALU"):
+        out["lane_utilisation"] = round(sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 3)
+    if "valu_issue_frac" in out and "lane_utilisation" in out:
+        out["valu_frac"] = round(out["valu_issue_frac"] * out["lane_utilisation"], 3)
+    if "valu_issue_frac" not in out and tr is None:
         out["bound"] = None
-    elif vb is not None and vb > 70.0:
+    elif out.get("valu_issue_frac", 0.0) > 0.70:
         out["bound"] = "valu"
-    elif out["dram_frac"] is not None and out["dram_frac"] > 0.5:
+    elif (out.get("dram_frac") or 0.0) > 0.5:
         out["bound"] = "hbm"
     else:
         out["bound"] = "latency"
-    if vb is not None:
-        out["valu_busy_pct"] = round(vb, 1)
-    ln = lookup(prof["lanes"], kernel)
-    if ln is not None:
-        out["lane_utilisation"] = round(ln, 2)
     return out
 
 
@@ -303,15 +346,13 @@ def main():
     if "ray_trace" in stages:
         stages["ray_trace"]["bytes"] = int(trace_bytes)
     prof = load_profile()
-    if not (world == 1 and (W, H) == (1920, 1080) and not args.obj and args.tier == "standard"):
-        # another frame size / scene than the profiled one: the per-launch counter traffic does not carry over; what the SQ counters say
-        # about the SAME kernels (VALU busy, lane utilisation -> `bound`) is kept as the best available classification
-        prof = dict(prof, traffic={})
+    profiled_config = world == 1 and (W, H) == (1920, 1080) and not args.obj and args.tier == "standard"
+    if not profiled_config:
+        # another frame size / scene than the profiled one: neither the per-launch counter traffic nor the durations carry over
+        prof = dict(prof, traffic={}, traffic_lo={}, avg_us={}, sq={})
     for n, s in stages.items():
-        kern = KERNEL_OF.get(("shadows", re.sub(r"_\d+$", "", n)), n)
-        if exact:
-            kern = kern.replace("kf_", "k_")
-        s.update(classify(prof, kern, s["ms"], s["bytes"]))
+        kern = kernel_of("shadows", n, exact) or n
+        s.update(classify(prof, kern, s["ms"], s["bytes"], gather=(n == "ray_trace")))
         s["GBps"] = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
 
     total_rays = rays_per_frame * args.steps * world
@@ -336,13 +377,18 @@ def main():
         "denoised_frames_per_s": round(args.steps / elapsed, 2),                  # frames of W x H (the whole tiled frame)
         "denoised_1080p_equiv_per_s": round(W * H / (args.width * args.height) * args.steps / elapsed, 2),
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
-        "roofline": {"kernel": dom[0], "bound": dom[1].get("bound") or "latency", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom[1]["frac"], "traffic": dom[1].get("traffic"), "dram_frac": dom[1].get("dram_frac"),
-                     "traffic_source": (prof["dir"] + "/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch)") if (prof["dir"] and dom[1].get("traffic")) else None,
-                     "bound_source": (prof["dir"] + "/sq_counters.txt (1080p bench frame)") if prof["dir"] else None,
+        "roofline": {"kernel": dom[0], "kernel_name": dom[1].get("kernel"), "bound": dom[1].get("bound") or "latency", "achieved": round(dom[1]["GBps"], 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dom[1]["frac"], "traffic": dom[1].get("traffic"), "traffic_lo": dom[1].get("traffic_lo"), "dram_frac": dom[1].get("dram_frac"),
+                     "valu_issue_frac": dom[1].get("valu_issue_frac"), "lane_utilisation": dom[1].get("lane_utilisation"), "valu_frac": dom[1].get("valu_frac"),
+                     "profile_avg_us": dom[1].get("profile_avg_us"), "live_event_us": round(dom[1]["ms"] * 1e3, 2),
+                     "traffic_source": ((prof["dir"] + "/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE per launch; traffic_lo = FETCH_SIZE + WRITE_SIZE: profiles/r3_calib)"
+                                         + ("" if dom[1].get("profile_state") != "stale" else " — STALE: the live kernel time is > 10 % off the profiled one")))
+                                       if (prof["dir"] and dom[1].get("traffic")) else None,
+                     "bound_source": (prof["dir"] + "/sq_counters.json (raw SQ_INSTS_VALU, GRBM_GUI_ACTIVE, SQ_THREAD_CYCLES_VALU, SQ_ACTIVE_INST_VALU; 1080p bench frame)") if prof["dir"] else None,
                      "algorithmic_bytes": int(dom[1]["bytes"]),
-                     "note": "achieved/frac divide the ALGORITHMIC bytes (SURVEY §8d: G-buffer + mask + visited BVH nodes x 80 B + tested triangles x 48 B) by the kernel time; "
-                             "the 15 MB BVH is served by L2 / Infinity Cache, so dram_frac (counter traffic) is the HBM-side figure and `bound` is what the SQ counters show"},
+                     "note": "achieved/frac divide the ALGORITHMIC bytes (SURVEY 8d: G-buffer + mask + visited BVH nodes x 80 B + tested triangles x 48 B) by the kernel time; "
+                             "the 15 MB BVH is served by L2 / Infinity Cache, so dram_frac (counter traffic) is the HBM-side figure; the operative roof of this kernel is "
+                             "VALU issue: valu_frac = valu_issue_frac x lane_utilisation is the share of the VALU roof doing useful work"},
         "stages": {n: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()} for n, s in stages.items()},
     }
 
@@ -404,17 +450,8 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     label = {"ao": "AO 4 spp + temporal + 2 blurs, 1920x1080 (configs[2])", "reflections": "reflections 1 spp at half resolution + SVGF + upsample, 1920x1080 frame (configs[3])",
              "ddgi": "DDGI 16x8x16 probes x 256 rays: trace + probe updates + per-pixel sample, 1920x1080", "shadows": "shadows 1 spp + SVGF, 1920x1080 (inside the hybrid frame)"}
     for n in ("ao", "reflections", "ddgi", "shadows"):
-        kern = {}
-        for s, (ms, b) in st[n].items():
-            k = KERNEL_OF.get((n, re.sub(r"(_\d+|_x|_y)$", "", s)), s)
-            if exact:
-                k = k.replace("kf_", "k_")
-            e = {"ms": round(ms, 4), "kernel": k}
-            c = classify(prof, k, ms, b if "ray_trace" not in s else 0)
-            e.update({kk: vv for kk, vv in c.items() if vv is not None})
-            kern[s] = e
         res[n] = {"workload": label[n], "ms_per_frame": round(wall[n], 4), "frames_per_s": round(1e3 / wall[n], 1), "rays_per_frame": rays[n],
-                  "Mrays_per_s": round(rays[n] / wall[n] / 1e3, 1), "kernels": kern}
+                  "Mrays_per_s": round(rays[n] / wall[n] / 1e3, 1), "kernels": kernel_entries(prof, n, st[n], exact)}
     res["hybrid_1080p"] = {"workload": "whole hybrid frame 1920x1080 on one GPU: shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, one stream",
                            "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1),
                            "concurrent_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
@@ -433,13 +470,32 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     r4 = hf4.ray_counts()
     hf4.concurrent_streams(True)
     ms43 = hf4.time(8, 4, repeats=3)
+    hf4.concurrent_streams(False)
+    st4 = hf4.stage_times(8)
+    prof4 = load_profile("_4k")
     res["hybrid_4k_one_gpu"] = {"workload": "whole hybrid frame 3840x2160 on ONE GPU (BASELINE configs[4] names 8)", "ms_per_frame": round(ms4, 4), "frames_per_s": round(1e3 / ms4, 1),
-                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "concurrent_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)}}
+                                "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "concurrent_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)},
+                                "kernels": {n: kernel_entries(prof4, n, st4[n], exact) for n in ("shadows", "ao", "ddgi", "reflections")},
+                                "kernels_note": "per-kernel HIP-event times of the 4K frame; counters from " + (prof4["dir"] or "(no 4K profile committed)") +
+                                                " (*_4k files: the working set of a 4K pass exceeds the 256 MiB Infinity Cache, so dram_frac is an HBM figure here)"}
     hf4.close()
-    res["note"] = ("kernel `frac` = algorithmic bytes (SURVEY §8d) / HIP-event time / 8 TB/s; `dram_frac`, `bound`, `valu_busy_pct`, `lane_utilisation` from the rocprofv3 "
-                   "counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + "; trace kernels carry no `frac` here (their BVH bytes need the "
-                   "instrumented build: see the headline's roofline)")
+    res["note"] = ("kernel `frac` = algorithmic bytes (SURVEY 8d) / HIP-event time / 8 TB/s; `traffic` / `dram_frac`, `valu_issue_frac`, `lane_utilisation`, `valu_frac`, `bound` from the "
+                   "rocprofv3 counters committed under " + (prof["dir"] or "profiles/ (none for this configuration)") + " by EXACT kernel instance; `profile_state` = stale when the live "
+                   "event time is > 10 % off the profiled duration; trace kernels carry no `frac` here (their BVH bytes need the instrumented build: see the headline's roofline)")
     return res
+
+
+def kernel_entries(prof, pass_, stage_times, exact):
+    """{stage: {ms, kernel, frac, traffic, dram_frac, valu_issue_frac, lane_utilisation, valu_frac, bound, profile_state}} for one pass"""
+    out = {}
+    for s, (ms, b) in stage_times.items():
+        k = kernel_of(pass_, s, exact)
+        e = {"ms": round(ms, 4)}
+        if k:
+            c = classify(prof, k, ms, b if s != "ray_trace" else 0, gather=(s == "ray_trace"))
+            e.update({kk: vv for kk, vv in c.items() if vv is not None})
+        out[s] = e
+    return out
 
 
 def hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact):

@@ -93,7 +93,7 @@ SCALE_FULL_RES, SCALE_HALF_RES, SCALE_QUARTER_RES = 0, 1, 2
 ABI_SYMBOLS = [
     "hr_status_string", "hr_last_error", "hr_version", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info",
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
-    "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_temporal",
+    "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
     "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
@@ -346,6 +346,10 @@ class RayTracedShadows(_Pass):
     def ray_trace(self, scene, inputs, stream=None):
         _check(lib().hr_shadows_ray_trace(self.h, scene.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_shadows_ray_trace")
 
+    def denoise(self, inputs, stream=None):
+        """everything of render() after the trace (the fused launches in tolerance mode)"""
+        _check(lib().hr_shadows_denoise(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_shadows_denoise")
+
     def temporal(self, inputs, stream=None):
         _check(lib().hr_shadows_temporal(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_shadows_temporal")
 
@@ -396,6 +400,9 @@ class RayTracedAO(_Pass):
     def ray_trace(self, scene, inputs, stream=None):
         _check(lib().hr_ao_ray_trace(self.h, scene.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_ray_trace")
 
+    def denoise(self, inputs, stream=None):
+        _check(lib().hr_ao_denoise(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_denoise")
+
     def temporal(self, inputs, stream=None):
         _check(lib().hr_ao_temporal(self.h, C.byref(inputs), C.byref(self.params), _stream_ptr(stream)), "hr_ao_temporal")
 
@@ -417,5 +424,5 @@ class RayTracedAO(_Pass):
 
 
 ABI_SYMBOLS += ["hr_ao_default_params", "hr_ao_create", "hr_ao_render", "hr_ao_output", "hr_ao_reset_history", "hr_ao_destroy", "hr_ao_ray_trace",
-                "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_history_apron_exceeded", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
+                "hr_ao_denoise", "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_history_apron_exceeded", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
                 "hr_ao_trace_stats"]

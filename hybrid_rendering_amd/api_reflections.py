@@ -48,6 +48,6 @@ class RayTracedReflections(_Pass):
 
 
 api.ABI_SYMBOLS += ["hr_reflections_default_params", "hr_reflections_create", "hr_reflections_render", "hr_reflections_output",
-                    "hr_reflections_reset_history", "hr_reflections_destroy", "hr_reflections_ray_trace", "hr_reflections_temporal",
+                    "hr_reflections_reset_history", "hr_reflections_destroy", "hr_reflections_ray_trace", "hr_reflections_denoise", "hr_reflections_temporal",
                     "hr_reflections_atrous_iteration", "hr_reflections_upsample", "hr_reflections_image", "hr_reflections_history_apron_exceeded", "hr_reflections_set_profiling",
                     "hr_reflections_get_stage_times", "hr_reflections_ray_count"]

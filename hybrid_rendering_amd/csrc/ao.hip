@@ -566,6 +566,25 @@ hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     return HR_OK;
 }
 
+// Everything of RayTracedAO::render after the ray trace (ray_traced_ao.cpp:102-111); see hr_shadows_denoise
+hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && in && prm);
+    p->last_denoise = prm->denoise != 0;
+    if (!prm->denoise) return HR_OK;
+    hr_status s;
+    if ((s = hr_ao_temporal(p, in, prm, stream)) != HR_OK) return s;
+    bool fused = false;
+    if (!prm->exact && p->fuse && prm->blur_radius == 4 && (s = ao_blur_xy(p, in, prm, stream, &fused)) != HR_OK) return s;
+    if (!fused)
+    {
+        if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
+        if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+    }
+    if (p->scale != 0 && (s = hr_ao_upsample(p, in, prm, stream)) != HR_OK) return s;
+    return HR_OK;
+}
+
 // RayTracedAO::render (ray_traced_ao.cpp:98-112)
 hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream)
 {
@@ -575,19 +594,7 @@ hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* i
     p->last_denoise = prm->denoise != 0;
     hr_status s = hr_ao_ray_trace(p, scene, in, prm, stream);
     if (s != HR_OK) return s;
-    if (prm->denoise)
-    {
-        if ((s = hr_ao_temporal(p, in, prm, stream)) != HR_OK) return s;
-        bool fused = false;
-        if (!prm->exact && p->fuse && prm->blur_radius == 4 && (s = ao_blur_xy(p, in, prm, stream, &fused)) != HR_OK) return s;
-        if (!fused)
-        {
-            if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
-            if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
-        }
-        if (p->scale != 0 && (s = hr_ao_upsample(p, in, prm, stream)) != HR_OK) return s;
-    }
-    return HR_OK;
+    return hr_ao_denoise(p, in, prm, stream);
 }
 
 static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)

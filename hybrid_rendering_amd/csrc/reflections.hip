@@ -637,6 +637,23 @@ hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, 
     return HR_OK;
 }
 
+// Everything of RayTracedReflections::render after the ray trace (ray_traced_reflections.cpp:113-122); see hr_shadows_denoise
+hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && in && prm);
+    p->last_denoise = prm->denoise != 0;
+    if (!prm->denoise) return HR_OK;
+    hr_status s;
+    if ((s = hr_reflections_temporal(p, in, prm, stream)) != HR_OK) return s;
+    bool fused = false;
+    if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+        (s = reflections_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+    for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
+        if ((s = hr_reflections_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    if (p->scale != 0 && (s = hr_reflections_upsample(p, in, prm, stream)) != HR_OK) return s;
+    return HR_OK;
+}
+
 hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
                                 const hr_reflections_params* prm, void* stream)
 {
@@ -646,17 +663,7 @@ hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const 
     p->last_denoise = prm->denoise != 0;
     hr_status s = hr_reflections_ray_trace(p, scene, in, env, ddgi, prm, stream);
     if (s != HR_OK) return s;
-    if (prm->denoise)
-    {
-        if ((s = hr_reflections_temporal(p, in, prm, stream)) != HR_OK) return s;
-        bool fused = false;
-        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
-            (s = reflections_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
-        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
-            if ((s = hr_reflections_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
-        if (p->scale != 0 && (s = hr_reflections_upsample(p, in, prm, stream)) != HR_OK) return s;
-    }
-    return HR_OK;
+    return hr_reflections_denoise(p, in, prm, stream);
 }
 
 static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)

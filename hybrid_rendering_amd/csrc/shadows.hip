@@ -875,6 +875,25 @@ hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr
     return HR_OK;
 }
 
+// Everything of RayTracedShadows::render after the ray trace (ray_traced_shadows.cpp:104-113): temporal accumulation, the a-trous
+// chain, the upsample of a scaled pass.  A caller that overlaps work with the trace (row bands: the history exchange) calls
+// hr_shadows_ray_trace + hr_shadows_denoise instead of hr_shadows_render and gets the same launches — in tolerance mode the fused ones.
+hr_status hr_shadows_denoise(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream)
+{
+    HR_CHECK_ARG(p && in && prm);
+    p->last_denoise = prm->denoise != 0;
+    if (!prm->denoise) return HR_OK;
+    hr_status s;
+    if ((s = hr_shadows_temporal(p, in, prm, stream)) != HR_OK) return s;
+    bool fused = false;
+    if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+        (s = shadows_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+    for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
+        if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    if (p->scale != 0 && (s = hr_shadows_upsample(p, in, prm, stream)) != HR_OK) return s;
+    return HR_OK;
+}
+
 hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream)
 {
     HR_CHECK_ARG(p && scene && in && prm);
@@ -883,17 +902,7 @@ hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame
     p->last_denoise = prm->denoise != 0;
     hr_status s = hr_shadows_ray_trace(p, scene, in, prm, stream);
     if (s != HR_OK) return s;
-    if (prm->denoise)
-    {
-        if ((s = hr_shadows_temporal(p, in, prm, stream)) != HR_OK) return s;
-        bool fused = false;
-        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
-            (s = shadows_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
-        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
-            if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
-        if (p->scale != 0 && (s = hr_shadows_upsample(p, in, prm, stream)) != HR_OK) return s;
-    }
-    return HR_OK;
+    return hr_shadows_denoise(p, in, prm, stream);
 }
 
 static void fill_view(hr_image_view* v, void* data, int w, int h, int bpp, hr_format f)

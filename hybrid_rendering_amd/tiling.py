@@ -236,10 +236,7 @@ class TiledShadows(_TiledPass):
         p = self.pass_
         p.ray_trace(scene, inputs, stream)
         self.wait_exchange()
-        if p.params.denoise:
-            p.temporal(inputs, stream)
-            for i in range(int(p.params.filter_iterations)):
-                p.atrous_iteration(inputs, i, stream)
+        p.denoise(inputs, stream)      # temporal + a-trous chain: the launches render() makes (tolerance mode: iterations 0 + 1 fused)
 
     def band_output(self, kind=None):
         from . import api

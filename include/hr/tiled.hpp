@@ -78,9 +78,7 @@ public:
         m_comm.wait(cmd_buf);
         if (m_pass.params.denoise)
         {
-            check(hr_shadows_temporal(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::temporal");
-            for (int i = 0; i < m_pass.params.filter_iterations; i++) check(hr_shadows_atrous_iteration(p, &f.inputs, &m_pass.params, i, cmd_buf), "TiledShadows::atrous");
-            if (m_pass.scale() != RAY_TRACE_SCALE_FULL_RES) check(hr_shadows_upsample(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::upsample");
+            check(hr_shadows_denoise(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::denoise");   // temporal + a-trous chain (+ upsample), as render()
             check(hr_shadows_exchange_history(p, m_comm.handle(), m_bounds.data(), f.inputs.ping_pong, kHistoryHalo, cmd_buf), "TiledShadows::exchange");
         }
     }

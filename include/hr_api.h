@@ -250,6 +250,9 @@ hr_status hr_shadows_destroy(hr_shadows* p);
 /* Stage-level entry points (the private methods ray_trace / temporal_accumulation / a_trous_filter /
  * upsample, ray_traced_shadows.cpp:972-1255) so a multi-GPU driver can exchange halos between them. */
 hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
+/* everything of render() after the trace: temporal + a-trous chain (+ upsample); hr_shadows_ray_trace + hr_shadows_denoise == hr_shadows_render.
+ * In tolerance mode this (like render) launches a-trous iterations 0 and 1 as ONE kernel; the per-iteration entry point below stays. */
+hr_status hr_shadows_denoise(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
 hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
 hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, int32_t iteration, void* stream);
 hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
@@ -303,6 +306,8 @@ hr_status hr_ao_destroy(hr_ao* p);
 /* stage-level entry points: ray_trace (:863-903), temporal_accumulation (:983-1028),
  * bilateral_blur pass 0 = direction (1,0), pass 1 = (0,1) (:1032-1137), upsample (:918-955) */
 hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
+/* temporal + blur X + blur Y (+ upsample); in tolerance mode (radius 4) the two blur passes are ONE kernel and IMG 5 (blur X) is not written */
+hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
 hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
 hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, int32_t pass, void* stream);
 hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
@@ -428,6 +433,8 @@ hr_status hr_reflections_destroy(hr_reflections* p);
 /* stage-level entry points: ray_trace (:997-1057), temporal_accumulation (:1087-1139), a_trous_filter iteration (:1143-1256), upsample (:1260-1296) */
 hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
                                    const hr_reflections_params* params, void* stream);
+/* temporal + a-trous chain (+ upsample); tolerance mode: iterations 0 and 1 as ONE kernel */
+hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, int32_t iteration, void* stream);
 hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);

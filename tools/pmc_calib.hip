@@ -42,6 +42,21 @@ __global__ void calib_gather4(const uint32_t* __restrict__ in, uint32_t* __restr
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// lanes 2j and 2j+1 of one load instruction read the two 64 B halves of ONE 128 B line (4 B each): one 128 B request (tallied as
+// 64 B => 32 B per lane) or two 64 B requests (=> 64 B per lane)?  Tells what a sparse gather's FETCH_SIZE has to be multiplied by.
+__global__ void calib_gather4_pair(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t lines, uint32_t per_lane)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (uint32_t r = 0; r < per_lane; ++r)
+    {
+        size_t k = (t >> 1) + (size_t)r * (total >> 1);
+        size_t line = (k * 2654435761ull) & (lines - 1);
+        acc ^= in[line * 32 + (t & 1) * 16 + (k & 15)];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 __global__ void calib_stream_write16(uint4* __restrict__ out, size_t n16)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -60,17 +75,19 @@ int main()
     const int grid = 256 * 32, block = 256;
     const size_t lines = bytes / 128;                      // 16 Mi lines of 128 B
     const uint32_t per_lane = 4;                           // grid * block * 4 = 8 Mi lanes-reads < lines: every read is a new line
-    struct { const char* name; double bytes_known; } rows[4] = {
+    struct { const char* name; double bytes_known; } rows[5] = {
         {"calib_stream_read16", (double)bytes}, {"calib_stream_read4", (double)bytes},
-        {"calib_gather4", (double)grid * block * per_lane * 4.0}, {"calib_stream_write16", (double)bytes}};
+        {"calib_gather4", (double)grid * block * per_lane * 4.0}, {"calib_stream_write16", (double)bytes},
+        {"calib_gather4_pair", (double)grid * block * per_lane * 4.0}};
     for (int rep = 0; rep < 3; ++rep)
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
         {
             CK(hipEventRecord(e0));
             if (k == 0) calib_stream_read16<<<grid, block>>>((const uint4*)buf, (uint32_t*)res, bytes / 16);
             if (k == 1) calib_stream_read4<<<grid, block>>>((const uint32_t*)buf, (uint32_t*)res, bytes / 4);
             if (k == 2) calib_gather4<<<grid, block>>>((const uint32_t*)buf, (uint32_t*)res, lines, per_lane);
             if (k == 3) calib_stream_write16<<<grid, block>>>((uint4*)buf, bytes / 16);
+            if (k == 4) calib_gather4_pair<<<grid, block>>>((const uint32_t*)buf, (uint32_t*)res, lines, per_lane);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
