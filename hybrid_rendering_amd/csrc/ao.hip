@@ -60,6 +60,12 @@ extern "C" int hr_debug_divergence_ao(uint64_t* out, int reset)
 #ifndef AO_TRACE_WAVES
 #define AO_TRACE_WAVES 1   // waves (8x8 tiles) per workgroup, see k_shadows_trace: finished waves' slots back-fill at once
 #endif
+#ifndef AO_SEQ
+#define AO_SEQ 0    // N: the sample rays of a pixel, N at a time, walked back to back per lane inside ONE wave loop (traverse.h trace_any_seq);
+                    // 0: one wave-level traversal per sample.  Measured (round 3, 4 spp, bit-identical masks): 1080p 395 us (0) / 468 (2) / 498 (4),
+                    // 4K 1303 / 1540 / 1563 — every iteration of the wave pays for the ray switch of whichever lane just finished, and the
+                    // triangle tests lose the wave-cooperative path; kept as a measured A/B path only
+#endif
 #ifndef AO_COOP
 #define AO_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop) for the AO rays: 0.418 -> 0.399 ms at 1080p, 4 spp
 #endif
@@ -70,7 +76,7 @@ template <bool STATS>
 __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(AOTraceArgs a)
 {
     __shared__ uint32_t s_stack[AO_TRACE_WAVES][HR_STACK_ENTRIES * 64];
-#if AO_COOP
+#if AO_COOP && !AO_SEQ
     __shared__ CoopWave s_coop[AO_TRACE_WAVES];
 #endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,10 +111,45 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
         const float r = a.ray_length * 1.0001f + 1e-4f;
         entry = entry_node_for_box(a.nodes, mk3(ro.x - r, ro.y - r, ro.z - r), mk3(ro.x + r, ro.y + r, ro.z + r));
     }
+#if AO_SEQ
+    if (!STATS)
+    {
+        // the sample rays of a pixel, AO_SEQ at a time, back to back inside one wave loop (traverse.h trace_any_seq)
+        for (int s0 = 0; s0 < a.spp; s0 += AO_SEQ)
+        {
+            f3 dir[AO_SEQ];
+            const int n = a.spp - s0 < AO_SEQ ? a.spp - s0 : AO_SEQ;
+#pragma unroll
+            for (int k = 0; k < AO_SEQ; k++)
+            {
+                dir[k] = mk3(0.0f, 0.0f, 1.0f);
+                if (active && k < n)
+                {
+                    const int   idx = (int)a.num_frames * a.spp + s0 + k;
+                    const float r0  = sample_blue_noise(x, y, idx, 0, a.sobol, a.sr), r1 = sample_blue_noise(x, y, idx, 1, a.sobol, a.sr);
+                    dir[k] = sample_cosine_lobe(N, r0, r1);
+                }
+            }
+            const uint32_t occ = trace_any_seq<AO_SEQ>(active, n, a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, entry HR_DIV(, &dv));
+            for (int k = 0; k < n; k++)
+            {
+                const unsigned long long bits = __ballot(active && !((occ >> k) & 1u));
+                if (lane == 0)
+                {
+                    const int my = ty * 2;
+                    uint32_t* m  = a.mask + (size_t)(s0 + k) * a.mh * a.mw;
+                    if (my * 4 >= a.y0 && my * 4 < a.y1) m[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
+                    if ((my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) m[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
+                }
+            }
+        }
+    }
+    else
+#endif
     for (int s = 0; s < a.spp; s++)
     {
         bool visible = false;
-#if AO_COOP
+#if AO_COOP && !AO_SEQ
         if (!STATS)
         {
             f3 dir = mk3(0.0f, 0.0f, 1.0f);

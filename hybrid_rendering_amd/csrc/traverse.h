@@ -394,6 +394,110 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
 }
 
 
+// ---- lane-sequential any-hit rays ---------------------------------------------------------------------------------------------
+// NB rays per lane (the sample rays of one AO pixel), walked back to back INSIDE one wave-level loop: a lane whose ray is done
+// (occluded, or its stack ran empty) switches to its next ray at once instead of idling until the slowest lane of the wave has
+// finished the current sample.  A wave then waits once for max_lanes(sum of its rays' steps) instead of NB times for
+// sum_rays(max_lanes(steps)) — the ray LENGTHS are what idles lanes, and a sum of NB lengths spreads less than
+// NB maxima.  No queue, no atomics, no cross-lane traffic: the rays of a lane are prepared up front and live in registers; a switch
+// is a handful of v_cndmask.  Decisions per ray are those of trace_any (same node / triangle tests, any-hit), so the masks are
+// bit-identical.  Returns the bit mask of OCCLUDED rays.
+struct RaySeq { float Sx, Sy, Sz, idx, idy, idz; uint32_t code; };   // code: kx | ky << 2 | kz << 4 | sel << 6
+
+HR_DEV RaySeq rayseq_pack(const RayPre& r)
+{
+    RaySeq q;
+    q.Sx = r.Sx; q.Sy = r.Sy; q.Sz = r.Sz; q.idx = r.idx; q.idy = r.idy; q.idz = r.idz;
+    q.code = (uint32_t)r.kx | ((uint32_t)r.ky << 2) | ((uint32_t)r.kz << 4) | (r.sel << 6);
+    return q;
+}
+HR_DEV void rayseq_unpack(RayPre& r, const RaySeq& q)
+{
+    r.Sx = q.Sx; r.Sy = q.Sy; r.Sz = q.Sz; r.idx = q.idx; r.idy = q.idy; r.idz = q.idz;
+    r.kx = (int)(q.code & 3u); r.ky = (int)((q.code >> 2) & 3u); r.kz = (int)((q.code >> 4) & 3u); r.sel = q.code >> 6;
+}
+template <int NB>
+HR_DEV RaySeq rayseq_select(const RaySeq (&q)[NB], int s)
+{
+    RaySeq o = q[0];
+#pragma unroll
+    for (int k = 1; k < NB; k++)
+        if (s == k) o = q[k];   // v_cndmask chains: `s` differs between the lanes
+    return o;
+}
+
+template <int NB>
+HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, const f3 (&dir)[NB],
+                              float t_min, float t_max, uint32_t* wave_stack, int lane, uint32_t entry, DivCounters* dv = nullptr)
+{
+    RaySeq q[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) q[k] = rayseq_pack(ray_prepare(o, dir[k]));
+    RayPre r;
+    r.o = o;
+    rayseq_unpack(r, q[0]);
+    uint32_t  spill_array[HR_SPILL_ENTRIES];
+    LaneStack st;
+    st.init(wave_stack, lane, spill_array);
+    bool      alive = active && entry != HR_NO_ENTRY && n_rays > 0;
+    const uint32_t first = (entry << 9) | 1u;
+    uint32_t  cur = first, occluded = 0u;
+    int       s = 0;
+    while (__any(alive))
+    {
+        if (alive)
+        {
+            uint32_t ni;
+            bool     go = walk_next<false>(cur, st, ni);
+            if (!go)
+            {
+                // this ray's stack ran empty: not occluded; next ray of the lane (walk_next on `first` always yields the entry node)
+                s++;
+                alive = s < n_rays;
+                if (alive)
+                {
+                    rayseq_unpack(r, rayseq_select<NB>(q, s));
+                    cur = first; st.sp = 0;
+                    go  = walk_next<false>(cur, st, ni);
+                }
+            }
+            if (go)
+            {
+                const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
+                HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
+                uint32_t trimask = walk_expand(h, cur, st);
+                bool     hit = false;
+                while (trimask)
+                {
+                    HR_DIV(if (dv) div_count(dv->lane_pairs, dv->wave_pairs);)
+                    const uint32_t i0 = (uint32_t)__builtin_ctz(trimask);
+                    trimask &= trimask - 1u;
+                    const bool     two = trimask != 0u;
+                    const uint32_t i1  = two ? (uint32_t)__builtin_ctz(trimask) : i0;
+                    trimask &= trimask - 1u;   // no-op on 0
+                    const TriRaw ta = load_tri_raw(tris, h.tri_base + i0), tb = load_tri_raw(tris, h.tri_base + i1);
+                    float t, u, v;
+                    const bool ha = ray_tri_raw<false>(r, ta, t_min, t_max, t, u, v);
+                    const bool hb = ray_tri_raw<false>(r, tb, t_min, t_max, t, u, v);
+                    if (ha || hb) { hit = true; break; }
+                }
+                if (hit)
+                {
+                    occluded |= 1u << s;
+                    s++;
+                    alive = s < n_rays;
+                    if (alive)
+                    {
+                        rayseq_unpack(r, rayseq_select<NB>(q, s));
+                        cur = first; st.sp = 0;
+                    }
+                }
+            }
+        }
+    }
+    return occluded;
+}
+
 // ---- step-wise any-hit traversal (for persistent waves that refill idle lanes from a ray queue) ------------------
 struct AnyHitLane
 {
