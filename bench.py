@@ -362,6 +362,19 @@ def main():
         total_rays = float(t.item()) * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
+    comm_info = None
+    if world > 1:
+        # what the driver's SCALE record needs to tell compute from communication: how many ranks RCCL really saw, the band cut, and
+        # the cost of one history exchange posted and waited for back to back (max over ranks; in the frame it hides under the next trace)
+        seen = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ex = torch.tensor([tiled.time_exchange(20)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        comm_info = {"backend": dist.get_backend(), "ranks_seen": int(seen.item()), "band_bounds": bounds, "history_rows_exchanged": tiled.history_rows,
+                     "exchange_us_per_frame": round(float(ex.item()), 1),
+                     "exchange_bytes_per_boundary": int(tiled.history_rows * W * (4 + 8)),
+                     "note": "one grouped ncclSend/ncclRecv pair per neighbour and frame (feedback image 4 B/px + moments 8 B/px of the 40 rows next to each band boundary), "
+                             "posted after the a-trous chain and waited for before the NEXT frame's temporal kernel; exchange_us_per_frame is its stand-alone cost"}
     dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
     out = {
         "metric": "shadow Mrays/s over the fully denoised frame (1 spp trace + SVGF temporal + 4x a-trous)",
@@ -391,6 +404,8 @@ def main():
                              "VALU issue: valu_frac = valu_issue_frac x lane_utilisation is the share of the VALU roof doing useful work"},
         "stages": {n: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()} for n, s in stages.items()},
     }
+    if comm_info:
+        out["comm"] = comm_info
 
     # ---- the other arithmetic mode, same frames, shorter run (reported, never `value`)
     other = tiling.TiledShadows(ctx, W, H, rank, world, bounds=bounds)
@@ -419,9 +434,15 @@ def main():
                 tm = t.clone()
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                cm = torch.tensor([hf.shadows.time_exchange(10), hf.ao.time_exchange(10), hf.refl.time_exchange(10), hf.gi.time_allgather(10)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(cm, op=dist.ReduceOp.MAX)
                 out["hybrid_4k"] = {"workload": "ONE 3840x2160 hybrid frame (shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections) row-tiled over the GPUs: strong scaling (BASELINE configs[4])",
                                     "n_gpus": world, "ms_per_frame": round(float(tm[0]), 4), "frames_per_s": round(1e3 / float(tm[0]), 1),
-                                    "Mrays_per_s": round(float(t[1]) / float(tm[0]) / 1e3, 1), "bands": hf.bounds, "bands_before_rebalancing": first_cut, "scaling": "strong"}
+                                    "Mrays_per_s": round(float(t[1]) / float(tm[0]) / 1e3, 1), "bands": hf.bounds, "bands_before_rebalancing": first_cut, "scaling": "strong",
+                                    "comm_us_per_frame": {"shadows_exchange": round(float(cm[0]), 1), "ao_exchange": round(float(cm[1]), 1), "reflections_exchange": round(float(cm[2]), 1),
+                                                          "ddgi_atlas_allgather": round(float(cm[3]), 1),
+                                                          "note": "stand-alone cost of each collective (posted and waited for back to back, max over ranks); the three exchanges overlap the next "
+                                                                  "frame's traces, the all-gather sits on the DDGI -> reflections chain"}}
                 hf.close()
         except Exception as e:   # a report next to the headline, never a reason to lose the bench line
             out["passes_error"] = repr(e)[:300]

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhr_comm.so")
 HR_COMM_ID_BYTES = 128
 ABI_SYMBOLS = ["hr_comm_get_unique_id", "hr_comm_create_rccl", "hr_comm_create_loopback", "hr_comm_destroy", "hr_comm_rank", "hr_comm_world",
-               "hr_comm_exchange_rows", "hr_comm_wait", "hr_comm_allgather_rows", "hr_shadows_exchange_history", "hr_ao_exchange_history",
+               "hr_comm_exchange_rows", "hr_comm_wait", "hr_comm_wait_ticket", "hr_comm_allgather_rows", "hr_shadows_exchange_history", "hr_ao_exchange_history",
                "hr_reflections_exchange_history", "hr_ddgi_allgather_atlases"]
 _lib = None
 
@@ -69,31 +69,45 @@ class NativeComm:
         dist.broadcast(t, src=0, group=group)
         return cls(ctx, world, rank, unique_id=bytes(t.cpu().numpy().tobytes()))
 
-    def exchange_rows(self, tensors, bounds, rows, stream=None):
+    # every collective returns its TICKET (hr_comm.h); wait(ticket) orders the stream behind everything posted up to that ticket only
+    def exchange_rows(self, tensors, bounds, rows, stream=None) -> int:
         """tensors: [H, W, ...] row-major cuda tensors addressed by absolute row"""
         ims = (hr_comm_image * len(tensors))(*[hr_comm_image(t.data_ptr(), t.stride(0) * t.element_size()) for t in tensors])
-        _check(lib().hr_comm_exchange_rows(self.h, ims, C.c_int32(len(tensors)), _bounds(bounds), C.c_int32(rows), _stream_ptr(stream)), "hr_comm_exchange_rows")
+        t = C.c_int64(0)
+        _check(lib().hr_comm_exchange_rows(self.h, ims, C.c_int32(len(tensors)), _bounds(bounds), C.c_int32(rows), _stream_ptr(stream), C.byref(t)), "hr_comm_exchange_rows")
+        return t.value
 
-    def allgather_rows(self, tensor, row_bounds, stream=None):
+    def allgather_rows(self, tensor, row_bounds, stream=None) -> int:
         im = hr_comm_image(tensor.data_ptr(), tensor.stride(0) * tensor.element_size())
-        _check(lib().hr_comm_allgather_rows(self.h, im, _bounds(row_bounds), _stream_ptr(stream)), "hr_comm_allgather_rows")
+        t = C.c_int64(0)
+        _check(lib().hr_comm_allgather_rows(self.h, im, _bounds(row_bounds), _stream_ptr(stream), C.byref(t)), "hr_comm_allgather_rows")
+        return t.value
 
-    def wait(self, stream=None):
-        _check(lib().hr_comm_wait(self.h, _stream_ptr(stream)), "hr_comm_wait")
+    def wait(self, stream=None, ticket=None):
+        if ticket is None:
+            _check(lib().hr_comm_wait(self.h, _stream_ptr(stream)), "hr_comm_wait")
+        else:
+            _check(lib().hr_comm_wait_ticket(self.h, C.c_int64(int(ticket)), _stream_ptr(stream)), "hr_comm_wait_ticket")
 
     # per-pass conveniences
-    def exchange_shadows(self, p, bounds, ping_pong, rows, stream=None):
-        _check(lib().hr_shadows_exchange_history(p.h, self.h, _bounds(bounds), C.c_int32(int(ping_pong)), C.c_int32(rows), _stream_ptr(stream)), "hr_shadows_exchange_history")
+    def _pass_exchange(self, fn, name, p, bounds, ping_pong, rows, stream):
+        t = C.c_int64(0)
+        _check(fn(p.h, self.h, _bounds(bounds), C.c_int32(int(ping_pong)), C.c_int32(rows), _stream_ptr(stream), C.byref(t)), name)
+        return t.value
 
-    def exchange_ao(self, p, bounds, ping_pong, rows, stream=None):
-        _check(lib().hr_ao_exchange_history(p.h, self.h, _bounds(bounds), C.c_int32(int(ping_pong)), C.c_int32(rows), _stream_ptr(stream)), "hr_ao_exchange_history")
+    def exchange_shadows(self, p, bounds, ping_pong, rows, stream=None) -> int:
+        return self._pass_exchange(lib().hr_shadows_exchange_history, "hr_shadows_exchange_history", p, bounds, ping_pong, rows, stream)
 
-    def exchange_reflections(self, p, bounds, ping_pong, rows, stream=None):
-        _check(lib().hr_reflections_exchange_history(p.h, self.h, _bounds(bounds), C.c_int32(int(ping_pong)), C.c_int32(rows), _stream_ptr(stream)),
-               "hr_reflections_exchange_history")
+    def exchange_ao(self, p, bounds, ping_pong, rows, stream=None) -> int:
+        return self._pass_exchange(lib().hr_ao_exchange_history, "hr_ao_exchange_history", p, bounds, ping_pong, rows, stream)
 
-    def allgather_ddgi(self, p, stream=None):
-        _check(lib().hr_ddgi_allgather_atlases(p.h, self.h, _stream_ptr(stream)), "hr_ddgi_allgather_atlases")
+    def exchange_reflections(self, p, bounds, ping_pong, rows, stream=None) -> int:
+        return self._pass_exchange(lib().hr_reflections_exchange_history, "hr_reflections_exchange_history", p, bounds, ping_pong, rows, stream)
+
+    def allgather_ddgi(self, p, stream=None) -> int:
+        t = C.c_int64(0)
+        _check(lib().hr_ddgi_allgather_atlases(p.h, self.h, _stream_ptr(stream), C.byref(t)), "hr_ddgi_allgather_atlases")
+        return t.value
 
     def close(self):
         if self.h:

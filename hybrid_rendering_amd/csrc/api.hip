@@ -222,6 +222,8 @@ const char* hr_status_string(hr_status s)
         case HR_ERR_NO_DEVICE: return "HR_ERR_NO_DEVICE";
         case HR_ERR_OUT_OF_MEMORY: return "HR_ERR_OUT_OF_MEMORY";
         case HR_ERR_UNSUPPORTED: return "HR_ERR_UNSUPPORTED";
+        case HR_ERR_TIMEOUT: return "HR_ERR_TIMEOUT";
+        case HR_ERR_COMM: return "HR_ERR_COMM";
         default: return "HR_ERR_UNKNOWN";
     }
 }

@@ -182,6 +182,24 @@ class _TiledPass:
         self.wait_exchange()
         self.pass_.render(scene, inputs, *extra, stream=stream)
 
+    def time_exchange(self, n: int = 20) -> float:
+        """microseconds per neighbour exchange of this pass's history rows, posted and waited for back to back on the current stream
+        (HIP events around n repetitions, one synchronisation): the communication cost of a frame that the overlap with the next
+        frame's ray trace hides — reported by bench.py next to the frame time so that compute and communication can be told apart"""
+        import torch
+        if self.world == 1:
+            return 0.0
+        self.wait_exchange()
+        imgs = self.history_images(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(n + 2):
+            if k == 2:
+                e0.record()
+            exchange_halo(imgs, self.height, self.world, self.rank, self.history_rows, self.group, wait=True, bounds=self.bounds)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
     def history_apron_exceeded(self) -> bool:
         """Runtime guard of the history apron: True if, since the last call, a history tap of this band fell on an image row this GPU
         does not hold (per-frame motion beyond ``history_rows`` minus the halo).  Such taps read as disoccluded, so the band is still a
@@ -348,6 +366,22 @@ class ShardedDDGI:
         allgather_slabs(dep, self.dep_side, self.cz, self.world, self.rank, self.group)
         p.sample_probe_grid(inputs, stream)
         p.end_frame()
+
+    def time_allgather(self, n: int = 20) -> float:
+        """microseconds per frame for the two atlas all-gathers (irradiance + depth), HIP events on the current stream"""
+        import torch
+        if self.world == 1:
+            return 0.0
+        irr, dep = self.pass_.current_write()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(n + 2):
+            if k == 2:
+                e0.record()
+            allgather_slabs(irr, self.irr_side, self.cz, self.world, self.rank, self.group)
+            allgather_slabs(dep, self.dep_side, self.cz, self.world, self.rank, self.group)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
 
     def band_output(self):
         return self.pass_.output()[self.b0:self.b1]

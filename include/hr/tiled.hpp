@@ -13,6 +13,8 @@
 #pragma once
 #include "../hr_comm.h"
 #include "passes.hpp"
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace hr {
@@ -35,7 +37,8 @@ public:
     ~Comm() { hr_comm_destroy(m_comm); }
     int      rank() const { return hr_comm_rank(m_comm); }
     int      world() const { return hr_comm_world(m_comm); }
-    void     wait(Stream s) { check(hr_comm_wait(m_comm, s), "hr_comm_wait"); }
+    void     wait(Stream s) { check(hr_comm_wait(m_comm, s), "hr_comm_wait"); }                                   // everything posted so far
+    void     wait(hr_comm_ticket t, Stream s) { check(hr_comm_wait_ticket(m_comm, t, s), "hr_comm_wait_ticket"); }   // up to ticket t only
     hr_comm* handle() const { return m_comm; }
     static void unique_id(uint8_t id[HR_COMM_ID_BYTES]) { check(hr_comm_get_unique_id(id), "hr_comm_get_unique_id"); }
 private:
@@ -54,6 +57,11 @@ inline std::vector<int32_t> uniform_bounds(int height, int world, int align = 8)
 }
 inline hr_band band_of(const std::vector<int32_t>& bounds, int rank, int halo, int history_halo)
 {
+    // the neighbour exchange refreshes `history_halo` rows per boundary from the DIRECT neighbour only: a shorter band would leave rows
+    // of the second neighbour stale (hr_comm_exchange_rows refuses it too; tiling._TiledPass has the same guard)
+    for (size_t r = 0; r + 1 < bounds.size(); r++)
+        if (bounds.size() > 2 && bounds[r + 1] - bounds[r] < history_halo)
+            throw std::invalid_argument("hr::Tiled*: band " + std::to_string(r) + " of the row-tiled frame is shorter than the " + std::to_string(history_halo) + "-row history apron: use fewer / taller bands");
     hr_band b;
     b.band_y0 = bounds[rank]; b.band_y1 = bounds[rank + 1]; b.halo = halo; b.history_halo = history_halo;
     return b;
@@ -75,11 +83,11 @@ public:
         const Frame f = make_frame(*m_common, *m_g_buffer, (int)m_pass.scale());
         hr_shadows* p = m_pass.handle();
         check(hr_shadows_ray_trace(p, f.scene->handle(), &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::ray_trace");
-        m_comm.wait(cmd_buf);
+        m_comm.wait(m_ticket, cmd_buf);   // the rows THIS pass exchanged last frame — not what another pass posted a moment ago
         if (m_pass.params.denoise)
         {
             check(hr_shadows_denoise(p, &f.inputs, &m_pass.params, cmd_buf), "TiledShadows::denoise");   // temporal + a-trous chain (+ upsample), as render()
-            check(hr_shadows_exchange_history(p, m_comm.handle(), m_bounds.data(), f.inputs.ping_pong, kHistoryHalo, cmd_buf), "TiledShadows::exchange");
+            check(hr_shadows_exchange_history(p, m_comm.handle(), m_bounds.data(), f.inputs.ping_pong, kHistoryHalo, cmd_buf, &m_ticket), "TiledShadows::exchange");
         }
     }
     // a history tap fell on an image row this GPU does not hold (motion beyond the history apron): it read as disoccluded
@@ -94,6 +102,7 @@ private:
     RayTracedShadows     m_pass;
     CommonResources*     m_common;
     GBuffer*             m_g_buffer;
+    hr_comm_ticket       m_ticket = 0;
 };
 
 class TiledAO
@@ -106,9 +115,9 @@ public:
     }
     void render(Stream cmd_buf)
     {
-        m_comm.wait(cmd_buf);
+        m_comm.wait(m_ticket, cmd_buf);
         m_pass.render(cmd_buf);
-        if (m_pass.params.denoise) check(hr_ao_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledAO::exchange");
+        if (m_pass.params.denoise) check(hr_ao_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf, &m_ticket), "TiledAO::exchange");
     }
     bool history_apron_exceeded() { int32_t v = 0; check(hr_ao_history_apron_exceeded(m_pass.handle(), &v), "history_apron_exceeded"); return v != 0; }
     RayTracedAO& pass() { return m_pass; }
@@ -118,6 +127,7 @@ private:
     hr_band              m_band;
     RayTracedAO          m_pass;
     CommonResources*     m_common;
+    hr_comm_ticket       m_ticket = 0;
 };
 
 // DDGI: probes partitioned by grid z-slab for the ray trace and both probe updates, atlas rows all-gathered, every rank samples the
@@ -137,8 +147,9 @@ public:
         hr_ddgi* p = m_pass.handle();
         check(hr_ddgi_ray_trace(p, f.scene->handle(), &f.inputs, f.environment, &m_pass.params, cmd_buf), "ShardedDDGI::ray_trace");
         check(hr_ddgi_probe_update(p, cmd_buf), "ShardedDDGI::probe_update");
-        check(hr_ddgi_allgather_atlases(p, m_comm.handle(), cmd_buf), "ShardedDDGI::allgather");
-        m_comm.wait(cmd_buf);   // loopback: the copies may sit on another rank's stream; RCCL: already ordered (no-op)
+        hr_comm_ticket t = 0;
+        check(hr_ddgi_allgather_atlases(p, m_comm.handle(), cmd_buf, &t), "ShardedDDGI::allgather");
+        m_comm.wait(t, cmd_buf);   // loopback: the copies may sit on another rank's stream; RCCL: already ordered on cmd_buf
         check(hr_ddgi_sample_probe_grid(p, &f.inputs, &m_pass.params, cmd_buf), "ShardedDDGI::sample_probe_grid");
         check(hr_ddgi_end_frame(p), "ShardedDDGI::end_frame");
     }
@@ -160,10 +171,10 @@ public:
     }
     void render(Stream cmd_buf, DDGI* ddgi)
     {
-        m_comm.wait(cmd_buf);
+        m_comm.wait(m_ticket, cmd_buf);
         m_pass.render(cmd_buf, ddgi);
         if (m_pass.params.denoise)
-            check(hr_reflections_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf), "TiledReflections::exchange");
+            check(hr_reflections_exchange_history(m_pass.handle(), m_comm.handle(), m_bounds.data(), m_common->ping_pong ? 1 : 0, kHalo, cmd_buf, &m_ticket), "TiledReflections::exchange");
     }
     bool history_apron_exceeded() { int32_t v = 0; check(hr_reflections_history_apron_exceeded(m_pass.handle(), &v), "history_apron_exceeded"); return v != 0; }
     RayTracedReflections& pass() { return m_pass; }
@@ -173,6 +184,7 @@ private:
     hr_band              m_band;
     RayTracedReflections m_pass;
     CommonResources*     m_common;
+    hr_comm_ticket       m_ticket = 0;
 };
 
 } // namespace hr

@@ -36,7 +36,9 @@ enum
     HR_ERR_HIP           = 2, /* a HIP runtime call failed; see hr_last_error() */
     HR_ERR_NO_DEVICE     = 3,
     HR_ERR_OUT_OF_MEMORY = 4,
-    HR_ERR_UNSUPPORTED   = 5
+    HR_ERR_UNSUPPORTED   = 5,
+    HR_ERR_TIMEOUT       = 6, /* hr_comm (loopback): a neighbour never posted its side of a collective */
+    HR_ERR_COMM          = 7  /* an RCCL call failed; see hr_last_error() */
 };
 
 const char* hr_status_string(hr_status s);

@@ -46,17 +46,31 @@ typedef struct
     int64_t row_pitch_bytes;
 } hr_comm_image;
 
+/* Every collective posted on a communicator gets the next TICKET (1, 2, ...; 0 = nothing to wait for).  hr_comm_wait_ticket(comm, t,
+ * stream) orders `stream` behind everything posted on `comm` up to and including ticket t — and nothing later: a pass keeps the ticket
+ * of the exchange it posted LAST frame and waits for that one, not for the exchange another pass posted microseconds ago (round-2
+ * review: one shared "pending" flag serialised every exchange against the next pass and dead-locked a single-threaded loopback host).
+ * One communicator serves several compute streams (the forked chains of hr::HybridFrame) as long as the host calls are serialised
+ * and every rank posts its collectives in the same order. */
+typedef int64_t hr_comm_ticket;
+
 /* Neighbour exchange.  bounds[0 .. world] are the band boundaries in rows of these images (bounds[r] .. bounds[r + 1] = rank r's
  * band; 0 and the image height at the ends).  For every image: my `rows` band rows next to each boundary go to that neighbour, the
- * neighbour's `rows` rows next to it arrive in my copy (min(rows, band height) when a band is shorter).
+ * neighbour's `rows` rows next to it arrive in my copy.  HR_ERR_INVALID_ARG when any band is shorter than `rows` (its apron rows would
+ * belong to the SECOND neighbour and stay stale).
  * Ordering: the transfer starts after everything already enqueued on `compute_stream`; nothing later on `compute_stream` waits for
- * it until hr_comm_wait(comm, compute_stream) — so the next frame's ray trace (which reads no history) overlaps the exchange. */
-hr_status hr_comm_exchange_rows(hr_comm* comm, const hr_comm_image* images, int32_t n_images, const int32_t* bounds, int32_t rows, void* compute_stream);
+ * it until hr_comm_wait_ticket(comm, *ticket, stream) — so the next frame's ray trace (which reads no history) overlaps the exchange.
+ * ticket may be NULL. */
+hr_status hr_comm_exchange_rows(hr_comm* comm, const hr_comm_image* images, int32_t n_images, const int32_t* bounds, int32_t rows, void* compute_stream, hr_comm_ticket* ticket);
+hr_status hr_comm_wait_ticket(hr_comm* comm, hr_comm_ticket ticket, void* compute_stream);
+/* everything posted so far (= hr_comm_wait_ticket with the newest ticket).  Loopback: blocks the host until the neighbours have posted
+ * their sides; HR_ERR_TIMEOUT after 10 s. */
 hr_status hr_comm_wait(hr_comm* comm, void* compute_stream);
 
 /* All-gather of row slabs: rank r owns rows row_bounds[r] .. row_bounds[r + 1] of `image` (slabs may be ragged or empty); afterwards
- * every rank holds all rows.  `compute_stream` continues only when the gather is complete (the sample / reflections passes read it). */
-hr_status hr_comm_allgather_rows(hr_comm* comm, hr_comm_image image, const int32_t* row_bounds, void* compute_stream);
+ * every rank holds all rows.  RCCL: `compute_stream` continues only when the gather is complete (the sample / reflections passes read
+ * it); loopback: call hr_comm_wait_ticket(comm, *ticket, stream) before the first reader. */
+hr_status hr_comm_allgather_rows(hr_comm* comm, hr_comm_image image, const int32_t* row_bounds, void* compute_stream, hr_comm_ticket* ticket);
 
 /* Per-pass conveniences over the calls above: they pick the images the NEXT frame's reprojection reads —
  *   shadows      feedback image (RG16F) + the moments written this frame (ping_pong)          hr_band.history_halo rows
@@ -64,10 +78,10 @@ hr_status hr_comm_allgather_rows(hr_comm* comm, hr_comm_image image, const int32
  *   reflections  feedback image + moments
  *   DDGI         irradiance + depth atlas rows of this rank's probe z-slabs [z0, z1) of `cz` slabs (hr_ddgi_set_shard)
  * bounds are in rows of the PASS image (full height >> scale). */
-hr_status hr_shadows_exchange_history(hr_shadows* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
-hr_status hr_ao_exchange_history(hr_ao* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
-hr_status hr_reflections_exchange_history(hr_reflections* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream);
-hr_status hr_ddgi_allgather_atlases(hr_ddgi* p, hr_comm* comm, void* compute_stream);
+hr_status hr_shadows_exchange_history(hr_shadows* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream, hr_comm_ticket* ticket);
+hr_status hr_ao_exchange_history(hr_ao* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream, hr_comm_ticket* ticket);
+hr_status hr_reflections_exchange_history(hr_reflections* p, hr_comm* comm, const int32_t* bounds, int32_t ping_pong, int32_t rows, void* compute_stream, hr_comm_ticket* ticket);
+hr_status hr_ddgi_allgather_atlases(hr_ddgi* p, hr_comm* comm, void* compute_stream, hr_comm_ticket* ticket);
 
 #ifdef __cplusplus
 }

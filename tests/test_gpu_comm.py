@@ -84,29 +84,35 @@ def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world):
         z0, z1 = tiling.probe_slabs(6, world, r)
         g.set_shard(z0, z1, bounds[r], bounds[r + 1])
     rng = np.random.RandomState(3)
+    tk = {k: [0] * world for k in ("sh", "ao", "gi", "rf")}
     for f in range(n_frames):
         cur, prev = helpers.to_cuda(frames[f]["gb"]), helpers.to_cuda(frames[f - 1 if f else 0]["gb"])
         fi = hr.frame_inputs(cur, prev, frames[f]["ubo"], f, f & 1, sob_d, sr_d, cur_full=cur, z_buffer_params=zbp)
         orient = synth_env.random_orientation(rng)
         w_sh.render(gsc, fi); w_ao.render(gsc, fi); w_gi.render(gsc, fi, env, orient); w_rf.render(gsc, fi, env, w_gi)
-        # one rank after the other, each doing its whole frame (the loopback queues the posts until the neighbour arrives)
+        # one rank after the other on ONE host thread, each driving its passes as hr::Tiled* do (include/hr/tiled.hpp): a pass waits for
+        # the TICKET of the exchange it posted last frame only — never for what another pass posted a moment ago, which the neighbour
+        # (driven later by this same thread) has not answered yet (round-2 review: a shared pending flag dead-locked exactly this loop)
         for r in range(world):
             c = comms[r]
-            c.wait()                                            # last frame's history rows have landed
+            c.wait(ticket=tk["sh"][r])
             t_sh[r].render(gsc, fi)
-            c.exchange_shadows(t_sh[r], bounds, f & 1, tiling.HISTORY_HALO)
+            tk["sh"][r] = c.exchange_shadows(t_sh[r], bounds, f & 1, tiling.HISTORY_HALO)
+            c.wait(ticket=tk["ao"][r])
             t_ao[r].render(gsc, fi)
-            c.exchange_ao(t_ao[r], bounds, f & 1, tiling.HALO)
+            tk["ao"][r] = c.exchange_ao(t_ao[r], bounds, f & 1, tiling.HALO)
             g = t_gi[r]
             g.set_orientation(orient)
             g.ray_trace(gsc, fi, env); g.probe_update()
-            c.allgather_ddgi(g)
+            tk["gi"][r] = c.allgather_ddgi(g)
         for r in range(world):                                  # the gather completes when the last rank has posted
-            comms[r].wait()
+            comms[r].wait(ticket=tk["gi"][r])
             g = t_gi[r]
             g.sample_probe_grid(fi); g.end_frame()
+            comms[r].wait(ticket=tk["rf"][r])
             t_rf[r].render(gsc, fi, env, g)
-            comms[r].exchange_reflections(t_rf[r], bounds, f & 1, tiling.HALO)
+            tk["rf"][r] = comms[r].exchange_reflections(t_rf[r], bounds, f & 1, tiling.HALO)
+            assert tk["rf"][r] > tk["gi"][r] > tk["ao"][r] > tk["sh"][r] > 0
         torch.cuda.synchronize()
         for r in range(world):
             b0, b1 = bounds[r], bounds[r + 1]
@@ -119,3 +125,35 @@ def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world):
             assert torch.equal(t_rf[r].output(hr.OUTPUT_UPSAMPLE)[b0:b1], w_rf.output(hr.OUTPUT_UPSAMPLE)[b0:b1]), f"frame {f} rank {r}: reflections"
     for c in comms:
         c.close()
+
+
+def test_exchange_refuses_bands_shorter_than_the_apron(hr, ctx):
+    """a band shorter than the exchanged apron would leave rows of the SECOND neighbour stale: HR_ERR_INVALID_ARG, not a silent clamp"""
+    import torch
+    from hybrid_rendering_amd import comm
+    world, H = 3, 96
+    comms = [comm.NativeComm(ctx, world, r, loopback_name="short") for r in range(world)]
+    img = torch.zeros((H, 8), dtype=torch.float32, device="cuda")
+    with pytest.raises(hr.HRError, match="shorter than"):
+        comms[0].exchange_rows([img], [0, 40, 48, 96], 16)       # band 1 holds 8 rows
+    assert comms[0].exchange_rows([img], [0, 40, 56, 96], 16) > 0
+    # a second rank 0 of the same group is refused, and the failed create leaves nothing behind
+    with pytest.raises(hr.HRError, match="already joined"):
+        comm.NativeComm(ctx, world, 0, loopback_name="short")
+    for c in comms:
+        c.close()
+
+
+def test_rccl_backend_loads_and_initialises_on_one_gpu(hr, ctx):
+    """what CAN run of the RCCL back end on a one-GPU box: librccl is dlopen'ed, every symbol resolves, ncclGetUniqueId and
+    ncclCommInitRank (world 1) succeed through the C ABI, the communicator tears down.  The send / recv path needs two devices:
+    tests/test_gpu_multi.py."""
+    import torch
+    from hybrid_rendering_amd import comm
+    uid = comm.NativeComm.unique_id()
+    assert len(uid) == comm.HR_COMM_ID_BYTES and any(uid)
+    c = comm.NativeComm(ctx, 1, 0, unique_id=uid)
+    img = torch.zeros((64, 8), dtype=torch.float32, device="cuda")
+    assert c.exchange_rows([img], [0, 64], 16) == 0     # a single band has no neighbour: nothing posted, ticket 0
+    c.wait()
+    c.close()
