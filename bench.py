@@ -463,8 +463,10 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     hf.time(6, 2)                                                   # warm every pass (history, atlases)
     wall = {n: hf.time(12, 4, only=n, repeats=3) for n in ("shadows", "ao", "ddgi", "reflections")}
     hybrid = hf.time(12, 4, repeats=3)
-    hf.concurrent_streams(True)
+    hf.concurrent_streams(True, "streams")
     hybrid3 = hf.time(12, 6, repeats=3)
+    hf.concurrent_streams(True, "graph")
+    hybridg = hf.time(12, 6, repeats=3)
     hf.concurrent_streams(False)
     rays = hf.ray_counts()
     st = hf.stage_times(10)
@@ -476,7 +478,11 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     res["hybrid_1080p"] = {"workload": "whole hybrid frame 1920x1080 on one GPU: shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, one stream",
                            "ms_per_frame": round(hybrid, 4), "frames_per_s": round(1e3 / hybrid, 1), "Mrays_per_s": round(sum(rays.values()) / hybrid / 1e3, 1),
                            "concurrent_streams": {"ms_per_frame": round(hybrid3, 4), "frames_per_s": round(1e3 / hybrid3, 1),
-                                                  "note": "shadows | AO | DDGI trace + update -> reflections | DDGI sample on four HIP streams, joined at the end of the frame (independent chains; same images)"}}
+                                                  "note": "hr_hybrid_frame HR_FRAME_STREAMS (C ABI; hr::HybridFrame in include/hr/passes.hpp): shadows | AO | DDGI trace + update -> reflections | "
+                                                          "DDGI sample forked over four HIP streams, joined at the end of the frame (independent chains; bit-identical images)"},
+                           "hip_graph": {"ms_per_frame": round(hybridg, 4), "frames_per_s": round(1e3 / hybridg, 1),
+                                         "note": "HR_FRAME_GRAPH: the same forked frame captured into one hipGraph per frame; the instantiated graph is updated in place (hipGraphExecUpdate) "
+                                                 "because UBO, frame counter and ping-pong parity travel in the kernel arguments"}}
     hf.close()
     # configs[3] read as FULL-resolution reflections (the reference's default, timed above, is half resolution)
     hfr = HybridFrame(ctx, scene, sd, 1920, 1080, exact=exact, refl_scale=0)
@@ -489,13 +495,16 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
     hf4 = HybridFrame(ctx, scene, sd, 3840, 2160, exact=exact)
     ms4 = hf4.time(8, 4, repeats=3)
     r4 = hf4.ray_counts()
-    hf4.concurrent_streams(True)
+    hf4.concurrent_streams(True, "streams")
     ms43 = hf4.time(8, 4, repeats=3)
+    hf4.concurrent_streams(True, "graph")
+    ms4g = hf4.time(8, 4, repeats=3)
     hf4.concurrent_streams(False)
     st4 = hf4.stage_times(8)
     prof4 = load_profile("_4k")
     res["hybrid_4k_one_gpu"] = {"workload": "whole hybrid frame 3840x2160 on ONE GPU (BASELINE configs[4] names 8)", "ms_per_frame": round(ms4, 4), "frames_per_s": round(1e3 / ms4, 1),
                                 "Mrays_per_s": round(sum(r4.values()) / ms4 / 1e3, 1), "concurrent_streams": {"ms_per_frame": round(ms43, 4), "frames_per_s": round(1e3 / ms43, 1)},
+                                "hip_graph": {"ms_per_frame": round(ms4g, 4), "frames_per_s": round(1e3 / ms4g, 1)},
                                 "kernels": {n: kernel_entries(prof4, n, st4[n], exact) for n in ("shadows", "ao", "ddgi", "reflections")},
                                 "kernels_note": "per-kernel HIP-event times of the 4K frame; counters from " + (prof4["dir"] or "(no 4K profile committed)") +
                                                 " (*_4k files: the working set of a 4K pass exceeds the 256 MiB Infinity Cache, so dram_frac is an HBM figure here)"}

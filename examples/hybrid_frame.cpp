@@ -96,6 +96,17 @@ double mean_of(const hr::ImageView& v, int nch, int c)
     return s / ((double)v.width * v.height);
 }
 
+// two views hold the same bytes
+bool same_image(const hr::ImageView& a, const hr::ImageView& b)
+{
+    if (a.width != b.width || a.height != b.height || a.row_pitch_bytes != b.row_pitch_bytes) return false;
+    const size_t n = (size_t)a.row_pitch_bytes * a.height;
+    std::vector<uint8_t> x(n), y(n);
+    (void)hipMemcpy(x.data(), a.data, n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(y.data(), b.data, n, hipMemcpyDeviceToHost);
+    return std::memcmp(x.data(), y.data(), n) == 0;
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -174,6 +185,17 @@ int main(int argc, char** argv)
         hr::DeferredShading       deferred(ctx, &common, &g_buffer);
         hr::TemporalAA            taa(ctx, W, H);
         hr::GroundTruthPathTracer ground_truth(ctx, &common, &g_buffer);
+        // hr::HybridFrame: the same four passes enqueued as the dependency graph they form — forked streams, and one hipGraph per frame.
+        // Two more sets of passes (each keeps its own temporal history) so that their outputs can be compared with the serial calls.
+        hr::RayTracedShadows      shadows_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), shadows_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::RayTracedAO           ao_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), ao_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DDGI                  ddgi_s(ctx, &common, &g_buffer, g), ddgi_g(ctx, &common, &g_buffer, g);
+        hr::RayTracedReflections  reflections_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), reflections_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::HybridFrame           frame_streams(ctx, &common, &g_buffer, &shadows_s, &ao_s, &ddgi_s, &reflections_s);
+        hr::HybridFrame           frame_graph(ctx, &common, &g_buffer, &shadows_g, &ao_g, &ddgi_g, &reflections_g);
+        hipStream_t               app_stream = nullptr;
+        HIP_OK(hipStreamCreateWithFlags(&app_stream, hipStreamNonBlocking));
+        int forked_mismatches = 0;
 
         // ---- G-buffers (two, ping-pong) + blue-noise tables ---------------------------------------------------------------
         void *gb1[2], *gb2[2], *gb3[2], *depth[2];
@@ -235,7 +257,16 @@ int main(int argc, char** argv)
             hr::ImageView color = deferred.output_ds();
             taa.render(cmd_buf, color, cur, pp != 0);
             ground_truth.render(cmd_buf);
+            // the same frame through hr::HybridFrame (one call instead of four): forked streams, then as a hipGraph
+            frame_streams.render(app_stream, hr::HybridFrame::STREAMS);
+            frame_graph.render(app_stream, hr::HybridFrame::GRAPH);
             HIP_OK(hipDeviceSynchronize());
+            const bool eq_s = same_image(shadows_s.output_ds(), shadows.output_ds()) && same_image(ao_s.output_ds(), ao.output_ds()) &&
+                              same_image(ddgi_s.output_ds(), ddgi.output_ds()) && same_image(reflections_s.output_ds(), reflections.output_ds());
+            const bool eq_g = same_image(shadows_g.output_ds(), shadows.output_ds()) && same_image(ao_g.output_ds(), ao.output_ds()) &&
+                              same_image(ddgi_g.output_ds(), ddgi.output_ds()) && same_image(reflections_g.output_ds(), reflections.output_ds());
+            std::printf("frame %u: hr::HybridFrame STREAMS %s serial, GRAPH %s serial\n", f, eq_s ? "==" : "DIFFERS FROM", eq_g ? "==" : "DIFFERS FROM");
+            forked_mismatches += (eq_s ? 0 : 1) + (eq_g ? 0 : 1);
             m_shadow = mean_of(s_v, s_v.format == HR_FORMAT_R16F ? 1 : 2, 0);
             m_ao = mean_of(a_v, 1, 0); m_gi = mean_of(g_v, 4, 1); m_refl = mean_of(r_v, 4, 1);
             m_final = mean_of(color, 4, 1); m_taa = mean_of(taa.output_ds(), 4, 1); m_gt = mean_of(ground_truth.output_ds(), 4, 1);
@@ -259,8 +290,11 @@ int main(int argc, char** argv)
         }
         m_ldr /= 3.0 * 255.0 * W * H;
         std::printf("tone-mapped frame: mean %.4f\n", m_ldr);
+        int inst = 0, upd = 0;
+        frame_graph.graph_stats(inst, upd);
+        std::printf("hr::HybridFrame GRAPH: %d graph instantiated, %d in-place updates; %d mismatching frames\n", inst, upd, forked_mismatches);
         std::printf("hybrid_frame: %d triangles, %dx%d, all passes ran\n", n_tris, W, H);
-        const bool ok = m_shadow > 0.05 && m_shadow < 1.0 && m_ao > 0.2 && m_ao <= 1.0 && m_gi > 0.0 && m_final > 0.0 && m_taa > 0.0 && m_gt > 0.0 &&
+        const bool ok = forked_mismatches == 0 && inst >= 1 && m_shadow > 0.05 && m_shadow < 1.0 && m_ao > 0.2 && m_ao <= 1.0 && m_gi > 0.0 && m_final > 0.0 && m_taa > 0.0 && m_gt > 0.0 &&
                         std::isfinite(m_refl) && std::isfinite(m_final) && m_ldr > 0.02 && m_ldr < 0.98;
         return ok ? 0 : 1;
     }

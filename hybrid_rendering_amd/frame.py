@@ -100,14 +100,17 @@ class HybridFrame:
             self._build_passes(new)
         return self.bounds
 
-    def concurrent_streams(self, on):
+    def concurrent_streams(self, on, mode="streams"):
+        """on: enqueue the frame as its dependency graph through the native hr_hybrid_frame (include/hr_api.h) instead of serially —
+        mode "streams" (fork / join over internal streams) or "graph" (one hipGraph per frame, updated in place).  One GPU only here:
+        the tiled (N > 1) frame keeps its exchanges on one compute stream."""
         import torch
-        if on and not hasattr(self, "_side"):
-            self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
-            self._ev_in, self._ev_atlas = torch.cuda.Event(), torch.cuda.Event()
-            self._ev_out = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]
+        from . import api_frame
         torch.cuda.synchronize()
-        self.concurrent = bool(on) and self.world == 1   # the tiled (N > 1) frame keeps its exchanges on one compute stream
+        self.concurrent = bool(on) and self.world == 1
+        self.frame_mode = {"streams": api_frame.FRAME_STREAMS, "graph": api_frame.FRAME_GRAPH, "serial": api_frame.FRAME_SERIAL}[mode]
+        if self.concurrent and getattr(self, "_native", None) is None:
+            self._native = api_frame.HybridFrame(self.ctx, self.shadows.pass_, self.ao.pass_, self.gi.pass_, self.refl.pass_)
 
     def passes(self):
         return dict(shadows=self.shadows.pass_, ao=self.ao.pass_, ddgi=self.gi.pass_, reflections=self.refl.pass_)
@@ -128,26 +131,8 @@ class HybridFrame:
         """frame k in the reference's order (main.cpp:80-83); `only`: one pass name (DDGI still runs before reflections once)"""
         fi, fl = self.inputs(k)
         if self.concurrent and only is None:
-            import torch
-            main = torch.cuda.current_stream()
-            self._ev_in.record(main)
-            # DDGI: the reflections' hit shading reads the ATLASES (ready after the probe update); the per-pixel probe-grid sample
-            # only feeds the composite, so it leaves the critical chain for a stream of its own
-            gp = self.gi.pass_
-            gp.set_orientation(self._orients[k & 15])
-            gp.ray_trace(self.scene, fi, self.env, None)
-            gp.probe_update(None)
-            for s_, work in zip(self._side[:2], ((lambda st: self.shadows.render(self.scene, fi, stream=st)), (lambda st: self.ao.render(self.scene, fi, stream=st)))):
-                s_.wait_event(self._ev_in)
-                work(s_)
-            self._ev_atlas.record(main)
-            self._side[2].wait_event(self._ev_atlas)
-            gp.sample_probe_grid(fi, self._side[2])
-            gp.end_frame()
-            self.refl.render(self.scene, fl, self.env, gp)
-            for s_, ev in zip(self._side, self._ev_out):
-                ev.record(s_)
-                main.wait_event(ev)
+            self.gi.pass_.set_orientation(self._orients[k & 15])
+            self._native.render(self.scene, self.env, fi, fi, fi, fl, mode=self.frame_mode)
             return
         if only in (None, "shadows"):
             self.shadows.render(self.scene, fi)
@@ -209,5 +194,8 @@ class HybridFrame:
         for t in getattr(self, "_passes", []):
             if hasattr(t, "wait_exchange"):
                 t.wait_exchange()
+        if getattr(self, "_native", None) is not None:
+            self._native.close()
+            self._native = None
         for p in self.passes().values():
             p.close()

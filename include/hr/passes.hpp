@@ -334,6 +334,59 @@ private:
     uint32_t        m_width, m_height;
 };
 
+// The frame of main.cpp:80-83 as ONE call: shadows, AO, DDGI, reflections enqueued as the dependency graph they form (hr_api.h
+// hr_hybrid_frame: shadows | AO | DDGI probe trace + updates -> reflections | DDGI per-pixel sample).  The reference gets this overlap
+// from recording the four render() calls into one Vulkan command buffer; a HIP host gets it here — as forked streams or as one hipGraph
+// per frame (captured, then updated in place) — with every pass output bit-identical to the four serial calls.
+//
+//   hr::HybridFrame frame(ctx, &common, &g_buffer, &shadows, &ao, &ddgi, &reflections);
+//   frame.render(cmd_buf);                                   // instead of shadows.render(cmd_buf); ao.render(cmd_buf); ddgi.render(cmd_buf); reflections.render(cmd_buf, &ddgi);
+class HybridFrame
+{
+public:
+    enum Mode { SERIAL = HR_FRAME_SERIAL, STREAMS = HR_FRAME_STREAMS, GRAPH = HR_FRAME_GRAPH };
+
+    HybridFrame(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTracedShadows* shadows, RayTracedAO* ao, DDGI* ddgi, RayTracedReflections* reflections) :
+        m_common_resources(common_resources), m_g_buffer(g_buffer), m_shadows(shadows), m_ao(ao), m_ddgi(ddgi), m_reflections(reflections)
+    {
+        check(hr_hybrid_frame_create(ctx.handle(), shadows ? shadows->handle() : nullptr, ao ? ao->handle() : nullptr, ddgi ? ddgi->handle() : nullptr,
+                                     reflections ? reflections->handle() : nullptr, &m_frame), "hr_hybrid_frame_create");
+    }
+    ~HybridFrame() { hr_hybrid_frame_destroy(m_frame); }
+    HybridFrame(const HybridFrame&) = delete;
+    HybridFrame& operator=(const HybridFrame&) = delete;
+
+    void render(Stream cmd_buf, Mode mode = STREAMS)
+    {
+        const CommonResources& c = *m_common_resources;
+        Frame fs, fa, fg, fr;
+        hr_hybrid_frame_desc d {};
+        d.environment = c.environment;
+        if (m_shadows) { fs = make_frame(c, *m_g_buffer, (int)m_shadows->scale()); d.shadows_inputs = &fs.inputs; d.shadows_params = &m_shadows->params; }
+        if (m_ao) { fa = make_frame(c, *m_g_buffer, (int)m_ao->scale()); d.ao_inputs = &fa.inputs; d.ao_params = &m_ao->params; }
+        if (m_ddgi) { fg = make_frame(c, *m_g_buffer, (int)m_ddgi->scale()); d.ddgi_inputs = &fg.inputs; d.ddgi_params = &m_ddgi->params; }
+        if (m_reflections)
+        {
+            for (int i = 0; i < 3; i++) m_reflections->params.camera_delta[i] = c.camera_delta[i];   // as RayTracedReflections::render(cmd_buf, ddgi)
+            m_reflections->params.frame_time = c.frame_time;
+            fr = make_frame(c, *m_g_buffer, (int)m_reflections->scale()); d.reflections_inputs = &fr.inputs; d.reflections_params = &m_reflections->params;
+        }
+        check(hr_hybrid_frame_render(m_frame, c.scene->handle(), &d, (hr_frame_mode)mode, cmd_buf), "HybridFrame::render");
+    }
+    // GRAPH mode: graphs instantiated so far (1 in steady state) and in-place updates
+    void graph_stats(int& instantiations, int& updates) { int32_t a = 0, b = 0; check(hr_hybrid_frame_graph_stats(m_frame, &a, &b), "graph_stats"); instantiations = a; updates = b; }
+    hr_hybrid_frame* handle() const { return m_frame; }
+
+private:
+    CommonResources*      m_common_resources;
+    GBuffer*              m_g_buffer;
+    RayTracedShadows*     m_shadows;
+    RayTracedAO*          m_ao;
+    DDGI*                 m_ddgi;
+    RayTracedReflections* m_reflections;
+    hr_hybrid_frame*      m_frame = nullptr;
+};
+
 // src/deferred_shading.h:15-60 — the shading (composite) part
 class DeferredShading
 {

@@ -447,6 +447,37 @@ hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);
 hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out);
 hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);
 
+/* ---- the frame (src/main.cpp:80-83) ------------------------------------------------------------------------------- */
+/* The reference records shadows, AO, DDGI and reflections into ONE command buffer with per-resource barriers, so the GPU overlaps the
+ * independent chains.  hr_hybrid_frame gives a HIP host the same: the four render() calls of a frame enqueued as the dependency graph
+ * they form (shadows | AO | DDGI probe trace + updates -> reflections | DDGI per-pixel sample), every output bit-identical to the serial
+ * order.  The passes are NOT owned; call order at the call site is the reference's, mode picks how the launches reach the GPU. */
+typedef struct hr_hybrid_frame hr_hybrid_frame;
+typedef enum
+{
+    HR_FRAME_SERIAL  = 0, /* one stream, the reference's order (= calling the four render() yourself) */
+    HR_FRAME_STREAMS = 1, /* fork / join over three internal streams + `stream` */
+    HR_FRAME_GRAPH   = 2  /* the forked frame captured into one hipGraph per frame; the instantiated graph is updated in place */
+} hr_frame_mode;
+typedef struct
+{
+    const hr_environment*        environment;          /* DDGI + reflections */
+    const hr_frame_inputs*       shadows_inputs;       /* each pass reads the G-buffer level of its own RayTraceScale */
+    const hr_shadows_params*     shadows_params;
+    const hr_frame_inputs*       ao_inputs;
+    const hr_ao_params*          ao_params;
+    const hr_frame_inputs*       ddgi_inputs;
+    const hr_ddgi_params*        ddgi_params;
+    const hr_frame_inputs*       reflections_inputs;
+    const hr_reflections_params* reflections_params;
+} hr_hybrid_frame_desc;
+/* any of the passes may be NULL (reflections need ddgi); they must outlive the frame object */
+hr_status hr_hybrid_frame_create(hr_ctx* ctx, hr_shadows* shadows, hr_ao* ao, hr_ddgi* ddgi, hr_reflections* reflections, hr_hybrid_frame** out);
+hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, const hr_hybrid_frame_desc* desc, hr_frame_mode mode, void* stream);
+/* HR_FRAME_GRAPH bookkeeping: graphs instantiated (1 in steady state) and in-place updates (one per later frame) */
+hr_status hr_hybrid_frame_graph_stats(hr_hybrid_frame* f, int32_t* instantiations, int32_t* updates);
+hr_status hr_hybrid_frame_destroy(hr_hybrid_frame* f);
+
 /* ---- DeferredShading composite (src/deferred_shading.h; SURVEY.md §8f "next" row 1) ------------------- */
 /* The consumer of the four passes: shaders/deferred.frag:177-205 as a per-pixel kernel.  Inputs are full-resolution views
  * (the passes' OUTPUT_UPSAMPLE outputs).  Like the reference every pixel is shaded; render_skybox then covers the sky texels. */

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     from hybrid_rendering_amd import api
     import importlib
-    for mod in ("api_gi", "api_reflections", "api_deferred", "api_post"):
+    for mod in ("api_gi", "api_reflections", "api_deferred", "api_post", "api_frame"):
         try:
             importlib.import_module("hybrid_rendering_amd." + mod)  # each mirror module registers its symbols
         except ModuleNotFoundError:

@@ -305,23 +305,31 @@ def test_fuzz_seed(oracle, hr, ctx, seed):
     fz.run_seed(seed, oracle, hr, ctx)
 
 
-def test_hybrid_frame_on_concurrent_streams_gives_the_same_images(hr, ctx):
-    """frame.HybridFrame(concurrent=True): shadows | AO | DDGI trace + update -> reflections | DDGI sample on four HIP streams, joined at the end of the frame.
-    The chains share no image, so every pass output must equal the one-stream frame's, bit for bit (both arithmetic modes' kernels
-    are deterministic)."""
+def test_hybrid_frame_forked_gives_the_same_images(hr, ctx):
+    """hr_hybrid_frame (include/hr_api.h): shadows | AO | DDGI trace + update -> reflections | DDGI sample forked over streams, and the
+    same captured as one hipGraph per frame (instantiated once, updated in place).  The chains share no image, so every pass output must
+    equal the serial frame's, bit for bit."""
     import torch
     from hybrid_rendering_amd import synth
     from hybrid_rendering_amd.frame import HybridFrame
     sd = synth.sponza_like(0.25)
     scene = hr.Scene(ctx, sd)
-    outs = []
-    for conc in (False, True):
-        f = HybridFrame(ctx, scene, sd, 480, 272, probes=(6, 3, 5), rays_per_probe=64, concurrent=conc)
-        for k in range(4):
+    outs = {}
+    for mode in ("serial_python", "serial", "streams", "graph"):
+        f = HybridFrame(ctx, scene, sd, 480, 272, probes=(6, 3, 5), rays_per_probe=64)
+        if mode != "serial_python":
+            f.concurrent_streams(True, mode)
+        for k in range(5):
             f.render(k)
         torch.cuda.synchronize()
-        outs.append({n: p.output().clone() for n, p in f.passes().items()})
+        outs[mode] = {n: p.output().clone() for n, p in f.passes().items()}
+        if mode == "graph":
+            inst, upd = f._native.graph_stats()
+            # the first frame of a pass clears its history images (extra memset nodes): its graph is instantiated, the second frame's
+            # topology is the steady-state one (instantiated once more), every later frame updates that graph in place
+            assert 1 <= inst <= 2 and inst + upd == 5 and upd >= 3, (inst, upd)
         f.close()
-    for n in outs[0]:
-        assert torch.equal(outs[0][n].view(torch.int16), outs[1][n].view(torch.int16)), f"{n}: three-stream frame differs from the one-stream frame"
+    for mode in ("serial", "streams", "graph"):
+        for n in outs[mode]:
+            assert torch.equal(outs["serial_python"][n].view(torch.int16), outs[mode][n].view(torch.int16)), f"{n}: {mode} frame differs from the serial frame"
     scene.close()
