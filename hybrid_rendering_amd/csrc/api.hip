@@ -228,7 +228,8 @@ const char* hr_status_string(hr_status s)
     }
 }
 const char* hr_last_error(void) { return g_last_error.c_str(); }
-const char* hr_version(void) { return "hybrid_rendering_amd 0.1 (gfx950)"; }
+const char* hr_version(void) { return "hybrid_rendering_amd 0.3 (gfx950)"; }
+int32_t hr_api_revision(void) { return HR_API_REVISION; }
 
 hr_status hr_ctx_create(int device_ordinal, hr_ctx** out)
 {

@@ -509,6 +509,7 @@ struct hr_shadows
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
     bool          want_stats = false;
+    int           latched_exact = -1;       // arithmetic mode of the last temporal stage: the `nd` side image it wrote has a mode-specific layout
     bool          fuse = true;              // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0)
     bool          persistent_waves = false; // HR_TRACE_KERNEL=queue selects the persistent-wave ray-queue kernel (A/B measurements)
     // developer switches (tools/timeline.py, tools/passbench.py), read from the environment ONCE in hr_shadows_create — the
@@ -758,6 +759,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     if (s != HR_OK) return s;
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
+    p->latched_exact = prm->exact ? 1 : 0;
     TemporalArgs a;
     for (int i = 0; i < 16; i++) a.vpi[i] = in->ubo.view_proj_inverse[i];
     a.mask = (const uint32_t*)p->mask.p; a.mw = p->mw; a.mh = p->mh;
@@ -789,11 +791,14 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     return HR_OK;
 }
 
+static hr_status check_mode(hr_shadows* p, const hr_shadows_params* prm);
+
 hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, int32_t i, void* stream_)
 {
     HR_CHECK_ARG(p && in && prm && i >= 0 && i < prm->filter_iterations && prm->filter_iterations <= 8 && prm->radius >= 0 && prm->radius <= 2);
     hr_status s = check_inputs(p, in, false);
     if (s != HR_OK) return s;
+    if ((s = check_mode(p, prm)) != HR_OK) return s;
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
     // ping-pong as a_trous_filter() (:1101-1107,1175): read = i odd, write = i even ? 1 : 0
@@ -824,11 +829,24 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     return HR_OK;
 }
 
+// the temporal stage writes the normal / depth side image `nd` in a mode-specific layout (packed uint2 in tolerance mode, float4 in the
+// parity mode): an a-trous stage in the other mode would read garbage — refuse it instead (round-2 advisor)
+static hr_status check_mode(hr_shadows* p, const hr_shadows_params* prm)
+{
+    if (p->latched_exact >= 0 && p->latched_exact != (prm->exact ? 1 : 0))
+    {
+        set_last_error("hr_shadows: params.exact changed between the temporal and the a-trous stage of one frame");
+        return HR_ERR_INVALID_ARG;
+    }
+    return HR_OK;
+}
+
 // tolerance mode, radius 1: iterations 0 and 1 in one launch (kf_shadows_atrous01; iteration 0's image stays in LDS)
 static hr_status shadows_atrous01(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_, bool* done)
 {
     hr_status s = check_inputs(p, in, false);
     if (s != HR_OK) return s;
+    if ((s = check_mode(p, prm)) != HR_OK) return s;
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
     AtrousArgs a;

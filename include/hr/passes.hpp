@@ -42,7 +42,12 @@ enum RayTraceScale { RAY_TRACE_SCALE_FULL_RES = HR_SCALE_FULL_RES, RAY_TRACE_SCA
 class Context
 {
 public:
-    explicit Context(int device = 0) { check(hr_ctx_create(device, &m_ctx), "hr_ctx_create"); }
+    explicit Context(int device = 0)
+    {
+        // the parameter structs carry no size field: a host compiled against another header revision must not call in
+        if (hr_api_revision() != HR_API_REVISION) throw std::runtime_error("hr::Context: libhybrid_rendering_amd was built from another revision of hr_api.h (" + std::to_string(hr_api_revision()) + " vs " + std::to_string(HR_API_REVISION) + ")");
+        check(hr_ctx_create(device, &m_ctx), "hr_ctx_create");
+    }
     ~Context() { hr_ctx_destroy(m_ctx); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;

@@ -177,3 +177,28 @@ def test_soft_shadow_mean_converges_to_the_light_disk_visibility(oracle, hr, ctx
     # Monte-Carlo noise: sigma <= 0.5 / sqrt(128) = 0.044 per pixel on each side
     assert diff.mean() < 0.02 and np.percentile(diff, 99) < 0.2 and abs(mean_gpu[geo].mean() - ref[geo].mean()) < 0.01, (diff.mean(), np.percentile(diff, 99))
     assert diff[pen].mean() < 0.07
+
+
+def test_arithmetic_mode_is_latched_at_the_temporal_stage(hr, ctx):
+    """the temporal stage writes its normal / depth side image in a mode-specific layout: an a-trous stage called with the other
+    `exact` is refused (HR_ERR_INVALID_ARG) instead of filtering garbage (round-2 advisor)"""
+    import torch
+    from hybrid_rendering_amd import synth
+    sd = synth.cornell32()
+    gsc = hr.Scene(ctx, sd)
+    ubo = synth.make_ubo(synth.cornell_camera(1.0), None, synth.cornell_light(hard=False))
+    gb = gsc.gbuffer(ubo, 64, 64)
+    sob, sr = synth.blue_noise_tables()
+    fi = hr.frame_inputs(gb, gb, ubo, 0, 0, torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda())
+    p = hr.RayTracedShadows(ctx, 64, 64)
+    p.params.exact = 0
+    p.ray_trace(gsc, fi)
+    p.temporal(fi)
+    p.params.exact = 1
+    with pytest.raises(hr.HRError, match="exact changed"):
+        p.atrous_iteration(fi, 0)
+    p.params.exact = 0
+    p.atrous_iteration(fi, 0)
+    torch.cuda.synchronize()
+    assert hr.lib().hr_api_revision() == 3
+    p.close(); gsc.close()
