@@ -130,7 +130,10 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
                     dir[k] = sample_cosine_lobe(N, r0, r1);
                 }
             }
-            const uint32_t occ = trace_any_seq<AO_SEQ>(active, n, a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, entry HR_DIV(, &dv));
+            float tm[AO_SEQ];
+#pragma unroll
+            for (int k = 0; k < AO_SEQ; k++) tm[k] = a.ray_length;
+            const uint32_t occ = trace_any_seq<AO_SEQ>(active, n, a.nodes, a.tris, ro, dir, 0.01f, tm, s_stack[wave], lane, entry HR_DIV(, &dv));
             for (int k = 0; k < n; k++)
             {
                 const unsigned long long bits = __ballot(active && !((occ >> k) & 1u));

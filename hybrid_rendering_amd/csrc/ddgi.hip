@@ -58,6 +58,11 @@ extern "C" int hr_debug_divergence_ddgi(uint64_t* out, int reset)
 #ifndef DDGI_TRACE_WAVES
 #define DDGI_TRACE_WAVES 1
 #endif
+#ifndef DDGI_SEQ
+#define DDGI_SEQ 0   // 1: the two visibility rays of a hit point as ONE lane-sequential wave loop (traverse.h trace_any_seq) instead of two wave-level
+                     // traversals.  Measured (round 3, 16x8x16x256, bit-identical atlases): 322.4 us vs 324.3 — the ray LENGTHS are heavy-tailed, one
+                     // straggler ray per wave sets the wave's time whether the other lanes' rays are summed or not; kept as a measured A/B path
+#endif
 #ifndef DDGI_COOP
 #define DDGI_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop); 0 = the per-lane loops
 #endif
@@ -112,7 +117,21 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
             const float r2x = next_float(rng), r2y = next_float(rng);
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
             HR_DIV(tc.dv = &dvs;)
+#if DDGI_SEQ
+            // the light ray and the sky ray of the hit point back to back per lane inside ONE wave loop (traverse.h trace_any_seq) instead of
+            // two wave-level traversals; the visibilities enter direct_lighting's result exactly as in shading.h DirectSplit
+            const DirectSplit ds = direct_lighting_split(a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky);
+            const f3    sdir[2] = { ds.ray1 ? ds.Wi1 : ds.Wi2, ds.Wi2 };
+            const float stm[2]  = { ds.ray1 ? ds.t_max1 : 10000.0f, 10000.0f };
+            const int   nsec    = ds.ray1 ? 2 : 1;
+            rays += (uint32_t)nsec;
+            const uint32_t occ = trace_any_seq<2>(true, nsec, a.nodes, a.tris, ds.origin, sdir, 0.01f, stm, s_stack[wave], lane, 0u HR_DIV(, &dvs));
+            const bool o1 = ds.ray1 && (occ & 1u), o2 = ds.ray1 ? ((occ >> 1) & 1u) != 0u : (occ & 1u) != 0u;
+            f3 Lo = o1 ? mk3(0.0f, 0.0f, 0.0f) : ds.P1;
+            if (!o2) Lo = add3(Lo, ds.P2);
+#else
             f3 Lo = direct_lighting(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
+#endif
 #ifndef HR_ABL_DDGI_NO_IRRADIANCE
             if (a.infinite_bounces == 1)
 #else

@@ -980,12 +980,26 @@ __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 #define FR_TW 32
 #define FR_TH 8
 #define FR_R 8
-__global__ __launch_bounds__(256, 5) void kf_refl_temporal(ReflTemporalArgs a)
+#ifndef FR_EU
+#define FR_EU 5        // minimum waves per SIMD the register allocator leaves room for (see FR_ALIAS)
+#endif
+#ifndef FR_ALIAS
+#define FR_ALIAS 0     // 1: the horizontal sums overwrite the colour tile (the sums are held in registers across a barrier): 27.6 -> 18.4 KB of
+                       // LDS per workgroup, 5 -> 8 workgroups per CU if the registers allow (FR_EU)
+#endif
+__global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs a)
 {
     constexpr int CW = FR_TW + 2 * FR_R, CH = FR_TH + 2 * FR_R;   // 48 x 24
+#if FR_ALIAS
+    __shared__ float4 s_raw[CH * FR_TW + CH * FR_TW / 2];          // 18.4 KB: first the colour tile (9.2 KB), then ha | hb
+    uint2  (*s_col)[CW]   = reinterpret_cast<uint2 (*)[CW]>(s_raw);
+    float4 (*s_ha)[FR_TW] = reinterpret_cast<float4 (*)[FR_TW]>(s_raw);
+    float2 (*s_hb)[FR_TW] = reinterpret_cast<float2 (*)[FR_TW]>(s_raw + CH * FR_TW);
+#else
     __shared__ uint2  s_col[CH][CW];        // rgb + ray length, fp16 as stored by the trace
     __shared__ float4 s_ha[CH][FR_TW];      // horizontal sums: sum r, g, b, sum r^2
     __shared__ float2 s_hb[CH][FR_TW];      //                  sum g^2, b^2
+#endif
     __shared__ int    s_flag[4];
     const int bx0 = blockIdx.x * FR_TW, by0 = a.y0 + blockIdx.y * FR_TH;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
@@ -1003,6 +1017,11 @@ __global__ __launch_bounds__(256, 5) void kf_refl_temporal(ReflTemporalArgs a)
         s_col[cy][cx] = a.in.raw(bx0 - FR_R + cx, by0 - FR_R + cy);
     }
     __syncthreads();
+#if FR_ALIAS
+    const uint2 cq = s_col[(threadIdx.x >> 5) + FR_R][(threadIdx.x & 31) + FR_R];   // the centre texel, before the tile is overwritten
+    float4 ha_out[4];
+    float2 hb_out[4];
+#endif
     if (threadIdx.x < CH * (FR_TW / 4))
     {
         const int r = threadIdx.x >> 3, g = (threadIdx.x & 7) * 4;   // row, first of four adjacent outputs
@@ -1032,13 +1051,29 @@ __global__ __launch_bounds__(256, 5) void kf_refl_temporal(ReflTemporalArgs a)
                     s1[0] += e[k].x; s1[1] += e[k].y; s1[2] += e[k].z;
                     s2[0] += e[k].x * e[k].x; s2[1] += e[k].y * e[k].y; s2[2] += e[k].z * e[k].z;
                 }
+#if FR_ALIAS
+            ha_out[j] = make_float4(s1[0], s1[1], s1[2], s2[0]);
+            hb_out[j] = make_float2(s2[1], s2[2]);
+#else
             s_ha[r][g + j] = make_float4(s1[0], s1[1], s1[2], s2[0]);
             s_hb[r][g + j] = make_float2(s2[1], s2[2]);
+#endif
         }
     }
+#if FR_ALIAS
+    __syncthreads();   // every thread has read its part of the colour tile
+    if (threadIdx.x < CH * (FR_TW / 4))
+    {
+        const int r = threadIdx.x >> 3, g = (threadIdx.x & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s_ha[r][g + j] = ha_out[j]; s_hb[r][g + j] = hb_out[j]; }
+    }
+#endif
     __syncthreads();
     const bool  live = have && d != 1.0f;
+#if !FR_ALIAS
     const uint2 cq = s_col[ly + FR_R][lx + FR_R];
+#endif
     Reproj<8, true, true> rp;
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };

@@ -402,11 +402,12 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
 // NB maxima.  No queue, no atomics, no cross-lane traffic: the rays of a lane are prepared up front and live in registers; a switch
 // is a handful of v_cndmask.  Decisions per ray are those of trace_any (same node / triangle tests, any-hit), so the masks are
 // bit-identical.  Returns the bit mask of OCCLUDED rays.
-struct RaySeq { float Sx, Sy, Sz, idx, idy, idz; uint32_t code; };   // code: kx | ky << 2 | kz << 4 | sel << 6
+struct RaySeq { float Sx, Sy, Sz, idx, idy, idz, t_max; uint32_t code; };   // code: kx | ky << 2 | kz << 4 | sel << 6
 
-HR_DEV RaySeq rayseq_pack(const RayPre& r)
+HR_DEV RaySeq rayseq_pack(const RayPre& r, float t_max)
 {
     RaySeq q;
+    q.t_max = t_max;
     q.Sx = r.Sx; q.Sy = r.Sy; q.Sz = r.Sz; q.idx = r.idx; q.idy = r.idy; q.idz = r.idz;
     q.code = (uint32_t)r.kx | ((uint32_t)r.ky << 2) | ((uint32_t)r.kz << 4) | (r.sel << 6);
     return q;
@@ -428,14 +429,15 @@ HR_DEV RaySeq rayseq_select(const RaySeq (&q)[NB], int s)
 
 template <int NB>
 HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, const f3 (&dir)[NB],
-                              float t_min, float t_max, uint32_t* wave_stack, int lane, uint32_t entry, DivCounters* dv = nullptr)
+                              float t_min, const float (&t_maxs)[NB], uint32_t* wave_stack, int lane, uint32_t entry, DivCounters* dv = nullptr)
 {
     RaySeq q[NB];
 #pragma unroll
-    for (int k = 0; k < NB; k++) q[k] = rayseq_pack(ray_prepare(o, dir[k]));
+    for (int k = 0; k < NB; k++) q[k] = rayseq_pack(ray_prepare(o, dir[k]), t_maxs[k]);
     RayPre r;
     r.o = o;
     rayseq_unpack(r, q[0]);
+    float t_max = q[0].t_max;
     uint32_t  spill_array[HR_SPILL_ENTRIES];
     LaneStack st;
     st.init(wave_stack, lane, spill_array);
@@ -456,7 +458,8 @@ HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__
                 alive = s < n_rays;
                 if (alive)
                 {
-                    rayseq_unpack(r, rayseq_select<NB>(q, s));
+                    const RaySeq nx = rayseq_select<NB>(q, s);
+                    rayseq_unpack(r, nx); t_max = nx.t_max;
                     cur = first; st.sp = 0;
                     go  = walk_next<false>(cur, st, ni);
                 }
@@ -488,7 +491,8 @@ HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__
                     alive = s < n_rays;
                     if (alive)
                     {
-                        rayseq_unpack(r, rayseq_select<NB>(q, s));
+                        const RaySeq nx = rayseq_select<NB>(q, s);
+                        rayseq_unpack(r, nx); t_max = nx.t_max;
                         cur = first; st.sp = 0;
                     }
                 }
