@@ -63,7 +63,7 @@ def kernel_of(pass_, stage, exact):
             return ("kf_shadows_atrous_lds<%d, true>" if step[stage] <= 2 else "kf_shadows_atrous<%d, true>") % step[stage]
     if pass_ == "ao":
         if stage == "ray_trace": return "k_ao_trace<false>"
-        if stage == "temporal_accumulation": return "k_ao_temporal" if exact else "kf_ao_temporal<true>"
+        if stage == "temporal_accumulation": return "k_ao_temporal<true>" if exact else "kf_ao_temporal<true>"
         if stage == "blur_xy": return "kf_ao_blur_xy<4, 16>"
         if stage in ("blur_x", "blur_y"): return "k_ao_blur<4>" if exact else "kf_ao_blur<4>"   # two launches of one instance: the counters average X and Y
     if pass_ == "ddgi":

@@ -8,6 +8,7 @@
 #include "hr_internal.h"
 #include "reproject.h"
 #include "traverse.h"
+#include "mask_window.h"
 #include "upsample.h"
 #include "pass_args.h"
 
@@ -198,9 +199,11 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
 
 // ------------------------------------------------------------------------------------------------
 
+template <bool MULTI>
 __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
 {
-    __shared__ uint32_t s_mask[4][18];
+    __shared__ uint32_t s_mask[4][4][18];
+    __shared__ MaskRows s_rows[4];
     __shared__ float    s_vpi[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
@@ -209,31 +212,12 @@ __global__ __launch_bounds__(256) void k_ao_temporal(AOTemporalArgs a)
     const int lx = lane & 7, ly = lane >> 3;
     const int x = tx * 8 + lx, y = ty * 8 + ly;
     if (threadIdx.x < 16) s_vpi[threadIdx.x] = a.vpi[threadIdx.x];
-    int sum = 0, own = 0;
-    for (int s = 0; s < a.spp; s++)
-    {
-        __syncthreads();
-        if (tile_ok && lane < 18)
-        {
-            // populate_cache (:101-119): masks outside the mask image read all-ones
-            const int cx = tx - 1 + lane % 3, cy = ty * 2 - 2 + lane / 3;
-            uint32_t  v  = 0xFFFFFFFFu;
-            if (cx >= 0 && cy >= 0 && cx < a.mw && cy < a.mh) v = a.mask[((size_t)s * a.mh + cy) * a.mw + cx];
-            s_mask[wave][lane] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int yy = -8; yy <= 8; yy++)
-        {
-            const int ry = ly + 8 + yy, mrow = ry >> 2, brow = ry & 3;
-            const uint32_t b0 = (s_mask[wave][mrow * 3 + 0] >> (brow * 8)) & 0xffu;
-            const uint32_t b1 = (s_mask[wave][mrow * 3 + 1] >> (brow * 8)) & 0xffu;
-            const uint32_t b2 = (s_mask[wave][mrow * 3 + 2] >> (brow * 8)) & 0xffu;
-            sum += __popc(((b0 | (b1 << 8) | (b2 << 16)) >> lx) & 0x1ffffu);
-        }
-        const int cry = ly + 8, crx = lx + 8;
-        own += (int)((s_mask[wave][(cry >> 2) * 3 + (crx >> 3)] >> ((cry & 3) * 8 + (crx & 7))) & 1u);
-    }
+    // the window sums are integer work: the bit-sliced row patterns of the tolerance-mode kernel (mask_window.h) give the same counts as
+    // one plane at a time (round-2 review item 7: 0-ulp structural change)
+    build_mask_rows<true>(s_rows[wave], s_mask[wave], a.mask, MULTI ? a.spp : 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
+    __syncthreads();   // s_vpi
+    int sum, own;
+    mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);
     if (!tile_ok) return;
     const float mean = __fdiv_rn((float)sum, 289.0f * (float)a.spp);
     const bool  in_image = x < a.w && y < a.h && y >= a.y0 && y < a.y1;
@@ -534,7 +518,8 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);
-    if (prm->exact) hipLaunchKernelGGL(k_ao_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    if (prm->exact && prm->spp > 1) hipLaunchKernelGGL(k_ao_temporal<true>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
+    else if (prm->exact) hipLaunchKernelGGL(k_ao_temporal<false>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
     else launch_ao_temporal_fast(a, a.tiles_x * a.tiles_y, st);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
