@@ -35,6 +35,8 @@ struct TraceArgs
     int             tiles_x, tiles_y, tile_y0, debug_skip_traversal, debug_only_tx, debug_only_ty;
     float           bias;
     uint32_t        num_frames;
+    uint32_t*       occluder;  // nullable: per pixel, the index (into tris) of the triangle that occluded its ray last frame (see k_shadows_trace)
+    uint32_t        n_tri_refs;
 };
 
 // One wave = one 8x8 pixel tile = two 8x4 mask words; lane l -> pixel (l & 7, l >> 3), so the
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
     const float    d_pre  = a.depth[pix];
     const uint2    g2_pre = a.gb2[pix];
     const uint32_t bn_pre = blue_noise_texel(x, y, a.sr);
+    const uint32_t occ_pre = a.occluder ? a.occluder[pix] : 0xffffffffu;
     if (kind)
     {
         const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
@@ -83,7 +86,34 @@ __global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
             if (att > 0.0f)
             {
                 fired = true;
-                lit   = a.debug_skip_traversal ? (ro.x + Wi.y > -1e30f) : !trace_any<STATS>(a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt);
+                // Occluder cache: "is ANY triangle hit in (t_min, t_max)" is a pure function of the geometry, so testing one particular
+                // triangle FIRST and answering "occluded" when it is hit cannot change the mask — and the triangle that shadowed this
+                // pixel last frame (static light, camera moving a fraction of a pixel) shadows it again almost always.  66 % of the bench
+                // frame's shadow rays are occluded; a tile whose lanes are all answered by their cached triangle skips the walk, and in
+                // mixed tiles the occluded lanes (the ones that would otherwise walk until their first hit) drop out of the wave's
+                // longest-lane race.  A stale or foreign index is harmless: the CURRENT scene's triangle at that index is tested.
+                bool occluded = false;
+                uint32_t hit_tri = 0xffffffffu;
+                if (a.occluder && kind == 1 && !a.debug_skip_traversal)
+                {
+                    const uint32_t c = occ_pre;
+                    if (c < a.n_tri_refs)
+                    {
+                        const RayPre rp = ray_prepare(ro, Wi);
+                        float t, u, v;
+                        occluded = ray_tri_raw<false>(rp, load_tri_raw(a.tris, c), 0.01f, t_max, t, u, v);
+                        if (STATS) nt++;
+                        hit_tri = c;
+                    }
+                }
+                if (a.debug_skip_traversal) lit = (ro.x + Wi.y > -1e30f);
+                else if (!occluded)
+                {
+                    hit_tri = 0xffffffffu;
+                    occluded = trace_any<STATS>(a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt, 0u, nullptr, &hit_tri);
+                }
+                if (!a.debug_skip_traversal) lit = !occluded;
+                if (a.occluder && kind == 1 && hit_tri != occ_pre) a.occluder[pix] = hit_tri;
             }
         }
     }
@@ -501,7 +531,8 @@ struct hr_shadows
     int     band_y0 = 0, band_y1 = 0;
     int     ry0 = 0, ry1 = 0;         // rows whose history / G-buffer may be read (band + history halo)
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0;
-    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters, nd, ray_slots;
+    DevBuf  mask, temporal_out, moments[2], prev_image, atrous[2], upsample, tile_class, counters, nd, ray_slots, occluder;
+    bool    occluder_cache = true;    // developer A/B switch HR_SHADOW_CACHE=0 (read once at create)
     bool    first_frame = true;
     int     read_idx = 0;             // ATrous::read_idx
     bool    last_denoise = true;
@@ -538,6 +569,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     { const char* e = getenv("HR_TRACE_KERNEL"); p->persistent_waves = (e && std::string(e) == "queue"); }
     if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &p->dbg_only_tx, &p->dbg_only_ty);
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
+    if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
     p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
     p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
     p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
@@ -577,7 +609,9 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     A(nd, px * 16)
     A(counters, 64)
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 2)
+    A(occluder, px * 4)
 #undef A
+    HR_HIP(hipMemset(p->occluder.p, 0xff, p->occluder.bytes));   // no cached occluder
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
@@ -689,6 +723,8 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     a.w = p->w; a.h = p->h; a.y0 = p->y0; a.y1 = p->y1; a.mw = p->mw;
     a.tile_y0 = p->y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(p->y1, 8) - a.tile_y0;
     a.bias = prm->bias; a.num_frames = in->num_frames;
+    a.occluder = p->occluder_cache ? (uint32_t*)p->occluder.p : nullptr;
+    a.n_tri_refs = (uint32_t)(scene->tris.bytes / sizeof(TriGPU));
     const int n_tiles = a.tiles_x * a.tiles_y;
     const int n_slots = n_tiles;
     a.debug_only_tx = p->dbg_only_tx; a.debug_only_ty = p->dbg_only_ty;

@@ -354,9 +354,12 @@ HR_DEV uint32_t entry_node_for_box(const Node8* __restrict__ nodes, f3 lo, f3 hi
     return ni;
 }
 
+// hit_tri (optional): index into `tris` of the triangle that occluded the ray (untouched on a miss) — the next frame's first guess
+// (shadow trace: occluder cache).
 template <bool STATS>
 HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u, DivCounters* dv = nullptr)
+                      uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u, DivCounters* dv = nullptr,
+                      uint32_t* hit_tri = nullptr)
 {
     if (entry == HR_NO_ENTRY) return false;
     RayPre    r = ray_prepare(o, d);
@@ -386,7 +389,7 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
             float t, u, v;
             const bool ha = ray_tri_raw_uniform<false>(r, pcode, ta, t_min, t_max, t, u, v);
             const bool hb = ray_tri_raw_uniform<false>(r, pcode, tb, t_min, t_max, t, u, v);
-            if (ha || hb) { hit = true; break; }
+            if (ha || hb) { hit = true; if (hit_tri) *hit_tri = h.tri_base + (ha ? i0 : i1); break; }
         }
         if (hit) break;
     }

@@ -202,3 +202,43 @@ def test_arithmetic_mode_is_latched_at_the_temporal_stage(hr, ctx):
     torch.cuda.synchronize()
     assert hr.lib().hr_api_revision() == 3
     p.close(); gsc.close()
+
+
+def test_occluder_cache_never_changes_the_mask(hr, ctx):
+    """k_shadows_trace tests the triangle that occluded a pixel's ray last frame before walking the BVH.  'Any triangle hit' is a pure
+    function of the geometry, so the masks must equal those of a pass created with HR_SHADOW_CACHE=0 — over moving frames, and when the
+    pass is suddenly pointed at ANOTHER scene (stale indices, some beyond the new scene's triangle count)."""
+    import os
+    import torch
+    from hybrid_rendering_amd import synth
+    W, H = 320, 184
+    big, small = synth.sponza_like(0.25), synth.cornell32()
+    scenes = [hr.Scene(ctx, big), hr.Scene(ctx, small)]
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    cached = hr.RayTracedShadows(ctx, W, H)
+    os.environ["HR_SHADOW_CACHE"] = "0"
+    try:
+        plain = hr.RayTracedShadows(ctx, W, H)
+    finally:
+        del os.environ["HR_SHADOW_CACHE"]
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=1.0) for f in range(7)]
+    occluded = 0
+    for f in range(6):
+        si = 0 if f < 4 else 1                      # frames 4, 5: the Cornell box through the Sponza view (32 triangles: most cached indices are out of range)
+        cam = cams[f + 1] if si == 0 else synth.cornell_camera(W / H)
+        lgt = light if si == 0 else synth.cornell_light(hard=False)
+        ubo = synth.make_ubo(cam, cams[f] if si == 0 else None, lgt)
+        gb = scenes[si].gbuffer(ubo, W, H)
+        fi = hr.frame_inputs(gb, gb, ubo, f, f & 1, sob_d, sr_d)
+        cached.ray_trace(scenes[si], fi)
+        plain.ray_trace(scenes[si], fi)
+        torch.cuda.synchronize()
+        a, b = cached.image(cached.IMG_MASK), plain.image(plain.IMG_MASK)
+        assert torch.equal(a, b), f"frame {f}: the occluder cache changed {int((a != b).sum())} mask words"
+        assert cached.ray_count() == plain.ray_count() > 1000
+        occluded += int(cached.ray_count())
+    cached.close(); plain.close()
+    for s in scenes:
+        s.close()
