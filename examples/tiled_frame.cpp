@@ -101,6 +101,7 @@ void rank_main(int rank, int device, bool use_rccl, const uint8_t* id, const std
         const std::vector<int32_t> bounds = hr::uniform_bounds(H, kWorld);
         hr::TiledShadows shadows(ctx, comm, &common, &g_buffer, bounds);
         hr::TiledAO      ao(ctx, comm, &common, &g_buffer, bounds, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::TiledHybridFrame tiled(ctx, &shadows, &ao, nullptr, nullptr);
         hr::RayTracedShadows whole_shadows(ctx, &common, &g_buffer);          // the un-tiled reference, rendered by every rank
         hr::RayTracedAO      whole_ao(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         void *gb1[2], *gb2[2], *gb3[2], *depth[2];
@@ -129,8 +130,10 @@ void rank_main(int rank, int device, bool use_rccl, const uint8_t* id, const std
             g_buffer.current[0] = cur;
             g_buffer.history[0] = f ? hr_gbuffer_level { gb1[!pp], gb2[!pp], gb3[!pp], (const float*)depth[!pp], W, H } : cur;
             common.num_frames = f; common.ping_pong = pp != 0;
-            shadows.render(stream);
-            ao.render(stream);
+            // main.cpp:80-81 for this rank's band: hr::TiledHybridFrame forks the two passes over its streams; each posts its neighbour
+            // exchange from inside render() (one communicator, per-pass tickets) — odd frames take the plain serial calls for comparison
+            if (f & 1) { shadows.render(stream); ao.render(stream); }
+            else tiled.render(stream);
             whole_shadows.render(stream);
             whole_ao.render(stream);
             (void)hipStreamSynchronize(stream);

@@ -53,4 +53,5 @@ class HybridFrame:
             self.h = C.c_void_p()
 
 
-api.ABI_SYMBOLS += ["hr_hybrid_frame_create", "hr_hybrid_frame_render", "hr_hybrid_frame_graph_stats", "hr_hybrid_frame_destroy"]
+api.ABI_SYMBOLS += ["hr_hybrid_frame_create", "hr_hybrid_frame_render", "hr_hybrid_frame_graph_stats", "hr_hybrid_frame_destroy", "hr_hybrid_frame_fork",
+                    "hr_hybrid_frame_join"]

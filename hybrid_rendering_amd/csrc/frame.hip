@@ -171,6 +171,36 @@ hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, cons
     return HR_OK;
 }
 
+// Fork / join for hosts that enqueue the chains themselves (the row-tiled passes of include/hr/tiled.hpp post their neighbour exchanges
+// from inside render(): hr::TiledHybridFrame).  fork: the three internal streams wait for everything enqueued on `main` so far and are
+// handed out; join: `main` waits for everything enqueued on them since.
+hr_status hr_hybrid_frame_fork(hr_hybrid_frame* f, void* main_, void** side_streams)
+{
+    HR_CHECK_ARG(f && side_streams);
+    hipStream_t main = (hipStream_t)main_;
+    HR_HIP(hipSetDevice(f->ctx->device));
+    HR_HIP(hipEventRecord(f->ev_in, main));
+    for (int i = 0; i < 3; i++)
+    {
+        HR_HIP(hipStreamWaitEvent(f->side[i], f->ev_in, 0));
+        side_streams[i] = (void*)f->side[i];
+    }
+    return HR_OK;
+}
+
+hr_status hr_hybrid_frame_join(hr_hybrid_frame* f, void* main_)
+{
+    HR_CHECK_ARG(f);
+    hipStream_t main = (hipStream_t)main_;
+    HR_HIP(hipSetDevice(f->ctx->device));
+    for (int i = 0; i < 3; i++)
+    {
+        HR_HIP(hipEventRecord(f->ev_out[i], f->side[i]));
+        HR_HIP(hipStreamWaitEvent(main, f->ev_out[i], 0));
+    }
+    return HR_OK;
+}
+
 hr_status hr_hybrid_frame_graph_stats(hr_hybrid_frame* f, int32_t* instantiations, int32_t* updates)
 {
     HR_CHECK_ARG(f);

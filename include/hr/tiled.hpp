@@ -187,4 +187,39 @@ private:
     hr_comm_ticket       m_ticket = 0;
 };
 
+// The row-tiled frame with its independent chains forked over streams (the N > 1 counterpart of hr::HybridFrame): shadows and AO on
+// two of the frame object's internal streams, DDGI -> reflections on cmd_buf.  Every pass still posts its own neighbour exchange from
+// inside render() — on its own stream, all through ONE communicator: the collectives reach the communication stream in host-call order,
+// which is the same on every rank, and each pass waits for its own ticket only (hr_comm.h).
+class TiledHybridFrame
+{
+public:
+    TiledHybridFrame(Context& ctx, TiledShadows* shadows, TiledAO* ao, ShardedDDGI* ddgi, TiledReflections* reflections) :
+        m_shadows(shadows), m_ao(ao), m_ddgi(ddgi), m_reflections(reflections)
+    {
+        check(hr_hybrid_frame_create(ctx.handle(), shadows ? shadows->pass().handle() : nullptr, ao ? ao->pass().handle() : nullptr,
+                                     ddgi ? ddgi->pass().handle() : nullptr, reflections ? reflections->pass().handle() : nullptr, &m_frame), "hr_hybrid_frame_create");
+    }
+    ~TiledHybridFrame() { hr_hybrid_frame_destroy(m_frame); }
+    TiledHybridFrame(const TiledHybridFrame&) = delete;
+    TiledHybridFrame& operator=(const TiledHybridFrame&) = delete;
+    // main.cpp:80-83 in one call; forked = false: the four render() calls on cmd_buf
+    void render(Stream cmd_buf, bool forked = true)
+    {
+        void* side[3] = { cmd_buf, cmd_buf, cmd_buf };
+        if (forked) check(hr_hybrid_frame_fork(m_frame, cmd_buf, side), "hr_hybrid_frame_fork");
+        if (m_ddgi) m_ddgi->render(cmd_buf);                         // the longest chain first
+        if (m_shadows) m_shadows->render(side[0]);
+        if (m_ao) m_ao->render(side[1]);
+        if (m_reflections) m_reflections->render(cmd_buf, &m_ddgi->pass());
+        if (forked) check(hr_hybrid_frame_join(m_frame, cmd_buf), "hr_hybrid_frame_join");
+    }
+private:
+    TiledShadows*     m_shadows;
+    TiledAO*          m_ao;
+    ShardedDDGI*      m_ddgi;
+    TiledReflections* m_reflections;
+    hr_hybrid_frame*  m_frame = nullptr;
+};
+
 } // namespace hr

@@ -482,6 +482,11 @@ typedef struct
 /* any of the passes may be NULL (reflections need ddgi); they must outlive the frame object */
 hr_status hr_hybrid_frame_create(hr_ctx* ctx, hr_shadows* shadows, hr_ao* ao, hr_ddgi* ddgi, hr_reflections* reflections, hr_hybrid_frame** out);
 hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, const hr_hybrid_frame_desc* desc, hr_frame_mode mode, void* stream);
+/* Fork / join for a host that enqueues the chains itself (hr::TiledHybridFrame: the row-tiled passes post their neighbour exchanges from
+ * inside render()).  fork: side_streams[0..2] (owned by the frame object) wait for everything enqueued on `stream` so far; join: `stream`
+ * waits for everything enqueued on them since. */
+hr_status hr_hybrid_frame_fork(hr_hybrid_frame* f, void* stream, void** side_streams);
+hr_status hr_hybrid_frame_join(hr_hybrid_frame* f, void* stream);
 /* HR_FRAME_GRAPH bookkeeping: graphs instantiated (1 in steady state) and in-place updates (one per later frame) */
 hr_status hr_hybrid_frame_graph_stats(hr_hybrid_frame* f, int32_t* instantiations, int32_t* updates);
 hr_status hr_hybrid_frame_destroy(hr_hybrid_frame* f);
