@@ -5,6 +5,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ ! -x $R/tools/_build/pmc_calib ] || [ $R/tools/pmc_calib.hip -nt $R/tools/_build/pmc_calib ]; then
+    mkdir -p $R/tools/_build && hipcc --offload-arch=gfx950 -O3 $R/tools/pmc_calib.hip -o $R/tools/_build/pmc_calib
+fi
 $R/tools/_build/pmc_calib > $OUT/calib_run.jsonl
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -- $R/tools/_build/pmc_calib > /dev/null 2> $OUT/cal_$c.err
