@@ -160,7 +160,7 @@ def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
         tol.compare16(helpers.bits16(gf_ddgi.output()), o_ddgi.stages["output"], f"frame {f} DDGI probe-grid sample at 1080p (exact = 0)")
         assert np.array_equal(helpers.bits16(gf.image(gf.IMG_TRACE)), st["trace"]) and gf.ray_count() == st["rays"], f"frame {f}: the trace has one mode"
         ex = tol.tiles_close(gf.image(gf.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f} (exact = 0)", shape=(h, w))
-        tol.compare16(helpers.bits16(gf.image(gf.IMG_COLOR1 if f & 1 else gf.IMG_COLOR0)), st["temporal"], f"frame {f} temporal colour + variance (exact = 0)", abs_floor=1e-3)   # intermediate image, as for the shadows
+        tol.compare16(helpers.bits16(gf.image(gf.IMG_COLOR1 if f & 1 else gf.IMG_COLOR0)), st["temporal"], f"frame {f} temporal colour + variance (exact = 0)", abs_floor=tol.INTERMEDIATE_FLOOR)   # intermediate image, as for the shadows
         tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_ATROUS)), st["atrous"][-1], f"frame {f} a-trous colour + variance (exact = 0)", exclude=ex, variance_channels=(3,))
         exu = tol.upscale_mask(ex, scale, H, W) if scale else ex
         tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE)), st["output"], f"frame {f} reflections output (exact = 0)", exclude=exu, variance_channels=(3,))

@@ -3,8 +3,9 @@ csrc/denoise_fast.hip) against the CPU oracle.
 
 Stated tolerance (north_star "AO / reflections / GI within a stated fp32 tolerance"):
   * visibility masks, ray counts: BIT-EXACT (the trace kernels have one mode);
-  * every fp16 output image: <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 error <= 1e-3 over those texels and <= 1e-2 over
-    ALL texels.  The remaining <= 0.1 % are discrete decisions flipped by an fp32 ulp (a reprojection validity threshold, a truncation
+  * every fp16 output image, EVERY channel: <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 error <= 1e-3 over those texels and
+    <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) also count |diff| <= 1e-4 as equal, the temporal stages'
+    intermediate images |diff| <= 2e-4 (both are differences of nearly equal numbers: m2 - m1^2, E[x^2] - E[x]^2).  The remaining <= 0.1 % are discrete decisions flipped by an fp32 ulp (a reprojection validity threshold, a truncation
     to a texel index, a tile whose only non-trivial pixel sits on the classification threshold) or 0/0 situations of the reference's
     own arithmetic (a DDGI pixel all of whose probe weights were crushed to the 1e-6 floor); their energy is bounded by the second
     L2 figure, not ignored;
@@ -21,6 +22,10 @@ pytestmark = pytest.mark.gpu
 
 
 VARIANCE_FLOOR = 1e-4     # absolute slack of the variance channels (see compare16)
+import os
+# absolute slack of the temporal stages' INTERMEDIATE images (round 3: 2e-4; rounds 1-2 allowed 1e-3.  Everything — the tests, the 1080p frames and
+# 295 random configurations of tools/fuzz_tolerance.py incl. 20-frame sequences — also passes at 1e-4; 2e-4 leaves a factor of two)
+INTERMEDIATE_FLOOR = float(os.environ.get("HR_TEST_INTERMEDIATE_FLOOR", 2e-4))
 
 
 def _key(bits):
@@ -114,8 +119,8 @@ def test_shadows_tolerance(oracle, hr, ctx, name, w, h, dolly, light, params, n_
         assert gp.ray_count() == st["rays"]
         ex = tiles_close(gp.image(gp.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f}", shape=(h, w))
         # intermediate images: the variance / second-moment channels are differences of nearly equal numbers
-        compare16(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"], f"frame {f} temporal", abs_floor=1e-3)
-        compare16(helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0)), st["moments"], f"frame {f} moments (m1, m2, history length, 0)", abs_floor=1e-3)
+        compare16(helpers.bits16(gp.image(gp.IMG_TEMPORAL)), st["temporal"], f"frame {f} temporal", abs_floor=INTERMEDIATE_FLOOR)
+        compare16(helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0)), st["moments"], f"frame {f} moments (m1, m2, history length, 0)", abs_floor=INTERMEDIATE_FLOOR)
         out, ref = helpers.bits16(gp.output(hr.OUTPUT_ATROUS)), st["output"]
         compare16(out, ref, f"frame {f} denoised visibility + filtered variance", exclude=ex, variance_channels=(1,))
         compare16(helpers.bits16(gp.image(gp.IMG_PREV)), op.prev_image, f"frame {f} feedback image (next frame's history)", exclude=ex, variance_channels=(1,))
