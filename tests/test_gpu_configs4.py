@@ -140,7 +140,7 @@ def test_4k_ao_4spp_matches_oracle(oracle, hr, ctx, sponza_full, frames4k):
 def test_1080p_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full):
     """the frame bench.py's `passes.hybrid` times (shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, exact = 0) through
     k_deferred, two moving frames, against the oracle's deferred composite of the oracle's pass outputs (deferred.frag:177-205).
-    Every pass output AND the final HDR image obey the image rule of DESIGN.md §3.6 — all channels."""
+    Every pass output AND the final HDR image obey the image rule of DESIGN.md §3.6 (2 fp16 ulp on >= 99.9 %, rel-L2 <= 1e-3) — all channels."""
     import torch
     from hybrid_rendering_amd import api_deferred, api_gi, api_reflections
     from oracle import pyoracle_ddgi as od, pyoracle_deferred as odf, pyoracle_reflections as orf
@@ -200,8 +200,8 @@ def test_1080p_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_ful
         tol.compare16(helpers.bits16(g_gi.output()), gi, f"frame {f} DDGI sample")
         tol.compare16(helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE)), rf, f"frame {f} reflections output", exclude=ex_rf, variance_channels=(3,))
         got = helpers.bits16(g_df.output())
-        # the composite multiplies / adds four images that are each within 2 ulp: its own bound is 4 ulp (stated here), same L2 rule
-        tol.compare16(got, ref, f"frame {f} final HDR image", ulps=4, exclude=ex_sh | ex_ao | ex_rf)
+        # the composite of four images that are each within 2 ulp obeys the SAME image rule (measured: it also holds at 2 ulp, not only at 4)
+        tol.compare16(got, ref, f"frame {f} final HDR image", exclude=ex_sh | ex_ao | ex_rf)
     img = oracle.f16(ref[..., :3])
     assert np.isfinite(img).all() and img.mean() > 0.01
     for g in (g_sh, g_ao, g_gi, g_rf, g_df):
