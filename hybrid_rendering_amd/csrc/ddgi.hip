@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
             hit_distance = 0.001f + h.t;
         }
         const size_t o = (size_t)probe * R + ray;
+#if defined(HR_TRACE_DIVERGENCE) && defined(HR_DDGI_DUMP_STEPS)   // developer study (tools/ddgi_sort_study.py): node steps of the primary ray in the unused .w
+        a.radiance[o] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, (float)dvp.lane_nodes));
+#else
         a.radiance[o] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, 0.0f));
+#endif
         a.dirdist[o]  = make_uint2(pack_h2(dir.x, dir.y), pack_h2(dir.z, hit_distance));
     }
     HR_DIV(div_flush(dvp, g_div_ddgi); div_flush(dvs, g_div_ddgi + 8);)
