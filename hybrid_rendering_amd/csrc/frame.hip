@@ -153,6 +153,7 @@ hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, cons
         if (hipGraphExecUpdate(f->exec, graph, &bad, &res) != hipSuccess)
         {
             (void)hipGetLastError();
+            (void)hipStreamSynchronize(main);   // the old graph may still be running (topology changes are rare: a pass's first frame)
             (void)hipGraphExecDestroy(f->exec);
             f->exec = nullptr;
             fresh = true;

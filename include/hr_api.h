@@ -465,7 +465,8 @@ typedef enum
 {
     HR_FRAME_SERIAL  = 0, /* one stream, the reference's order (= calling the four render() yourself) */
     HR_FRAME_STREAMS = 1, /* fork / join over three internal streams + `stream` */
-    HR_FRAME_GRAPH   = 2  /* the forked frame captured into one hipGraph per frame; the instantiated graph is updated in place */
+    HR_FRAME_GRAPH   = 2  /* the forked frame captured into one hipGraph per frame; the instantiated graph is updated in place.
+                             Stage profiling (hr_*_set_profiling) must be off: timing events cannot be read back from a captured launch */
 } hr_frame_mode;
 typedef struct
 {
