@@ -6,8 +6,9 @@
      (gi_probe_update.glsl:58-130), border update, per-pixel sample (ddgi.cpp:896-899).  Ray images + atlases bit-exact in both
      arithmetic modes, the 4K sample bit-exact (exact = 1) / within the stated tolerance (exact = 0);
  (b) AO at 4 spp on the 3840x2160 frame (two moving frames, every stage) and on one 270-row band of the 8-GPU decomposition;
- (c) the 1080p hybrid frame in the mode bench.py times (exact = 0) through the deferred composite (deferred.frag:177-205) against
-     the oracle's composite of the oracle's pass outputs — the end-to-end image a user sees.
+ (c) the hybrid frame in the mode bench.py times (exact = 0), at 1920x1080 and at 3840x2160 — configs[4] on one GPU end to end —
+     through the deferred composite (deferred.frag:177-205) against the oracle's composite of the oracle's pass outputs: the image a
+     user sees.
 """
 import numpy as np
 import pytest
@@ -137,14 +138,14 @@ def test_4k_ao_4spp_matches_oracle(oracle, hr, ctx, sponza_full, frames4k):
         g.close()
 
 
-def test_1080p_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full):
-    """the frame bench.py's `passes.hybrid` times (shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, exact = 0) through
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])
+def test_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full, W, H):
+    """the frame bench.py's `passes.hybrid_1080p` / `hybrid_4k_one_gpu` times (shadows + AO 4 spp + DDGI 16x8x16x256 + half-res reflections, exact = 0) through
     k_deferred, two moving frames, against the oracle's deferred composite of the oracle's pass outputs (deferred.frag:177-205).
     Every pass output AND the final HDR image obey the image rule of DESIGN.md §3.6 (2 fp16 ulp on >= 99.9 %, rel-L2 <= 1e-3) — all channels."""
     import torch
     from hybrid_rendering_amd import api_deferred, api_gi, api_reflections
     from oracle import pyoracle_ddgi as od, pyoracle_deferred as odf, pyoracle_reflections as orf
-    W, H = 1920, 1080
     sd, gsc = sponza_full["sd"], sponza_full["scene"]
     osc = oracle.Scene(sd)
     lo, hi = sd.bounds()
