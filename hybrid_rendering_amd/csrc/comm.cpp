@@ -519,7 +519,10 @@ hr_status hr_reflections_exchange_history(hr_reflections* p, hr_comm* c, const i
     if (!p) return HR_ERR_INVALID_ARG;
     hr_image_view prev, mom;
     hr_status s;
-    if ((s = hr_reflections_image(p, 5, &prev)) != HR_OK) return s;
+    // the colour history of the next frame: the feedback image only with blur_as_input, else THIS frame's temporal output (the reference's
+    // default; round 3: the feedback image was exchanged unconditionally, so with the default parameters the apron rows kept locally
+    // computed history that degrades by the per-frame vertical motion — found by the 8-band 4K test of tests/test_gpu_comm.py)
+    if ((s = hr_reflections_image(p, 10, &prev)) != HR_OK) return s;
     if ((s = hr_reflections_image(p, ping_pong ? 4 : 3, &mom)) != HR_OK) return s;
     const hr_comm_image im[2] = { as_image(prev), as_image(mom) };
     return hr_comm_exchange_rows(c, im, 2, bounds, rows, cs, ticket);

@@ -405,6 +405,7 @@ struct hr_reflections
     DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots;
     bool    first_frame = true, last_denoise = true;
     int     read_idx = 0, last_pp = 0;
+    bool    last_blur_as_input = false;   // which image the NEXT frame's temporal stage reads as colour history (hr_reflections_image 10)
     bool    fuse = true;   // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0, read once at create)
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
@@ -553,6 +554,7 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     const float* cd = prm->camera_delta;
     a.moving = (sqrtf((cd[0] * cd[0] + cd[1] * cd[1]) + cd[2] * cd[2]) > 0.0f) ? 1 : 0; // compute_max_accumulated_frame :162-168
     p->last_pp = pp;
+    p->last_blur_as_input = prm->blur_as_input != 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 80);
     if (prm->exact) hipLaunchKernelGGL(k_refl_temporal, dim3(cdiv(w, RT_TW), cdiv(y1 - y0, RT_TH)), dim3(256), 0, st, a);
@@ -683,6 +685,9 @@ hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* 
         case 3: ptr = p->moments[0].p; break;
         case 4: ptr = p->moments[1].p; break;
         case 5: ptr = p->prev_image.p; break;
+        // 10: the colour history the next frame's temporal stage will read — the feedback image with blur_as_input, else the temporal
+        // output written this frame (ray_traced_reflections.cpp:1124,1218): what a row-tiled host exchanges with its neighbours
+        case 10: ptr = p->last_blur_as_input ? p->prev_image.p : p->color[p->last_pp].p; break;
         case 6: ptr = p->atrous[0].p; break;
         case 7: ptr = p->atrous[1].p; break;
         case 8: fill_view(v, p->upsample.p, p->full_w, p->full_h, 8, HR_FORMAT_RGBA16F); return HR_OK;

@@ -299,8 +299,11 @@ class TiledReflections(_TiledPass):
         self.params = self.pass_.params
 
     def history_images(self, ping_pong: int) -> List:
+        # colour history of the NEXT frame's temporal stage: the feedback image only with blur_as_input, else this frame's temporal
+        # output (ray_traced_reflections.cpp:1124,1218 — the reference's default); + the moments written this frame
         p = self.pass_
-        return [p.image(p.IMG_PREV), p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
+        colour = p.image(p.IMG_PREV) if int(p.params.blur_as_input) else p.image(p.IMG_COLOR1 if ping_pong else p.IMG_COLOR0)
+        return [colour, p.image(p.IMG_MOMENTS1 if ping_pong else p.IMG_MOMENTS0)]
 
     def _render(self, scene, inputs, stream, env, ddgi):
         self.wait_exchange()

@@ -449,6 +449,8 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
 hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, int32_t iteration, void* stream);
 hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 /* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes */
+/* which = 10: the colour history the NEXT frame's temporal stage will read (feedback image with blur_as_input, else this frame's temporal
+ * output) — the image a row-tiled host exchanges with its neighbours (hr_reflections_exchange_history does) */
 hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* view);
 hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
 hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);

@@ -54,13 +54,14 @@ def test_exchange_rows_and_allgather_loopback(hr, ctx):
         c.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world):
+@pytest.mark.parametrize("world,name", [(2, "sponza_small"), (3, "sponza_small"), (2, "cornell"), (3, "cornell")])
+def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world, name):
     """shadows + AO + DDGI + reflections on `world` bands through the C-ABI exchange / all-gather calls: every band row equals the
-    un-tiled render bit for bit (exact mode) over 4 frames with camera motion."""
+    un-tiled render bit for bit (exact mode) over 6 frames with camera motion — sideways in the Sponza-like scene, with a VERTICAL component
+    in the Cornell box (history rows then really cross the band boundaries: the reflections' colour history must be the exchanged one)."""
     import torch
     from hybrid_rendering_amd import api_gi, api_reflections, comm
-    name, W, H, n_frames = "sponza_small", 192, 264, 4
+    W, H, n_frames = 192, 264, 6
     sd = helpers.scene_data(name)
     osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
     frames = helpers.make_frames(oracle, osc, name, W, H, n_frames, 2.0)
@@ -73,7 +74,7 @@ def test_tiled_frame_native_comm_equals_untiled(oracle, hr, ctx, world):
     f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
     env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 16, 5, f16(synth_env.brdf_lut(16)))
     bounds = [tiling.band_rows(H, world, r)[0] for r in range(world)] + [H]
-    comms = [comm.NativeComm(ctx, world, r, loopback_name=f"frame{world}") for r in range(world)]
+    comms = [comm.NativeComm(ctx, world, r, loopback_name=f"frame{world}{name}") for r in range(world)]
     band = lambda r: (bounds[r], bounds[r + 1], tiling.HALO, tiling.HISTORY_HALO)
     w_sh, w_ao, w_gi, w_rf = hr.RayTracedShadows(ctx, W, H), hr.RayTracedAO(ctx, W, H, 0), api_gi.DDGI(ctx, W, H, ddgi_u), api_reflections.RayTracedReflections(ctx, W, H, 0)
     t_sh = [hr.RayTracedShadows(ctx, W, H, 0, band=band(r)) for r in range(world)]
@@ -157,3 +158,83 @@ def test_rccl_backend_loads_and_initialises_on_one_gpu(hr, ctx):
     assert c.exchange_rows([img], [0, 64], 16) == 0     # a single band has no neighbour: nothing posted, ticket 0
     c.wait()
     c.close()
+
+
+def test_4k_eight_bands_native_comm_equals_untiled(hr, ctx):
+    """BASELINE configs[4]'s decomposition in full: the 3840x2160 hybrid frame (shadows + AO 4 spp + DDGI 16x8x16 x 256 rays + half-res
+    reflections, exact = 0 — the mode and parameters bench.py times) cut into EIGHT row bands / probe slabs, all eight ranks driven through
+    the native transport (loopback wire, per-pass tickets) on the one GPU, three moving frames: every band row of every pass equals the
+    un-tiled render bit for bit."""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections, comm
+    W, H, world, n_frames = 3840, 2160, 8, 3
+    sd = helpers.scene_data("sponza")
+    gsc = hr.Scene(ctx, sd)
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(n_frames + 1)]
+    ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(n_frames)]
+    gbs = [gsc.gbuffer(u, W, H) for u in ubos]
+    lows = [hr.gbuffer_mip(g, 1) for g in gbs]
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    zbp = synth.z_buffer_params()
+    lo, hi = sd.bounds()
+    ddgi_u = synth_env.ddgi_uniforms(lo, hi, probe_counts=(16, 8, 16), rays_per_probe=256, normal_bias=0.1)
+    sky = synth_env.sky_cubemap(32)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 32, 5, f16(synth_env.brdf_lut(32)))
+    bounds = [((H // 16) * r // world) * 16 for r in range(world)] + [H]      # 16-row cuts: the half-res bands stay on the 8-row tile grid
+    hb = [b // 2 for b in bounds]
+    comms = [comm.NativeComm(ctx, world, r, loopback_name="frame4k") for r in range(world)]
+
+    def mk(cls, scale, b, r, hh):
+        return cls(ctx, W, H, scale, band=(b[r], b[r + 1], tiling.HALO, hh))
+    w_sh, w_ao, w_gi, w_rf = hr.RayTracedShadows(ctx, W, H), hr.RayTracedAO(ctx, W, H, 0), api_gi.DDGI(ctx, W, H, ddgi_u), api_reflections.RayTracedReflections(ctx, W, H, 1)
+    t_sh = [mk(hr.RayTracedShadows, 0, bounds, r, tiling.HISTORY_HALO) for r in range(world)]
+    t_ao = [mk(hr.RayTracedAO, 0, bounds, r, tiling.HALO) for r in range(world)]
+    t_rf = [mk(api_reflections.RayTracedReflections, 1, hb, r, tiling.HALO) for r in range(world)]
+    t_gi = [api_gi.DDGI(ctx, W, H, ddgi_u) for _ in range(world)]
+    for r, g in enumerate(t_gi):
+        z0, z1 = tiling.probe_slabs(16, world, r)
+        g.set_shard(z0, z1, bounds[r], bounds[r + 1])
+    for p in [w_sh, w_ao, w_gi, w_rf] + t_sh + t_ao + t_rf + t_gi:
+        p.params.exact = 0
+    for p in [w_ao] + t_ao:
+        p.params.spp = 4
+    rng = np.random.RandomState(4)
+    tk = {k: [0] * world for k in ("sh", "ao", "gi", "rf")}
+    for f in range(n_frames):
+        fi = hr.frame_inputs(gbs[f], gbs[f - 1 if f else 0], ubos[f], f, f & 1, sob_d, sr_d, cur_full=gbs[f], z_buffer_params=zbp)
+        fl = hr.frame_inputs(lows[f], lows[f - 1 if f else 0], ubos[f], f, f & 1, sob_d, sr_d, cur_full=gbs[f], z_buffer_params=zbp)
+        orient = synth_env.random_orientation(rng)
+        w_sh.render(gsc, fi); w_ao.render(gsc, fi); w_gi.render(gsc, fi, env, orient); w_rf.render(gsc, fl, env, w_gi)
+        for r in range(world):
+            c = comms[r]
+            c.wait(ticket=tk["sh"][r]); t_sh[r].render(gsc, fi); tk["sh"][r] = c.exchange_shadows(t_sh[r], bounds, f & 1, tiling.HISTORY_HALO)
+            c.wait(ticket=tk["ao"][r]); t_ao[r].render(gsc, fi); tk["ao"][r] = c.exchange_ao(t_ao[r], bounds, f & 1, tiling.HALO)
+            g = t_gi[r]
+            g.set_orientation(orient)
+            g.ray_trace(gsc, fi, env); g.probe_update()
+            tk["gi"][r] = c.allgather_ddgi(g)
+        for r in range(world):
+            c, g = comms[r], t_gi[r]
+            c.wait(ticket=tk["gi"][r])
+            g.sample_probe_grid(fi); g.end_frame()
+            c.wait(ticket=tk["rf"][r]); t_rf[r].render(gsc, fl, env, g); tk["rf"][r] = c.exchange_reflections(t_rf[r], hb, f & 1, tiling.HALO)
+        torch.cuda.synchronize()
+        for r in range(world):
+            b0, b1 = bounds[r], bounds[r + 1]
+            assert torch.equal(t_sh[r].output(hr.OUTPUT_ATROUS)[b0:b1], w_sh.output(hr.OUTPUT_ATROUS)[b0:b1]), f"frame {f} rank {r}: shadows"
+            assert torch.equal(t_ao[r].output(hr.OUTPUT_UPSAMPLE)[b0:b1], w_ao.output(hr.OUTPUT_UPSAMPLE)[b0:b1]), f"frame {f} rank {r}: AO"
+            gi_r, gd_r = t_gi[r].current_read()
+            wi, wd = w_gi.current_read()
+            assert torch.equal(gi_r, wi) and torch.equal(gd_r, wd), f"frame {f} rank {r}: gathered atlases"
+            assert torch.equal(t_gi[r].output()[b0:b1], w_gi.output()[b0:b1]), f"frame {f} rank {r}: DDGI sample"
+            assert torch.equal(t_rf[r].output(hr.OUTPUT_ATROUS)[hb[r]:hb[r + 1]], w_rf.output(hr.OUTPUT_ATROUS)[hb[r]:hb[r + 1]]), f"frame {f} rank {r}: reflections (a-trous)"
+            assert torch.equal(t_rf[r].output(hr.OUTPUT_UPSAMPLE)[b0:b1], w_rf.output(hr.OUTPUT_UPSAMPLE)[b0:b1]), f"frame {f} rank {r}: reflections (upsampled)"
+        assert not any(t.history_apron_exceeded() for t in t_sh + t_ao + t_rf), f"frame {f}: a history tap left the apron"
+    for c in comms:
+        c.close()
+    for p in [w_sh, w_ao, w_gi, w_rf] + t_sh + t_ao + t_rf + t_gi:
+        p.close()
+    gsc.close()

@@ -1,6 +1,7 @@
 """GPU developer tool: random frame sizes (ragged widths / heights), band counts and cost-like random band boundaries —
-every band of TiledShadows / TiledAO (hosted on this one GPU, the neighbour exchange emulated with device copies along
-tiling.exchange_plan) must equal the un-tiled pass on its rows, over several frames with a moving camera.
+every band of TiledShadows / TiledAO / TiledReflections (hosted on this one GPU, the neighbour exchange emulated with device copies
+along tiling.exchange_plan) must equal the un-tiled pass on its rows, over several frames with a moving camera (sideways in the
+Sponza-like scene, with a vertical component in the Cornell box: history rows then cross the band boundaries).
     python tools/fuzz_tiling.py [seed] [n_configs]"""
 import os, sys
 import numpy as np
@@ -8,32 +9,46 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
-from hybrid_rendering_amd import api as hr, synth, tiling
+from hybrid_rendering_amd import api as hr, api_gi, api_reflections, synth, synth_env, tiling
 from oracle import pyoracle as oracle
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ctx = hr.Context(0)
-name = "sponza_small"
-sd = helpers.scene_data(name)
-osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+scenes = {nm: (helpers.scene_data(nm), oracle.Scene(helpers.scene_data(nm)), hr.Scene(ctx, helpers.scene_data(nm))) for nm in ("sponza_small", "cornell")}
+sky = synth_env.sky_cubemap(16)
+f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+env = api_gi.environment(f16(sky), f16(synth_env.prefiltered_chain(sky, 5)), 16, 5, f16(synth_env.brdf_lut(16)))
 sob, sr = synth.blue_noise_tables()
 sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
 bad = 0
 for trial in range(n):
     world = int(rng.randint(2, 5))
+    name = str(rng.choice(["sponza_small", "cornell"]))
+    sd, osc, gsc = scenes[name]
     W, H = int(rng.randint(60, 260)), int(rng.randint(40 * world, 110 * world))
     bounds = None
     if rng.randint(2):
         cuts = np.sort(rng.choice(np.arange(4, (H + 7) // 8 - 4), world - 1, replace=False)) * 8
         if np.all(np.diff(np.concatenate([[0], cuts, [H]])) >= 32):
             bounds = [0] + [int(c) for c in cuts] + [H]
-    frames = helpers.make_frames(oracle, osc, name, W, H, 4, float(rng.uniform(0.5, 2.5)), str(rng.choice(["default", "point"])))
+    frames = helpers.make_frames(oracle, osc, name, W, H, 4, float(rng.uniform(0.5, 2.5)), str(rng.choice(["default", "point"])) if name != "cornell" else "soft")
+    lo, hi = sd.bounds()
+    gi = api_gi.DDGI(ctx, W, H, synth_env.ddgi_uniforms(lo, hi, probe_counts=(4, 3, 4), rays_per_probe=32, normal_bias=0.1))
+    orients = [synth_env.random_orientation(rng) for _ in range(4)]
     res = []
     exact = int(rng.randint(2))           # both arithmetic modes: bands must equal the whole frame bit for bit in either
-    for label in ("shadows", "ao"):
+    for label in ("shadows", "ao", "reflections"):
         try:
-            if label == "shadows":
+            if label == "reflections":
+                if bounds is not None and any((b1 - b0) < 24 for b0, b1 in zip(bounds, bounds[1:])):
+                    raise ValueError("band shorter than the apron")
+                bands = [tiling.TiledReflections(ctx, W, H, r, world, scale=0, bounds=bounds) for r in range(world)]
+                whole, out_id = api_reflections.RayTracedReflections(ctx, W, H, 0), hr.OUTPUT_UPSAMPLE
+                if rng.randint(2):
+                    for q in [whole] + [b.pass_ for b in bands]:
+                        q.params.blur_as_input = 1
+            elif label == "shadows":
                 bands = [tiling.TiledShadows(ctx, W, H, r, world, bounds=bounds) for r in range(world)]
                 whole, out_id = hr.RayTracedShadows(ctx, W, H), hr.OUTPUT_ATROUS
             else:
@@ -49,10 +64,16 @@ for trial in range(n):
         ok, ping = True, False
         for f in range(4):
             fi = hr.frame_inputs(helpers.to_cuda(frames[f]["gb"]), helpers.to_cuda(frames[f - 1]["gb"] if f else frames[f]["gb"]), frames[f]["ubo"], f, ping,
-                                 sob_d, sr_d, z_buffer_params=synth.z_buffer_params())
-            whole.render(gsc, fi)
-            for b in bands:
-                b.render(gsc, fi)
+                                 sob_d, sr_d, cur_full=helpers.to_cuda(frames[f]["gb"]), z_buffer_params=synth.z_buffer_params())
+            if label == "reflections":
+                gi.render(gsc, fi, env, orients[f])
+                whole.render(gsc, fi, env, gi)
+                for b in bands:
+                    b.render(gsc, fi, env, gi)
+            else:
+                whole.render(gsc, fi)
+                for b in bands:
+                    b.render(gsc, fi)
             for r, b in enumerate(bands):
                 for peer, (s0, s1), (r0, r1) in tiling.exchange_plan(H, world, r, b.history_rows, bounds):
                     for mine, theirs in zip(b.history_images(int(ping)), bands[peer].history_images(int(ping))):
@@ -67,5 +88,6 @@ for trial in range(n):
         whole.close()
         for b in bands:
             b.pass_.close()
-    print(trial, (W, H), "world", world, "bounds", bounds, "exact", exact, res, flush=True)
+    gi.close()
+    print(trial, name, (W, H), "world", world, "bounds", bounds, "exact", exact, res, flush=True)
 print("mismatches:", bad)
