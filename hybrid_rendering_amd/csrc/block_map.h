@@ -1,0 +1,48 @@
+// Workgroup -> tile mapping for the image kernels (denoise, blur, upsample, probe-grid sample).
+//
+// The dispatcher deals the workgroups of a launch round-robin over the 8 XCDs in linear order (x fastest), and every XCD has
+// its own L2: with the identity mapping a tile's apron (the a-trous rings, the blur's reach, the reprojection footprint) is
+// fetched by up to eight L2s, which the FETCH_SIZE counters show as 1.5-1.9x the algorithmic bytes.
+// block_xy<R>() hands XCD k runs of R whole tile rows instead (dealt round-robin down the screen, so every XCD still samples the
+// whole image), so horizontally — and for R > 1 vertically — neighbouring tiles share one L2.
+//
+// Measured (round 3): it pays for exactly two kernels, the fused AO blur (-12 % at 1080p) and the fused reflections
+// a-trous 0 + 1 (-7..12 %); every other image kernel is FASTER with the identity (shadows a-trous 2 / 3 +12 %, upsample +10 %,
+// probe-grid sample +3 %: the fine interleave spreads the concurrently running tiles over more DRAM channels, and the kernels
+// with a per-tile early-out lose their load balance), and one contiguous eighth per XCD (R = -1) is 30-60 % slower for those.
+// The trace kernels need the round-robin deal as their load balancer (§4.2).
+#pragma once
+#include "device_math.h"
+
+#ifndef HR_XCD_ROWS_ALL
+#define HR_XCD_ROWS_ALL -2     // A/B switch: force one mapping on every image kernel (-2: each kernel's own choice)
+#endif
+
+namespace hr {
+
+// ROWS = 0: identity; ROWS > 0: runs of ROWS tile rows per XCD; ROWS = -1: one contiguous eighth of the tiles per XCD
+template <int ROWS_>
+HR_DEV uint2 block_xy()
+{
+    constexpr int ROWS = HR_XCD_ROWS_ALL == -2 ? ROWS_ : HR_XCD_ROWS_ALL;
+    if constexpr (ROWS == 0) {
+        return make_uint2(blockIdx.x, blockIdx.y);
+    } else {
+        const uint32_t gx = gridDim.x, n = gx * gridDim.y;
+        const uint32_t lin = blockIdx.y * gx + blockIdx.x;
+        uint32_t       l2;
+        if constexpr (ROWS < 0) {
+            // XCD k owns the linear ids k, k + 8, ...: q + (k < r) of them; its eighth starts after the eighths of XCDs 0..k-1
+            const uint32_t q = n >> 3, r = n & 7u, xcd = lin & 7u;
+            l2 = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+        } else {
+            // groups of 8 R tile rows: inside a group XCD k (linear ids = k mod 8) walks rows [k R, k R + R); the ragged tail keeps the identity
+            const uint32_t C = gx * ROWS, S = 8u * C, g = lin / S, rem = lin - g * S;
+            l2 = (g + 1) * S <= n ? g * S + (rem & 7u) * C + (rem >> 3) : lin;
+        }
+        const uint32_t y = l2 / gx;
+        return make_uint2(l2 - y * gx, y);
+    }
+}
+
+}  // namespace hr

@@ -18,6 +18,7 @@
 #include "pass_args.h"
 #include "fast_math.h"
 #include "mask_window.h"
+#include "block_map.h"
 
 #pragma clang fp contract(fast)
 
@@ -224,13 +225,14 @@ struct Reproj
 #endif
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     __shared__ uint32_t s_mask[FT_WAVES][1][18];
     __shared__ MaskRows s_rows[FT_WAVES];
     const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // grid = (tile columns / FT_WAVES, tile rows): no integer division per wave
-    const int  txr = blockIdx.x * FT_WAVES + wave;
+    const int  txr = BLK.x * FT_WAVES + wave;
     const bool tile_ok = txr < a.tiles_x;
-    const int  tx = tile_ok ? txr : 0, ty = (int)blockIdx.y + a.tile_y0;
+    const int  tx = tile_ok ? txr : 0, ty = (int)BLK.y + a.tile_y0;
     const int  lx = lane & 7, ly = lane >> 3;
     const int  x = tx * 8 + lx, y = ty * 8 + ly;
     // order of the memory round trips: centre texels -> (mask words, LDS) -> history taps -> (popcounts) -> resolve
@@ -310,8 +312,9 @@ HR_DEV float edge_weight_fast(const EdgeK& k, float cd, float sd, f3 cn, f3 sn, 
 template <int STEP, bool N32>
 __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint2 BLK = block_xy<0>();
+    const int x = BLK.x * 32 + (threadIdx.x & 31);
+    const int y = a.y0 + BLK.y * 8 + (threadIdx.x >> 5);
     if (x >= a.w || y >= a.y1) return;
     const uint32_t o = (uint32_t)(y * a.w + x);
     uint32_t* outp  = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + o * 4u);
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
     const int step = STEP > 0 ? STEP : a.step;
     const int R    = STEP > 0 ? 1 : a.radius;
     // a workgroup whose whole footprint lies inside the resident rows needs no bounds test at all (uniform branch)
-    const int  fx0 = (int)blockIdx.x * 32, fy0 = a.y0 + (int)blockIdx.y * 8;
+    const int  fx0 = (int)BLK.x * 32, fy0 = a.y0 + (int)BLK.y * 8;
     const int  reach = step * R > 1 ? step * R : 1;
     const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= (a.y0 > 0 ? a.y0 : 0) && fy0 + 7 + reach < (a.y1 < a.h ? a.y1 : a.h);
     const uint32_t c   = fm::ld<uint32_t>(a.in.p, o * 4u);
@@ -456,11 +459,12 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
 template <int STEP, bool N32>
 __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     constexpr int TW = 32 + 2 * STEP, TH = 8 + 2 * STEP;
     __shared__ uint32_t s_in[TH * TW];
     __shared__ float4   s_nz[TH * TW];   // unit normal, linear z
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * 8;
+    const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * 8;
     const int x = bx0 + lx, y = by0 + ly;
     const bool inside = x < a.w && y < a.y1;
     const uint32_t cls = inside ? a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] : 0u;
@@ -551,11 +555,12 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
 template <int TH, bool N32>
 __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_t* out_first2, float power1)
 {
+    const uint2 BLK = block_xy<0>();
     constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
     __shared__ uint32_t s_in[AH * AW];
     __shared__ float4   s_nz[AH * AW];   // unit normal, linear z
     __shared__ uint32_t s_mid[BH * BW];  // iteration 0, as the RG16F image would hold it
-    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * TH;
     const int ry0 = a.y0 > 0 ? a.y0 : 0, ry1 = a.y1 < a.h ? a.y1 : a.h;
     // tile classes of this workgroup's own tiles: all shadow => every output is 0 and nothing is staged
     int any_cls = 0;
@@ -664,13 +669,14 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
 template <bool MULTI>
 __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     __shared__ uint32_t s_mask[FT_WAVES][4][18];
     __shared__ MaskRows s_rows[FT_WAVES];
     const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // grid = (tile columns / FT_WAVES, tile rows): no integer division per wave
-    const int  txr = blockIdx.x * FT_WAVES + wave;
+    const int  txr = BLK.x * FT_WAVES + wave;
     const bool tile_ok = txr < a.tiles_x;
-    const int  tx = tile_ok ? txr : 0, ty = (int)blockIdx.y + a.tile_y0;
+    const int  tx = tile_ok ? txr : 0, ty = (int)BLK.y + a.tile_y0;
     const int  lx = lane & 7, ly = lane >> 3;
     const int  x = tx * 8 + lx, y = ty * 8 + ly;
     const bool in_image = tile_ok && x < a.w && y < a.h && y >= a.y0 && y < a.y1;
@@ -737,15 +743,16 @@ HR_DEV float gaussian_weight_fast(float offset, float deviation)
 template <int RADIUS>
 __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     constexpr int kMaxTexels = 32 * (8 + 2 * RADIUS);   // the vertical pass is the larger footprint
     __shared__ float4 s_nz[kMaxTexels];                 // unit normal, linear eye depth
     __shared__ float  s_ao[kMaxTexels];
     __shared__ float  s_gauss[2 * RADIUS + 1];
     const int SW = 32 + 2 * RADIUS * a.dx, SH = 8 + 2 * RADIUS * a.dy;
-    const int ox = (int)blockIdx.x * 32 - RADIUS * a.dx, oy = a.y0 + (int)blockIdx.y * 8 - RADIUS * a.dy;
+    const int ox = (int)BLK.x * 32 - RADIUS * a.dx, oy = a.y0 + (int)BLK.y * 8 - RADIUS * a.dy;
     // the centre's own reads (tile class, depth) travel with the staging loads: one memory round trip before the barrier
     const int  lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int  x = (int)blockIdx.x * 32 + lx, y = a.y0 + (int)blockIdx.y * 8 + ly;
+    const int  x = (int)BLK.x * 32 + lx, y = a.y0 + (int)BLK.y * 8 + ly;
     const bool have = x < a.w && y < a.y1;
     const uint32_t o = have ? (uint32_t)(y * a.w + x) : (uint32_t)(a.y0 * a.w);
     const uint8_t  tclass = a.tile_class[have ? (size_t)(y >> 3) * a.tiles_x + (x >> 3) : 0];
@@ -797,13 +804,14 @@ __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
 template <int RADIUS, int TH>
 __global__ __launch_bounds__(256) void kf_ao_blur_xy(AOBlurArgs a)
 {
+    const uint2 BLK = block_xy<1>();
     constexpr int SW = 32 + 2 * RADIUS, SH = TH + 2 * RADIUS;
     __shared__ float4  s_nz[SH * SW];      // unit normal, linear eye depth
     __shared__ float   s_ao[SH * SW];
     __shared__ uint8_t s_kind[SH * SW];    // 0: not resident (reads as zeros), 1: cleared tile or sky (1.0), 2: filtered
     __shared__ float   s_x[SH * 32];       // X pass, as the R16F image would hold it
     __shared__ float   s_gauss[2 * RADIUS + 1];
-    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * TH;
     const int ox = bx0 - RADIUS, oy = by0 - RADIUS;
     if ((int)threadIdx.x <= 2 * RADIUS) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - RADIUS), (float)RADIUS * (1.0f / 1.5f));
     for (int i = threadIdx.x; i < SW * SH; i += 256)
@@ -877,10 +885,11 @@ __global__ __launch_bounds__(256) void kf_ao_blur_xy(AOBlurArgs a)
 // run-time radius: plain gathers
 __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     __shared__ float s_gauss[2 * 32 + 1];
     if ((int)threadIdx.x <= 2 * a.radius) s_gauss[threadIdx.x] = gaussian_weight_fast((float)((int)threadIdx.x - a.radius), (float)a.radius * (1.0f / 1.5f));
     __syncthreads();
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int x = BLK.x * 32 + (threadIdx.x & 31), y = a.y0 + BLK.y * 8 + (threadIdx.x >> 5);
     if (x >= a.w || y >= a.y1) return;
     const uint32_t o = (uint32_t)(y * a.w + x);
     uint16_t* outp = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * 2u);
@@ -929,6 +938,7 @@ __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 #endif
 __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs a)
 {
+    const uint2 BLK = block_xy<0>();
     constexpr int CW = FR_TW + 2 * FR_R, CH = FR_TH + 2 * FR_R;   // 48 x 24
 #if FR_ALIAS
     __shared__ float4 s_raw[CH * FR_TW + CH * FR_TW / 2];          // 18.4 KB: first the colour tile (9.2 KB), then ha | hb
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
     __shared__ float2 s_hb[CH][FR_TW];      //                  sum g^2, b^2
 #endif
     __shared__ int    s_flag[4];
-    const int bx0 = blockIdx.x * FR_TW, by0 = a.y0 + blockIdx.y * FR_TH;
+    const int bx0 = BLK.x * FR_TW, by0 = a.y0 + BLK.y * FR_TH;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int x = bx0 + lx, y = by0 + ly;
     const bool have = x < a.w && y < a.y1;
@@ -1088,7 +1098,8 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
 template <int STEP, bool N32>
 __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint2 BLK = block_xy<0>();
+    const int x = BLK.x * 32 + (threadIdx.x & 31), y = a.y0 + BLK.y * 8 + (threadIdx.x >> 5);
     if (x >= a.w || y >= a.y1) return;
     const uint32_t o = (uint32_t)(y * a.w + x);
     const uint2    c = fm::ld<uint2>(a.in.p, o * 8u);
@@ -1096,7 +1107,7 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
     if (a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)])
     {
         const int  step = STEP > 0 ? STEP : a.step, R = STEP > 0 ? 1 : a.radius;
-        const int  fx0 = (int)blockIdx.x * 32, fy0 = a.y0 + (int)blockIdx.y * 8, reach = step * R > 1 ? step * R : 1;
+        const int  fx0 = (int)BLK.x * 32, fy0 = a.y0 + (int)BLK.y * 8, reach = step * R > 1 ? step * R : 1;
         const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= a.in.y0 && fy0 + 7 + reach < a.in.y1;
         const f3    cc = mk3(fm::lo(c.x), fm::hi(c.x), fm::lo(c.y));
         const float center_luma = fm::fmax_(0.299f * cc.x + 0.587f * cc.y + 0.114f * cc.z, 0.0001f);
@@ -1196,12 +1207,13 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
 template <int TH, bool N32>
 __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2* out_first2)
 {
+    const uint2 BLK = block_xy<1>();
     constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
     __shared__ uint2  s_in[AH * AW];
     __shared__ float4 s_nz[AH * AW];    // unit normal (0 outside the image), linear z
     __shared__ float  s_r[AH * AW];     // roughness; -1: sky texel
     __shared__ uint2  s_mid[BH * BW];
-    const int bx0 = (int)blockIdx.x * 32, by0 = a.y0 + (int)blockIdx.y * TH;
+    const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * TH;
     for (int i = threadIdx.x; i < AH * AW; i += 256)
     {
         const int  cy = i / AW, cx = i - cy * AW;
@@ -1318,7 +1330,8 @@ HR_DEV Bilin bilin_setup(float x, float y, int w, int h)   // x, y in texel unit
 
 __global__ __launch_bounds__(256) void kf_ddgi_sample(DDGISampleArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = a.y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint2 BLK = block_xy<0>();
+    const int x = BLK.x * 32 + (threadIdx.x & 31), y = a.y0 + BLK.y * 8 + (threadIdx.x >> 5);
     if (x >= a.w || y >= a.y1) return;
     const uint32_t o  = (uint32_t)(y * a.w + x);
     uint2* outp = reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out) + o * 8u);
@@ -1405,7 +1418,8 @@ __global__ __launch_bounds__(256) void kf_ddgi_sample(DDGISampleArgs a)
 template <int CH>
 __global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint2 BLK = block_xy<0>();
+    const int x = BLK.x * 32 + (threadIdx.x & 31), y = BLK.y * 8 + (threadIdx.x >> 5);
     if (x >= a.W || y >= a.H) return;
     const uint32_t o  = (uint32_t)(y * a.W + x);
     uint16_t*      op = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + o * (2u * CH));
