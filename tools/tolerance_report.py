@@ -79,7 +79,8 @@ elif which == "ao":
         report("temporal AO", b16(pf.image(a)), b16(pe.image(a)))
         l = pe.IMG_LEN1 if f & 1 else pe.IMG_LEN0
         report("history length", b16(pf.image(l)), b16(pe.image(l)))
-        report("blur x", b16(pf.image(pf.IMG_BLUR0)), b16(pe.image(pe.IMG_BLUR0)))
+        if os.environ.get("HR_FUSE", "1") == "0":   # the fused X + Y launch of the tolerance mode keeps the X image in LDS: nothing to compare
+            report("blur x", b16(pf.image(pf.IMG_BLUR0)), b16(pe.image(pe.IMG_BLUR0)))
         report("blur y", b16(pf.image(pf.IMG_BLUR1)), b16(pe.image(pe.IMG_BLUR1)))
 elif which in ("ddgi", "reflections"):
     lo, hi = sd.bounds()
