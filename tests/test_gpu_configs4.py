@@ -207,3 +207,48 @@ def test_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full, W, 
     assert np.isfinite(img).all() and img.mean() > 0.01
     for g in (g_sh, g_ao, g_gi, g_rf, g_df):
         g.close()
+
+
+def test_8k_shadows_two_frames_match_oracle(oracle, hr, ctx, sponza_full):
+    """maximum size: 7680x4320 (33 M pixels, 4x configs[4]; image offsets, mask words and tile counts well past 2^24) — two moving
+    frames of the whole shadow pass against the oracle: masks / ray counts / tile classes bit-exact in both modes, every stage image
+    bit-exact (exact = 1) or within the stated tolerance (exact = 0); plus rank 13 of a 16-way cut as a band"""
+    import torch
+    W, H = 7680, 4320
+    light = synth.sponza_light()
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(3)]
+    ubos = [synth.make_ubo(cams[i + 1], cams[i], light) for i in range(2)]
+    gbs_d = [sponza_full["scene"].gbuffer(u, W, H) for u in ubos]
+    gbs = [_host(g) for g in gbs_d]
+    osc = oracle.Scene(sponza_full["sd"])
+    sob, sr, sob_d, sr_d = _tables()
+    gsc = sponza_full["scene"]
+    o = oracle.ShadowsPass(W, H)
+    g_ex, g_fast = hr.RayTracedShadows(ctx, W, H), hr.RayTracedShadows(ctx, W, H)
+    g_fast.params.exact = 0
+    b0, b1 = tiling.band_rows(H, 16, 13)
+    g_band = hr.RayTracedShadows(ctx, W, H, 0, band=(b0, b1, tiling.HALO, tiling.HISTORY_HALO))
+    for f in range(2):
+        cur, prev = gbs[f], gbs[f - 1 if f else 0]
+        o.render(osc, ubos[f], cur, prev, sob, sr, f)
+        st = o.stages
+        fi = hr.frame_inputs(gbs_d[f], gbs_d[f - 1 if f else 0], ubos[f], f, f & 1, sob_d, sr_d)
+        g_ex.render(gsc, fi)
+        g_fast.render(gsc, fi)
+        torch.cuda.synchronize()
+        assert st["rays"] > 8_000_000
+        for g, mode in ((g_ex, "exact = 1"), (g_fast, "exact = 0")):
+            assert np.array_equal(g.image(g.IMG_MASK).cpu().numpy().view(np.uint32), st["mask"]), f"frame {f} ({mode}): visibility mask"
+            assert g.ray_count() == st["rays"], f"frame {f} ({mode}): ray count"
+        assert np.array_equal(g_ex.image(g_ex.IMG_TILES).cpu().numpy(), st["tiles"]), f"frame {f}: tile classes"
+        assert np.array_equal(helpers.bits16(g_ex.image(g_ex.IMG_TEMPORAL)), st["temporal"]), f"frame {f}: temporal"
+        assert np.array_equal(helpers.bits16(g_ex.image(g_ex.IMG_MOMENTS1 if f & 1 else g_ex.IMG_MOMENTS0)), st["moments"]), f"frame {f}: moments"
+        assert np.array_equal(helpers.bits16(g_ex.output(hr.OUTPUT_ATROUS)), st["output"]), f"frame {f}: a-trous output"
+        ex = tol.tiles_close(g_fast.image(g_fast.IMG_TILES).cpu().numpy(), st["tiles"], f"frame {f} (exact = 0)", shape=(H, W))
+        tol.compare16(helpers.bits16(g_fast.output(hr.OUTPUT_ATROUS)), st["output"], f"frame {f} a-trous output (exact = 0)", exclude=ex, variance_channels=(1,))
+        if f == 0:
+            g_band.render(gsc, fi)
+            torch.cuda.synchronize()
+            assert np.array_equal(helpers.bits16(g_band.output(hr.OUTPUT_ATROUS))[b0:b1], st["output"][b0:b1]), f"band rows [{b0}, {b1}) of the 16-way cut"
+    for g in (g_ex, g_fast, g_band):
+        g.close()
