@@ -16,11 +16,32 @@ def scene_data(name: str):
         return synth.sponza_like(0.25)
     if name == "sponza":
         return synth.sponza_like(1.0)
+    if name.startswith("one_triangle"):
+        return one_triangle_scene(int(name[len("one_triangle_x"):]) if name.startswith("one_triangle_x") else 1)
     raise KeyError(name)
 
 
+def one_triangle_scene(copies: int = 1):
+    """degenerate scene: ONE triangle in the middle of the Cornell set-up (the BVH root is a leaf), optionally `copies` times over
+    (coincident duplicates with their own mesh ids: equal t, the tie rule decides)"""
+    import dataclasses
+    base = synth.cornell32()
+    lo, hi = base.bounds()
+    c, e = (lo + hi) * 0.5, (hi - lo) * 0.35
+    tri = np.array([[[c[0] - e[0], c[1] - e[1], c[2]], [c[0] + e[0], c[1] - e[1], c[2] + 0.2 * e[2]], [c[0], c[1] + e[1], c[2] - 0.1 * e[2]]]], np.float32)
+    n = np.cross(tri[0, 1] - tri[0, 0], tri[0, 2] - tri[0, 0])
+    n = (n / np.linalg.norm(n)).astype(np.float32)
+    return dataclasses.replace(base, verts=np.repeat(tri, copies, 0), normals=np.repeat(np.broadcast_to(n, (1, 3, 3)).copy(), copies, 0),
+                               tri_material=np.zeros(copies, np.uint32), tri_mesh_id=np.arange(1, copies + 1, dtype=np.uint32),
+                               uvs=None, tangents=None, material_textures=None, textures=None, name=f"one_triangle_x{copies}")
+
+
+def _cornell_setup(name: str) -> bool:
+    return name == "cornell" or name.startswith("one_triangle")
+
+
 def cameras(name: str, aspect: float, n_frames: int, dolly: float):
-    if name == "cornell":
+    if _cornell_setup(name):
         base = synth.cornell_camera(aspect)
         cams = []
         for f in range(n_frames):
@@ -31,7 +52,7 @@ def cameras(name: str, aspect: float, n_frames: int, dolly: float):
 
 
 def light_for(name: str, kind: str = "default"):
-    if name == "cornell":
+    if _cornell_setup(name):
         return synth.cornell_light(hard=(kind != "soft"))
     if kind == "point":
         return synth.make_light(synth.LIGHT_POINT, position=(100.0, 300.0, 20.0), radius=4.0, intensity=50000.0)
