@@ -144,3 +144,20 @@ def test_ddgi_and_reflections_on_degenerate_inputs(oracle, hr, ctx, name, w, h):
             # some rays hit ...) carry none and cannot hold on a one-triangle scene or a 1x1 image
             if str(e).lstrip().startswith("frame"):
                 raise AssertionError(f"{label} on {name} {w}x{h}: {e}")
+
+
+@pytest.mark.parametrize("dolly", [0.0, 0.05])
+def test_forty_frames_of_temporal_feedback(oracle, hr, ctx, dolly):
+    """long runs: 40 frames with a static / slowly moving camera — the history length saturates at 32 (`min(32, len + 1)`, reached only
+    after 32 successful reprojections), alpha falls to its floor, ping-pong parity and the a-trous feedback run 40 times; DDGI's
+    hysteresis blend and its infinite-bounce feedback run 12 frames.  Every stage image of every frame bit for bit."""
+    import test_gpu_shadows, test_gpu_ao, test_gpu_ddgi, test_gpu_reflections
+    for label, fn in (("shadows", lambda: test_gpu_shadows._run_case(oracle, hr, ctx, "cornell", 56, 40, 40, dolly)),
+                      ("ao", lambda: test_gpu_ao._run_case(oracle, hr, ctx, "cornell", 56, 40, 0, 40, dolly, spp=2)),
+                      ("ddgi", lambda: test_gpu_ddgi._run(oracle, hr, ctx, "cornell", 40, 24, (3, 2, 3), 32, 12)),
+                      ("reflections", lambda: test_gpu_reflections._run(oracle, hr, ctx, "cornell", 56, 40, 0, 36, dolly, counts=(3, 2, 3)))):
+        try:
+            fn()
+        except AssertionError as e:
+            if str(e).lstrip().startswith("frame"):   # parity assertions carry "frame N: ..."; scene-coverage checks do not apply here
+                raise AssertionError(f"{label}: {e}")
