@@ -161,3 +161,38 @@ def test_forty_frames_of_temporal_feedback(oracle, hr, ctx, dolly):
         except AssertionError as e:
             if str(e).lstrip().startswith("frame"):   # parity assertions carry "frame N: ..."; scene-coverage checks do not apply here
                 raise AssertionError(f"{label}: {e}")
+
+
+def test_hybrid_frame_modes_survive_parameter_changes(hr, ctx):
+    """hr_hybrid_frame with the knobs turned BETWEEN frames: AO spp 4 -> 1 -> 3, shadows filter_iterations 4 -> 2 (fewer launches: the
+    captured graph's topology changes, hipGraphExecUpdate must be refused and the graph re-instantiated), shadows denoise off and on
+    again, reflections a-trous radius 1 -> 2, the arithmetic mode flipped for one pass, mixed serial / streams / graph frames on one
+    object.  Every pass output of every frame equals the plain serial render() calls of a twin set of passes, bit for bit."""
+    import torch
+    from hybrid_rendering_amd import api_frame
+    from hybrid_rendering_amd.frame import HybridFrame
+    sd = synth.sponza_like(0.25)
+    scene = hr.Scene(ctx, sd)
+    ref = HybridFrame(ctx, scene, sd, 328, 184, probes=(5, 3, 4), rays_per_probe=64)
+    sched = {2: lambda f: setattr(f.ao.params, "spp", 1),
+             3: lambda f: setattr(f.shadows.params, "filter_iterations", 2),
+             4: lambda f: setattr(f.shadows.params, "denoise", 0),
+             5: lambda f: (setattr(f.shadows.params, "denoise", 1), setattr(f.ao.params, "spp", 3)),
+             6: lambda f: setattr(f.refl.params, "radius", 2),
+             7: lambda f: setattr(f.ao.params, "exact", 1),
+             8: lambda f: (setattr(f.ao.params, "exact", 0), setattr(f.shadows.params, "filter_iterations", 4), setattr(f.refl.params, "radius", 1))}
+    modes = ["graph", "graph", "graph", "graph", "streams", "graph", "graph", "serial", "graph", "graph", "streams", "graph"]
+    twin = HybridFrame(ctx, scene, sd, 328, 184, probes=(5, 3, 4), rays_per_probe=64)
+    for k, mode in enumerate(modes):
+        for f in (ref, twin):
+            if k in sched:
+                sched[k](f)
+        ref.render(k)
+        twin.concurrent_streams(True, mode)
+        twin.render(k)
+        torch.cuda.synchronize()
+        for n, p in ref.passes().items():
+            assert torch.equal(p.output(), twin.passes()[n].output()), f"frame {k} ({mode}): {n} output differs from the serial render() calls"
+    inst, upd = twin._native.graph_stats()
+    assert inst >= 4 and upd >= 2, (inst, upd)   # topology changes re-instantiate, argument-only changes update in place
+    ref.close(); twin.close(); scene.close()
