@@ -196,3 +196,37 @@ def test_hybrid_frame_modes_survive_parameter_changes(hr, ctx):
     inst, upd = twin._native.graph_stats()
     assert inst >= 4 and upd >= 2, (inst, upd)   # topology changes re-instantiate, argument-only changes update in place
     ref.close(); twin.close(); scene.close()
+
+
+def test_create_destroy_does_not_leak_device_memory(hr, ctx):
+    """60 rounds of create -> one frame -> destroy of every pass object (+ the frame orchestrator in graph mode, a scene, a band
+    instance): the device's free memory comes back to where it was (hipMalloc'd images, events, streams, graphs)"""
+    import torch
+    from hybrid_rendering_amd.frame import HybridFrame
+    sd = synth.sponza_like(0.25)
+
+    def one_round(k):
+        scene = hr.Scene(ctx, sd)
+        f = HybridFrame(ctx, scene, sd, 256, 144, probes=(4, 2, 4), rays_per_probe=64)
+        f.concurrent_streams(True, ("graph", "streams")[k & 1])
+        f.render(0); f.render(1)
+        band = hr.RayTracedShadows(ctx, 256, 144, 0, band=(48, 96, 24, 24))
+        torch.cuda.synchronize()
+        band.close(); f.close(); scene.close()
+
+    def outside_torch():
+        # bytes of device memory in use that are NOT torch's caching pool (the library's hipMalloc'd images, events, streams, graphs)
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free - torch.cuda.memory_reserved()
+
+    import gc
+    for k in range(4):          # module loading, graph caches, HIP's own pools settle
+        one_round(k)
+    gc.collect()
+    used0 = outside_torch()
+    for k in range(60):
+        one_round(k)
+    gc.collect()
+    used1 = outside_torch()
+    assert used1 - used0 < 4 << 20, f"{(used1 - used0) / 2**20:.1f} MiB of device memory did not come back after 60 create / destroy rounds"
