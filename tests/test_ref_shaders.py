@@ -513,3 +513,45 @@ def test_ground_truth_with_the_reference_bounce_uncommented(oracle, rh, name, ki
         ref = rh.ground_truth(osc, rsc, fr["ubo"], sky, W, H, fi, prev, max_ray_bounces=bounces, trace_indirect=True)
         assert np.array_equal(ref, out), f"frame {k}"
         assert (out != base.render(osc, fr["ubo"], sky)).any(-1).mean() > 0.05
+
+
+def _shadows_and_ao_vs_reference(oracle, rh, osc, frames, w, h, what):
+    sob, sr = synth.blue_noise_tables()
+    zbp = synth.z_buffer_params()
+    op, rp = oracle.ShadowsPass(w, h), rh.RefShadowsPass(w, h)
+    oa, ra = oracle.AOPass(w, h, zbp=zbp), rh.RefAOPass(w, h, zbp)
+    for k, fr in enumerate(frames):
+        prev = frames[k - 1]["gb"] if k else fr["gb"]
+        for o, r in ((op, rp), (oa, ra)):
+            o.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+            r.render(osc, fr["ubo"], fr["gb"], prev, sob, sr, k)
+        a, b = op.stages, rp.stages
+        assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["tiles"], b["tiles"]), f"{what}: shadows frame {k}: mask / tiles"
+        assert np.array_equal(a["temporal"], b["temporal"]) and np.array_equal(a["moments"], b["moments"]), f"{what}: shadows frame {k}: reprojection"
+        assert all(np.array_equal(x, y) for x, y in zip(a["atrous"], b["atrous"])), f"{what}: shadows frame {k}: a-trous"
+        c, d = oa.stages, ra.stages
+        assert np.array_equal(c["mask"][0], d["mask"]) and np.array_equal(c["tiles"], d["tiles"]), f"{what}: AO frame {k}: mask / tiles"
+        assert np.array_equal(c["temporal"], d["temporal"]) and np.array_equal(c["length"], d["length"]) and np.array_equal(c["blur1"], d["blur1"]), f"{what}: AO frame {k}"
+    return op, oa
+
+
+def test_degenerate_inputs_against_the_reference_shaders(oracle, rh):
+    """the edge cases tests/test_gpu_edge.py runs on the GPU, pinned here one level up — oracle against the REFERENCE's shaders:
+    frames in which every pixel is sky (no ray; the history of an empty frame), a one-triangle scene with coincident duplicates, a
+    1x1 image, and a 40-frame run with a static camera (the history length reaches its cap of 32: `min(32, len + 1)`,
+    shadows_denoise_reprojection.comp / ao_denoise_reprojection.comp)"""
+    sd, osc, frames = _frames(oracle, "cornell", 48, 32, 4, 0.3)
+    for f in (0, 2):
+        gb = {k: v.copy() for k, v in frames[f]["gb"].items()}
+        gb["depth"][...] = 1.0
+        frames[f] = dict(frames[f], gb=gb)
+    op, oa = _shadows_and_ao_vs_reference(oracle, rh, osc, frames, 48, 32, "all-sky frames 0 and 2")
+    assert op.stages["rays"] > 0        # frame 3 has geometry again
+    sd, osc, frames = _frames(oracle, "one_triangle_x3", 64, 40, 3, 0.3)
+    assert 0.02 < (frames[0]["gb"]["depth"] != 1.0).mean() < 0.9
+    _shadows_and_ao_vs_reference(oracle, rh, osc, frames, 64, 40, "one triangle x3")
+    sd, osc, frames = _frames(oracle, "cornell", 1, 1, 3, 0.4)
+    _shadows_and_ao_vs_reference(oracle, rh, osc, frames, 1, 1, "1x1")
+    sd, osc, frames = _frames(oracle, "cornell", 40, 24, 40, 0.0)
+    op, oa = _shadows_and_ao_vs_reference(oracle, rh, osc, frames, 40, 24, "40 static frames")
+    assert oracle.f16(op.stages["moments"][..., 2]).max() == 32.0 and oracle.f16(oa.stages["length"]).max() == 32.0
