@@ -1,5 +1,7 @@
-// C++ host example of the native multi-GPU path (include/hr_comm.h, include/hr/tiled.hpp): RayTracedShadows + RayTracedAO row-tiled
-// over TWO ranks, one host thread per rank, three frames with a moving camera; every band row is compared with an un-tiled render.
+// C++ host example of the native multi-GPU path (include/hr_comm.h, include/hr/tiled.hpp): the whole hybrid frame — RayTracedShadows,
+// RayTracedAO, DDGI (probes sharded by z-slab, atlas rows all-gathered) and RayTracedReflections (fed by the DDGI atlases) — row-tiled
+// over TWO ranks, one host thread per rank, four frames with a moving camera; every band row of every pass is compared with an
+// un-tiled render of the same frame.
 // With two or more GPUs visible the ranks run on GPU 0 and 1 and talk RCCL over xGMI; on a one-GPU box both ranks share the device
 // and the in-process loopback back end carries the rows (RCCL refuses two ranks on one device).  No Python, no torch.
 //
@@ -54,7 +56,30 @@ bool invert(const float* m, float* inv)
     return true;
 }
 
-constexpr int W = 256, H = 192, kFrames = 3, kWorld = 2;
+uint16_t f2h(float f) // round to nearest even, finite inputs of moderate size only
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t  e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    const uint32_t m = u & 0x7fffffu;
+    if (e <= 0) return (uint16_t)sign;
+    if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+    uint32_t h = (uint32_t)(e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+template <typename T>
+T* upload(const std::vector<T>& v)
+{
+    void* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return (T*)d;
+}
+
+constexpr int W = 256, H = 192, kFrames = 4, kWorld = 2;
 std::atomic<int> g_failures { 0 };
 
 void fill_ubo(hr_ubo& u, uint32_t f, float* prev_vp)
@@ -94,16 +119,48 @@ void rank_main(int rank, int device, bool use_rccl, const uint8_t* id, const std
         hr::Comm comm = use_rccl ? hr::Comm(ctx, kWorld, rank, id) : hr::Comm::loopback(ctx, kWorld, rank, "tiled_frame");
         hipStream_t stream;
         (void)hipStreamCreate(&stream);
+        // environment: a 16^2 sky cubemap (blue above, dark below), a nearest-decimated chain, a flat BRDF LUT
+        const int SK = 16, LV = 4;
+        std::vector<uint16_t> sky((size_t)6 * SK * SK * 4), pre, lut((size_t)16 * 16 * 2);
+        for (int f = 0; f < 6; f++)
+            for (int i = 0; i < SK * SK; i++)
+            {
+                const bool  up = f == 2 || (f != 3 && (i / SK) < SK / 2);
+                const float c[3] = { up ? 0.35f : 0.08f, up ? 0.55f : 0.07f, up ? 0.9f : 0.06f };
+                for (int k = 0; k < 3; k++) sky[((size_t)f * SK * SK + i) * 4 + k] = f2h(c[k]);
+                sky[((size_t)f * SK * SK + i) * 4 + 3] = f2h(1.0f);
+            }
+        for (int l = 0, sz = SK; l < LV; l++, sz >>= 1)
+            for (int f = 0; f < 6; f++)
+                for (int y = 0; y < sz; y++)
+                    for (int x = 0; x < sz; x++)
+                        for (int k = 0; k < 4; k++) pre.push_back(sky[(((size_t)f * SK + (y << l)) * SK + (x << l)) * 4 + k]);
+        for (size_t i = 0; i < lut.size(); i += 2) { lut[i] = f2h(0.9f); lut[i + 1] = f2h(0.05f); }
+        hr_environment env {};
+        env.sky = upload(sky); env.sky_size = SK;
+        env.prefiltered = upload(pre); env.prefiltered_size = SK; env.prefiltered_levels = LV;
+        env.brdf_lut = upload(lut); env.brdf_lut_size = 16;
+        // DDGI grid 5 x 5 x 5 over the room (ddgi.cpp:150-169, :197-201): rank 0 traces and updates z-slabs [0, 2), rank 1 [2, 5)
+        hr_ddgi_uniforms g {};
+        for (int a = 0; a < 3; a++) { g.grid_start_position[a] = 0.0f; g.grid_step[a] = 100.0f / 3.0f; g.probe_counts[a] = 5; }
+        g.max_distance = g.grid_step[0] * 1.5f; g.depth_sharpness = 50.0f; g.hysteresis = 0.98f; g.normal_bias = 1.0f; g.energy_preservation = 0.85f;
+        g.irradiance_probe_side_length = 8; g.depth_probe_side_length = 16; g.rays_per_probe = 64; g.visibility_test = 1;
+        g.irradiance_texture_width = 10 * 25 + 2; g.irradiance_texture_height = 10 * 5 + 2;
+        g.depth_texture_width = 18 * 25 + 2; g.depth_texture_height = 18 * 5 + 2;
         hr::CommonResources common;
         hr::GBuffer         g_buffer;
-        common.scene = &scene;
+        common.scene = &scene; common.environment = &env;
         g_buffer.current[0].width = W; g_buffer.current[0].height = H;
         const std::vector<int32_t> bounds = hr::uniform_bounds(H, kWorld);
-        hr::TiledShadows shadows(ctx, comm, &common, &g_buffer, bounds);
-        hr::TiledAO      ao(ctx, comm, &common, &g_buffer, bounds, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::TiledHybridFrame tiled(ctx, &shadows, &ao, nullptr, nullptr);
-        hr::RayTracedShadows whole_shadows(ctx, &common, &g_buffer);          // the un-tiled reference, rendered by every rank
-        hr::RayTracedAO      whole_ao(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::TiledShadows     shadows(ctx, comm, &common, &g_buffer, bounds);
+        hr::TiledAO          ao(ctx, comm, &common, &g_buffer, bounds, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::ShardedDDGI      ddgi(ctx, comm, &common, &g_buffer, g, bounds);
+        hr::TiledReflections reflections(ctx, comm, &common, &g_buffer, bounds, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::TiledHybridFrame tiled(ctx, &shadows, &ao, &ddgi, &reflections);
+        hr::RayTracedShadows     whole_shadows(ctx, &common, &g_buffer);          // the un-tiled reference, rendered by every rank
+        hr::RayTracedAO          whole_ao(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
+        hr::DDGI                 whole_ddgi(ctx, &common, &g_buffer, g);
+        hr::RayTracedReflections whole_reflections(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         void *gb1[2], *gb2[2], *gb3[2], *depth[2];
         for (int i = 0; i < 2; i++)
         {
@@ -132,10 +189,12 @@ void rank_main(int rank, int device, bool use_rccl, const uint8_t* id, const std
             common.num_frames = f; common.ping_pong = pp != 0;
             // main.cpp:80-81 for this rank's band: hr::TiledHybridFrame forks the two passes over its streams; each posts its neighbour
             // exchange from inside render() (one communicator, per-pass tickets) — odd frames take the plain serial calls for comparison
-            if (f & 1) { shadows.render(stream); ao.render(stream); }
+            if (f & 1) tiled.render(stream, /*forked=*/false);
             else tiled.render(stream);
             whole_shadows.render(stream);
             whole_ao.render(stream);
+            whole_ddgi.render(stream);
+            whole_reflections.render(stream, &whole_ddgi);
             (void)hipStreamSynchronize(stream);
             // band rows of this rank == the same rows of the un-tiled render, bit for bit
             whole_shadows.set_current_output(hr::RayTracedShadows::OUTPUT_ATROUS);
@@ -145,8 +204,26 @@ void rank_main(int rank, int device, bool use_rccl, const uint8_t* id, const std
             const size_t s0 = (size_t)bounds[rank] * vs.row_pitch_bytes, s1 = (size_t)bounds[rank + 1] * vs.row_pitch_bytes;
             const size_t a0 = (size_t)bounds[rank] * va.row_pitch_bytes, a1 = (size_t)bounds[rank + 1] * va.row_pitch_bytes;
             const bool ok_s = std::memcmp(a.data() + s0, b.data() + s0, s1 - s0) == 0, ok_a = std::memcmp(c.data() + a0, d.data() + a0, a1 - a0) == 0;
-            std::printf("rank %d frame %u: rows %d-%d  shadows %s  ao %s\n", rank, f, bounds[rank], bounds[rank + 1], ok_s ? "==" : "DIFFER", ok_a ? "==" : "DIFFER");
-            if (!ok_s || !ok_a) g_failures++;
+            // DDGI: this rank's rows of the per-pixel sample, and BOTH whole atlases (own slabs traced here, the others all-gathered)
+            const hr::ImageView vd = ddgi.pass().output_ds(), wd = whole_ddgi.output_ds();
+            const std::vector<uint8_t> dd = download(vd), dw = download(wd);
+            const size_t d0 = (size_t)bounds[rank] * vd.row_pitch_bytes, d1 = (size_t)bounds[rank + 1] * vd.row_pitch_bytes;
+            bool ok_d = std::memcmp(dd.data() + d0, dw.data() + d0, d1 - d0) == 0;
+            hr::ImageView ti, td, wi, wdep;
+            ddgi.pass().current_read_ds(ti, td);
+            whole_ddgi.current_read_ds(wi, wdep);
+            ok_d = ok_d && download(ti) == download(wi) && download(td) == download(wdep);
+            // reflections: a-trous output rows of the band (full resolution here, so no upsample stage)
+            whole_reflections.set_current_output(hr::RayTracedReflections::OUTPUT_ATROUS);
+            reflections.pass().set_current_output(hr::RayTracedReflections::OUTPUT_ATROUS);
+            const hr::ImageView vr = reflections.pass().output_ds(), wr = whole_reflections.output_ds();
+            const std::vector<uint8_t> rr = download(vr), rw = download(wr);
+            const size_t r0 = (size_t)bounds[rank] * vr.row_pitch_bytes, r1 = (size_t)bounds[rank + 1] * vr.row_pitch_bytes;
+            const bool ok_r = std::memcmp(rr.data() + r0, rw.data() + r0, r1 - r0) == 0;
+            std::printf("rank %d frame %u (%s): rows %d-%d  shadows %s  ao %s  ddgi %s  reflections %s\n", rank, f, (f & 1) ? "serial" : "forked", bounds[rank], bounds[rank + 1],
+                        ok_s ? "==" : "DIFFER", ok_a ? "==" : "DIFFER", ok_d ? "==" : "DIFFER", ok_r ? "==" : "DIFFER");
+            if (!ok_s || !ok_a || !ok_d || !ok_r) g_failures++;
+            if (shadows.history_apron_exceeded() || ao.history_apron_exceeded() || reflections.history_apron_exceeded()) { std::printf("rank %d frame %u: motion beyond the history apron\n", rank, f); g_failures++; }
         }
         comm.wait(stream);
         (void)hipStreamSynchronize(stream);

@@ -211,7 +211,7 @@ public:
         if (m_ddgi) m_ddgi->render(cmd_buf);                         // the longest chain first
         if (m_shadows) m_shadows->render(side[0]);
         if (m_ao) m_ao->render(side[1]);
-        if (m_reflections) m_reflections->render(cmd_buf, &m_ddgi->pass());
+        if (m_reflections) m_reflections->render(cmd_buf, m_ddgi ? &m_ddgi->pass() : nullptr);
         if (forked) check(hr_hybrid_frame_join(m_frame, cmd_buf), "hr_hybrid_frame_join");
     }
 private:
