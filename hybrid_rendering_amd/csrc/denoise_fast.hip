@@ -1530,7 +1530,7 @@ void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
 }
 
 #ifndef FT_AO_BLUR_TH
-#define FT_AO_BLUR_TH 16   // tile height: 8 / 16 / 32 -> 1080p 26.9 / 23.5 / 25.7 us, 4K 72 / 66.5 / 70.5 (32: 1.56x instead of 1.88x apron reads, but 38.7 KB of LDS per workgroup)
+#define FT_AO_BLUR_TH 16   // tile height: 16 against 8 -> 24.8 against 26.5 us; 16 against 32 -> 1080p 23.5 against 25.7 us, 4K 66.5 against 70.5 (32: 1.56x instead of 1.88x apron reads, but 38.7 KB of LDS per workgroup)
 #endif
 bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
 {
