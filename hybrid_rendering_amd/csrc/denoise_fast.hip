@@ -220,8 +220,9 @@ struct Reproj
 // shadows_denoise_reprojection.comp:196-293 (+ reset_args / tile classification), tolerance mode
 #define FT_WAVES 4
 #ifndef FT_SHADOWS_EU
-#define FT_SHADOWS_EU 5   // minimum waves per SIMD the register allocator must leave room for.  Measured at 1080p: 5 (83 VGPRs, no
-                          // spill) 49.8 us; 6 (80 VGPRs + 44 B of scratch) 68.8 us; 8 (64 VGPRs, more scratch) 108.6 us — spills cost more than waves buy
+#define FT_SHADOWS_EU 5   // minimum waves per SIMD the register allocator must leave room for.  5 and 6 give the same 77 VGPRs (= 6 waves per SIMD), no
+                          // spill: 48-50 us at 1080p, 208 at 4K; 7 (72 VGPRs + 24 B of scratch) 58.7 / 252.8; 8 (64 VGPRs, more scratch) 81.4 / 362 — spills
+                          // cost far more than waves buy
 #endif
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
