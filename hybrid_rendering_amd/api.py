@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_bvh_selfcheck", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -225,6 +225,16 @@ def bvh_build_info(verts) -> hr_scene_info:
     info = hr_scene_info()
     _check(lib().hr_bvh_build_info(v.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(v.shape[0]), C.byref(info)), "hr_bvh_build_info")
     return info
+
+
+def bvh_selfcheck(verts, samples_per_triangle: int = 12) -> int:
+    """Host-only: (triangle, surface point) pairs that the BVH built over ``verts`` fails to cover (0 for a correct tree)."""
+    v = np.ascontiguousarray(verts, np.float32)
+    bad = C.c_int64(-1)
+    L = lib()
+    L.hr_bvh_selfcheck.argtypes = [C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    _check(L.hr_bvh_selfcheck(v.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(v.shape[0]), C.c_int32(samples_per_triangle), C.byref(bad)), "hr_bvh_selfcheck")
+    return int(bad.value)
 
 
 def gbuffer_mip(g, level, stream=None):

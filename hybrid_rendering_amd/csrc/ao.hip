@@ -67,6 +67,9 @@ extern "C" int hr_debug_divergence_ao(uint64_t* out, int reset)
                     // 4K 1303 / 1540 / 1563 — every iteration of the wave pays for the ray switch of whichever lane just finished, and the
                     // triangle tests lose the wave-cooperative path; kept as a measured A/B path only
 #endif
+#ifndef AO_ORDER
+#define AO_ORDER HR_ORDER_SLOTS   // the short AO rays (97 % of them miss) gain nothing from a visiting order (tools/bvh_eval.cpp): plain slot order, no rev logic
+#endif
 #ifndef AO_COOP
 #define AO_COOP 1   // wave-cooperative triangle tests (traverse.h trace_coop) for the AO rays: 0.418 -> 0.399 ms at 1080p, 4 spp
 #endif
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
             float tm[AO_SEQ];
 #pragma unroll
             for (int k = 0; k < AO_SEQ; k++) tm[k] = a.ray_length;
-            const uint32_t occ = trace_any_seq<AO_SEQ>(active, n, a.nodes, a.tris, ro, dir, 0.01f, tm, s_stack[wave], lane, entry HR_DIV(, &dv));
+            const uint32_t occ = trace_any_seq<AO_SEQ, AO_ORDER>(active, n, a.nodes, a.tris, ro, dir, 0.01f, tm, s_stack[wave], lane, entry HR_DIV(, &dv));
             for (int k = 0; k < n; k++)
             {
                 const unsigned long long bits = __ballot(active && !((occ >> k) & 1u));
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
                 const float r0  = sample_blue_noise(x, y, idx, 0, a.sobol, a.sr), r1 = sample_blue_noise(x, y, idx, 1, a.sobol, a.sr);
                 dir = sample_cosine_lobe(N, r0, r1);
             }
-            visible = trace_coop<true>(active, a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], s_coop[wave], lane, entry).prim != 0 && active;
+            visible = trace_coop<true, AO_ORDER>(active, a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], s_coop[wave], lane, entry).prim != 0 && active;
         }
         else
 #endif
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
             const int   idx = (int)a.num_frames * a.spp + s;
             const float r0  = sample_blue_noise(x, y, idx, 0, a.sobol, a.sr), r1 = sample_blue_noise(x, y, idx, 1, a.sobol, a.sr);
             const f3    dir = sample_cosine_lobe(N, r0, r1);
-            visible         = !trace_any<STATS>(a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, nn, nt, entry HR_DIV(, &dv));
+            visible         = !trace_any<STATS, AO_ORDER>(a.nodes, a.tris, ro, dir, 0.01f, a.ray_length, s_stack[wave], lane, nn, nt, entry HR_DIV(, &dv));
         }
         const unsigned long long bits = __ballot(visible);
         if (lane == 0)

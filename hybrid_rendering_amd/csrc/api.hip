@@ -293,6 +293,25 @@ hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_inf
     }
 }
 
+// Host-only: builds the same BVH and checks that every triangle is found from every point of its surface (bvh.h
+// check_bvh8_coverage) — the invariant the spatial splits of the builder have to keep.
+hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t samples_per_triangle, int64_t* uncovered)
+{
+    HR_CHECK_ARG(uncovered && n_tris >= 0 && samples_per_triangle > 0 && (positions || n_tris == 0));
+    try
+    {
+        BuiltBVH b;
+        build_bvh8(positions, n_tris, b);
+        *uncovered = check_bvh8_coverage(positions, n_tris, b, samples_per_triangle);
+        return HR_OK;
+    }
+    catch (const std::bad_alloc&)
+    {
+        set_last_error("hr_bvh_selfcheck: host allocation failed");
+        return HR_ERR_OUT_OF_MEMORY;
+    }
+}
+
 // No exception crosses the C ABI: the builder's and the staging vectors' allocation failures become HR_ERR_OUT_OF_MEMORY.
 hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* d, hr_scene** out)
 {

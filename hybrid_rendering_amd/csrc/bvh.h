@@ -6,7 +6,7 @@
 //        counts = n_internal | n_children << 4.  Slots 0..n_internal-1 are the internal children (slot i is node
 //        child_base + i), slots n_internal..n_children-1 the leaves, the rest empty.
 //   [16] child_base (index of first internal child), tri_base (index of first leaf triangle),
-//        meta[8]: 0 = empty slot; internal: 0x10 | slot;
+//        meta[8]: 0 = empty slot; internal: 0x10 (slot 0: 0x10 | the axis 0..2 the internal children are sorted along);
 //                 leaf: (count << 5) | offset  (triangles tri_base+offset .. +count-1), count 1..4
 //   [32] qlo.x[8] qlo.y[8]   [48] qlo.z[8] qhi.x[8]   [64] qhi.y[8] qhi.z[8]   (uint8 grid coords)
 //   child box = origin + q * 2^(e-127), lo floored / hi ceiled => conservative.
@@ -56,5 +56,9 @@ struct BuiltBVH
 
 // positions: [n][3][3].  Deterministic (single-threaded, no RNG).
 void build_bvh8(const float* positions, int n_tris, BuiltBVH& out);
+
+// Host-side self-check (bvh_build.cpp): number of (triangle, sample point) pairs that reach no leaf holding the triangle — 0 for a
+// correct tree.
+int64_t check_bvh8_coverage(const float* positions, int n_tris, const BuiltBVH& b, int samples_per_triangle);
 
 } // namespace hr

@@ -1,8 +1,16 @@
-// Host-side builder of the compressed 8-wide BVH (see bvh.h).  Replaces the driver's
-// acceleration-structure build behind dw::RayTracedScene (reference: main.cpp:74,
-// common.cpp:355-521).  Steps: binned-SAH binary tree down to single triangles -> SAH-optimal
-// collapse to 8-wide nodes with leaf children of <= 4 triangles (dynamic programme) ->
-// breadth-first layout with contiguous children / leaf triangles -> 8-bit conservative quantisation.
+// Host-side builder of the compressed 8-wide BVH (see bvh.h).  Replaces the driver's acceleration-structure build behind
+// dw::RayTracedScene (reference: main.cpp:74 build_tlas, common.cpp:355-521 initialize_for_ray_tracing).  Steps:
+//   1. binary tree over triangle REFERENCES down to single references: binned-SAH object splits against chopped-binning
+//      SPATIAL splits (Stich, Friedrich, Dietrich 2009, "Spatial splits in bounding volume hierarchies") — a triangle that
+//      straddles the chosen plane is referenced from both sides with its box clipped to each side (or kept whole on one side when
+//      that is cheaper: reference unsplitting), within a duplication budget;
+//   2. insertion-based optimisation of that tree (Bittner, Hapala, Havran 2013): subtrees are removed and re-inserted at the
+//      position that minimises the surface-area cost, largest nodes first;
+//   3. SAH-optimal collapse to 8-wide nodes with leaf children of <= 4 triangles (dynamic programme, Ylitie et al. 2017);
+//   4. breadth-first layout with contiguous children / leaf triangles, 8-bit conservative quantisation.
+// Every reference points at its ORIGINAL triangle and the leaves store the unmodified vertices, so the ray/triangle test and its
+// results — any-hit: a function of the geometry; closest hit: of (t, original index) — do not depend on any of this: only the boxes
+// get tighter.  Deterministic (single-threaded, no RNG).
 #include "bvh.h"
 #include <algorithm>
 #include <cfloat>
@@ -10,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <queue>
 
 namespace hr {
@@ -35,147 +44,48 @@ struct Box
             if (b.hi[a] > hi[a]) hi[a] = b.hi[a];
         }
     }
+    void clip_to(const Box& b)
+    {
+        for (int a = 0; a < 3; a++)
+        {
+            if (b.lo[a] > lo[a]) lo[a] = b.lo[a];
+            if (b.hi[a] < hi[a]) hi[a] = b.hi[a];
+        }
+    }
+    bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+    bool same(const Box& b) const { return std::memcmp(lo, b.lo, 12) == 0 && std::memcmp(hi, b.hi, 12) == 0; }
     double half_area() const
     {
         double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
-        if (x < 0) return 0.0;
+        if (x < 0 || y < 0 || z < 0) return 0.0;
         return x * y + y * z + z * x;
     }
 };
+inline Box merged(const Box& a, const Box& b) { Box r = a; r.add(b); return r; }
 
 struct Bin2
 {
     Box     box;
     int32_t a = -1, b = -1; // children, or -1 for leaf
-    int32_t first = 0, count = 0;
+    int32_t parent = -1;
+    int32_t first = 0, count = 0;   // references of the subtree: Builder::leaves[first .. first + count)
 };
 
-constexpr int kBins    = 64;   // 32 -> 64: nodes per shadow ray 6.38 -> 6.30, frame -1.3% (8 bins: 7.25, +5%)
-constexpr int kMaxLeaf = 4;   // triangles per leaf CHILD of an 8-wide node (count field of the meta byte, 8 x 4 = 32-bit mask)
+constexpr int kBins        = 64;   // 32 -> 64: nodes per shadow ray 6.38 -> 6.30, frame -1.3% (8 bins: 7.25, +5%)
+constexpr int kSpatialBins = 32;
+constexpr int kMaxLeaf     = 4;    // triangles per leaf CHILD of an 8-wide node (count field of the meta byte, 8 x 4 = 32-bit mask)
 
-// SAH bin of a centroid.  `k` = kBins / extent overflows to +inf when the extent is subnormal and the product is then inf or
+// SAH bin of a coordinate.  `k` = bins / extent overflows to +inf when the extent is subnormal and the product is then inf or
 // NaN (0 * inf): compare in a way that sends both to a valid bin instead of converting them to int (undefined).
-static inline int bin_of(float c, float lo, float k)
+static inline int bin_of(float c, float lo, float k, int bins = kBins)
 {
     const float f = (c - lo) * k;
     if (!(f > 0.0f)) return 0;               // also NaN
-    if (f >= (float)(kBins - 1)) return kBins - 1;
+    if (f >= (float)(bins - 1)) return bins - 1;
     return (int)f;
 }
 
-struct Builder
-{
-    const float*          pos;
-    std::vector<Box>      tbox;
-    std::vector<float>    tcen;
-    std::vector<int32_t>  idx;
-    std::vector<int32_t>  prim;   // reference -> original triangle
-    std::vector<Bin2>     n2;
-    int                   bvh2_leaf = kMaxLeaf;   // binary-tree leaf size (1 for the optimal collapse: it forms the leaves)
-
-    // SAH splits down to binary depth kSahDepth, object-median splits below it: a median split halves the count, so the
-    // binary tree is never deeper than kSahDepth + ceil(log2 n) <= 40 + 24 = 64 levels.  The 8-wide collapse only removes
-    // levels, and the traversal keeps ONE stack entry per level (traverse.h: walk_expand), so HR_STACK_ENTRIES +
-    // HR_SPILL_ENTRIES = 64 entries always suffice — also for adversarial input (a chain of slivers of geometrically growing
-    // size makes the SAH peel one triangle per level, n levels deep; tests/test_gpu_trace.py::test_degenerate_sliver_chain).
-    static constexpr int kSahDepth = 40;
-    int sah_depth = kSahDepth;   // HR_BVH_SAH_DEPTH lowers it (developer switch: exercises the median fallback in tests)
-    int32_t split(int32_t first, int32_t count, int depth = 0)
-    {
-        int32_t me = (int32_t)n2.size();
-        n2.emplace_back();
-        Box nb, cb;
-        for (int32_t i = first; i < first + count; i++)
-        {
-            nb.add(tbox[idx[i]]);
-            cb.add(&tcen[(size_t)idx[i] * 3]);
-        }
-        n2[me].box   = nb;
-        n2[me].first = first;
-        n2[me].count = count;
-        if (count <= bvh2_leaf) return me;
-
-        double  best     = DBL_MAX;
-        int     bax      = -1;
-        int     bsplit   = 0;
-        if (depth >= sah_depth)
-        {
-            int ax = 0;
-            for (int k = 1; k < 3; k++)
-                if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
-            const int32_t mid = first + count / 2;
-            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count, [&](int32_t a, int32_t b) {
-                const float ca = tcen[(size_t)a * 3 + ax], cb_ = tcen[(size_t)b * 3 + ax];
-                return ca < cb_ || (ca == cb_ && a < b);
-            });
-            const int32_t l = split(first, mid - first, depth + 1);
-            const int32_t r = split(mid, first + count - mid, depth + 1);
-            n2[me].a = l;
-            n2[me].b = r;
-            return me;
-        }
-        for (int ax = 0; ax < 3; ax++)
-        {
-            float ext = cb.hi[ax] - cb.lo[ax];
-            if (!(ext > 0.0f)) continue;
-            Box   bbox[kBins];
-            int   bcnt[kBins] = { 0 };
-            float k           = (float)kBins / ext;
-            for (int32_t i = first; i < first + count; i++)
-            {
-                int t = idx[i];
-                const int b = bin_of(tcen[(size_t)t * 3 + ax], cb.lo[ax], k);
-                bbox[b].add(tbox[t]);
-                bcnt[b]++;
-            }
-            double rarea[kBins];
-            int    rcnt[kBins];
-            Box    acc;
-            int    c = 0;
-            for (int b = kBins - 1; b >= 1; b--)
-            {
-                acc.add(bbox[b]);
-                c += bcnt[b];
-                rarea[b] = acc.half_area();
-                rcnt[b]  = c;
-            }
-            Box lacc;
-            int lc = 0;
-            for (int b = 0; b < kBins - 1; b++)
-            {
-                lacc.add(bbox[b]);
-                lc += bcnt[b];
-                if (lc == 0 || rcnt[b + 1] == 0) continue;
-                double cost = lacc.half_area() * lc + rarea[b + 1] * rcnt[b + 1];
-                if (cost < best) { best = cost; bax = ax; bsplit = b; }
-            }
-        }
-        int32_t mid;
-        if (bax < 0) mid = first + count / 2;
-        else
-        {
-            float ext = cb.hi[bax] - cb.lo[bax];
-            float k   = (float)kBins / ext;
-            float lo  = cb.lo[bax];
-            auto  it  = std::partition(idx.begin() + first, idx.begin() + first + count, [&](int32_t t) {
-                return bin_of(tcen[(size_t)t * 3 + bax], lo, k) <= bsplit;
-            });
-            mid = (int32_t)(it - idx.begin());
-            if (mid == first || mid == first + count) mid = first + count / 2;
-        }
-        int32_t l = split(first, mid - first, depth + 1);
-        int32_t r = split(mid, first + count - mid, depth + 1);
-        n2[me].a  = l;
-        n2[me].b  = r;
-        return me;
-    }
-};
-
-// ---- triangle reference splitting ("early split clipping") -----------------------------------------------------------
-// Large triangles (walls, floors) drag their whole bounding box into every node above them, and a ray that travels along
-// such a surface visits all of those nodes.  Before the SAH build each triangle whose box is longer than `limit` is cut by
-// axis-aligned planes into pieces with tight boxes; the BVH is built over the pieces ("references"), every piece points at
-// the ORIGINAL triangle, so the ray/triangle test and its results are untouched — only the boxes get tighter.
+// A triangle reference: the box of (triangle ∩ the region its ancestors' spatial splits left it), and the original triangle.
 struct Ref
 {
     Box     box;
@@ -208,32 +118,33 @@ inline void clip_poly(const Poly& in, int ax, double plane, bool keep_below, Pol
     }
 }
 
+// outward-rounded float bounds of a polygon with double coordinates, clamped to the piece it was cut from
 inline Box poly_box(const Poly& p, const Box& parent)
 {
     Box b;
     for (int i = 0; i < p.n; i++)
-    {
-        float f[3];
         for (int k = 0; k < 3; k++)
         {
-            // outward-rounded float bounds of the double coordinate, clamped to the parent piece
             float lo = (float)p.v[i][k], hi = lo;
             if ((double)lo > p.v[i][k]) lo = std::nextafter(lo, -FLT_MAX);
             if ((double)hi < p.v[i][k]) hi = std::nextafter(hi, FLT_MAX);
             if (lo < b.lo[k]) b.lo[k] = lo;
             if (hi > b.hi[k]) b.hi[k] = hi;
-            f[k] = lo;
         }
-        (void)f;
-    }
-    for (int k = 0; k < 3; k++)
-    {
-        if (b.lo[k] < parent.lo[k]) b.lo[k] = parent.lo[k];
-        if (b.hi[k] > parent.hi[k]) b.hi[k] = parent.hi[k];
-    }
+    b.clip_to(parent);
     return b;
 }
 
+inline void tri_poly(const float* positions, int32_t prim, Poly& poly)
+{
+    const float* p = positions + (size_t)prim * 9;
+    poly.n = 3;
+    for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 3; k++) poly.v[v][k] = p[v * 3 + k];
+}
+
+// ---- early split clipping (HR_BVH_SPLIT=<fraction of the scene diagonal>, developer switch; the spatial splits of the SAH build
+// below do the same job adaptively): every triangle whose box is longer than `limit` is cut in halves before the build.
 void split_refs(const Poly& poly, const Box& box, int32_t prim, float limit, int depth, std::vector<Ref>& out)
 {
     int ax = 0;
@@ -257,6 +168,403 @@ void split_refs(const Poly& poly, const Box& box, int32_t prim, float limit, int
     split_refs(l, poly_box(l, box), prim, limit, depth + 1, out);
     split_refs(r, poly_box(r, box), prim, limit, depth + 1, out);
 }
+
+struct Builder
+{
+    const float*      pos;
+    std::vector<Bin2> n2;
+    std::vector<Ref>  leaves;         // references in leaf order
+    int               bvh2_leaf = 1;  // binary-tree leaf size (1 for the optimal collapse: it forms the leaves)
+    bool              spatial   = true;
+    double            alpha     = 1e-3;   // spatial splits are tried when the object split's children overlap by more than alpha x root area
+    double            root_area = 0.0;
+    long              budget    = 0;      // references the spatial splits may still add
+    long              n_spatial = 0, n_unsplit = 0;
+
+    // SAH splits down to binary depth kSahDepth, object-median splits below it: a median split halves the count, so the
+    // binary tree is never deeper than kSahDepth + ceil(log2 n_refs) <= 36 + 26 = 62 levels (hr_scene_create refuses 2^26
+    // references).  The 8-wide collapse only removes levels, and the traversal keeps ONE stack entry per level (traverse.h:
+    // walk_expand), so HR_STACK_ENTRIES + HR_SPILL_ENTRIES = 64 entries always suffice — also for adversarial input (a chain of
+    // slivers of geometrically growing size makes the SAH peel one triangle per level, n levels deep;
+    // tests/test_gpu_trace.py::test_degenerate_sliver_chain).
+    static constexpr int kSahDepth = 36;
+    int sah_depth = kSahDepth;   // HR_BVH_SAH_DEPTH lowers it (developer switch: exercises the median fallback in tests)
+
+    static inline float centre(const Ref& r, int ax) { return 0.5f * (r.box.lo[ax] + r.box.hi[ax]); }
+
+    // Builds the subtree over A[first .. first + count).  Object and median splits partition that range in place; a spatial split
+    // writes its two (longer) reference lists into vectors of their own and recurses into those.
+    int32_t build(std::vector<Ref>& A, size_t first, size_t count, int depth, int32_t parent)
+    {
+        const int32_t me = (int32_t)n2.size();
+        n2.emplace_back();
+        Ref* const refs = A.data() + first;
+        Box nb, cb;
+        for (size_t i = 0; i < count; i++)
+        {
+            nb.add(refs[i].box);
+            const float c[3] = { centre(refs[i], 0), centre(refs[i], 1), centre(refs[i], 2) };
+            cb.add(c);
+        }
+        n2[me].box    = nb;
+        n2[me].parent = parent;
+        n2[me].count  = (int32_t)count;
+        if ((int)count <= bvh2_leaf)
+        {
+            n2[me].first = (int32_t)leaves.size();
+            leaves.insert(leaves.end(), refs, refs + count);
+            return me;
+        }
+        size_t mid = 0;   // object / median split: A[first .. first + mid) | A[first + mid .. first + count)
+        if (depth >= sah_depth) mid = median_split(refs, count, cb);
+        else
+        {
+            // ---- object split: binned SAH over the reference centres, all three axes
+            double best = DBL_MAX;
+            int    bax = -1, bsplit = 0;
+            Box    obj_l, obj_r;
+            for (int ax = 0; ax < 3; ax++)
+            {
+                const float ext = cb.hi[ax] - cb.lo[ax];
+                if (!(ext > 0.0f)) continue;
+                Box         bbox[kBins];
+                int         bcnt[kBins] = { 0 };
+                const float k           = (float)kBins / ext;
+                for (size_t i = 0; i < count; i++)
+                {
+                    const int b = bin_of(centre(refs[i], ax), cb.lo[ax], k);
+                    bbox[b].add(refs[i].box);
+                    bcnt[b]++;
+                }
+                Box    racc[kBins];
+                int    rcnt[kBins];
+                Box    acc;
+                int    c = 0;
+                for (int b = kBins - 1; b >= 1; b--)
+                {
+                    acc.add(bbox[b]);
+                    c += bcnt[b];
+                    racc[b] = acc;
+                    rcnt[b] = c;
+                }
+                Box lacc;
+                int lc = 0;
+                for (int b = 0; b < kBins - 1; b++)
+                {
+                    lacc.add(bbox[b]);
+                    lc += bcnt[b];
+                    if (lc == 0 || rcnt[b + 1] == 0) continue;
+                    const double cost = lacc.half_area() * lc + racc[b + 1].half_area() * rcnt[b + 1];
+                    if (cost < best) { best = cost; bax = ax; bsplit = b; obj_l = lacc; obj_r = racc[b + 1]; }
+                }
+            }
+            // ---- spatial split: only where the object split leaves its children overlapping
+            if (spatial && budget > 0 && bax >= 0)
+            {
+                Box ov = obj_l;
+                ov.clip_to(obj_r);
+                if (ov.valid() && ov.half_area() > alpha * root_area)
+                {
+                    std::vector<Ref> L, R;
+                    if (spatial_split(refs, count, nb, best, L, R))
+                    {
+                        const int32_t l = build(L, 0, L.size(), depth + 1, me);
+                        std::vector<Ref>().swap(L);
+                        const int32_t r = build(R, 0, R.size(), depth + 1, me);
+                        n2[me].a = l;
+                        n2[me].b = r;
+                        return me;
+                    }
+                }
+            }
+            if (bax < 0) mid = median_split(refs, count, cb);
+            else
+            {
+                const float k = (float)kBins / (cb.hi[bax] - cb.lo[bax]), lo = cb.lo[bax];
+                mid = (size_t)(std::partition(refs, refs + count, [&](const Ref& r) { return bin_of(centre(r, bax), lo, k) <= bsplit; }) - refs);
+                if (mid == 0 || mid == count) mid = median_split(refs, count, cb);
+            }
+        }
+        const int32_t l = build(A, first, mid, depth + 1, me);
+        const int32_t r = build(A, first + mid, count - mid, depth + 1, me);
+        n2[me].a = l;
+        n2[me].b = r;
+        return me;
+    }
+
+    // halves the references by the centre along the widest axis of the centre bounds (ties: original index, then box)
+    size_t median_split(Ref* refs, size_t count, const Box& cb)
+    {
+        int ax = 0;
+        for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+        const size_t mid = count / 2;
+        std::nth_element(refs, refs + mid, refs + count, [&](const Ref& a, const Ref& b) {
+            const float ca = centre(a, ax), cb_ = centre(b, ax);
+            if (ca != cb_) return ca < cb_;
+            if (a.prim != b.prim) return a.prim < b.prim;
+            return a.box.lo[ax] < b.box.lo[ax];
+        });
+        return mid;
+    }
+
+    // Chopped binning over the node's box on every axis; performs the split (filling L, R) and returns true when the best plane
+    // beats the object split's cost `object_cost`.
+    bool spatial_split(const Ref* refs_, size_t count, const Box& nb, double object_cost, std::vector<Ref>& L, std::vector<Ref>& R)
+    {
+        struct Range { const Ref *b, *e; const Ref* begin() const { return b; } const Ref* end() const { return e; } } refs { refs_, refs_ + count };
+        double best = object_cost;
+        int    bax = -1, bsplit = 0;
+        for (int ax = 0; ax < 3; ax++)
+        {
+            const float ext = nb.hi[ax] - nb.lo[ax];
+            if (!(ext > 0.0f)) continue;
+            const float  k = (float)kSpatialBins / ext;
+            const double w = (double)ext / kSpatialBins;
+            Box bbox[kSpatialBins];
+            int enter[kSpatialBins] = { 0 }, leave[kSpatialBins] = { 0 };
+            for (const Ref& r : refs)
+            {
+                const int b0 = bin_of(r.box.lo[ax], nb.lo[ax], k, kSpatialBins), b1 = bin_of(r.box.hi[ax], nb.lo[ax], k, kSpatialBins);
+                enter[b0]++; leave[b1]++;
+                if (b0 == b1) { bbox[b0].add(r.box); continue; }
+                Poly rest, piece, next;
+                tri_poly(pos, r.prim, rest);
+                for (int j = b0; j <= b1 && rest.n >= 3; j++)
+                {
+                    if (j < b1)
+                    {
+                        const double plane = (double)nb.lo[ax] + w * (j + 1);
+                        clip_poly(rest, ax, plane, true, piece);
+                        clip_poly(rest, ax, plane, false, next);
+                    }
+                    else { piece = rest; next.n = 0; }
+                    if (piece.n >= 3)
+                    {
+                        const Box pb = poly_box(piece, r.box);
+                        if (pb.valid()) bbox[j].add(pb);
+                    }
+                    rest = next;
+                }
+            }
+            Box racc[kSpatialBins];
+            int rcnt[kSpatialBins];
+            Box acc;
+            int c = 0;
+            for (int b = kSpatialBins - 1; b >= 1; b--)
+            {
+                acc.add(bbox[b]);
+                c += leave[b];
+                racc[b] = acc;
+                rcnt[b] = c;
+            }
+            Box lacc;
+            int lc = 0;
+            for (int b = 0; b < kSpatialBins - 1; b++)
+            {
+                lacc.add(bbox[b]);
+                lc += enter[b];
+                if (lc == 0 || rcnt[b + 1] == 0) continue;
+                const double cost = lacc.half_area() * lc + racc[b + 1].half_area() * rcnt[b + 1];
+                if (cost < best) { best = cost; bax = ax; bsplit = b; }
+            }
+        }
+        if (bax < 0) return false;
+        const int    ax    = bax;
+        const double w     = ((double)nb.hi[ax] - nb.lo[ax]) / kSpatialBins;
+        const double plane = (double)nb.lo[ax] + w * (bsplit + 1);
+        struct Straddler { Ref whole, l, r; };
+        std::vector<Straddler> st;
+        Box lb, rb;
+        for (const Ref& r : refs)
+        {
+            if ((double)r.box.hi[ax] <= plane) { L.push_back(r); lb.add(r.box); }
+            else if ((double)r.box.lo[ax] >= plane) { R.push_back(r); rb.add(r.box); }
+            else
+            {
+                Poly tri, pl, pr;
+                tri_poly(pos, r.prim, tri);
+                clip_poly(tri, ax, plane, true, pl);
+                clip_poly(tri, ax, plane, false, pr);
+                Straddler s;
+                s.whole = r;
+                s.l = Ref { poly_box(pl, r.box), r.prim };
+                s.r = Ref { poly_box(pr, r.box), r.prim };
+                const bool lv = pl.n >= 3 && s.l.box.valid(), rv = pr.n >= 3 && s.r.box.valid();
+                if (lv && rv) st.push_back(s);
+                else if (lv) { L.push_back(r); lb.add(r.box); }
+                else { R.push_back(r); rb.add(r.box); }
+            }
+        }
+        // reference unsplitting: a straddler goes to one side whole when that is cheaper than referencing it from both
+        long nl = (long)L.size(), nr = (long)R.size(), dup = 0;
+        for (const Straddler& s : st)
+        {
+            const Box    lub = merged(lb, s.whole.box), rub = merged(rb, s.whole.box), ldb = merged(lb, s.l.box), rdb = merged(rb, s.r.box);
+            const double c_split = ldb.half_area() * (nl + 1) + rdb.half_area() * (nr + 1);
+            const double c_left  = lub.half_area() * (nl + 1) + rb.half_area() * nr;
+            const double c_right = lb.half_area() * nl + rub.half_area() * (nr + 1);
+            if (c_split < c_left && c_split < c_right && dup < budget)
+            {
+                L.push_back(s.l); R.push_back(s.r); lb = ldb; rb = rdb; nl++; nr++; dup++;
+            }
+            else if (c_left <= c_right) { L.push_back(s.whole); lb = lub; nl++; n_unsplit++; }
+            else { R.push_back(s.whole); rb = rub; nr++; n_unsplit++; }
+        }
+        if (L.empty() || R.empty())
+        {
+            L.clear(); R.clear();
+            return false;
+        }
+        budget -= dup;
+        n_spatial++;
+        return true;
+    }
+
+    // ---- insertion-based optimisation (Bittner et al. 2013) ----------------------------------------------------------------
+    // A node v is cut out together with its parent p (v's sibling takes p's place), the tree above is refitted, and v is put back
+    // beside the node x that minimises  area(x ∪ v) + Σ over x's ancestors of the growth of their area  (branch and bound from the
+    // root, cheapest induced cost first); p is re-used as the common parent of x and v.  The old position is among the candidates,
+    // so the SAH cost never rises.  Per pass the `fraction` of the nodes with the largest area are processed, largest first.
+    int32_t root = 0;
+    void refit_up(int32_t i)
+    {
+        while (i >= 0)
+        {
+            const Box b = merged(n2[n2[i].a].box, n2[n2[i].b].box);
+            if (b.same(n2[i].box)) break;
+            n2[i].box = b;
+            i = n2[i].parent;
+        }
+    }
+    int32_t find_best(const Box& vb)
+    {
+        struct Item { double induced; int32_t node; bool operator<(const Item& o) const { return induced > o.induced; } };
+        static thread_local std::vector<Item> heap;
+        heap.clear();
+        const double va = vb.half_area();
+        double  best_cost = DBL_MAX;
+        int32_t best = root;
+        heap.push_back({ 0.0, root });
+        while (!heap.empty())
+        {
+            std::pop_heap(heap.begin(), heap.end());
+            const Item it = heap.back();
+            heap.pop_back();
+            if (it.induced + va >= best_cost) break;
+            const Bin2&  x      = n2[it.node];
+            const double direct = merged(x.box, vb).half_area(), total = it.induced + direct;
+            if (total < best_cost) { best_cost = total; best = it.node; }
+            const double child_induced = total - x.box.half_area();
+            if (x.a >= 0 && child_induced + va < best_cost)
+            {
+                heap.push_back({ child_induced, x.a }); std::push_heap(heap.begin(), heap.end());
+                heap.push_back({ child_induced, x.b }); std::push_heap(heap.begin(), heap.end());
+            }
+        }
+        return best;
+    }
+    bool reinsert(int32_t v)
+    {
+        const int32_t p = n2[v].parent;
+        if (p < 0 || n2[p].parent < 0) return false;   // the root and its children stay
+        const int32_t g = n2[p].parent, s = n2[p].a == v ? n2[p].b : n2[p].a;
+        (n2[g].a == p ? n2[g].a : n2[g].b) = s;
+        n2[s].parent = g;
+        refit_up(g);
+        const int32_t x = find_best(n2[v].box), px = n2[x].parent;
+        if (px >= 0) (n2[px].a == x ? n2[px].a : n2[px].b) = p;
+        else root = p;
+        n2[p].parent = px;
+        n2[p].a = x; n2[p].b = v;
+        n2[x].parent = p; n2[v].parent = p;
+        n2[p].box = merged(n2[x].box, n2[v].box);
+        refit_up(px);
+        return x != s;
+    }
+    int depth_of_tree() const
+    {
+        std::vector<std::pair<int32_t, int>> st;
+        st.push_back({ root, 1 });
+        int d = 0;
+        while (!st.empty())
+        {
+            const auto [n, dn] = st.back();
+            st.pop_back();
+            if (dn > d) d = dn;
+            if (n2[n].a >= 0) { st.push_back({ n2[n].a, dn + 1 }); st.push_back({ n2[n].b, dn + 1 }); }
+        }
+        return d;
+    }
+    double sah() const
+    {
+        double c = 0;
+        for (const Bin2& n : n2) c += n.box.half_area();
+        return c / (root_area > 0 ? root_area : 1.0);
+    }
+    long optimise(int passes, double fraction)
+    {
+        long moved = 0;
+        std::vector<std::pair<double, int32_t>> cand;
+        for (int pass = 0; pass < passes; pass++)
+        {
+            cand.clear();
+            for (int32_t i = 0; i < (int32_t)n2.size(); i++)
+                if (n2[i].parent >= 0 && n2[n2[i].parent].parent >= 0) cand.push_back({ n2[i].box.half_area(), i });
+            const size_t take = (size_t)((double)cand.size() * fraction);
+            if (take == 0) break;
+            std::partial_sort(cand.begin(), cand.begin() + take, cand.end(), [](const auto& a, const auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+            long m = 0;
+            for (size_t i = 0; i < take; i++) m += reinsert(cand[i].second) ? 1 : 0;
+            moved += m;
+            if (m == 0) break;
+        }
+        return moved;
+    }
+
+    // After the optimisation the subtrees are no longer contiguous in `leaves`: re-emit the references in depth-first order, set
+    // first / count of every node, pad the boxes and return the nodes children-before-parents.
+    std::vector<int32_t> finalise(float pad)
+    {
+        std::vector<int32_t> post;
+        post.reserve(n2.size());
+        std::vector<Ref> out;
+        out.reserve(leaves.size());
+        std::vector<std::pair<int32_t, bool>> st;
+        st.push_back({ root, false });
+        while (!st.empty())
+        {
+            const auto [n, seen] = st.back();
+            st.pop_back();
+            Bin2& c = n2[n];
+            if (c.a < 0)
+            {
+                const int32_t first = (int32_t)out.size();
+                Box b;
+                for (int32_t t = 0; t < c.count; t++) { out.push_back(leaves[c.first + t]); b.add(leaves[c.first + t].box); }
+                c.first = first;
+                for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
+                c.box = b;
+                post.push_back(n);
+            }
+            else if (!seen)
+            {
+                st.push_back({ n, true });
+                st.push_back({ c.b, false });
+                st.push_back({ c.a, false });
+            }
+            else
+            {
+                c.first = n2[c.a].first;
+                c.count = n2[c.a].count + n2[c.b].count;
+                c.box   = merged(n2[c.a].box, n2[c.b].box);
+                post.push_back(n);
+            }
+        }
+        leaves.swap(out);
+        return post;
+    }
+};
 
 inline uint8_t exponent_for(float extent)
 {
@@ -302,10 +610,14 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         out.pad = (float)(3e-5 * diag);
         if (!(out.pad > 0.0f)) out.pad = 1e-6f;
     }
-    // references: one per triangle, or several tight pieces for triangles longer than diag * split_fraction
-    // Off by default: the bench scene is finely tessellated and splitting at diag/16 .. diag/100 changed nodes/ray by
-    // < 2% and the trace time by < 1.5% (tools/passbench.py).  HR_BVH_SPLIT=<fraction of the scene diagonal> enables it
-    // for scenes with wall-sized triangles (original Sponza: two triangles per wall).
+    if (n_tris == 0)
+    {
+        Node8 n;
+        std::memset(&n, 0, sizeof(n));
+        n.ex = n.ey = n.ez = 1;
+        out.nodes.push_back(n);
+        return;
+    }
     double split_fraction = 0.0;
     if (const char* e = getenv("HR_BVH_SPLIT")) split_fraction = atof(e);
     const float limit = split_fraction > 0.0 ? (float)(diag * split_fraction) : FLT_MAX;
@@ -317,41 +629,50 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         Box tb;
         tb.add(p); tb.add(p + 3); tb.add(p + 6);
         Poly poly;
-        poly.n = 3;
-        for (int v = 0; v < 3; v++)
-            for (int k = 0; k < 3; k++) poly.v[v][k] = p[v * 3 + k];
+        tri_poly(positions, i, poly);
         split_refs(poly, tb, i, limit, 0, refs);
     }
-    const int n_refs = (int)refs.size();
-    out.n_refs = n_refs;
-    B.tbox.resize(n_refs);
-    B.tcen.resize((size_t)n_refs * 3);
-    B.idx.resize(n_refs);
-    B.prim.resize(n_refs);
-    for (int i = 0; i < n_refs; i++)
-    {
-        B.tbox[i] = refs[i].box;
-        B.prim[i] = refs[i].prim;
-        for (int a = 0; a < 3; a++)
-        {
-            B.tcen[(size_t)i * 3 + a] = 0.5f * (B.tbox[i].lo[a] + B.tbox[i].hi[a]);
-            B.tbox[i].lo[a] -= out.pad; B.tbox[i].hi[a] += out.pad;
-        }
-        B.idx[i] = i;
-    }
-
-    if (n_tris == 0)
-    {
-        Node8 n;
-        std::memset(&n, 0, sizeof(n));
-        n.ex = n.ey = n.ez = 1;
-        out.nodes.push_back(n);
-        return;
-    }
+    // developer switches (A/B of the build steps; tests/test_bvh_host.py, tools/bvh_eval.cpp)
     B.bvh2_leaf = getenv("HR_BVH_GREEDY") ? kMaxLeaf : 1;
     if (const char* e = getenv("HR_BVH_SAH_DEPTH")) { const int v = atoi(e); if (v >= 0 && v < Builder::kSahDepth) B.sah_depth = v; }
-    B.n2.reserve((size_t)n_refs * 2);
-    int32_t root2 = B.split(0, n_refs);
+    if (const char* e = getenv("HR_BVH_SBVH")) B.spatial = atoi(e) != 0;
+    if (const char* e = getenv("HR_BVH_ALPHA")) B.alpha = atof(e);
+    double budget_fraction = 0.3;
+    if (const char* e = getenv("HR_BVH_BUDGET")) budget_fraction = atof(e);
+    int    passes = 2;
+    double fraction = 0.1;
+    if (const char* e = getenv("HR_BVH_REINSERT")) passes = atoi(e);
+    if (const char* e = getenv("HR_BVH_REINSERT_FRACTION")) fraction = atof(e);
+    B.budget    = (long)(budget_fraction * (double)refs.size());
+    B.root_area = all.half_area();
+    B.n2.reserve(refs.size() * 2 + refs.size() / 2);
+    B.leaves.reserve(refs.size() + refs.size() / 3);
+    const size_t n_input_refs = refs.size();
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    B.root = B.build(refs, 0, refs.size(), 0, -1);
+    const double t_built = since();
+    std::vector<Ref>().swap(refs);
+    const double sah_built = getenv("HR_BVH_STATS") ? B.sah() : 0.0;
+    long moved = 0;
+    if (passes > 0 && B.bvh2_leaf == 1 && B.n2.size() > 8)
+    {
+        // the optimisation may deepen the tree; the traversal stack bounds the depth (see kSahDepth): keep the built tree if it does
+        const int depth_limit = kMaxTraversalDepth - 2;
+        const std::vector<Bin2> backup = B.n2;
+        const int32_t           root_backup = B.root;
+        moved = B.optimise(passes, fraction);
+        if (B.depth_of_tree() > depth_limit) { B.n2 = backup; B.root = root_backup; moved = 0; }
+    }
+    const double t_opt = since();
+    if (getenv("HR_BVH_STATS"))
+        fprintf(stderr, "bvh2: build %.2f s, optimise %.2f s\n", t_built, t_opt - t_built);
+    if (getenv("HR_BVH_STATS"))
+        fprintf(stderr, "bvh2: %d triangles, %zu input refs, %zu refs (%ld spatial splits, %ld unsplit), %zu nodes, SAH %.3f -> %.3f (%ld reinsertions), depth %d\n", n_tris,
+                n_input_refs, B.leaves.size(), B.n_spatial, B.n_unsplit, B.n2.size(), sah_built, B.sah(), moved, B.depth_of_tree());
+    const std::vector<int32_t> post = B.finalise(out.pad);
+    const int32_t root2 = B.root;
+    const int     n_refs = (int)B.leaves.size();
 
     // ---- optimal collapse (Ylitie, Karras, Laine 2017, sec. 3.1): dynamic programme over the binary tree -----------------
     // c(n, i) = least SAH cost of representing the subtree of n by a forest of at most i roots, a root being either a leaf
@@ -365,10 +686,12 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     {
         const size_t nn = B.n2.size();
         // one node step ~230 VALU + 80 B, one triangle test ~80 VALU + 48 B; the result is flat in C_prim (0.15 .. 1.2: 0.253-0.256 ms)
-        const double C_node = 1.0, C_prim = 0.35;
+        double C_node = 1.0, C_prim = 0.35;
+        if (const char* e = getenv("HR_BVH_CPRIM")) C_prim = atof(e);   // developer switch (tools/bvh_eval.cpp sweeps it)
         cost.assign(nn * 8, 0.0); best_k.assign(nn * 8, 0); use_split.assign(nn * 8, 0); as_leaf.assign(nn, 0);
-        for (size_t r = nn; r-- > 0;)   // children are allocated after their parent: reverse order is bottom-up
+        for (const int32_t r_ : post)   // children before parents
         {
+            const size_t r = (size_t)r_;
             const Bin2& c = B.n2[r];
             const double area = c.box.half_area();
             const double leaf = c.count <= kMaxLeaf ? area * c.count * C_prim : 1e300;
@@ -491,13 +814,16 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         n.ey = exponent_for(nb.hi[1] - nb.lo[1]);
         n.ez = exponent_for(nb.hi[2] - nb.lo[2]);
         const uint8_t eb[3] = { n.ex, n.ey, n.ez };
+        int sort_axis = 0;
         {
-            // Internal children are ordered along the node's longest axis — the axis with the largest scale exponent, first
-            // one on ties, which the traversal re-derives from the exponent bytes — so that a ray can walk them near to far
-            // (ascending slots for a positive direction component, descending for a negative one).
+            // Internal children are ordered along the node's longest axis (largest scale exponent, first one on ties; the centre
+            // spread of the children was tried as the criterion: no better), stored in the spare bits of slot 0's meta byte (bvh.h),
+            // so that a ray can walk them in order of distance: ascending slots for a positive direction component, descending
+            // for a negative one — closest-hit queries near to far, any-hit queries far to near (traverse.h).
             int ax = 0;
             if (eb[1] > eb[0]) ax = 1;
             if (eb[2] > eb[ax]) ax = 2;
+            sort_axis = ax;
             std::stable_sort(kids, kids_mid, [&](int32_t x, int32_t y) {
                 const Box& bx = B.n2[x].box; const Box& by = B.n2[y].box;
                 return (double)bx.lo[ax] + bx.hi[ax] < (double)by.lo[ax] + by.hi[ax];
@@ -525,15 +851,24 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
             }
             if (i < n_int_kids)
             {
-                n.meta[i] = (uint8_t)(0x10 | n_internal);
+                n.meta[i] = (uint8_t)(0x10 | (i == 0 ? sort_axis : 0));
                 n_internal++;
             }
             else
             {
-                n.meta[i] = (uint8_t)((c.count << 5) | tri_off);
+                // a leaf may hold two references to one triangle (pieces that a spatial split separated and the collapse
+                // joined again): the triangle is stored once
+                int32_t prims[kMaxLeaf];
+                int     np = 0;
                 for (int t = 0; t < c.count; t++)
                 {
-                    int32_t      prim = B.prim[B.idx[c.first + t]];
+                    const int32_t prim = B.leaves[c.first + t].prim;
+                    if (std::find(prims, prims + np, prim) == prims + np) prims[np++] = prim;
+                }
+                n.meta[i] = (uint8_t)((np << 5) | tri_off);
+                for (int t = 0; t < np; t++)
+                {
+                    const int32_t prim = prims[t];
                     const float* p    = positions + (size_t)prim * 9;
                     TriGPU       tg;
                     std::memset(&tg, 0, sizeof(tg));
@@ -543,7 +878,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
                     tg.prim = (uint32_t)prim;
                     out.tris.push_back(tg);
                 }
-                tri_off += (uint32_t)c.count;
+                tri_off += (uint32_t)np;
             }
         }
         n.counts = (uint8_t)(n_internal | (nk << 4));
@@ -555,6 +890,7 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         for (int i = 0; i < nk; i++)
             if (i < n_int_kids) q.push({ kids[i], (int32_t)(base + slot++), pd.depth + 1 });
     }
+    out.n_refs = (int)out.tris.size();
     if (getenv("HR_BVH_STATS"))
     {
         long hist[9] = { 0 }, ihist[9] = { 0 };
@@ -565,6 +901,63 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         for (int i = 0; i <= 8; i++) fprintf(stderr, " %d:%ld", i, ihist[i]);
         fprintf(stderr, "\n");
     }
+}
+
+
+// Host-side self-check of the property every query relies on: a ray that meets triangle T at point p must find T in a leaf it
+// reaches through boxes that all contain p.  With spatial splits a triangle is referenced from several leaves, each covering the
+// part of it inside that leaf's (clipped) box — the pieces together must cover the triangle.  For `samples` points of every
+// triangle (corners, edge midpoints, centroid, then hashed barycentric points) the tree is descended through the dequantised
+// child boxes that contain the point; returns how many (triangle, point) pairs reach no leaf holding the triangle.
+int64_t check_bvh8_coverage(const float* positions, int n_tris, const BuiltBVH& b, int samples)
+{
+    if (n_tris == 0) return 0;
+    int64_t bad = 0;
+    std::vector<uint32_t> stack;
+    for (int t = 0; t < n_tris; t++)
+    {
+        const float* p = positions + (size_t)t * 9;
+        for (int s = 0; s < samples; s++)
+        {
+            double w[3];
+            if (s < 3) { w[0] = s == 0; w[1] = s == 1; w[2] = s == 2; }
+            else if (s < 6) { w[0] = s == 5 ? 0.5 : (s == 3 ? 0.5 : 0.0); w[1] = s == 3 ? 0.5 : (s == 4 ? 0.5 : 0.0); w[2] = 1.0 - w[0] - w[1]; }
+            else if (s == 6) { w[0] = w[1] = 1.0 / 3.0; w[2] = 1.0 - w[0] - w[1]; }
+            else
+            {
+                uint32_t h = (uint32_t)t * 2654435761u + (uint32_t)s * 40503u;
+                h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+                double u = (h & 0xffff) / 65536.0, v = (h >> 16) / 65536.0;
+                if (u + v > 1.0) { u = 1.0 - u; v = 1.0 - v; }
+                w[0] = u; w[1] = v; w[2] = 1.0 - u - v;
+            }
+            double q[3];
+            for (int k = 0; k < 3; k++) q[k] = w[0] * p[k] + w[1] * p[3 + k] + w[2] * p[6 + k];
+            bool found = false;
+            stack.clear();
+            stack.push_back(0u);
+            while (!stack.empty() && !found)
+            {
+                const Node8& n = b.nodes[stack.back()];
+                stack.pop_back();
+                const double sc[3] = { std::ldexp(1.0, (int)n.ex - 127), std::ldexp(1.0, (int)n.ey - 127), std::ldexp(1.0, (int)n.ez - 127) };
+                const double o[3]  = { n.ox, n.oy, n.oz };
+                const int    nk = n.counts >> 4, nin = n.counts & 15;
+                for (int i = 0; i < nk && !found; i++)
+                {
+                    bool in = true;
+                    for (int a = 0; a < 3; a++) in = in && q[a] >= o[a] + n.qlo[a][i] * sc[a] && q[a] <= o[a] + n.qhi[a][i] * sc[a];
+                    if (!in) continue;
+                    if (i < nin) stack.push_back(n.child_base + (uint32_t)i);
+                    else
+                        for (uint32_t k = 0; k < (uint32_t)(n.meta[i] >> 5); k++)
+                            if (b.tris[n.tri_base + (n.meta[i] & 31u) + k].prim == (uint32_t)t) found = true;
+                }
+            }
+            if (!found) bad++;
+        }
+    }
+    return bad;
 }
 
 } // namespace hr

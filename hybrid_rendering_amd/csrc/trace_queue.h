@@ -111,9 +111,9 @@ __global__ __launch_bounds__(64) void k_trace_queue(TraceQueueArgs a)
         if (alive && pend == 0u)
         {
             uint32_t ni;
-            if (walk_next<!ANY>(cur, st, ni))
+            if (walk_next<(ANY ? HR_ANY_ORDER : HR_ORDER_NEAR) != HR_ORDER_SLOTS>(cur, st, ni))
             {
-                const NodeHits h = test_node<!ANY>(load_node(a.nodes, ni), r, t_min, tfar);
+                const NodeHits h = test_node<ANY ? HR_ANY_ORDER : HR_ORDER_NEAR>(load_node(a.nodes, ni), r, t_min, tfar);
                 pend      = walk_expand(h, cur, st);
                 pend_base = h.tri_base;
             }

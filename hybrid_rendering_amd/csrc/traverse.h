@@ -158,7 +158,20 @@ HR_DEV NodeRaw load_node(const Node8* __restrict__ nodes, uint32_t ni)
     return n;
 }
 
-template <bool ORDERED>
+// ORDER: in which order the walk visits the hit internal children of a node (they are sorted along one axis of the node,
+// bvh.h).  HR_ORDER_NEAR: near to far — closest-hit queries, the far limit shrinks soonest.  HR_ORDER_FAR: far to near — any-hit
+// queries: their rays run from a surface towards a light or the sky, and what blocks those is mostly the building's envelope
+// (roof slabs, walls, hanging fabric) at the far end, not the geometry around the origin: on the CPU replay of the bench frame
+// (tools/bvh_eval.cpp) the wave-level node steps of the hard tier's shadow rays fall by 55 %, the hit shaders' light / sky rays by
+// 12-60 %, the standard tier is unchanged.  HR_ORDER_SLOTS: ascending slots whatever the direction.  The answer of a query does
+// not depend on the order (any-hit: a function of the geometry; closest hit: smallest t, ties to the smallest index).
+#define HR_ORDER_SLOTS 0
+#define HR_ORDER_NEAR 1
+#define HR_ORDER_FAR 2
+#ifndef HR_ANY_ORDER
+#define HR_ANY_ORDER HR_ORDER_FAR   // developer A/B: HR_CFLAGS=-DHR_ANY_ORDER=0
+#endif
+template <int ORDER>
 HR_DEV NodeHits test_node(const NodeRaw& n, const RayPre& r, float t_near, float t_far)
 {
     const uint4 q0 = n.q0, q1 = n.q1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
@@ -177,13 +190,11 @@ HR_DEV NodeHits test_node(const NodeRaw& n, const RayPre& r, float t_near, float
     h.child_base = q1.x; h.tri_base = q1.y; h.meta_lo = q1.z; h.meta_hi = q1.w;
     h.n_internal = (q0.w >> 24) & 15u;
     h.rev = 0u;
-    if (ORDERED)
+    if (ORDER != HR_ORDER_SLOTS)
     {
-        // axis of the largest scale exponent (first on ties) = the builder's sort axis for the internal children
-        const uint32_t ex = q0.w & 0xffu, ey = (q0.w >> 8) & 0xffu, ez = (q0.w >> 16) & 0xffu;
-        uint32_t ax = ey > ex ? 1u : 0u;
-        if (ez > (ax ? ey : ex)) ax = 2u;
-        h.rev = (r.sel >> ax) & 1u;
+        // the builder's sort axis of the internal children sits in the low bits of slot 0's meta byte
+        const uint32_t along = (r.sel >> (q1.z & 3u)) & 1u;   // the ray runs against the axis
+        h.rev = ORDER == HR_ORDER_NEAR ? along : along ^ 1u;
     }
     uint32_t hits = 0;
 #pragma unroll
@@ -280,8 +291,7 @@ HR_DEV bool ray_tri_raw(const RayPre& r, const TriRaw& q, float t_min, float t_m
 // that are still to be visited (rev: take the highest slot first — the children are sorted along the node's longest axis
 // and the ray runs against it).  The entry being consumed stays in a register (`cur`); it goes to the stack only when a
 // newly tested node has internal hits of its own while `cur` still has siblings left.
-// ORDERED (closest hit): near-to-far order pays — reflections trace 0.28 -> 0.26 ms; any-hit queries skip it (their answer
-// does not improve with order, and the extra instructions cost 5-7% there).
+// ORDERED: the entry's `rev` bit picks the end of the mask to start from (test_node's ORDER).
 template <bool ORDERED>
 HR_DEV bool walk_next(uint32_t& cur, LaneStack& st, uint32_t& ni)
 {
@@ -356,7 +366,7 @@ HR_DEV uint32_t entry_node_for_box(const Node8* __restrict__ nodes, f3 lo, f3 hi
 
 // hit_tri (optional): index into `tris` of the triangle that occluded the ray (untouched on a miss) — the next frame's first guess
 // (shadow trace: occluder cache).
-template <bool STATS>
+template <bool STATS, int ORDER = HR_ANY_ORDER>
 HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
                       uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t entry = 0u, DivCounters* dv = nullptr,
                       uint32_t* hit_tri = nullptr)
@@ -369,9 +379,9 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
     uint32_t cur = (entry << 9) | 1u, ni;   // the entry node (root = 0) = "child 0 of child_base entry"
     bool     hit = false;
     const int pcode = wave_perm_code(r);
-    while (walk_next<false>(cur, st, ni))
+    while (walk_next<ORDER != HR_ORDER_SLOTS>(cur, st, ni))
     {
-        const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
+        const NodeHits h = test_node<ORDER>(load_node(nodes, ni), r, t_min, t_max);
         if (STATS) n_nodes++;
         HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
         uint32_t trimask = walk_expand(h, cur, st);
@@ -430,7 +440,7 @@ HR_DEV RaySeq rayseq_select(const RaySeq (&q)[NB], int s)
     return o;
 }
 
-template <int NB>
+template <int NB, int ORDER = HR_ANY_ORDER>
 HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, const f3 (&dir)[NB],
                               float t_min, const float (&t_maxs)[NB], uint32_t* wave_stack, int lane, uint32_t entry, DivCounters* dv = nullptr)
 {
@@ -453,7 +463,7 @@ HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__
         if (alive)
         {
             uint32_t ni;
-            bool     go = walk_next<false>(cur, st, ni);
+            bool     go = walk_next<ORDER != HR_ORDER_SLOTS>(cur, st, ni);
             if (!go)
             {
                 // this ray's stack ran empty: not occluded; next ray of the lane (walk_next on `first` always yields the entry node)
@@ -464,12 +474,12 @@ HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__
                     const RaySeq nx = rayseq_select<NB>(q, s);
                     rayseq_unpack(r, nx); t_max = nx.t_max;
                     cur = first; st.sp = 0;
-                    go  = walk_next<false>(cur, st, ni);
+                    go  = walk_next<ORDER != HR_ORDER_SLOTS>(cur, st, ni);
                 }
             }
             if (go)
             {
-                const NodeHits h = test_node<false>(load_node(nodes, ni), r, t_min, t_max);
+                const NodeHits h = test_node<ORDER>(load_node(nodes, ni), r, t_min, t_max);
                 HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
                 uint32_t trimask = walk_expand(h, cur, st);
                 bool     hit = false;
@@ -528,8 +538,8 @@ template <bool STATS>
 HR_DEV int anyhit_step(AnyHitLane& s, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, uint32_t& n_nodes, uint32_t& n_tris)
 {
     uint32_t ni;
-    if (!walk_next<false>(s.cur, s.st, ni)) return 2;
-    const NodeHits h  = test_node<false>(load_node(nodes, ni), s.r, s.t_min, s.t_max);
+    if (!walk_next<HR_ANY_ORDER != HR_ORDER_SLOTS>(s.cur, s.st, ni)) return 2;
+    const NodeHits h  = test_node<HR_ANY_ORDER>(load_node(nodes, ni), s.r, s.t_min, s.t_max);
     if (STATS) n_nodes++;
     uint32_t trimask = walk_expand(h, s.cur, s.st);
     while (trimask)
@@ -567,7 +577,7 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
     while (walk_next<true>(cur, st, ni))
     {
         const float    tfar = best.prim < 0 ? t_max : best.t * 1.0000005f;
-        const NodeHits h    = test_node<true>(load_node(nodes, ni), r, t_min, tfar);
+        const NodeHits h    = test_node<HR_ORDER_NEAR>(load_node(nodes, ni), r, t_min, tfar);
         HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
@@ -650,7 +660,7 @@ HR_DEV void coop_flush(CoopWave& cw, const TriGPU* __restrict__ tris, const RayP
 
 // Closest hit (ANY = false: smallest t, ties to the smallest original triangle index — trace_closest's answer bit for bit) or
 // any-hit (ANY = true: HitRec.prim = 0 if occluded, -1 if not; t, u, v unset).
-template <bool ANY>
+template <bool ANY, int ORDER = (ANY ? HR_ANY_ORDER : HR_ORDER_NEAR)>
 HR_DEV HitRec trace_coop(bool active, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
                          uint32_t* wave_stack, CoopWave& cw, int lane, uint32_t entry = 0u, DivCounters* dv = nullptr)
 {
@@ -671,9 +681,9 @@ HR_DEV HitRec trace_coop(bool active, const Node8* __restrict__ nodes, const Tri
         if (alive && pend == 0u)
         {
             uint32_t ni;
-            if (walk_next<!ANY>(cur, st, ni))
+            if (walk_next<ORDER != HR_ORDER_SLOTS>(cur, st, ni))
             {
-                const NodeHits h = test_node<!ANY>(load_node(nodes, ni), r, t_min, tfar);
+                const NodeHits h = test_node<ORDER>(load_node(nodes, ni), r, t_min, tfar);
                 HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
                 pend      = walk_expand(h, cur, st);
                 pend_base = h.tri_base;

@@ -168,6 +168,10 @@ hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* desc, hr_scene** out
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info);
 /* Host only (no device needed): the shape of the BVH hr_scene_create would build over `positions` ([n_tris][3][3] floats). */
 hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_info* info);
+/* Host only: builds the same BVH and descends it from `samples_per_triangle` points of every triangle (corners, edge midpoints,
+ * centroid, then pseudo-random interior points); *uncovered = the (triangle, point) pairs that reach no leaf holding the triangle.
+ * 0 for a correct tree: the builder references a triangle from several leaves (spatial splits) and the pieces must cover it. */
+hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t samples_per_triangle, int64_t* uncovered);
 hr_status hr_scene_destroy(hr_scene* scene);
 
 /* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).
