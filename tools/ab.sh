@@ -7,7 +7,7 @@ PASSES=$1; shift
 for v in "$@"; do
     if [ "$v" = base ]; then unset HR_LIBRARY; else export HR_LIBRARY=$R/hybrid_rendering_amd/variants/libhybrid_rendering_amd.$v.so; fi
     echo "== $v"
-    timeout 300 python $R/tools/passbench.py --exact ${EXACT:-0} --passes $PASSES --frames ${FRAMES:-20} 2>/dev/null | python -c "
+    timeout 300 python $R/tools/passbench.py --exact ${EXACT:-0} --passes $PASSES --frames ${FRAMES:-20} ${PB_ARGS:-} 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); print(' ', d['pass_'], d['ms_per_frame'], {k: v['ms'] for k, v in d['stages'].items()})

@@ -261,7 +261,7 @@ static uint32_t entry_node_for_box(const BuiltBVH& b, V3 lo, V3 hi)
     return ni;
 }
 
-struct SetStats { double rays = 0, nodes = 0, tris = 0, wnodes = 0, wtris = 0, waves = 0, hits = 0; };
+struct SetStats { double rays = 0, nodes = 0, tris = 0, wnodes = 0, wtris = 0, waves = 0, hits = 0, worst = 0; std::vector<float> wc; };
 static void add_wave(SetStats& s, const Counts* c, int n_lanes, int rays_per_lane = 1)
 {
     uint32_t mn = 0, mt = 0;
@@ -271,12 +271,17 @@ static void add_wave(SetStats& s, const Counts* c, int n_lanes, int rays_per_lan
         mn = std::max(mn, c[i].nodes); mt = std::max(mt, c[i].tris);
     }
     s.wnodes += mn; s.wtris += mt; s.waves += 1;
+    // critical path of the wave: its slowest lane's steps (a lane's node steps and triangle tests are serial)
+    float cp = 0; for (int i = 0; i < n_lanes; i++) cp = std::max(cp, c[i].nodes * 230.0f + c[i].tris * 80.0f);
+    s.wc.push_back(cp); s.worst = std::max(s.worst, (double)cp);
 }
 static void report(const char* name, const SetStats& s)
 {
-    printf("%-8s rays %9.0f  hit %.3f  nodes/ray %7.3f  tris/ray %7.3f  | wave-max: nodes %8.2f tris %8.2f per wave   cost/ray %8.1f  wavecost %10.0f\n", name, s.rays,
+    std::vector<float> w = s.wc; std::sort(w.begin(), w.end());
+    const float p99 = w.empty() ? 0 : w[(size_t)(w.size() * 0.99)], p999 = w.empty() ? 0 : w[(size_t)(w.size() * 0.999)];
+    printf("%-8s rays %9.0f  hit %.3f  nodes/ray %7.3f  tris/ray %7.3f  | wave-max: nodes %8.2f tris %8.2f per wave   cost/ray %8.1f  wavecost %10.0f  slowest-lane path: p99 %6.0f p99.9 %6.0f max %6.0f\n", name, s.rays,
            s.hits / std::max(1.0, s.rays), s.nodes / std::max(1.0, s.rays), s.tris / std::max(1.0, s.rays), s.wnodes / std::max(1.0, s.waves), s.wtris / std::max(1.0, s.waves),
-           (s.nodes * 230.0 + s.tris * 80.0) / std::max(1.0, s.rays), (s.wnodes * 230.0 + s.wtris * 80.0) / std::max(1.0, s.waves));
+           (s.nodes * 230.0 + s.tris * 80.0) / std::max(1.0, s.rays), (s.wnodes * 230.0 + s.wtris * 80.0) / std::max(1.0, s.waves), p99, p999, s.worst);
 }
 
 int main(int argc, char** argv)
@@ -461,6 +466,7 @@ int main(int argc, char** argv)
             {
                 pp.first->rays += pp.second->rays; pp.first->nodes += pp.second->nodes; pp.first->tris += pp.second->tris; pp.first->wnodes += pp.second->wnodes;
                 pp.first->wtris += pp.second->wtris; pp.first->waves += pp.second->waves; pp.first->hits += pp.second->hits;
+                pp.first->worst = std::max(pp.first->worst, pp.second->worst); pp.first->wc.insert(pp.first->wc.end(), pp.second->wc.begin(), pp.second->wc.end());
             }
         }
     }
@@ -511,7 +517,8 @@ int main(int argc, char** argv)
                 }
             }
 #pragma omp critical
-            { g2.rays += lg2.rays; g2.nodes += lg2.nodes; g2.tris += lg2.tris; g2.wnodes += lg2.wnodes; g2.wtris += lg2.wtris; g2.waves += lg2.waves; g2.hits += lg2.hits;
+            { g2.wc.insert(g2.wc.end(), lg2.wc.begin(), lg2.wc.end()); gi.wc.insert(gi.wc.end(), l.wc.begin(), l.wc.end()); g2.worst = std::max(g2.worst, lg2.worst); gi.worst = std::max(gi.worst, l.worst);
+              g2.rays += lg2.rays; g2.nodes += lg2.nodes; g2.tris += lg2.tris; g2.wnodes += lg2.wnodes; g2.wtris += lg2.wtris; g2.waves += lg2.waves; g2.hits += lg2.hits;
               gi.rays += l.rays; gi.nodes += l.nodes; gi.tris += l.tris; gi.wnodes += l.wnodes; gi.wtris += l.wtris; gi.waves += l.waves; gi.hits += l.hits; }
         }
     }
