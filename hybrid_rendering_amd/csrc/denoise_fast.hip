@@ -36,7 +36,13 @@ struct ReprojOut { float col[3]; float mom[2]; float length; };
 // Two phases so that a kernel can put independent work (mask popcounts, LDS passes) between them:
 //   issue()    history coordinates + all 21 loads of the 2x2 bilinear footprint and the history-length texel — nothing is waited for;
 //   resolve()  validity tests, weighting, normalisation (+ the rare 3x3 fallback with its own loads).
-template <int HIST_BPP, bool MOMENTS, bool REFL>
+// GEO: where the previous frame's geometry comes from.  false: the caller's previous G-buffer — oct normal from GB2 (.x word of an
+// 8-byte texel), mesh id from GB3 (.y word), i.e. two images of which half of every cache line is used.  true: the pass's own
+// 8-byte geometry record {oct normal, mesh id | linear z} that its temporal kernel wrote LAST frame (it writes one anyway, for the
+// a-trous taps; the two halves of the buffer alternate), and — with MOMENTS — the history length comes out of the 8-byte moments texel of
+// the nearest tap, which is always one of the four bilinear taps: 4 images, 16 loads, every line fully used, against 5 images and 21
+// loads.  Same values (the record holds copies of the G-buffer words), so the results are bit-identical.
+template <int HIST_BPP, bool MOMENTS, bool REFL, bool GEO = false>
 struct Reproj
 {
     static constexpr int NC = HIST_BPP == 8 ? 3 : 1;
@@ -47,6 +53,7 @@ struct Reproj
     const void* __restrict__  hist;
     const void* __restrict__  hist_moments;
     const void* __restrict__  hist_len;
+    const void* __restrict__  geo;          // GEO: previous frame's {oct normal, mesh id | linear z} records
     HistGeom   g;
     f3         cur_pos, cur_n;
     float      cur_id, hfx, hfy;
@@ -54,6 +61,7 @@ struct Reproj
     bool       inb, lok, tok[4], apron_miss;   // apron_miss: the footprint touched an image row that is not resident (row bands)
     fm::Unproj hb;
     uint32_t   g2x[4], g3y[4], mm[4], hx[4], hy[4], lraw;
+    uint32_t   mlen[4];
     float      td[4];
 
     // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel; branch-free
@@ -130,13 +138,32 @@ struct Reproj
 #pragma unroll
         for (int s = 0; s < 4; s++)
         {
-            g2x[s] = fm::ld<uint32_t>(pgb2, off[s] * 8u);
-            g3y[s] = fm::ld<uint32_t>(pgb3, off[s] * 8u + 4u);
+            if constexpr (GEO)
+            {
+                const uint2 q = fm::ld<uint2>(geo, off[s] * 8u);
+                g2x[s] = q.x; g3y[s] = q.y;
+            }
+            else
+            {
+                g2x[s] = fm::ld<uint32_t>(pgb2, off[s] * 8u);
+                g3y[s] = fm::ld<uint32_t>(pgb3, off[s] * 8u + 4u);
+            }
             td[s]  = fm::ld<float>(pdepth, off[s] * 4u);
             hist_load(off[s], hx[s], hy[s]);
-            mm[s] = MOMENTS ? fm::ld<uint32_t>(hist_moments, off[s] * 8u) : 0u;
+            if constexpr (MOMENTS && GEO)
+            {
+                const uint2 m = fm::ld<uint2>(hist_moments, off[s] * 8u);
+                mm[s] = m.x; mlen[s] = m.y;
+            }
+            else mm[s] = MOMENTS ? fm::ld<uint32_t>(hist_moments, off[s] * 8u) : 0u;
         }
-        if (MOMENTS) lraw = fm::ld<uint32_t>(hist_moments, loff * 8u + 4u);
+        if constexpr (MOMENTS && GEO)
+        {
+            // the nearest history texel (hcx, hcy) is one of the four taps: bx <= hcx <= bx + 1 (truncation on both sides)
+            const int sel = (hcx - bx) + 2 * (hcy - by);
+            lraw = sel == 0 ? mlen[0] : (sel == 1 ? mlen[1] : (sel == 2 ? mlen[2] : mlen[3]));
+        }
+        else if (MOMENTS) lraw = fm::ld<uint32_t>(hist_moments, loff * 8u + 4u);
         else lraw = fm::ld<uint16_t>(hist_len, loff * 2u);
     }
 
@@ -183,7 +210,9 @@ struct Reproj
             {
                 bool           ok;
                 const uint32_t qo = tap_offset(hcx + k % 3 - 1, hcy + k / 3 - 1, ok);
-                const uint32_t q2 = fm::ld<uint32_t>(pgb2, qo * 8u), q3 = fm::ld<uint32_t>(pgb3, qo * 8u + 4u);
+                uint32_t q2, q3;
+                if constexpr (GEO) { const uint2 q = fm::ld<uint2>(geo, qo * 8u); q2 = q.x; q3 = q.y; }
+                else { q2 = fm::ld<uint32_t>(pgb2, qo * 8u); q3 = fm::ld<uint32_t>(pgb3, qo * 8u + 4u); }
                 const float    qd = fm::ld<float>(pdepth, qo * 4u);
                 uint32_t       qx, qy;
                 hist_load(qo, qx, qy);
@@ -224,6 +253,7 @@ struct Reproj
                           // spill: 48-50 us at 1080p, 208 at 4K; 7 (72 VGPRs + 24 B of scratch) 58.7 / 252.8; 8 (64 VGPRs, more scratch) 81.4 / 362 — spills
                           // cost far more than waves buy
 #endif
+template <bool GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
     const uint2 BLK = block_xy<0>();
@@ -248,8 +278,9 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_tempo
     const uint2 cg2 = edge ? make_uint2(0u, 0u) : cg2_raw, cg3 = edge ? make_uint2(0u, 0u) : cg3_raw;
     const f3    cn  = fm::oct_unit(cg2.x);
     const bool  live = (in_image || edge) && d != 1.0f;
-    Reproj<4, true, false> rp;
+    Reproj<4, true, false, GEO> rp;
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
+    rp.geo = a.geo_hist;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     const bool reproj = live && !a.debug_skip_reproject;
     if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
@@ -288,7 +319,7 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_tempo
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + pix * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hlen, 0.0f));
         // for the a-trous iterations: the centre's octahedral normal and linear depth, 8 bytes (copies of the G-buffer's fp16 values —
         // the exact mode keeps 16 bytes of decoded fp32; decoding per tap is cheaper than the extra 8 B x 5 passes of HBM traffic)
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.nd) + pix * 8u)         = make_uint2(cg2.x, cg3.y >> 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.nd) + pix * 8u)         = make_uint2(cg2.x, cg3.y);
         *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + pix * 4u)     = fm::pack2(out_v, out_var);
     }
     const unsigned long long any = __ballot(flag);
@@ -333,8 +364,8 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
     const int  reach = step * R > 1 ? step * R : 1;
     const bool interior = fx0 - reach >= 0 && fx0 + 31 + reach < a.w && fy0 - reach >= (a.y0 > 0 ? a.y0 : 0) && fy0 + 7 + reach < (a.y1 < a.h ? a.y1 : a.h);
     const uint32_t c   = fm::ld<uint32_t>(a.in.p, o * 4u);
-    const uint2    cnd = fm::ld<uint2>(a.nd, o * 8u);   // oct normal (fp16 x 2), linear z (fp16)
-    const float    cz  = fm::lo(cnd.y);
+    const uint2    cnd = fm::ld<uint2>(a.nd, o * 8u);   // oct normal (fp16 x 2), mesh id | linear z (fp16 x 2)
+    const float    cz  = fm::hi(cnd.y);
     float var = 0.0f;
     // compute_variance_center (:65-88): 3x3 gaussian of the variance channel, unit taps
     if (interior)
@@ -407,7 +438,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                 const int   k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                 const float kk = (xx == 0 ? 1.0f : 2.0f / 3.0f) * (yy == 0 ? 1.0f : 2.0f / 3.0f);
                 const float sv = fm::lo(t_in[t]);
-                float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::lo(t_nd[t].y), cn, fm::oct_unit(t_nd[t].x), cv, sv), kk);
+                float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::hi(t_nd[t].y), cn, fm::oct_unit(t_nd[t].x), cv, sv), kk);
                 if (!t_ok[t]) wv = 0.0f;
                 sum_w += wv;
                 sum_v += wv * sv;
@@ -429,7 +460,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous(AtrousArgs a)
                     const uint32_t s  = fm::ld<uint32_t>(a.in.p, so * 4u);
                     const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
                     const float sv = fm::lo(s);
-                    const float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::lo(nd.y), cn, fm::oct_unit(nd.x), cv, sv), kx * ky);
+                    const float wv = fm::mul_rn(edge_weight_fast(ek, cz, fm::hi(nd.y), cn, fm::oct_unit(nd.x), cv, sv), kx * ky);
                     sum_w += wv;
                     sum_v += wv * sv;
                     sum_var += (wv * wv) * fm::hi(s);
@@ -484,7 +515,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
             const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
             const f3       n  = fm::oct_unit(nd.x);
             s_in[i] = res ? v : 0u;
-            s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::lo(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::hi(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
     }
@@ -593,7 +624,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
         const uint2    nd = fm::ld<uint2>(a.nd, so * 8u);
         const f3       n  = fm::oct_unit(nd.x);
         s_in[i] = res ? v : 0u;
-        s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::lo(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_nz[i] = res ? make_float4(n.x, n.y, n.z, fm::hi(nd.y)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
     EdgeK ek;
@@ -1481,7 +1512,8 @@ namespace hr {
 
 void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st)
 {
-    hipLaunchKernelGGL(kf_shadows_temporal, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
+    if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<true>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(kf_shadows_temporal<false>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)

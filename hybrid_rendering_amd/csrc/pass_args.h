@@ -20,6 +20,8 @@ struct TemporalArgs
     uint2*          out_moments;    // RGBA16F
     uint8_t*        tile_class;
     float4*         nd;             // decoded normal.xyz + linear z (GB3.w), written for the a-trous iterations
+    const void*     geo_hist;       // tolerance mode: LAST frame's `nd` records {oct normal, mesh id | linear z} when they stand for the
+                                    // caller's previous G-buffer (hr_shadows_temporal decides), else nullptr -> pgb2 / pgb3 are read
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha, moments_alpha;

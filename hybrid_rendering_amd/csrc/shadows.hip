@@ -549,6 +549,17 @@ struct hr_shadows
     bool          dbg_skip_traversal = false, dbg_skip_reproject = false, dbg_timeline_stats = false;
     std::string   dbg_timeline;             // HR_DEBUG_TIMELINE=<file>
     uint64_t      last_wave_max_steps = 0; // sum over waves of the slowest lane's (node + triangle) steps
+    // Tolerance mode: the temporal kernel writes an 8-byte geometry record per pixel {oct normal, mesh id | linear z} — copies of the
+    // current G-buffer's words — for the a-trous taps; the two halves of `nd` alternate, so last frame's records are still there when
+    // the next frame reprojects.  They stand for the caller's PREVIOUS G-buffer exactly when the caller hands back, as in->prev, the
+    // images it passed as in->cur in the previous call (the reference's ping-pong, g_buffer.cpp:208-211): then the reprojection reads
+    // them (4 images, 16 gathers per pixel, full cache lines) instead of prev GB2 / GB3 (5 images, 21 gathers, half of every line).
+    bool          geo_history = true;       // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
+    bool          geo_valid = false;        // `nd` half geo_parity holds the records of the last frame this pass rendered
+    int           geo_parity = 0;
+    const void*   geo_gb2 = nullptr;        // in->cur.gb2 / gb3 of that frame
+    const void*   geo_gb3 = nullptr;
+    void*         nd_cur = nullptr;         // the side image of the frame in flight (a-trous stages)
 };
 
 extern "C" {
@@ -570,6 +581,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &p->dbg_only_tx, &p->dbg_only_ty);
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
+    if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
     p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
     p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
@@ -633,6 +645,7 @@ hr_status hr_shadows_reset_history(hr_shadows* p)
 {
     HR_CHECK_ARG(p);
     p->first_frame = true;
+    p->geo_valid = false;
     return HR_OK;
 }
 
@@ -811,6 +824,21 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.out = (uint32_t*)p->temporal_out.p; a.out_moments = (uint2*)p->moments[in->ping_pong ? 1 : 0].p;
     a.tile_class = (uint8_t*)p->tile_class.p;
     a.nd = (float4*)p->nd.p;
+    a.geo_hist = nullptr;
+    if (!prm->exact)
+    {
+        // the records of the last frame stand for in->prev when the caller hands back what it passed as in->cur then; a band keeps to
+        // the caller's images (its records cover the rows it computed, not the history apron its neighbours own)
+        const size_t half = (size_t)p->w * p->h * 8;
+        const bool   whole = p->y0 == 0 && p->y1 == p->h;
+        if (p->geo_history && p->geo_valid && whole && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3)
+            a.geo_hist = (const char*)p->nd.p + (size_t)p->geo_parity * half;
+        p->geo_parity ^= 1;
+        a.nd = (float4*)((char*)p->nd.p + (size_t)p->geo_parity * half);
+        p->geo_valid = true; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+    }
+    else p->geo_valid = false;   // the parity mode's float4 layout covers both halves
+    p->nd_cur = a.nd;
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha;
@@ -842,7 +870,7 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
     AtrousArgs a;
     const int w = p->w, y0 = p->y0, y1 = p->y1;
     a.in  = ImgRG16F { (const uint32_t*)(i == 0 ? p->temporal_out.p : p->atrous[read_idx].p), w, y0, y1 };
-    a.nd = (const float4*)p->nd.p;
+    a.nd = (const float4*)(p->nd_cur ? p->nd_cur : p->nd.p);
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out  = (uint32_t*)p->atrous[write_idx].p;
     a.out2 = (prm->feedback_iteration == i) ? (uint32_t*)p->prev_image.p : nullptr; // vkCmdCopyImage :1177-1207
@@ -888,7 +916,7 @@ static hr_status shadows_atrous01(hr_shadows* p, const hr_frame_inputs* in, cons
     AtrousArgs a;
     const int w = p->w, y0 = p->y0, y1 = p->y1;
     a.in  = ImgRG16F { (const uint32_t*)p->temporal_out.p, w, y0, y1 };
-    a.nd = (const float4*)p->nd.p;
+    a.nd = (const float4*)(p->nd_cur ? p->nd_cur : p->nd.p);
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out  = (uint32_t*)p->atrous[0].p;   // iteration 1 writes atrous[0] (ping-pong of a_trous_filter(), :1101-1107)
     a.out2 = (prm->feedback_iteration == 1) ? (uint32_t*)p->prev_image.p : nullptr;
