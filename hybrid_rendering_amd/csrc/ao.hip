@@ -357,12 +357,22 @@ struct hr_ao
     hr_ctx* ctx = nullptr;
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, band_y0 = 0, band_y1 = 0;
     int     mw = 0, mh = 0, tiles_x = 0, tiles_y = 0, max_spp = 4;
-    DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters, ray_slots;
+    DevBuf  mask, color[2], length[2], blur[2], upsample, tile_class, counters, ray_slots, geo[2];
     bool    first_frame = true, last_denoise = true, want_stats = false;
     bool    fuse = true;   // tolerance mode: both blur passes in one launch (developer A/B switch HR_FUSE=0, read once at create)
     int     last_pp = 0;
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
+    // Tolerance mode: the temporal kernel also writes an 8-byte record per pixel {oct normal, mesh id | AO} — copies of the current
+    // G-buffer's words and of its own output — into geo[geo_parity].  When the caller hands back, as in->prev, the images it passed as
+    // in->cur in the previous call (the reference's ping-pong, g_buffer.cpp:208-211) and alternates ping_pong, those records ARE the
+    // previous G-buffer + the AO history, and the next frame reprojects from them: 2 images + the history length, 9 gathers per pixel
+    // instead of 5 images, 17 gathers with half of every G-buffer line unused.
+    bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
+    bool          geo_valid = false;
+    int           geo_parity = 0, geo_pp = -1;
+    const void*   geo_gb2 = nullptr;
+    const void*   geo_gb3 = nullptr;
 };
 
 extern "C" {
@@ -379,6 +389,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     hr_ao* p = new hr_ao();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
+    if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
@@ -399,6 +410,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     A(tile_class, (size_t)p->tiles_x * p->tiles_y)
     A(counters, 64)
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
+    if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
@@ -415,7 +427,7 @@ hr_status hr_ao_destroy(hr_ao* p)
     delete p;
     return HR_OK;
 }
-hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; return HR_OK; }
 hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
 {
     HR_CHECK_ARG(p && exceeded);
@@ -518,6 +530,15 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha;
+    a.geo_hist = nullptr; a.geo_out = nullptr;
+    if (!prm->exact && p->geo[0].p)
+    {
+        if (p->geo_valid && !p->first_frame && pp != p->geo_pp && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3) a.geo_hist = p->geo[p->geo_parity].p;
+        p->geo_parity ^= 1;
+        a.geo_out = p->geo[p->geo_parity].p;
+        p->geo_valid = true; p->geo_pp = pp; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+    }
+    else p->geo_valid = false;
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);

@@ -41,8 +41,10 @@ struct ReprojOut { float col[3]; float mom[2]; float length; };
 // 8-byte geometry record {oct normal, mesh id | linear z} that its temporal kernel wrote LAST frame (it writes one anyway, for the
 // a-trous taps; the two halves of the buffer alternate), and — with MOMENTS — the history length comes out of the 8-byte moments texel of
 // the nearest tap, which is always one of the four bilinear taps: 4 images, 16 loads, every line fully used, against 5 images and 21
-// loads.  Same values (the record holds copies of the G-buffer words), so the results are bit-identical.
-template <int HIST_BPP, bool MOMENTS, bool REFL, bool GEO = false>
+// loads.  Same values (the record holds copies of the G-buffer words), so the results are bit-identical.  GEO = 1: as described
+// (shadows, reflections).  GEO = 2 (AO, whose history value is a single fp16): the record is {oct normal, mesh id | AO history}, i.e. the
+// colour history rides in the record too — 2 images + the history length, 9 loads against 17.
+template <int HIST_BPP, bool MOMENTS, bool REFL, int GEO = 0>
 struct Reproj
 {
     static constexpr int NC = HIST_BPP == 8 ? 3 : 1;
@@ -138,7 +140,7 @@ struct Reproj
 #pragma unroll
         for (int s = 0; s < 4; s++)
         {
-            if constexpr (GEO)
+            if constexpr (GEO != 0)
             {
                 const uint2 q = fm::ld<uint2>(geo, off[s] * 8u);
                 g2x[s] = q.x; g3y[s] = q.y;
@@ -149,15 +151,16 @@ struct Reproj
                 g3y[s] = fm::ld<uint32_t>(pgb3, off[s] * 8u + 4u);
             }
             td[s]  = fm::ld<float>(pdepth, off[s] * 4u);
-            hist_load(off[s], hx[s], hy[s]);
-            if constexpr (MOMENTS && GEO)
+            if constexpr (GEO == 2) { hx[s] = g3y[s] >> 16; hy[s] = 0u; }
+            else hist_load(off[s], hx[s], hy[s]);
+            if constexpr (MOMENTS && GEO != 0)
             {
                 const uint2 m = fm::ld<uint2>(hist_moments, off[s] * 8u);
                 mm[s] = m.x; mlen[s] = m.y;
             }
             else mm[s] = MOMENTS ? fm::ld<uint32_t>(hist_moments, off[s] * 8u) : 0u;
         }
-        if constexpr (MOMENTS && GEO)
+        if constexpr (MOMENTS && GEO != 0)
         {
             // the nearest history texel (hcx, hcy) is one of the four taps: bx <= hcx <= bx + 1 (truncation on both sides)
             const int sel = (hcx - bx) + 2 * (hcy - by);
@@ -211,11 +214,12 @@ struct Reproj
                 bool           ok;
                 const uint32_t qo = tap_offset(hcx + k % 3 - 1, hcy + k / 3 - 1, ok);
                 uint32_t q2, q3;
-                if constexpr (GEO) { const uint2 q = fm::ld<uint2>(geo, qo * 8u); q2 = q.x; q3 = q.y; }
+                if constexpr (GEO != 0) { const uint2 q = fm::ld<uint2>(geo, qo * 8u); q2 = q.x; q3 = q.y; }
                 else { q2 = fm::ld<uint32_t>(pgb2, qo * 8u); q3 = fm::ld<uint32_t>(pgb3, qo * 8u + 4u); }
                 const float    qd = fm::ld<float>(pdepth, qo * 4u);
                 uint32_t       qx, qy;
-                hist_load(qo, qx, qy);
+                if constexpr (GEO == 2) { qx = q3 >> 16; qy = 0u; }
+                else hist_load(qo, qx, qy);
                 const uint32_t qm = MOMENTS ? fm::ld<uint32_t>(hist_moments, qo * 8u) : 0u;
                 if (tap_valid(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f))
                 {
@@ -253,7 +257,7 @@ struct Reproj
                           // spill: 48-50 us at 1080p, 208 at 4K; 7 (72 VGPRs + 24 B of scratch) 58.7 / 252.8; 8 (64 VGPRs, more scratch) 81.4 / 362 — spills
                           // cost far more than waves buy
 #endif
-template <bool GEO>
+template <int GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
     const uint2 BLK = block_xy<0>();
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
 
 // ------------------------------------------------------------------------------------------------------------------------
 // ao_denoise_reprojection.comp:191-260, tolerance mode; spp = 1..4 sample planes (BASELINE configs[2]: 4)
-template <bool MULTI>
+template <bool MULTI, int GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArgs a)
 {
     const uint2 BLK = block_xy<0>();
@@ -723,8 +727,9 @@ __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArg
     const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_raw;
     const uint32_t cg3y = edge ? 0u : cg3y_raw;
     const bool     live = (in_image || edge) && d != 1.0f;
-    Reproj<2, false, false> rp;
+    Reproj<2, false, false, GEO> rp;
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = nullptr; rp.hist_len = a.hist_len.p;
+    rp.geo = a.geo_hist;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
     if (a.apron_flag && __ballot(live && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
@@ -754,6 +759,8 @@ __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArg
         {
             *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + pix * 2u)     = fm::half_bits(out);
             *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out_len) + pix * 2u) = fm::half_bits(hlen);
+            // next frame's reprojection record: this pixel's oct normal, mesh id and AO value (copies of what the images hold)
+            if (a.geo_out) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.geo_out) + pix * 8u) = make_uint2(cg2.x, (cg3y & 0xffffu) | ((uint32_t)fm::half_bits(out) << 16));
         }
         flag = out < 1.0f;
     }
@@ -968,6 +975,7 @@ __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 #define FR_ALIAS 0     // 1: the horizontal sums overwrite the colour tile (the sums are held in registers across a barrier): 27.6 -> 18.4 KB of
                        // LDS per workgroup, 5 -> 8 workgroups per CU if the registers allow (FR_EU)
 #endif
+template <int GEO>
 __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs a)
 {
     const uint2 BLK = block_xy<0>();
@@ -1056,8 +1064,9 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
 #if !FR_ALIAS
     const uint2 cq = s_col[ly + FR_R][lx + FR_R];
 #endif
-    Reproj<8, true, true> rp;
+    Reproj<8, true, true, GEO> rp;
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
+    rp.geo = a.geo_hist;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
     if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]), a.pvp, fm::hi(cq.y));
     if (a.apron_flag && live && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) atomicOr(a.apron_flag, 1u);   // rare
@@ -1114,6 +1123,9 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
         }
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + o * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hl, 0.0f));
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out) + o * 8u)         = make_uint2(fm::pack2(r0, r1), fm::pack2(r2, r3));
+        // geometry record {oct normal, mesh id | linear z}: copies of the G-buffer's words, for this frame's a-trous taps and the next
+        // frame's reprojection
+        if (a.geo_out) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.geo_out) + o * 8u) = make_uint2(cg2.x, cg3.y);
         if (d != 1.0f && roughness >= 0.05f) flag = (a.approximate_with_ddgi == 1) ? (roughness <= 0.75f) : true;
     }
     // tile classification per 8x8 tile (4 tiles per workgroup): :262-272
@@ -1188,7 +1200,9 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
                         const int      k = t < 4 ? t : t + 1, xx = k % 3 - 1, yy = k / 3 - 1;
                         const uint32_t so = (uint32_t)((y + yy * STEP) * a.w + (x + xx * STEP));
                         t_ok[t] = true;
-                        t_in[t] = fm::ld<uint2>(a.in.p, so * 8u); t_g2[t] = fm::ld<uint32_t>(a.gb2.p, so * 8u); t_g3[t] = fm::ld<uint32_t>(a.gb3.p, so * 8u + 4u);
+                        t_in[t] = fm::ld<uint2>(a.in.p, so * 8u);
+                        if (a.geo) { const uint2 q = fm::ld<uint2>(a.geo, so * 8u); t_g2[t] = q.x; t_g3[t] = q.y; }   // uniform branch
+                        else { t_g2[t] = fm::ld<uint32_t>(a.gb2.p, so * 8u); t_g3[t] = fm::ld<uint32_t>(a.gb3.p, so * 8u + 4u); }
                     }
                 }
                 else
@@ -1512,8 +1526,8 @@ namespace hr {
 
 void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st)
 {
-    if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<true>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
-    else hipLaunchKernelGGL(kf_shadows_temporal<false>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
+    if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<1>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(kf_shadows_temporal<0>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
@@ -1551,8 +1565,13 @@ bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, flo
 void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st)
 {
     const dim3 grid(cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
-    if (a.spp > 1) hipLaunchKernelGGL(kf_ao_temporal<true>, grid, dim3(64 * FT_WAVES), 0, st, a);
-    else hipLaunchKernelGGL(kf_ao_temporal<false>, grid, dim3(64 * FT_WAVES), 0, st, a);
+    if (a.geo_hist)
+    {
+        if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 2>), grid, dim3(64 * FT_WAVES), 0, st, a);
+        else hipLaunchKernelGGL((kf_ao_temporal<false, 2>), grid, dim3(64 * FT_WAVES), 0, st, a);
+    }
+    else if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 0>), grid, dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL((kf_ao_temporal<false, 0>), grid, dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
@@ -1574,7 +1593,8 @@ bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
 
 void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(kf_refl_temporal, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
+    if (a.geo_hist) hipLaunchKernelGGL(kf_refl_temporal<1>, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(kf_refl_temporal<0>, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
 }
 
 void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)

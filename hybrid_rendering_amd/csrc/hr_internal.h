@@ -49,6 +49,16 @@ struct DevBuf
             p = nullptr;
             return e == hipErrorOutOfMemory ? HR_ERR_OUT_OF_MEMORY : HR_ERR_HIP;
         }
+        // Every pass image starts as zeros: rows a pass never writes (a band's history apron before the first exchange, the other
+        // half of a ping-pong pair) then read the same on every run and in every object, instead of whatever the allocator recycled.
+        e = hipMemset(p, 0, n);
+        if (e != hipSuccess)
+        {
+            set_last_error(std::string("hipMemset(") + std::to_string(n) + ") failed: " + hipGetErrorString(e));
+            (void)hipFree(p);
+            p = nullptr;
+            return HR_ERR_HIP;
+        }
         bytes = n;
         return HR_OK;
     }

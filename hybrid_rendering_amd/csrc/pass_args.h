@@ -55,6 +55,9 @@ struct AOTemporalArgs
     uint16_t*       out;
     uint16_t*       out_len;
     uint8_t*        tile_class;
+    const void*     geo_hist;       // tolerance mode: last frame's records {oct normal, mesh id | AO} when they stand for the caller's
+                                    // previous G-buffer + the AO history (hr_ao_temporal decides), else nullptr
+    void*           geo_out;        // tolerance mode: this frame's records, or nullptr
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha;
@@ -83,6 +86,9 @@ struct ReflTemporalArgs
     uint2*      out;
     uint2*      out_moments;
     uint8_t*    tile_class;
+    const void* geo_hist;           // tolerance mode: last frame's records {oct normal, mesh id | linear z} when they stand for the caller's
+                                    // previous G-buffer (hr_reflections_temporal decides), else nullptr -> pgb2 / pgb3 are read
+    void*       geo_out;            // tolerance mode: this frame's records, or nullptr
     int         w, h, y0, y1, tiles_x;
     float       alpha, moments_alpha;
     int         approximate_with_ddgi, moving;
@@ -94,6 +100,8 @@ struct ReflAtrousArgs
 {
     ImgRGBA16F     in, gb2, gb3;
     ImgR32F        depth;
+    const void*    geo;     // tolerance mode: this frame's records {oct normal, mesh id | linear z} (the taps' two half-used G-buffer
+                            // gathers become one 8-byte load), or nullptr
     const uint8_t* tile_class;
     uint2*         out;
     uint2*         out2;

@@ -402,13 +402,23 @@ struct hr_reflections
 {
     hr_ctx* ctx = nullptr;
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, band_y0 = 0, band_y1 = 0, tiles_x = 0, tiles_y = 0;
-    DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots;
+    DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots, geo[2];
     bool    first_frame = true, last_denoise = true;
     int     read_idx = 0, last_pp = 0;
     bool    last_blur_as_input = false;   // which image the NEXT frame's temporal stage reads as colour history (hr_reflections_image 10)
     bool    fuse = true;   // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0, read once at create)
     StageProfiler prof;
     hipStream_t   last_stream = nullptr;
+    // Tolerance mode: the temporal kernel writes an 8-byte geometry record per pixel {oct normal, mesh id | linear z} (copies of the
+    // current G-buffer's words) into geo[geo_parity]: this frame's a-trous taps read it instead of two half-used G-buffer lines, and —
+    // when the caller hands back as in->prev the images it passed as in->cur (the reference's ping-pong, g_buffer.cpp:208-211) — so does
+    // the next frame's reprojection (see hr_shadows).
+    bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
+    bool          geo_valid = false;
+    int           geo_parity = 0;
+    const void*   geo_gb2 = nullptr;
+    const void*   geo_gb3 = nullptr;
+    const void*   geo_cur = nullptr;    // this frame's records (a-trous stages), nullptr in the parity mode / for bands
 };
 
 extern "C" {
@@ -428,6 +438,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     hr_reflections* p = new hr_reflections();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
+    if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
@@ -442,6 +453,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
 #define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
     A(trace, px * 8) A(color[0], px * 8) A(color[1], px * 8) A(moments[0], px * 8) A(moments[1], px * 8) A(prev_image, px * 8)
     A(atrous[0], px * 8) A(atrous[1], px * 8) A(upsample, (size_t)full_width * full_height * 8) A(tile_class, (size_t)p->tiles_x * p->tiles_y) A(counters, 64) A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
+    if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
 #undef A
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
@@ -457,7 +469,7 @@ hr_status hr_reflections_destroy(hr_reflections* p)
     delete p;
     return HR_OK;
 }
-hr_status hr_reflections_reset_history(hr_reflections* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_reflections_reset_history(hr_reflections* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; return HR_OK; }
 hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
 {
     HR_CHECK_ARG(p && exceeded);
@@ -553,6 +565,16 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     a.alpha = prm->alpha; a.moments_alpha = prm->moments_alpha; a.approximate_with_ddgi = prm->approximate_with_ddgi ? 1 : 0;
     const float* cd = prm->camera_delta;
     a.moving = (sqrtf((cd[0] * cd[0] + cd[1] * cd[1]) + cd[2] * cd[2]) > 0.0f) ? 1 : 0; // compute_max_accumulated_frame :162-168
+    a.geo_hist = nullptr; a.geo_out = nullptr; p->geo_cur = nullptr;
+    if (!prm->exact && p->geo[0].p)
+    {
+        if (p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3) a.geo_hist = p->geo[p->geo_parity].p;
+        p->geo_parity ^= 1;
+        a.geo_out = p->geo[p->geo_parity].p;
+        p->geo_cur = a.geo_out;
+        p->geo_valid = true; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+    }
+    else p->geo_valid = false;
     p->last_pp = pp;
     p->last_blur_as_input = prm->blur_as_input != 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
@@ -574,6 +596,7 @@ hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inpu
     auto img = [&](const void* ptr) { return ImgRGBA16F { (const uint2*)ptr, w, y0, y1 }; };
     a.in = img(i == 0 ? p->color[p->last_pp].p : p->atrous[read_idx].p);
     a.gb2 = img(in->cur.gb2); a.gb3 = img(in->cur.gb3); a.depth = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.geo = prm->exact ? nullptr : p->geo_cur;
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out = (uint2*)p->atrous[write_idx].p;
     a.out2 = (prm->feedback_iteration == i && prm->blur_as_input) ? (uint2*)p->prev_image.p : nullptr; // :1218
@@ -602,6 +625,7 @@ static hr_status reflections_atrous01(hr_reflections* p, const hr_frame_inputs* 
     auto img = [&](const void* ptr) { return ImgRGBA16F { (const uint2*)ptr, w, y0, y1 }; };
     a.in = img(p->color[p->last_pp].p);
     a.gb2 = img(in->cur.gb2); a.gb3 = img(in->cur.gb3); a.depth = ImgR32F { in->cur.depth, w, y0, y1 };
+    a.geo = nullptr;   // the fused kernel stages every texel's full GB3 word pair (roughness) anyway
     a.tile_class = (const uint8_t*)p->tile_class.p;
     a.out = (uint2*)p->atrous[0].p;
     a.out2 = (prm->feedback_iteration == 1 && prm->blur_as_input) ? (uint2*)p->prev_image.p : nullptr;
