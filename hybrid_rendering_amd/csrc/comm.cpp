@@ -244,6 +244,18 @@ static void plan(const int32_t* bounds, int rows, int upper, int& up_s0, int& up
     lo_s0 = bounds[upper + 1]; lo_s1 = bounds[upper + 1] + rows;   // the lower rank's first rows
 }
 
+// loopback: retire the collectives that are kTicketRing tickets old and have met their partners (their done-events have long fired;
+// a waiter that comes this late is ordered behind them by the newer entries of the same streams anyway, as with the RCCL ring)
+static void prune(hr_comm* c)
+{
+    for (auto it = c->open.begin(); it != c->open.end() && it->first + kTicketRing < c->next_ticket;)
+    {
+        if (it->second->open > 0) { ++it; continue; }
+        for (hipEvent_t e : it->second->done) (void)hipEventDestroy(e);
+        it = c->open.erase(it);
+    }
+}
+
 // RCCL: stamps the collective just enqueued on comm_stream with the next ticket
 static hr_status stamp(hr_comm* c, hr_comm_ticket* ticket)
 {
@@ -302,6 +314,7 @@ hr_status hr_comm_exchange_rows(hr_comm* c, const hr_comm_image* images, int32_t
     // ---- loopback
     std::lock_guard<std::mutex> lk(g_mu);
     Group& g = g_groups[c->name];
+    prune(c);   // a host that never waits (a pass dropped after its last exchange) must not grow `open` without bound
     auto mine_t = std::make_shared<TicketState>();
     const int64_t tno = c->next_ticket++;
     c->open[tno] = mine_t;
@@ -318,9 +331,15 @@ hr_status hr_comm_exchange_rows(hr_comm* c, const hr_comm_image* images, int32_t
         mine.images.assign(images, images + n_images);
         mine.s0 = me == 0 ? us0 : ls0; mine.s1 = me == 0 ? us1 : ls1;
         mine.ticket = mine_t;
-        CK_HIP(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(mine.ready, cs);
-        if (e != hipSuccess) { (void)hipEventDestroy(mine.ready); hr::set_last_error(std::string("hipEventRecord: ") + hipGetErrorString(e)); return HR_ERR_HIP; }
+        hipError_t e = hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming);
+        if (e == hipSuccess && (e = hipEventRecord(mine.ready, cs)) != hipSuccess) (void)hipEventDestroy(mine.ready);
+        if (e != hipSuccess)
+        {
+            // nothing of this side was queued; a first side that was stays posted (its partner will complete it) and keeps the ticket
+            if (mine_t->open == 0) c->open.erase(tno);
+            hr::set_last_error(std::string("hr_comm_exchange_rows (loopback post): ") + hipGetErrorString(e));
+            return HR_ERR_HIP;
+        }
         mine_t->open++;
         b.q[me].push_back(mine);
         while (!b.q[0].empty() && !b.q[1].empty())
@@ -392,16 +411,14 @@ hr_status hr_comm_wait_ticket(hr_comm* c, hr_comm_ticket ticket, void* compute_s
         hr::set_last_error("hr_comm_wait (loopback): a neighbour has not posted its side of an exchange / all-gather within 10 s");
         return HR_ERR_TIMEOUT;
     }
+    // One communicator serves several compute streams (the forked tiled frame waits for its shadows / AO / DDGI tickets on three
+    // of them): a wait only ORDERS `cs` behind the done-events of the collectives up to `ticket`, it does not consume them — another
+    // stream may still have to wait for an older ticket.  Entries are retired once they are kTicketRing tickets old (prune()).
     hr_status st = HR_OK;
-    for (auto it = c->open.begin(); it != c->open.end() && it->first <= ticket;)
-    {
+    for (auto it = c->open.begin(); it != c->open.end() && it->first <= ticket; ++it)
         for (hipEvent_t e : it->second->done)
-        {
             if (st == HR_OK && hipStreamWaitEvent(cs, e, 0) != hipSuccess) { hr::set_last_error("hr_comm_wait: hipStreamWaitEvent failed"); st = HR_ERR_HIP; }
-            (void)hipEventDestroy(e);
-        }
-        it = c->open.erase(it);
-    }
+    prune(c);
     return st;
 }
 
@@ -448,13 +465,16 @@ hr_status hr_comm_allgather_rows(hr_comm* c, hr_comm_image image, const int32_t*
     Group& g = g_groups[c->name];
     GatherPost mine;
     mine.image = image;
+    CK_HIP(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
+    {
+        const hipError_t e = hipEventRecord(mine.ready, cs);
+        if (e != hipSuccess) { (void)hipEventDestroy(mine.ready); hr::set_last_error(std::string("hr_comm_allgather_rows (loopback post): ") + hipGetErrorString(e)); return HR_ERR_HIP; }
+    }
     mine.ticket = std::make_shared<TicketState>();
     mine.ticket->open = 1;
     const int64_t tno = c->next_ticket++;
-    c->open[tno] = mine.ticket;
+    c->open[tno] = mine.ticket;   // registered only now that the post cannot fail any more
     if (ticket) *ticket = tno;
-    CK_HIP(hipEventCreateWithFlags(&mine.ready, hipEventDisableTiming));
-    CK_HIP(hipEventRecord(mine.ready, cs));
     g.gather[c->rank].push_back(mine);
     for (;;)
     {

@@ -57,3 +57,10 @@ def test_cpp_tiled_frame_example_runs(hr):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "every band row equals the un-tiled render" in out.stdout, out.stdout
     assert out.stdout.count("shadows ==  ao ==  ddgi ==  reflections ==") == 8, out.stdout
+    # no host synchronisation between frames, every frame forked over the side streams: the order between a frame's temporal kernels and
+    # the neighbour's apron rows of the frame before rests on the communicator's tickets alone (round-3 advisor: a wait for the newest
+    # ticket on one stream used to consume the older tickets the side streams still had to wait for)
+    out = subprocess.run([exe, "--free-running"], capture_output=True, text=True, env=env, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "every band row equals the un-tiled render" in out.stdout, out.stdout
+    assert out.stdout.count("(forked)") == 2 and out.stdout.count("shadows ==  ao ==  ddgi ==  reflections ==") == 2, out.stdout
