@@ -248,8 +248,18 @@ typedef struct
                                    (2-4x faster);
                                    every fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels, with relative L2 error <= 1e-3 over
                                    those texels and <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) additionally count
-                                   |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles (tests/test_gpu_tolerance.py);
-                                   visibility masks, ray counts and traversal are identical in both modes */
+                                   |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles.  HARD CAP per texel: outside the
+                                   neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle, except
+                                   for at most max(4, 1e-5 of the pixels) pixels per image which — like the texels next to a flipped tile — stay
+                                   within the value range of the channel: discrete decisions of the reference's own formulas (a reprojection
+                                   tap's validity, the DDGI Chebyshev branch over a flat depth texel) that one fp32 ulp flips
+                                   (tests/test_gpu_tolerance.py compare16; measured figures: profiles/r4_d);
+                                   visibility masks, ray counts and traversal are identical in both modes.
+                                   Tolerance mode also reprojects from the pass's own copy of the previous frame's geometry (normal, mesh id,
+                                   linear z — written by its temporal kernel) instead of in->prev.gb2 / gb3 whenever in->prev.gb2 / gb3 are the
+                                   pointers the previous call received as in->cur.gb2 / gb3 (the reference's G-buffer ping-pong,
+                                   g_buffer.cpp:208-211): same values, 5 fewer gathers per pixel.  A caller that rewrites those images between
+                                   the two calls must call hr_*_reset_history (or pass other pointers). */
 } hr_shadows_params;
 
 void      hr_shadows_default_params(hr_shadows_params* p);

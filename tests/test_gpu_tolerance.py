@@ -9,6 +9,17 @@ Stated tolerance (north_star "AO / reflections / GI within a sta
     to a texel index, a tile whose only non-trivial pixel sits on the classification threshold) or 0/0 situations of the reference's
     own arithmetic (a DDGI pixel all of whose probe weights were crushed to the 1e-6 floor); their energy is bounded by the second
     L2 figure, not ignored;
+  * HARD CAPS on every single texel (round 4: the 0.1 % above had no per-texel bound): outside the neighbourhoods of flipped tiles
+    <= 32 fp16 ulp OR |diff| <= 2^-10, except for a COUNTED handful — at most max(4, 1e-5 of the pixels) pixels per image
+    (OUTLIER_PIXELS) — which, like every texel inside a flipped-tile neighbourhood (a flipped tile is copied / cleared instead of
+    filtered), must stay within the value range of the reference image's channel.  The handful is what discrete decisions of the
+    REFERENCE's own formulas cost when an fp32 ulp flips them: (1) a reprojection tap's validity (plane distance > 5, (n.n')^2 > 0.1,
+    reprojection.glsl:11-67) or the truncation of a history coordinate onto a texel: the bilinear history is then re-weighted over other
+    texels (measured: 1 pixel of the half-resolution and 13 of the full-resolution 1080p reflections' temporal image, <= 80 ulp; none in
+    the shadows / AO images); (2) the DDGI probe-grid sample's `weight *= dist <= mean ? 1 : cheb^3` with cheb = var / (var + (dist -
+    mean)^2) (gi_common.glsl:262-282), which jumps from 1 to 0 where a probe's depth texels are flat (var == 0) and the pixel sits exactly
+    at the mean distance: a 1-ulp difference in `dist` moves one of the eight probe weights from 1 to the 1e-6 floor (measured: 3 pixels
+    of a 1080p frame, 9-16 of a 4K frame);
   * tile classes: equal on >= 99.5 % of the tiles;
   * DDGI atlases are produced by the exact kernels in both modes (bit-exact); the per-pixel probe-grid sample obeys the image rule.
 The runs are several frames long with a moving camera, so the bound holds through the temporal feedback loops."""
@@ -35,7 +46,15 @@ def _key(bits):
     return np.where(b & 0x8000, -mag, mag)
 
 
-def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None, variance_channels=(), variance_floor=VARIANCE_FLOOR):
+CAP_ULPS = int(os.environ.get("HR_TEST_CAP_ULPS", 32))     # hard per-texel cap (every texel outside flipped-tile neighbourhoods) ...
+CAP_ABS = float(os.environ.get("HR_TEST_CAP_ABS", 2.0 ** -10))   # ... OR this absolute difference
+REPORT = os.environ.get("HR_TEST_TOLERANCE_REPORT")          # print the achieved figures of every image
+OUTLIER_PIXELS = 1e-5   # share of the PIXELS of an image (at least 4) that may exceed the hard cap, bounded by the channel's value range (see above)
+DDGI_OUTLIERS = OUTLIER_PIXELS
+
+
+def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None, variance_channels=(), variance_floor=VARIANCE_FLOOR,
+              cap_ulps=None, cap_abs=None, outlier_pixels=OUTLIER_PIXELS):
     """got / ref: uint16 fp16 bit patterns, ALL channels of the image.  abs_floor: differences below it count as equal (intermediate
     images whose small values are differences of nearly equal numbers, e.g. variance = m2 - m1^2).  exclude: bool [H, W] of texels
     left out of the per-texel bound (neighbourhoods of tiles whose classification differs — a discrete decision; they stay in the L2
@@ -54,6 +73,37 @@ def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, ex
     if exclude is not None:
         ex = exclude if ok.ndim == 2 else exclude[..., None]
         ok = ok | ex
+    # hard caps: no texel may be arbitrarily wrong
+    cap_ulps = CAP_ULPS if cap_ulps is None else cap_ulps
+    cap_abs = max(CAP_ABS if cap_abs is None else cap_abs, abs_floor)
+    ulp_d, abs_d = np.abs(_key(got) - _key(ref)), np.abs(g - r)
+    capped = (ulp_d <= cap_ulps) | (abs_d <= cap_abs)
+    for c in variance_channels:
+        capped[..., c] |= abs_d[..., c] <= max(cap_abs, variance_floor)
+    exb = None if exclude is None else (exclude if ok.ndim == 2 else np.broadcast_to(exclude[..., None], ok.shape))
+    outside = capped if exb is None else (capped | exb)
+    if REPORT:
+        sel_o = np.ones(ok.shape, bool) if exb is None else ~exb
+        print(f"[tolerance] {what}: {ok.mean() * 100:.4f} % within {ulps} ulp, max {int(ulp_d[sel_o].max()) if sel_o.any() else 0} ulp / {abs_d[sel_o].max() if sel_o.any() else 0:.3e} abs outside flipped-tile "
+              f"neighbourhoods ({0 if exb is None else int(exb.sum())} texels inside), rel-L2 {rl2:.2e}", flush=True)
+    n_pixels = int(np.prod(ok.shape[:2]))
+    allowed = int(max(4, outlier_pixels * n_pixels)) if outlier_pixels > 0 else 0
+    beyond_px = (~outside).reshape(ok.shape[0], ok.shape[1], -1).any(axis=2)
+    if allowed and 0 < beyond_px.sum() <= allowed:
+        # the counted allowance: these pixels are bounded by the channel's value range instead
+        rngc = (r.max(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None) - r.min(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None)) + cap_abs
+        assert not (abs_d > rngc).any(), f"{what}: an outlier pixel differs by more than the channel's value range (max {abs_d.max():.3e})"
+        if REPORT:
+            print(f"[tolerance] {what}: {int(beyond_px.sum())} pixels beyond the hard cap, inside the allowance of {allowed}", flush=True)
+    elif not outside.all():
+        w = np.argwhere(~outside)
+        raise AssertionError(f"{what}: {len(w)} texels beyond the hard cap ({cap_ulps} fp16 ulp or {cap_abs:.2e}); worst {int(ulp_d[~outside].max())} ulp / {abs_d[~outside].max():.3e}; "
+                             f"first (y, x, ...): {w[:6].tolist()} got {g[tuple(w[:6].T)].tolist()} ref {r[tuple(w[:6].T)].tolist()}")
+    if exb is not None and exb.any():
+        # inside the neighbourhood of a flipped tile: bounded by the value range of the channel (a copied / cleared tile swaps values, it does not invent them)
+        rng = (r.max(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None) - r.min(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None)) + cap_abs
+        over = (abs_d > rng) & exb
+        assert not over.any(), f"{what}: {int(over.sum())} texels next to a flipped tile differ by more than the channel's value range (max {abs_d[exb].max():.3e})"
     f = ok.mean()
     bad = np.argwhere(~ok)
     where = f"; first offenders (y, x, ...): {bad[:6].tolist()} got {g[tuple(bad[:6].T)].tolist()} ref {r[tuple(bad[:6].T)].tolist()}" if len(bad) else ""
@@ -251,7 +301,7 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
         torch.cuda.synchronize()
         gi, gd = g_ddgi.current_read()
         assert np.array_equal(helpers.bits16(gi), irr) and np.array_equal(helpers.bits16(gd), dep), f"frame {f}: DDGI atlases are exact in both modes"
-        compare16(helpers.bits16(g_ddgi.output()), o_ddgi.stages["output"], f"frame {f} DDGI probe-grid sample")
+        compare16(helpers.bits16(g_ddgi.output()), o_ddgi.stages["output"], f"frame {f} DDGI probe-grid sample", outlier_pixels=DDGI_OUTLIERS)
         st = op.stages
         assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TRACE)), st["trace"]), f"frame {f}: reflection trace has one mode"
         assert gp.ray_count() == st["rays"]
