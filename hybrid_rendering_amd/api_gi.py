@@ -79,6 +79,12 @@ class DDGI(_Pass):
     def ray_trace(self, scene, inputs, env, stream=None):
         _check(lib().hr_ddgi_ray_trace(self.h, scene.h, C.byref(inputs), C.byref(env), C.byref(self.params), _stream_ptr(stream)), "hr_ddgi_ray_trace")
 
+    def trace_stats(self, scene, inputs, env, stream=None):
+        """(rays, BVH node steps, triangle tests) of the ray-trace stage from the instrumented kernel (probe rays + light / sky rays)."""
+        out = (C.c_uint64 * 3)()
+        _check(lib().hr_ddgi_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(env), C.byref(self.params), out, _stream_ptr(stream)), "hr_ddgi_trace_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def probe_update(self, stream=None):
         _check(lib().hr_ddgi_probe_update(self.h, _stream_ptr(stream)), "hr_ddgi_probe_update")
 
@@ -112,4 +118,4 @@ class DDGI(_Pass):
 
 api.ABI_SYMBOLS += ["hr_ddgi_default_params", "hr_ddgi_create", "hr_ddgi_render", "hr_ddgi_output", "hr_ddgi_current_read",
                     "hr_ddgi_restart_accumulation", "hr_ddgi_destroy", "hr_ddgi_ray_trace", "hr_ddgi_probe_update", "hr_ddgi_sample_probe_grid",
-                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count", "hr_ddgi_set_shard", "hr_ddgi_current_write"]
+                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count", "hr_ddgi_set_shard", "hr_ddgi_current_write", "hr_ddgi_trace_stats"]

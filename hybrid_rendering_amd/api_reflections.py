@@ -41,6 +41,13 @@ class RayTracedReflections(_Pass):
         _check(lib().hr_reflections_render(self.h, scene.h, C.byref(inputs), C.byref(env), ddgi.h, C.byref(self.params), _stream_ptr(stream)),
                "hr_reflections_render")
 
+    def trace_stats(self, scene, inputs, env, ddgi, stream=None):
+        """(rays, BVH node steps, triangle tests) of the ray-trace stage from the instrumented kernel (reflection rays + light rays)."""
+        out = (C.c_uint64 * 3)()
+        _check(lib().hr_reflections_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(env), ddgi.h, C.byref(self.params), out, _stream_ptr(stream)),
+               "hr_reflections_trace_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def ray_count(self) -> int:
         n = C.c_uint64(0)
         _check(lib().hr_reflections_ray_count(self.h, C.byref(n)), "hr_reflections_ray_count")
@@ -50,4 +57,4 @@ class RayTracedReflections(_Pass):
 api.ABI_SYMBOLS += ["hr_reflections_default_params", "hr_reflections_create", "hr_reflections_render", "hr_reflections_output",
                     "hr_reflections_reset_history", "hr_reflections_destroy", "hr_reflections_ray_trace", "hr_reflections_denoise", "hr_reflections_temporal",
                     "hr_reflections_atrous_iteration", "hr_reflections_upsample", "hr_reflections_image", "hr_reflections_history_apron_exceeded", "hr_reflections_set_profiling",
-                    "hr_reflections_get_stage_times", "hr_reflections_ray_count"]
+                    "hr_reflections_get_stage_times", "hr_reflections_ray_count", "hr_reflections_trace_stats"]

@@ -42,6 +42,7 @@ struct DDGITraceArgs
     float         gi_intensity;
     int           n_probes;      // one past the last probe traced
     int           probe_begin;   // first probe traced (probe shard: z-slabs of the grid)
+    unsigned long long* stats;   // instrumented build only (k_ddgi_trace<true>): [0] node steps, [1] triangle tests, [2] rays
 };
 
 // one thread per (probe, ray); a wave covers 64 consecutive rays of one probe (same origin: the rays share the nodes around
@@ -69,6 +70,10 @@ extern "C" int hr_debug_divergence_ddgi(uint64_t* out, int reset)
 #ifndef DDGI_TRACE_EU
 #define DDGI_TRACE_EU 6   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 325 / 318 / 338 us
 #endif
+// STATS: the instrumented build behind hr_ddgi_trace_stats — per-lane closest-hit walk (same hits as the cooperative one), every node
+// step and triangle test of the probe rays and of the hit shader's light / sky rays counted (the BVH term of the
+// algorithmic bytes).  The product launches <false>.
+template <bool STATS>
 __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_trace(DDGITraceArgs a)
 {
     __shared__ uint32_t s_stack[DDGI_TRACE_WAVES][HR_STACK_ENTRIES * 64];
@@ -91,12 +96,19 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
         dir = normalize3(mk3((M[0] * f.x + M[3] * f.y) + M[6] * f.z, (M[1] * f.x + M[4] * f.y) + M[7] * f.z, (M[2] * f.x + M[5] * f.y) + M[8] * f.z));
         rays++;
     }
+    uint32_t st_n = 0, st_t = 0;
 #if DDGI_COOP
-    const HitRec h = trace_coop<false>(valid, a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+    HitRec h;
+    if (!STATS) h = trace_coop<false>(valid, a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+    else
+    {
+        h.prim = -1;
+        if (valid) h = trace_closest<STATS>(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane, nullptr, &st_n, &st_t);
+    }
 #else
     HitRec h;
     h.prim = -1;
-    if (valid) h = trace_closest(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp));
+    if (valid) h = trace_closest<STATS>(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp), &st_n, &st_t);
 #endif
     if (valid)
     {
@@ -130,7 +142,8 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
             f3 Lo = o1 ? mk3(0.0f, 0.0f, 0.0f) : ds.P1;
             if (!o2) Lo = add3(Lo, ds.P2);
 #else
-            f3 Lo = direct_lighting(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
+            f3 Lo = direct_lighting<STATS>(tc, a.light, Wo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), true, r2x, r2y, a.sky, rays);
+            if (STATS) { st_n += tc.nn; st_t += tc.nt; }
 #endif
 #ifndef HR_ABL_DDGI_NO_IRRADIANCE
             if (a.infinite_bounces == 1)
@@ -157,6 +170,11 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
     HR_DIV(div_flush(dvp, g_div_ddgi); div_flush(dvs, g_div_ddgi + 8);)
     for (int o = 32; o > 0; o >>= 1) rays += __shfl_down(rays, o);
     if (lane == 0) a.ray_slots[blockIdx.x * DDGI_TRACE_WAVES + wave] = rays;
+    if (STATS)
+    {
+        for (int o = 32; o > 0; o >>= 1) { st_n += __shfl_down(st_n, o); st_t += __shfl_down(st_t, o); }
+        if (lane == 0) { atomicAdd(a.stats + 0, (unsigned long long)st_n); atomicAdd(a.stats + 1, (unsigned long long)st_t); atomicAdd(a.stats + 2, (unsigned long long)rays); }
+    }
 }
 
 // ---- wavefront form of ray_trace() (trace_queue.h): gen -> closest-hit queue -> shade + secondary queue -> any-hit queue -> combine
@@ -437,6 +455,7 @@ struct hr_ddgi
     DDGIU   d;
     int     n_probes = 0;
     DevBuf  radiance, dirdist, irr[2], dep[2], sample, counters, ray_slots;
+    bool    want_stats = false;   // hr_ddgi_trace_stats: launch the instrumented trace kernel
     DevBuf  wf_rays, wf_hits, wf_sec_rays, wf_occluded, wf_part;   // wavefront ray_trace (trace_queue.h); counters + 32: queue words
     bool    wavefront = false;  // developer A/B (HR_DDGI_WAVEFRONT=1): measured slower than the single kernel, DESIGN.md §4
     bool    first_frame = true, ping_pong = false;
@@ -554,7 +573,18 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     a.gi_intensity = prm->infinite_bounce_intensity;
     const int slab = p->d.probe_counts[0] * p->d.probe_counts[1];
     a.probe_begin = p->z0 * slab; a.n_probes = p->z1 * slab;
+    a.stats = nullptr;
     const long long n = (long long)(a.n_probes - a.probe_begin) * p->d.rays_per_probe;
+    if (p->want_stats)
+    {
+        // instrumented build of the same kernel (hr_ddgi_trace_stats): counters + 8 .. 32
+        HR_HIP(hipMemsetAsync((char*)p->counters.p + 8, 0, 24, st));
+        a.stats = (unsigned long long*)((char*)p->counters.p + 8);
+        const int tb = 64 * DDGI_TRACE_WAVES;
+        hipLaunchKernelGGL(k_ddgi_trace<true>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
     if (p->wavefront)
     {
@@ -579,10 +609,26 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
     else
     {
         const int tb = 64 * DDGI_TRACE_WAVES;
-        hipLaunchKernelGGL(k_ddgi_trace, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
+        hipLaunchKernelGGL(k_ddgi_trace<false>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);
     }
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+// Instrumented ray trace (same rays, same results; the radiance / direction images are rewritten with the same values): out3 = rays
+// traced (probe rays + light / sky rays of the hit points), BVH node steps, triangle tests — the BVH term of SURVEY §8d's algorithmic bytes.
+hr_status hr_ddgi_trace_stats(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* prm, uint64_t* out3, void* stream)
+{
+    HR_CHECK_ARG(p && out3);
+    p->want_stats = true;
+    const hr_status s = hr_ddgi_ray_trace(p, scene, in, env, prm, stream);
+    p->want_stats = false;
+    if (s != HR_OK) return s;
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t host[3];
+    HR_HIP(hipMemcpy(host, (char*)p->counters.p + 8, 24, hipMemcpyDeviceToHost));
+    out3[0] = host[2]; out3[1] = host[0]; out3[2] = host[1];
     return HR_OK;
 }
 

@@ -82,6 +82,7 @@ struct ReflTraceArgs
     uint32_t       num_frames;
     int            sample_gi, approximate_with_ddgi;
     float          gi_intensity, rough_ddgi_intensity, ibl_intensity;
+    unsigned long long* stats;   // instrumented build only (k_refl_trace<true>): [0] node steps, [1] triangle tests, [2] rays
 };
 
 #ifdef HR_TRACE_DIVERGENCE
@@ -102,6 +103,8 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 #ifndef REFL_TRACE_EU
 #define REFL_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 216 / 226 / 235 us
 #endif
+// STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false>.
+template <bool STATS>
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)
 {
     __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
@@ -150,12 +153,19 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
         }
     }
     if (trace) rays++;
+    uint32_t st_n = 0, st_t = 0;
 #if REFL_COOP
-    const HitRec hit = trace_coop<false>(trace, a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+    HitRec hit;
+    if (!STATS) hit = trace_coop<false>(trace, a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], s_coop[wave], lane, 0u HR_DIV(, &dvp));
+    else
+    {
+        hit.prim = -1;
+        if (trace) hit = trace_closest<STATS>(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane, nullptr, &st_n, &st_t);
+    }
 #else
     HitRec hit;
     hit.prim = -1;
-    if (trace) hit = trace_closest(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp));
+    if (trace) hit = trace_closest<STATS>(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp), &st_n, &st_t);
 #endif
     if (trace)
     {
@@ -169,7 +179,8 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
             HR_DIV(tc.dv = &dvs;)
             CubeMap  none { nullptr, 0 };
-            f3 Lo = direct_lighting(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
+            f3 Lo = direct_lighting<STATS>(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
+            if (STATS) { st_n += tc.nn; st_t += tc.nt; }
             if (a.sample_gi == 1)
             {
                 const f3    R   = reflect3(neg3(hWo), s.N);
@@ -191,6 +202,11 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
     HR_DIV(div_flush(dvp, g_div_refl); div_flush(dvs, g_div_refl + 8);)
     for (int o2 = 32; o2 > 0; o2 >>= 1) rays += __shfl_down(rays, o2);
     if (lane == 0) a.ray_slots[tile] = rays;
+    if (STATS)
+    {
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { st_n += __shfl_down(st_n, o2); st_t += __shfl_down(st_t, o2); }
+        if (lane == 0) { atomicAdd(a.stats + 0, (unsigned long long)st_n); atomicAdd(a.stats + 1, (unsigned long long)st_t); atomicAdd(a.stats + 2, (unsigned long long)rays); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,7 +419,7 @@ struct hr_reflections
     hr_ctx* ctx = nullptr;
     int     full_w = 0, full_h = 0, w = 0, h = 0, scale = 0, y0 = 0, y1 = 0, band_y0 = 0, band_y1 = 0, tiles_x = 0, tiles_y = 0;
     DevBuf  trace, color[2], moments[2], prev_image, atrous[2], upsample, tile_class, counters, ray_slots, geo[2];
-    bool    first_frame = true, last_denoise = true;
+    bool    first_frame = true, last_denoise = true, want_stats = false;
     int     read_idx = 0, last_pp = 0;
     bool    last_blur_as_input = false;   // which image the NEXT frame's temporal stage reads as colour history (hr_reflections_image 10)
     bool    fuse = true;   // tolerance mode: a-trous iterations 0 + 1 in one launch (developer A/B switch HR_FUSE=0, read once at create)
@@ -536,10 +552,39 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     a.sample_gi = prm->sample_gi ? 1 : 0; a.approximate_with_ddgi = prm->approximate_with_ddgi ? 1 : 0;
     a.gi_intensity = prm->gi_intensity; a.rough_ddgi_intensity = prm->rough_ddgi_intensity; a.ibl_intensity = prm->ibl_indirect_specular_intensity;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    a.stats = nullptr;
+    if (p->want_stats)
+    {
+        // instrumented build of the same kernel (hr_reflections_trace_stats): counters + 8 .. 32
+        HR_HIP(hipMemsetAsync((char*)p->counters.p + 8, 0, 24, st));
+        a.stats = (unsigned long long*)((char*)p->counters.p + 8);
+        hipLaunchKernelGGL(k_refl_trace<true>, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+        HR_HIP(hipGetLastError());
+        return HR_OK;
+    }
     int ev = p->prof.begin("ray_trace", st, px * 28);
-    hipLaunchKernelGGL(k_refl_trace, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+    hipLaunchKernelGGL(k_refl_trace<false>, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    return HR_OK;
+}
+
+// Instrumented ray trace (same rays, same trace image): out3 = rays traced (reflection rays + the hit shader's light rays), BVH node
+// steps, triangle tests — the BVH term of SURVEY §8d's algorithmic bytes.
+hr_status hr_reflections_trace_stats(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
+                                     const hr_reflections_params* prm, uint64_t* out3, void* stream)
+{
+    HR_CHECK_ARG(p && out3);
+    const bool first = p->first_frame;
+    p->want_stats = true;
+    const hr_status s = hr_reflections_ray_trace(p, scene, in, env, ddgi, prm, stream);
+    p->want_stats = false;
+    p->first_frame = first;   // a statistics pass is not a frame: the next render() still clears the history as it would have
+    if (s != HR_OK) return s;
+    HR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t host[3];
+    HR_HIP(hipMemcpy(host, (char*)p->counters.p + 8, 24, hipMemcpyDeviceToHost));
+    out3[0] = host[2]; out3[1] = host[0]; out3[2] = host[1];
     return HR_OK;
 }
 

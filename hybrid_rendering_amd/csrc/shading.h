@@ -461,10 +461,12 @@ struct TraceCtx
     uint32_t*     wave_stack;
     int           lane;
     DivCounters*  dv = nullptr;   // developer instrumentation (traverse.h)
+    uint32_t      nn = 0, nt = 0; // direct_lighting<true>: node steps / triangle tests of the light and sky rays (hr_*_trace_stats)
 };
 
 // direct_lighting (lighting.glsl:117-196)
-HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N, f3 P, f3 F0, f3 diffuse_color, float roughness, f3 T,
+template <bool STATS = false>
+HR_DEV f3 direct_lighting(TraceCtx& tc, const hr_light& light, f3 Wo, f3 N, f3 P, f3 F0, f3 diffuse_color, float roughness, f3 T,
                           bool sample_sky, float r2x, float r2y, const CubeMap& sky, uint32_t& rays)
 {
     f3       Lo = mk3(0.0f, 0.0f, 0.0f);
@@ -478,7 +480,7 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         if (attenuation > 0.0f)
         {
             rays++;
-            attenuation = attenuation * (trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
+            attenuation = attenuation * (trace_any<STATS>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, t_max, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
         }
 #endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
@@ -491,11 +493,12 @@ HR_DEV f3 direct_lighting(const TraceCtx& tc, const hr_light& light, f3 Wo, f3 N
         const f3 Wh = normalize3(add3(Wo, Wi));
 #ifndef HR_ABL_NO_SECONDARY
         rays++;
-        Li = scale3(Li, trace_any<false>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
+        Li = scale3(Li, trace_any<STATS>(tc.nodes, tc.tris, ray_origin, Wi, 0.01f, 10000.0f, tc.wave_stack, tc.lane, nn, nt, 0u, tc.dv) ? 0.0f : 1.0f);
 #endif
         const f3 brdf = evaluate_uber_brdf(diffuse_color, roughness, N, F0, Wo, Wh, Wi);
         Lo = add3(Lo, mul3(mul3(T, brdf), Li));
     }
+    if (STATS) { tc.nn += nn; tc.nt += nt; }
     return Lo;
 }
 

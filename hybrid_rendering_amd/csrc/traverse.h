@@ -564,8 +564,10 @@ struct HitRec
 
 // Closest hit: smallest t, ties broken by the smallest original triangle index (so the answer
 // does not depend on traversal order).
+// STATS: count node steps / triangle tests into *n_nodes / *n_tris (the instrumented builds behind hr_*_trace_stats).
+template <bool STATS = false>
 HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                            uint32_t* wave_stack, int lane, DivCounters* dv = nullptr)
+                            uint32_t* wave_stack, int lane, DivCounters* dv = nullptr, uint32_t* n_nodes = nullptr, uint32_t* n_tris = nullptr)
 {
     RayPre    r = ray_prepare(o, d);
     uint32_t  spill_array[HR_SPILL_ENTRIES];
@@ -578,6 +580,7 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
     {
         const float    tfar = best.prim < 0 ? t_max : best.t * 1.0000005f;
         const NodeHits h    = test_node<HR_ORDER_NEAR>(load_node(nodes, ni), r, t_min, tfar);
+        if (STATS) (*n_nodes)++;
         HR_DIV(if (dv) div_count(dv->lane_nodes, dv->wave_nodes);)
         uint32_t trimask = walk_expand(h, cur, st);
         while (trimask)
@@ -586,6 +589,7 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
             const uint32_t i = (uint32_t)__builtin_ctz(trimask);
             trimask &= trimask - 1u;
             const TriRaw tri = load_tri_raw(tris, h.tri_base + i);
+            if (STATS) (*n_tris)++;
             float t, u, v;
             if (ray_tri_raw<true>(r, tri, t_min, t_max, t, u, v))
             {

@@ -407,6 +407,9 @@ hr_status hr_ddgi_destroy(hr_ddgi* p);
 /* stage-level entry points (ddgi.cpp:767-986); probe range [probe0, probe1) lets a multi-GPU driver
  * split G1-G4 by z-slab and all-gather the atlas rows */
 hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, void* stream);
+/* Instrumented ray trace (the counter build of the same kernel; same rays and results): out3 = rays traced (probe rays + the light / sky
+ * rays of the hit points), BVH node steps, triangle tests — the BVH term of the trace pass's algorithmic bytes.  Synchronises. */
+hr_status hr_ddgi_trace_stats(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, uint64_t* out3, void* stream);
 hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream);
 hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const hr_ddgi_params* params, void* stream);
 hr_status hr_ddgi_end_frame(hr_ddgi* p); /* m_first_frame = false; m_ping_pong = !m_ping_pong (ddgi.cpp:101-103) */
@@ -457,6 +460,9 @@ hr_status hr_reflections_destroy(hr_reflections* p);
 /* stage-level entry points: ray_trace (:997-1057), temporal_accumulation (:1087-1139), a_trous_filter iteration (:1143-1256), upsample (:1260-1296) */
 hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
                                    const hr_reflections_params* params, void* stream);
+/* Instrumented ray trace, as hr_ddgi_trace_stats: out3 = rays (reflection rays + light rays of the hit points), node steps, triangle tests. */
+hr_status hr_reflections_trace_stats(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
+                                     const hr_reflections_params* params, uint64_t* out3, void* stream);
 /* temporal + a-trous chain (+ upsample); tolerance mode: iterations 0 and 1 as ONE kernel */
 hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);

@@ -71,6 +71,13 @@ def _run(oracle, hr, ctx, name, W, H, scale, n_frames, dolly, params=None, count
         assert np.array_equal(at, st["atrous"][-1]), f"frame {f}: a-trous output differs in {(at != st['atrous'][-1]).sum()} halfs"
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         assert np.array_equal(out, st["output"]), f"frame {f}: final output differs in {(out != st['output']).sum()} halfs"
+        if f == n_frames - 1:
+            # the instrumented build of the two trace kernels (hr_*_trace_stats: SURVEY 8d's BVH term): same rays, same image
+            rays, nodes, tris = gp.trace_stats(gsc, fi, env, g_ddgi)
+            assert rays == st["rays"] and nodes > rays > 0 and tris > 0, (rays, nodes, tris, st["rays"])
+            assert np.array_equal(helpers.bits16(gp.image(gp.IMG_TRACE)), st["trace"]), "the statistics pass must leave the trace image as it was"
+            drays, dnodes, dtris = g_ddgi.trace_stats(gsc, fi_full, env)
+            assert drays == g_ddgi.ray_count() and dnodes > drays > 0 and dtris > 0, (drays, dnodes, dtris)
         ping = not ping
     rough = oracle.f16(lvl(frames[-1])["gb3"][..., 0])
     sky_px = lvl(frames[-1])["depth"] == 1.0
