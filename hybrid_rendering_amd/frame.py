@@ -55,6 +55,9 @@ class HybridFrame:
         # the SIMD slots the VALU-bound trace kernels of another leave idle.  Joined on the caller's stream at the end of the frame.
         self.concurrent = False
         self.concurrent_streams(concurrent)
+        import os
+        self.forked = world > 1 and os.environ.get("HR_FRAME_FORKED", "0") == "1"   # opt-in (never exercised on a real multi-GPU node yet)
+        self.forked_error = None
 
     def _build_passes(self, bounds):
         """(re)creates the tiled passes of this rank for the band boundaries `bounds` (full-resolution rows; None: one GPU)"""
@@ -127,9 +130,36 @@ class HybridFrame:
         fi.num_frames = fl.num_frames = k
         return fi, fl
 
+    def _render_forked(self, fi, fl, k):
+        """N > 1, HR_FRAME_FORKED=1: the three independent chains of the frame — shadows | AO | DDGI -> reflections — on three torch streams
+        (torch.distributed orders its RCCL operations against the CURRENT stream, so each chain's exchange stays in its own ordering
+        domain; every rank issues the collectives in the same host order), joined on the caller's stream."""
+        import torch
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
+            self._ev = [torch.cuda.Event() for _ in range(3)]
+        self._ev[0].record(main)
+        for s in self._side:
+            s.wait_event(self._ev[0])
+        self.shadows.render(self.scene, fi, stream=self._side[0])
+        self.ao.render(self.scene, fi, stream=self._side[1])
+        self.gi.render(self.scene, fi, self.env, self._orients[k & 15])
+        self.refl.render(self.scene, fl, self.env, self.gi.pass_)
+        for i, s in enumerate(self._side):
+            self._ev[1 + i].record(s)
+            main.wait_event(self._ev[1 + i])
+
     def render(self, k, only=None):
         """frame k in the reference's order (main.cpp:80-83); `only`: one pass name (DDGI still runs before reflections once)"""
         fi, fl = self.inputs(k)
+        if self.world > 1 and only is None and getattr(self, "forked", False):
+            try:
+                return self._render_forked(fi, fl, k)
+            except Exception as e:   # automatic fall-back to the serial frame (bench.py reports `forked_error`)
+                import torch
+                self.forked, self.forked_error = False, repr(e)[:200]
+                torch.cuda.synchronize()
         if self.concurrent and only is None:
             self.gi.pass_.set_orientation(self._orients[k & 15])
             self._native.render(self.scene, self.env, fi, fi, fi, fl, mode=self.frame_mode)
@@ -145,6 +175,24 @@ class HybridFrame:
 
     def ray_counts(self):
         return {n: int(p.ray_count()) for n, p in self.passes().items()}
+
+    def trace_stats(self, k=200):
+        """{pass: (rays, BVH node steps, triangle tests)} of the four ray-trace kernels on frame k, from their instrumented builds
+        (hr_*_trace_stats): the BVH term of the trace passes' algorithmic bytes"""
+        fi, fl = self.inputs(k)
+        self.gi.pass_.set_orientation(self._orients[k & 15])
+        return dict(shadows=self.shadows.pass_.trace_stats(self.scene, fi), ao=self.ao.pass_.trace_stats(self.scene, fi),
+                    ddgi=self.gi.pass_.trace_stats(self.scene, fi, self.env), reflections=self.refl.pass_.trace_stats(self.scene, fl, self.env, self.gi.pass_))
+
+    def trace_bytes(self, k=200):
+        """algorithmic bytes of each ray-trace kernel per launch: pixels (or rays) x (inputs + output) + node steps x 80 B + triangle tests x 48 B"""
+        st = self.trace_stats(k)
+        px = self.W * self.H
+        lpx = (self.W >> self.refl_scale) * (self.H >> self.refl_scale)
+        n_probe_rays = int(np.prod(self.probes)) * self.rays_per_probe
+        fixed = dict(shadows=px * 12.125, ao=px * (12.0 + self.ao_spp / 8.0), reflections=lpx * 28.0, ddgi=n_probe_rays * 16.0)
+        return {n: dict(bytes=int(fixed[n] + st[n][1] * 80 + st[n][2] * 48), rays=st[n][0], nodes_per_ray=round(st[n][1] / max(st[n][0], 1), 2),
+                        tris_per_ray=round(st[n][2] / max(st[n][0], 1), 2)) for n in st}
 
     def time(self, frames, warmup=4, only=None, barrier=None, repeats=1):
         """wall-clock ms per frame between device synchronisations (+ `barrier()` across ranks); the best of `repeats` runs of

@@ -129,6 +129,15 @@ def _host_backend_fence(tensors, group=None):
         torch.cuda.synchronize()
 
 
+# the collective this rank posted last, and how many it has posted (bench.py's watchdog prints it when a run hangs on a real multi-GPU node)
+LAST_COLLECTIVE = {"name": None, "count": 0}
+
+
+def _note_collective(name: str):
+    LAST_COLLECTIVE["name"] = name
+    LAST_COLLECTIVE["count"] += 1
+
+
 def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: int, group=None, wait: bool = True, bounds: Sequence[int] = None):
     """Grouped neighbour exchange of ``rows`` halo rows for every [H, W, ...] tensor in ``images`` (all ranks
     pass the same list in the same order).  Works on any backend (nccl on GPUs, gloo in the CPU tests).
@@ -148,6 +157,7 @@ def exchange_halo(images: Sequence, height: int, world: int, rank: int, rows: in
             ops.append(dist.P2POp(dist.isend, send, peer, group))
             ops.append(dist.P2POp(dist.irecv, recv, peer, group))
             recvs.append(send)  # keep alive until the batch completes
+    _note_collective(f"exchange_halo({len(images)} images x {rows} rows, rank {rank}/{world})")
     reqs = dist.batch_isend_irecv(ops)
     if not wait:
         return [(reqs, recvs)]
@@ -330,6 +340,7 @@ def allgather_slabs(atlas, side: int, cz: int, world: int, rank: int, group=None
         return
     rows = [slab_rows(side, *probe_slabs(cz, world, r)) for r in range(world)]
     _host_backend_fence([atlas], group)
+    _note_collective(f"allgather_slabs(side {side}, rank {rank}/{world})")
     if len({b - a for a, b in rows}) == 1:
         outs = [atlas[a:b] for a, b in rows]
         dist.all_gather(outs, atlas[rows[rank][0]:rows[rank][1]].clone(), group=group)
