@@ -57,22 +57,22 @@ def kernel_of(pass_, stage, exact):
     step = {"atrous_0": 1, "atrous_1": 2, "atrous_2": 4, "atrous_3": 8}
     if pass_ == "shadows":
         if stage == "ray_trace": return "k_shadows_trace<false>"
-        if stage == "temporal_accumulation": return "k_shadows_temporal" if exact else "kf_shadows_temporal"
+        if stage == "temporal_accumulation": return "k_shadows_temporal" if exact else "kf_shadows_temporal<1>"   # <1>: reprojection from the pass's geometry records
         if stage == "atrous_01": return "kf_shadows_atrous01<16, true>"
         if stage in step:
             if exact: return "k_shadows_atrous<1, true>"       # one instance serves the four iterations in the parity mode
             return ("kf_shadows_atrous_lds<%d, true>" if step[stage] <= 2 else "kf_shadows_atrous<%d, true>") % step[stage]
     if pass_ == "ao":
         if stage == "ray_trace": return "k_ao_trace<false>"
-        if stage == "temporal_accumulation": return "k_ao_temporal<true>" if exact else "kf_ao_temporal<true>"
+        if stage == "temporal_accumulation": return "k_ao_temporal<true>" if exact else "kf_ao_temporal<true, 2>"
         if stage == "blur_xy": return "kf_ao_blur_xy<4, 16>"
         if stage in ("blur_x", "blur_y"): return "k_ao_blur<4>" if exact else "kf_ao_blur<4>"   # two launches of one instance: the counters average X and Y
     if pass_ == "ddgi":
-        return {"ray_trace": "k_ddgi_trace", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
+        return {"ray_trace": "k_ddgi_trace<false>", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
                 "sample_probe_grid": "k_ddgi_sample" if exact else "kf_ddgi_sample"}.get(stage)
     if pass_ == "reflections":
-        if stage == "ray_trace": return "k_refl_trace"
-        if stage == "temporal_accumulation": return "k_refl_temporal" if exact else "kf_refl_temporal"
+        if stage == "ray_trace": return "k_refl_trace<false>"
+        if stage == "temporal_accumulation": return "k_refl_temporal" if exact else "kf_refl_temporal<1>"
         if stage == "atrous_01": return "kf_refl_atrous01<16, true>"
         if stage in step: return "k_refl_atrous<1>" if exact else "kf_refl_atrous<%d, true>" % step[stage]
         if stage == "upsample": return "k_upsample<4>" if exact else "kf_upsample<4>"
@@ -720,6 +720,9 @@ def kernel_entries(prof, pass_, stage_times, exact, trace=None):
             bf = binding_frac(c)
             if bf is not None:
                 e["binding_frac"] = bf
+            if (e.get("frac") or 0) > 1.0:
+                e["frac_note"] = ("> 1: SURVEY 8d counts every lane's BVH node / triangle fetch (80 / 48 B each); they are L1 / L2 hits (the BVH is ~17 MB), "
+                                  "not HBM traffic — the kernel is VALU-bound: read binding_frac / dram_frac")
         elif b and ms > 0:
             e["frac"] = round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out[s] = e

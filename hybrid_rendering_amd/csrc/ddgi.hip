@@ -651,7 +651,8 @@ hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
     if (p->d.depth_sharpness == 50.0f) hipLaunchKernelGGL((k_ddgi_probe_update<true, true>), grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
     else hipLaunchKernelGGL((k_ddgi_probe_update<true, false>), grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
     p->prof.end(ev, st);
-    ev = p->prof.begin("border_update", st, 0);
+    // algorithmic bytes: every border texel is read from an interior texel and written once (4 side + 4 texels per probe and atlas)
+    ev = p->prof.begin("border_update", st, (uint64_t)grid.x * grid.y * 2ull * ((4ull * p->d.irradiance_probe_side_length + 4) * 8 + (4ull * p->d.depth_probe_side_length + 4) * 4));
     // one thread per border texel: 4 * side + 4 (hr_ddgi_create bounds the sides), rounded up to whole waves
     hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(cdiv(4 * p->d.irradiance_probe_side_length + 4, 64) * 64), 0, st, p->d, p->irr[wr].p, p->z0);
     hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(cdiv(4 * p->d.depth_probe_side_length + 4, 64) * 64), 0, st, p->d, p->dep[wr].p, p->z0);
