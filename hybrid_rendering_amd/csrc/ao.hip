@@ -375,6 +375,8 @@ struct hr_ao
     const void*   geo_gb3 = nullptr;
 };
 
+bool hr::profiling_enabled(const hr_ao* p) { return p && p->prof.enabled; }
+
 extern "C" {
 
 void hr_ao_default_params(hr_ao_params* p)

@@ -465,6 +465,8 @@ struct hr_ddgi
     hipStream_t   last_stream = nullptr;
 };
 
+bool hr::profiling_enabled(const hr_ddgi* p) { return p && p->prof.enabled; }
+
 extern "C" {
 
 void hr_ddgi_default_params(hr_ddgi_params* p)

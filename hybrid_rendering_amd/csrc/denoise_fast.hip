@@ -581,8 +581,9 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
 }
 
 // A-trous iterations 0 and 1 (tap distances 1 and 2, radius 1) in ONE launch: iteration 0's image never leaves LDS.
-// Per 32 x TH output tile: region A = the tile + 4 texels all round is staged once (value/variance + decoded normal + linear z);
-// iteration 0 runs on region B = the tile + 3 (iteration 1 reads B at distance 2 and its 3x3 variance prefilter at distance 1) and
+// Per 32 x TH output tile: region A = the tile + 3 texels all round is staged once (value/variance + decoded normal + linear z);
+// iteration 0 runs on region B = the tile + 2 (iteration 1 reads B at distance 2 for its taps, at distance 1 around the centre only for its
+// 3x3 variance prefilter; iteration 0 reads A at distance 1) and
 // is rounded to RG16F exactly as the stored image would be; iteration 1 runs on the tile.  Saves one launch, one 4 B/px image write
 // and the second pass's re-fetch of the 8 B/px normal/depth image at the cost of (B + tile) / (2 tile) filter evaluations.
 // Texel rules are those of kf_shadows_atrous_lds: a texel outside the image / the band's resident rows is (0, normal 0) in BOTH
@@ -592,7 +593,7 @@ template <int TH, bool N32>
 __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_t* out_first2, float power1)
 {
     const uint2 BLK = block_xy<0>();
-    constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
+    constexpr int AW = 38, AH = TH + 6, BW = 36, BH = TH + 4;   // A = tile + 3 all round, B = tile + 2 (round-3 advisor: one ring too many each)
     __shared__ uint32_t s_in[AH * AW];
     __shared__ float4   s_nz[AH * AW];   // unit normal, linear z
     __shared__ uint32_t s_mid[BH * BW];  // iteration 0, as the RG16F image would hold it
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
     for (int i = threadIdx.x; i < AH * AW; i += 256)
     {
         const int  cy = i / AW, cx = i - cy * AW;
-        const int  gx = bx0 - 4 + cx, gy = by0 - 4 + cy;
+        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
         const bool res = gx >= 0 && gx < a.w && gy >= ry0 && gy < ry1;
         const uint32_t so = res ? (uint32_t)(gy * a.w + gx) : (uint32_t)(ry0 * a.w);
         const uint32_t v  = fm::ld<uint32_t>(a.in.p, so * 4u);
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
     for (int j = threadIdx.x; j < BH * BW; j += 256)
     {
         const int  cy = j / BW, cx = j - cy * BW;
-        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
+        const int  gx = bx0 - 2 + cx, gy = by0 - 2 + cy;
         const bool res = gx >= 0 && gx < a.w && gy >= ry0 && gy < ry1;
         uint32_t   r = 0u;
         if (res && a.tile_class[(size_t)(gy >> 3) * a.tiles_x + (gx >> 3)])
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
             r = filter(s_in, AW, ci, ci, 1, 0.0f);
         }
         s_mid[j] = r;
-        if (out_first2 && res && cx >= 3 && cx < 35 && cy >= 3 && cy < 3 + TH && gy < a.y1) out_first2[(uint32_t)(gy * a.w + gx)] = r;
+        if (out_first2 && res && cx >= 2 && cx < 34 && cy >= 2 && cy < 2 + TH && gy < a.y1) out_first2[(uint32_t)(gy * a.w + gx)] = r;
     }
     __syncthreads();
     // iteration 1 on the tile
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
         if (x >= a.w || y >= a.y1) continue;
         const uint32_t o = (uint32_t)(y * a.w + x);
         uint32_t r = 0u;
-        if (a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) r = filter(s_mid, BW, (ly + 3) * BW + lx + 3, (ly + 4) * AW + lx + 4, 2, power1);
+        if (a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)]) r = filter(s_mid, BW, (ly + 2) * BW + lx + 2, (ly + 3) * AW + lx + 3, 2, power1);
         a.out[o] = r;
         if (a.out2) a.out2[o] = r;
     }
@@ -1254,7 +1255,7 @@ template <int TH, bool N32>
 __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2* out_first2)
 {
     const uint2 BLK = block_xy<1>();
-    constexpr int AW = 40, AH = TH + 8, BW = 38, BH = TH + 6;
+    constexpr int AW = 38, AH = TH + 6, BW = 36, BH = TH + 4;   // A = tile + 3 all round, B = tile + 2 (round-3 advisor: one ring too many each)
     __shared__ uint2  s_in[AH * AW];
     __shared__ float4 s_nz[AH * AW];    // unit normal (0 outside the image), linear z
     __shared__ float  s_r[AH * AW];     // roughness; -1: sky texel
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2*
     for (int i = threadIdx.x; i < AH * AW; i += 256)
     {
         const int  cy = i / AW, cx = i - cy * AW;
-        const int  gx = bx0 - 4 + cx, gy = by0 - 4 + cy;
+        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
         const bool img = gx >= 0 && gx < a.w && gy >= 0 && gy < a.h;
         const bool res = img && gy >= a.in.y0 && gy < a.in.y1;
         const uint32_t so = res ? (uint32_t)(gy * a.w + gx) : (uint32_t)(a.in.y0 * a.w);
@@ -1321,13 +1322,13 @@ __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2*
     for (int j = threadIdx.x; j < BH * BW; j += 256)
     {
         const int  cy = j / BW, cx = j - cy * BW;
-        const int  gx = bx0 - 3 + cx, gy = by0 - 3 + cy;
+        const int  gx = bx0 - 2 + cx, gy = by0 - 2 + cy;
         const bool res = gx >= 0 && gx < a.w && gy >= (a.y0 > 0 ? a.y0 : 0) && gy < (a.y1 < a.h ? a.y1 : a.h);
         const int  ci = (cy + 1) * AW + cx + 1;
         uint2      r = make_uint2(0u, 0u);
         if (res) r = a.tile_class[(size_t)(gy >> 3) * a.tiles_x + (gx >> 3)] ? filter(s_in, AW, ci, ci, 1) : s_in[ci];
         s_mid[j] = r;
-        if (out_first2 && res && cx >= 3 && cx < 35 && cy >= 3 && cy < 3 + TH) out_first2[(uint32_t)(gy * a.w + gx)] = r;
+        if (out_first2 && res && cx >= 2 && cx < 34 && cy >= 2 && cy < 2 + TH) out_first2[(uint32_t)(gy * a.w + gx)] = r;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < TH * 32; j += 256)
@@ -1335,8 +1336,8 @@ __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2*
         const int lx = j & 31, ly = j >> 5, x = bx0 + lx, y = by0 + ly;
         if (x >= a.w || y >= a.y1) continue;
         const uint32_t o = (uint32_t)(y * a.w + x);
-        const int vi = (ly + 3) * BW + lx + 3;
-        const uint2 r = a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] ? filter(s_mid, BW, vi, (ly + 4) * AW + lx + 4, 2) : s_mid[vi];
+        const int vi = (ly + 2) * BW + lx + 2;
+        const uint2 r = a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] ? filter(s_mid, BW, vi, (ly + 3) * AW + lx + 3, 2) : s_mid[vi];
         a.out[o] = r;
         if (a.out2) a.out2[o] = r;
     }

@@ -9,7 +9,7 @@
 // The reference records the passes into one Vulkan command buffer with per-resource barriers only, so the GPU overlaps them as far as
 // the barriers allow; a serial HIP stream forbids that.  The chains share no image (shadows, AO and DDGI read the G-buffer only;
 // reflections read the DDGI ATLASES, which are final after the probe updates; the per-pixel probe-grid sample feeds only the
-// composite), so every output is bit-identical to the serial order (tests/test_gpu_frame.py).  What the overlap buys: the
+// composite), so every output is bit-identical to the serial order (tests/test_gpu_configs.py::test_hybrid_frame_*).  What the overlap buys: the
 // latency-bound denoise kernels of one chain fill the SIMD slots the VALU-bound trace kernels of another leave idle.
 //
 // Three ways to enqueue the same launches:
@@ -34,10 +34,21 @@ struct hr_hybrid_frame
     hipStream_t     capture = nullptr;                         // origin stream of the graph capture (the caller's may be the legacy stream)
     hipEvent_t      ev_in = nullptr, ev_atlas = nullptr, ev_out[3] = { nullptr, nullptr, nullptr }, ev_done = nullptr;
     hipGraphExec_t  exec = nullptr;
+    hipStream_t     last_launch = nullptr;                     // stream of the last hipGraphLaunch (synchronised before the exec is destroyed)
     int             instantiations = 0, updates = 0;
 };
 
 namespace {
+
+// A frame that was captured but never ran (capture / instantiate / launch failed) has still advanced the passes' host state — ping-pong
+// parities, first-frame flags, the DDGI atlas swap: restart their histories so that the next frame does not read images nobody wrote.
+void reset_after_failed_frame(hr_hybrid_frame* f)
+{
+    if (f->shadows) (void)hr_shadows_reset_history(f->shadows);
+    if (f->ao) (void)hr_ao_reset_history(f->ao);
+    if (f->reflections) (void)hr_reflections_reset_history(f->reflections);
+    if (f->ddgi) (void)hr_ddgi_restart_accumulation(f->ddgi);
+}
 
 // the forked frame on `main` + the three side streams (used directly by HR_FRAME_STREAMS and under capture by HR_FRAME_GRAPH)
 hr_status enqueue_forked(hr_hybrid_frame* f, const hr_scene* scene, const hr_hybrid_frame_desc* d, hipStream_t main)
@@ -137,14 +148,20 @@ hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, cons
     }
     if (mode == HR_FRAME_STREAMS) return enqueue_forked(f, scene, d, main);
     if (mode != HR_FRAME_GRAPH) { set_last_error("hr_hybrid_frame_render: unknown mode"); return HR_ERR_INVALID_ARG; }
+    if ((f->shadows && hr::profiling_enabled(f->shadows)) || (f->ao && hr::profiling_enabled(f->ao)) || (f->ddgi && hr::profiling_enabled(f->ddgi)) ||
+        (f->reflections && hr::profiling_enabled(f->reflections)))
+    {
+        set_last_error("hr_hybrid_frame_render: HR_FRAME_GRAPH cannot carry the passes' per-stage profiling events (timing events are not capturable); switch profiling off or use HR_FRAME_STREAMS");
+        return HR_ERR_INVALID_ARG;
+    }
     // ---- one hipGraph per frame: capture the forked frame (the side streams join the capture through their event waits), then update
     // the instantiated graph in place — topology and kernels are those of the last frame, only the argument blocks differ
     HR_HIP(hipStreamBeginCapture(f->capture, hipStreamCaptureModeThreadLocal));
     s = enqueue_forked(f, scene, d, f->capture);
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(f->capture, &graph);
-    if (s != HR_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
-    if (ce != hipSuccess || !graph) { set_last_error(std::string("hr_hybrid_frame_render: stream capture failed: ") + hipGetErrorString(ce)); return HR_ERR_HIP; }
+    if (s != HR_OK) { if (graph) (void)hipGraphDestroy(graph); reset_after_failed_frame(f); return s; }
+    if (ce != hipSuccess || !graph) { reset_after_failed_frame(f); set_last_error(std::string("hr_hybrid_frame_render: stream capture failed: ") + hipGetErrorString(ce)); return HR_ERR_HIP; }
     bool fresh = f->exec == nullptr;
     if (!fresh)
     {
@@ -153,7 +170,9 @@ hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, cons
         if (hipGraphExecUpdate(f->exec, graph, &bad, &res) != hipSuccess)
         {
             (void)hipGetLastError();
-            (void)hipStreamSynchronize(main);   // the old graph may still be running (topology changes are rare: a pass's first frame)
+            // the old graph may still be running — on the stream it was LAUNCHED on, which need not be this frame's (topology changes are rare: a pass's first frame)
+            if (f->last_launch && f->last_launch != main) (void)hipStreamSynchronize(f->last_launch);
+            (void)hipStreamSynchronize(main);
             (void)hipGraphExecDestroy(f->exec);
             f->exec = nullptr;
             fresh = true;
@@ -164,11 +183,15 @@ hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, cons
     if (fresh)
     {
         const hipError_t ie = hipGraphInstantiate(&f->exec, graph, nullptr, nullptr, 0);
-        if (ie != hipSuccess) { (void)hipGraphDestroy(graph); f->exec = nullptr; set_last_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); return HR_ERR_HIP; }
+        if (ie != hipSuccess) { (void)hipGraphDestroy(graph); f->exec = nullptr; reset_after_failed_frame(f); set_last_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); return HR_ERR_HIP; }
         f->instantiations++;
     }
     (void)hipGraphDestroy(graph);
-    HR_HIP(hipGraphLaunch(f->exec, main));
+    {
+        const hipError_t le = hipGraphLaunch(f->exec, main);
+        if (le != hipSuccess) { reset_after_failed_frame(f); set_last_error(std::string("hipGraphLaunch: ") + hipGetErrorString(le)); return HR_ERR_HIP; }
+    }
+    f->last_launch = main;
     return HR_OK;
 }
 

@@ -34,6 +34,12 @@ void set_last_error(const std::string& s);
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// is per-stage event profiling switched on for this pass? (frame.hip: timing events cannot be captured into a hipGraph)
+bool profiling_enabled(const hr_shadows* p);
+bool profiling_enabled(const hr_ao* p);
+bool profiling_enabled(const hr_ddgi* p);
+bool profiling_enabled(const hr_reflections* p);
+
 struct DevBuf
 {
     void*  p     = nullptr;

@@ -437,6 +437,8 @@ struct hr_reflections
     const void*   geo_cur = nullptr;    // this frame's records (a-trous stages), nullptr in the parity mode / for bands
 };
 
+bool hr::profiling_enabled(const hr_reflections* p) { return p && p->prof.enabled; }
+
 extern "C" {
 
 void hr_reflections_default_params(hr_reflections_params* p)

@@ -562,6 +562,8 @@ struct hr_shadows
     void*         nd_cur = nullptr;         // the side image of the frame in flight (a-trous stages)
 };
 
+bool hr::profiling_enabled(const hr_shadows* p) { return p && p->prof.enabled; }
+
 extern "C" {
 
 void hr_shadows_default_params(hr_shadows_params* p)
@@ -787,9 +789,14 @@ hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps)
 hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
 {
     HR_CHECK_ARG(p && out3);
+    // the counts are those of the WALK (SURVEY 8d's BVH term, comparable between frames and builds): the occluder cache, whose
+    // contents depend on the previous frames, is bypassed for the statistics pass
+    const bool cache = p->occluder_cache;
     p->want_stats = true;
+    p->occluder_cache = false;
     hr_status s = hr_shadows_ray_trace(p, scene, in, prm, stream);
     p->want_stats = false;
+    p->occluder_cache = cache;
     if (s != HR_OK) return s;
     HR_HIP(hipStreamSynchronize((hipStream_t)stream));
     uint64_t host[5];
