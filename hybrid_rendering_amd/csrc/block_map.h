@@ -2,15 +2,15 @@
 //
 // The dispatcher deals the workgroups of a launch round-robin over the 8 XCDs in linear order (x fastest), and every XCD has
 // its own L2: with the identity mapping a tile's apron (the a-trous rings, the blur's reach, the reprojection footprint) is
-// fetched by up to eight L2s, which the FETCH_SIZE counters show as 1.5-1.9x the algorithmic bytes.
+// fetched by up to eight L2s, which the FETCH_SIZE counters show as 1.5-1.9x the algorithmic bytes (docs/EXPERIMENTS.md §4.4).
 // block_xy<R>() hands XCD k runs of R whole tile rows instead (dealt round-robin down the screen, so every XCD still samples the
 // whole image), so horizontally — and for R > 1 vertically — neighbouring tiles share one L2.
 //
-// Measured (round 3): it pays for exactly two kernels, the fused AO blur (-12 % at 1080p) and the fused reflections
+// Measured (round 3, docs/EXPERIMENTS.md §4.4): it pays for exactly two kernels, the fused AO blur (-12 % at 1080p) and the fused reflections
 // a-trous 0 + 1 (-7..12 %); every other image kernel is FASTER with the identity (shadows a-trous 2 / 3 +12 %, upsample +10 %,
 // probe-grid sample +3 %: the fine interleave spreads the concurrently running tiles over more DRAM channels, and the kernels
 // with a per-tile early-out lose their load balance), and one contiguous eighth per XCD (R = -1) is 30-60 % slower for those.
-// The trace kernels need the round-robin deal as their load balancer (§4.2).
+// The trace kernels need the round-robin deal as their load balancer (docs/EXPERIMENTS.md §4.2).
 #pragma once
 #include "device_math.h"
 

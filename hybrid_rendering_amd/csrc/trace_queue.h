@@ -1,5 +1,5 @@
 // Wavefront ray queues for the DDGI hit-shading pass: the traversal of a ray batch as its own kernel — a developer A/B path
-// (HR_DDGI_WAVEFRONT=1), NOT the default: measured slower than the single kernel.
+// (HR_DDGI_WAVEFRONT=1), NOT the default: measured slower than the single kernel (docs/EXPERIMENTS.md §4.3).
 //
 // The reference traces these rays from a ray-generation shader whose closest-hit shader traces further rays (gi_ray_trace.rgen:96 ->
 // gi_ray_trace.rchit:95-128 -> ray_query.glsl): on RT cores the driver's scheduler regroups that work.  One HIP kernel doing the same

@@ -411,7 +411,7 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
 // NB rays per lane (the sample rays of one AO pixel), walked back to back INSIDE one wave-level loop: a lane whose ray is done
 // (occluded, or its stack ran empty) switches to its next ray at once instead of idling until the slowest lane of the wave has
 // finished the current sample.  A wave then waits once for max_lanes(sum of its rays' steps) instead of NB times for
-// sum_rays(max_lanes(steps)) — the ray LENGTHS are what idles lanes, and a sum of NB lengths spreads less than
+// sum_rays(max_lanes(steps)) — the ray LENGTHS are what idles lanes (docs/EXPERIMENTS.md §4.3), and a sum of NB lengths spreads less than
 // NB maxima.  No queue, no atomics, no cross-lane traffic: the rays of a lane are prepared up front and live in registers; a switch
 // is a handful of v_cndmask.  Decisions per ray are those of trace_any (same node / triangle tests, any-hit), so the masks are
 // bit-identical.  Returns the bit mask of OCCLUDED rays.

@@ -1,6 +1,6 @@
 // Issue cost of single VALU instructions on gfx950 (wave64): cycles per wave instruction per SIMD with 8 waves resident on every SIMD
 // (inline asm, 64 back-to-back copies of ONE instruction per loop step over rotating registers).  Calibrates the "4 cycles per VALU
-// instruction" model behind bench.py's valu_issue_frac and shows where the cycles of the BVH node test go.
+// instruction" model behind bench.py's valu_issue_frac and shows where the cycles of the BVH node test go (docs/EXPERIMENTS.md §4.2).
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe.hip -o tools/_build/valu_rate_probe && tools/_build/valu_rate_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
