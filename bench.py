@@ -568,9 +568,9 @@ def run(args, torch, dist, rank, world, local_rank):
                      "algorithmic_bytes": int(dom[1]["bytes"]),
                      "note": "achieved/frac divide the ALGORITHMIC bytes (SURVEY 8d: G-buffer + mask + visited BVH nodes x 80 B + tested triangles x 48 B) by the kernel time; "
                              "the 15 MB BVH is served by L2 / Infinity Cache, so dram_frac (counter traffic) is the HBM-side figure; the operative roof of this kernel is "
-                             "VALU issue: valu_frac = valu_issue_frac x lane_utilisation is the share of the VALU roof doing useful work.  Round 3's occluder cache "
-                             "(a ray first tests the triangle that occluded its pixel last frame) produces the same mask from ~20 % fewer visited nodes in ~3 % less time, "
-                             "so `frac` FELL (0.59 -> 0.49) while the kernel got faster: compare rounds by `value`, `ms_per_step` and `valu_frac`"},
+                             "VALU issue: valu_frac = valu_issue_frac x lane_utilisation is the share of the VALU roof doing useful work (= binding_frac).  The node / triangle counts are those of "
+                             "the full WALK: the statistics pass bypasses the occluder cache (a ray first tests the triangle that occluded its pixel last frame; ~20 % fewer "
+                             "node steps in the timed kernel), so that `frac` stays comparable between frames, builds and rounds"},
         "stages": {n: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()} for n, s in stages.items()},
     }
     if comm_info:
