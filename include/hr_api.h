@@ -47,7 +47,8 @@ const char* hr_version(void);
 /* Revision of this header's struct layouts and entry points.  The parameter structs are passed by pointer WITHOUT a size field, so a host
  * built against another revision must not call into this library: compare hr_api_revision() with HR_API_REVISION once at start-up
  * (hr::Context does).  Revision 3 = round 3: hr_*_denoise, hr_hybrid_frame, ticketed hr_comm, HR_ERR_TIMEOUT / HR_ERR_COMM. */
-#define HR_API_REVISION 3
+/* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
+#define HR_API_REVISION 4
 int32_t hr_api_revision(void);
 
 /* ---- formats -------------------------------------------------------------------------------- */
