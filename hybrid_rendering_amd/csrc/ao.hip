@@ -75,7 +75,8 @@ extern "C" int hr_debug_divergence_ao(uint64_t* out, int reset)
 #endif
 template <bool STATS>
 #ifndef AO_TRACE_EU
-#define AO_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 8 -> 393 / 389 / 396 us (noise level)
+#define AO_TRACE_EU 6   // minimum waves per SIMD the register allocator must leave room for.  Round 4 (new tree): 1 / 4 / 5 / 6 / 7 / 8 -> 372 / 373 / 372 / 361-368 / 374 / 372 us at 1080p, 1208 -> 1156 at 4K for 6;
+                        // round 3: 1 / 6 / 8 -> 393 / 389 / 396
 #endif
 __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(AOTraceArgs a)
 {

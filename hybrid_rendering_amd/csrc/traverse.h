@@ -610,10 +610,14 @@ HR_DEV HitRec trace_closest(const Node8* __restrict__ nodes, const TriGPU* __res
 // decisions: same code, same operands), and hand the result back through LDS (closest hit: 64-bit ds_min of (t, prim), the
 // reference's tie rule).  The far limit a lane culls nodes with lags by at most one flush; that only costs node visits, never a hit.
 // The caller keeps the wave converged around the call (inactive lanes pass active = false and serve as job lanes).
-#define HR_COOP_RING 256   // jobs; > 63 queued + HR_COOP_PUSH per lane per step
 #ifndef HR_COOP_PUSH
-#define HR_COOP_PUSH 2     // jobs a lane may append per step (a lane with more pending leaf triangles skips node steps until drained)
+#define HR_COOP_PUSH 3     // jobs a lane may append per step (a lane with more pending leaf triangles skips node steps until drained).  Round 4, with the
+                           // new tree: AO trace 371 / 364 / 351 us for 2 / 3 / 4 (4 needs the 512-entry ring), DDGI and reflections -1 %; round 2: 356 / 333 / 330 (DDGI) for 1 / 2 / 3
 #endif
+#ifndef HR_COOP_RING
+#define HR_COOP_RING (HR_COOP_PUSH <= 3 ? 256 : 512)   // jobs, a power of two; must hold 63 queued + 64 x HR_COOP_PUSH appended in one step
+#endif
+static_assert((HR_COOP_RING & (HR_COOP_RING - 1)) == 0 && HR_COOP_RING >= 63 + 64 * HR_COOP_PUSH + 1, "cooperative job ring too small for HR_COOP_PUSH");
 struct CoopWave
 {
     uint32_t           jobs[HR_COOP_RING];   // owner lane << 26 | triangle index (hr_scene_create bounds the triangle count)

@@ -47,10 +47,13 @@ def test_gpu_two_ranks_on_one_gpu_report_comm_error():
     import torch
     if torch.cuda.device_count() != 1:
         pytest.skip("needs a one-GPU box (RCCL refuses two ranks on one device)")
-    env = dict(os.environ, HR_DIST_BACKEND="nccl", HR_FORCE_DEVICE="0", HR_BENCH_TIMEOUT_S="400")
+    # RCCL mostly refuses at once ("duplicate GPU"), but has been seen to sit in its bootstrap for minutes on a loaded box: the watchdog is
+    # set short, and BOTH endings are accepted — the refusal (local fallback numbers) and the watchdog (the line as far as it is known)
+    env = dict(os.environ, HR_DIST_BACKEND="nccl", HR_FORCE_DEVICE="0", HR_BENCH_TIMEOUT_S="90")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29732",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-passes", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=400)
     d = _last_json(out.stdout)
     assert d["comm"]["error"], d
-    assert d["requested_gpus"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0, d
+    if "watchdog" not in d["comm"]["error"]:
+        assert d["requested_gpus"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0, d
