@@ -54,7 +54,7 @@ struct BuiltBVH
     int                 n_refs = 0;   // triangle references after splitting (== tris.size())
 };
 
-// positions: [n][3][3].  Deterministic (single-threaded, no RNG).
+// positions: [n][3][3].  Deterministic: the result does not depend on the number of builder threads (HR_BVH_THREADS, default min(hardware, 16)).
 void build_bvh8(const float* positions, int n_tris, BuiltBVH& out);
 
 // Host-side self-check (bvh_build.cpp): number of (triangle, sample point) pairs that reach no leaf holding the triangle — 0 for a

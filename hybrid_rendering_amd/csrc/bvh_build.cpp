@@ -10,7 +10,8 @@
 //   4. breadth-first layout with contiguous children / leaf triangles, 8-bit conservative quantisation.
 // Every reference points at its ORIGINAL triangle and the leaves store the unmodified vertices, so the ray/triangle test and its
 // results — any-hit: a function of the geometry; closest hit: of (t, original index) — do not depend on any of this: only the boxes
-// get tighter.  Deterministic (single-threaded, no RNG).
+// get tighter.  Deterministic: no RNG, and the subtrees that are built on several threads (step 1) are merged in left-right order, so
+// the tree does not depend on the number of threads (HR_BVH_THREADS) or on scheduling.
 #include "bvh.h"
 #include <algorithm>
 #include <cfloat>
@@ -18,8 +19,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <chrono>
+#include <future>
 #include <queue>
+#include <thread>
 
 namespace hr {
 namespace {
@@ -178,7 +182,6 @@ struct Builder
     bool              spatial   = true;
     double            alpha     = 1e-3;   // spatial splits are tried when the object split's children overlap by more than alpha x root area
     double            root_area = 0.0;
-    long              budget    = 0;      // references the spatial splits may still add
     long              n_spatial = 0, n_unsplit = 0;
 
     // SAH splits down to binary depth kSahDepth, object-median splits below it: a median split halves the count, so the
@@ -194,7 +197,64 @@ struct Builder
 
     // Builds the subtree over A[first .. first + count).  Object and median splits partition that range in place; a spatial split
     // writes its two (longer) reference lists into vectors of their own and recurses into those.
-    int32_t build(std::vector<Ref>& A, size_t first, size_t count, int depth, int32_t parent)
+    // `budget`: references the spatial splits of THIS subtree may still add (split between the children in proportion to their
+    // reference counts, so the tree does not depend on the order in which subtrees are built).
+    // Subtrees of more than kParallelMin references are built by two threads — each child into a Builder of its own, merged back in
+    // left-right order with shifted indices — as long as the thread allowance (HR_BVH_THREADS, default min(hardware, 16)) lasts: the
+    // node numbering, the leaf order and therefore the whole BVH are those of the single-threaded build.
+    static constexpr size_t kParallelMin = 16384;
+    std::atomic<int>* threads_left = nullptr;
+
+    void adopt(Builder& c, int32_t parent_node)
+    {
+        // append the nodes / leaves of a child context (root = its node 0) behind ours
+        const int32_t no = (int32_t)n2.size(), lo = (int32_t)leaves.size();
+        for (Bin2 n : c.n2)
+        {
+            if (n.a >= 0) { n.a += no; n.b += no; }
+            else n.first += lo;
+            n.parent = n.parent >= 0 ? n.parent + no : parent_node;
+            n2.push_back(n);
+        }
+        leaves.insert(leaves.end(), c.leaves.begin(), c.leaves.end());
+        n_spatial += c.n_spatial; n_unsplit += c.n_unsplit;
+    }
+    Builder child_context() const
+    {
+        Builder c;
+        c.pos = pos; c.bvh2_leaf = bvh2_leaf; c.spatial = spatial; c.alpha = alpha; c.root_area = root_area; c.sah_depth = sah_depth;
+        c.threads_left = threads_left; c.max_area_fraction = max_area_fraction;
+        return c;
+    }
+    // builds the two children of node `me` over (AL, fl, cl) and (AR, fr, cr); returns their node indices
+    void build_children(int32_t me, std::vector<Ref>& AL, size_t fl, size_t cl, std::vector<Ref>& AR, size_t fr, size_t cr, int depth, long budget, int32_t& l, int32_t& r)
+    {
+        const long bl = (cl + cr) ? (long)((double)budget * (double)cl / (double)(cl + cr)) : 0, br = budget - bl;
+        bool parallel = false;
+        if (threads_left && cl >= kParallelMin && cr >= kParallelMin)
+        {
+            int have = threads_left->load();
+            while (have > 0 && !threads_left->compare_exchange_weak(have, have - 1)) {}
+            parallel = have > 0;
+        }
+        if (!parallel)
+        {
+            l = build(AL, fl, cl, depth + 1, me, bl);
+            r = build(AR, fr, cr, depth + 1, me, br);
+            return;
+        }
+        Builder lc = child_context(), rc = child_context();
+        std::future<void> fut = std::async(std::launch::async, [&] { lc.build(AL, fl, cl, depth + 1, -1, bl); });
+        rc.build(AR, fr, cr, depth + 1, -1, br);
+        fut.get();
+        threads_left->fetch_add(1);
+        l = (int32_t)n2.size();
+        adopt(lc, me);
+        r = (int32_t)n2.size();
+        adopt(rc, me);
+    }
+
+    int32_t build(std::vector<Ref>& A, size_t first, size_t count, int depth, int32_t parent, long budget)
     {
         const int32_t me = (int32_t)n2.size();
         n2.emplace_back();
@@ -266,11 +326,11 @@ struct Builder
                 if (ov.valid() && ov.half_area() > alpha * root_area)
                 {
                     std::vector<Ref> L, R;
-                    if (spatial_split(refs, count, nb, best, L, R))
+                    long dup = 0;
+                    if (spatial_split(refs, count, nb, best, L, R, budget, dup))
                     {
-                        const int32_t l = build(L, 0, L.size(), depth + 1, me);
-                        std::vector<Ref>().swap(L);
-                        const int32_t r = build(R, 0, R.size(), depth + 1, me);
+                        int32_t l, r;
+                        build_children(me, L, 0, L.size(), R, 0, R.size(), depth, budget - dup, l, r);
                         n2[me].a = l;
                         n2[me].b = r;
                         return me;
@@ -285,8 +345,8 @@ struct Builder
                 if (mid == 0 || mid == count) mid = median_split(refs, count, cb);
             }
         }
-        const int32_t l = build(A, first, mid, depth + 1, me);
-        const int32_t r = build(A, first + mid, count - mid, depth + 1, me);
+        int32_t l, r;
+        build_children(me, A, first, mid, A, first + mid, count - mid, depth, budget, l, r);
         n2[me].a = l;
         n2[me].b = r;
         return me;
@@ -310,7 +370,7 @@ struct Builder
 
     // Chopped binning over the node's box on every axis; performs the split (filling L, R) and returns true when the best plane
     // beats the object split's cost `object_cost`.
-    bool spatial_split(const Ref* refs_, size_t count, const Box& nb, double object_cost, std::vector<Ref>& L, std::vector<Ref>& R)
+    bool spatial_split(const Ref* refs_, size_t count, const Box& nb, double object_cost, std::vector<Ref>& L, std::vector<Ref>& R, long budget, long& dup_out)
     {
         struct Range { const Ref *b, *e; const Ref* begin() const { return b; } const Ref* end() const { return e; } } refs { refs_, refs_ + count };
         double best = object_cost;
@@ -398,6 +458,7 @@ struct Builder
         }
         // reference unsplitting: a straddler goes to one side whole when that is cheaper than referencing it from both
         long nl = (long)L.size(), nr = (long)R.size(), dup = 0;
+        dup_out = 0;
         for (const Straddler& s : st)
         {
             const Box    lub = merged(lb, s.whole.box), rub = merged(rb, s.whole.box), ldb = merged(lb, s.l.box), rdb = merged(rb, s.r.box);
@@ -416,7 +477,7 @@ struct Builder
             L.clear(); R.clear();
             return false;
         }
-        budget -= dup;
+        dup_out = dup;
         n_spatial++;
         return true;
     }
@@ -649,14 +710,18 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     if (const char* e = getenv("HR_BVH_REINSERT")) passes = atoi(e);
     if (const char* e = getenv("HR_BVH_REINSERT_FRACTION")) fraction = atof(e);
     if (const char* e = getenv("HR_BVH_REINSERT_MAX_AREA")) B.max_area_fraction = atof(e);
-    B.budget    = (long)(budget_fraction * (double)refs.size());
+    const long budget = (long)(budget_fraction * (double)refs.size());
+    int n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("HR_BVH_THREADS")) n_threads = std::max(1, atoi(e));
+    std::atomic<int> threads_left(n_threads - 1);
+    B.threads_left = n_threads > 1 ? &threads_left : nullptr;
     B.root_area = all.half_area();
     B.n2.reserve(refs.size() * 2 + refs.size() / 2);
     B.leaves.reserve(refs.size() + refs.size() / 3);
     const size_t n_input_refs = refs.size();
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
-    B.root = B.build(refs, 0, refs.size(), 0, -1);
+    B.root = B.build(refs, 0, refs.size(), 0, -1, budget);
     const double t_built = since();
     std::vector<Ref>().swap(refs);
     const double sah_built = getenv("HR_BVH_STATS") ? B.sah() : 0.0;

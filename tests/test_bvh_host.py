@@ -83,10 +83,21 @@ def test_spatial_splits_happen_and_stay_within_the_budget(monkeypatch):
     assert api.bvh_build_info(v).tri_bytes <= int(len(v) * 1.01) * 48
 
 
-def test_build_is_deterministic():
+def test_build_is_deterministic(monkeypatch):
+    """same input -> same tree, whatever the number of builder threads (subtrees above 16k references are built concurrently and merged in
+    left-right order; the duplication budget is split by reference count, not consumed in build order)"""
     v = _big_and_small(seed=9, n_small=1500)
     a, b = api.bvh_build_info(v), api.bvh_build_info(v)
     assert (a.n_nodes, a.max_depth, a.tri_bytes, a.node_bytes) == (b.n_nodes, b.max_depth, b.tri_bytes, b.node_bytes)
+    big = synth.sponza_like(0.6).verts      # ~100k triangles: several parallel levels
+    shapes = []
+    for t in ("1", "2", "7"):
+        monkeypatch.setenv("HR_BVH_THREADS", t)
+        i = api.bvh_build_info(big)
+        shapes.append((i.n_nodes, i.max_depth, i.tri_bytes, i.node_bytes))
+    assert shapes[0] == shapes[1] == shapes[2], shapes
+    monkeypatch.setenv("HR_BVH_THREADS", "5")
+    assert api.bvh_selfcheck(big, 8) == 0
 
 
 def test_empty_and_single_triangle():

@@ -326,6 +326,10 @@ int main(int argc, char** argv)
                 else { cl += a * (n.meta[i] >> 5); nleaf++; nleaftri += n.meta[i] >> 5; }
             }
         }
+        unsigned long long hsh = 1469598103934665603ull;
+        auto mix = [&](const void* ptr, size_t n) { const unsigned char* c = (const unsigned char*)ptr; for (size_t i = 0; i < n; i++) { hsh ^= c[i]; hsh *= 1099511628211ull; } };
+        mix(b.nodes.data(), b.nodes.size() * sizeof(Node8)); mix(b.tris.data(), b.tris.size() * sizeof(TriGPU));
+        printf("bvh checksum %016llx\n", hsh);
         printf("tris %d refs %zu nodes %zu depth %d  build %.2f s   SAH: nodes %.3f  leaves %.3f  (x root area)  leaves %ld avg %.2f tris\n", n_tris, b.tris.size(), b.nodes.size(), b.max_depth,
                build_s, cn / root_area, cl / root_area, nleaf, (double)nleaftri / std::max(1L, nleaf));
     }
