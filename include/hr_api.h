@@ -283,7 +283,10 @@ hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, 
 hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
 /* Views of intermediates for halo exchange / golden taps: 0 mask, 1 temporal out, 2/3 moments[0/1],
  * 4 prev (feedback) image, 5/6 à-trous ping/pong, 7 upsample, 8 tile classes (uint8 as R8 in an R32 view is not
- * representable: width/height are in tiles, format HR_FORMAT_R32_UINT is NOT implied — 1 byte per tile). */
+ * representable: width/height are in tiles, format HR_FORMAT_R32_UINT is NOT implied — 1 byte per tile).
+ * STALE IMAGES: what render() / hr_shadows_denoise launch in tolerance mode (radius 1) fuses a-trous iterations 0 and 1, so the image
+ * iteration 0 would have written (6) holds an older frame — read the pass's result through hr_shadows_output, or run the iterations one by
+ * one (hr_shadows_atrous_iteration) when every intermediate is wanted. */
 hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* view);
 /* Row bands: did a history tap of the frames rendered since the last call fall on an image row this GPU does not hold (per-frame
  * motion beyond hr_band.history_halo)?  Such taps read as disoccluded: the band stays a valid image but stops being identical to the
@@ -336,7 +339,8 @@ hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params*
 hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
 hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, int32_t pass, void* stream);
 hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
-/* 0 mask planes, 1/2 AO[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes (1 byte per tile) */
+/* 0 mask planes, 1/2 AO[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes (1 byte per tile).
+ * STALE IMAGE: in tolerance mode (blur radius 4) render() / hr_ao_denoise blur X and Y in one kernel and image 5 (blur X) is not written. */
 hr_status hr_ao_image(hr_ao* p, int32_t which, hr_image_view* view);
 hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
 hr_status hr_ao_set_profiling(hr_ao* p, int32_t enable);
@@ -469,7 +473,9 @@ hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, c
 hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
 hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, int32_t iteration, void* stream);
 hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
-/* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes */
+/* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes.
+ * STALE IMAGE: in tolerance mode (radius 1) render() / hr_reflections_denoise fuse a-trous iterations 0 and 1; the image iteration 0 would
+ * have written (7) holds an older frame (see hr_shadows_image). */
 /* which = 10: the colour history the NEXT frame's temporal stage will read (feedback image with blur_as_input, else this frame's temporal
  * output) — the image a row-tiled host exchanges with its neighbours (hr_reflections_exchange_history does) */
 hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* view);
