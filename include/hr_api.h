@@ -251,7 +251,7 @@ typedef struct
                                    those texels and <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) additionally count
                                    |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles.  HARD CAP per texel: outside the
                                    neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle, except
-                                   for at most max(4, 1e-5 of the pixels) pixels per image which — like the texels next to a flipped tile — stay
+                                   for at most max(4, 1e-5 of the pixels) pixels per image (x 5 * 4^scale in a scaled pass's upsampled output) which — like the texels next to a flipped tile — stay
                                    within the value range of the channel: discrete decisions of the reference's own formulas (a reprojection
                                    tap's validity, the DDGI Chebyshev branch over a flat depth texel) that one fp32 ulp flips
                                    (tests/test_gpu_tolerance.py compare16; measured figures: profiles/r4_d);

@@ -163,7 +163,7 @@ def test_reflections_1080p_matches_oracle(oracle, hr, ctx, sponza_full, scale):
         tol.compare16(helpers.bits16(gf.image(gf.IMG_COLOR1 if f & 1 else gf.IMG_COLOR0)), st["temporal"], f"frame {f} temporal colour + variance (exact = 0)", abs_floor=tol.INTERMEDIATE_FLOOR)   # intermediate image, as for the shadows
         tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_ATROUS)), st["atrous"][-1], f"frame {f} a-trous colour + variance (exact = 0)", exclude=ex, variance_channels=(3,))
         exu = tol.upscale_mask(ex, scale, H, W) if scale else ex
-        tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE)), st["output"], f"frame {f} reflections output (exact = 0)", exclude=exu, variance_channels=(3,))
+        tol.compare16(helpers.bits16(gf.output(hr.OUTPUT_UPSAMPLE)), st["output"], f"frame {f} reflections output (exact = 0)", exclude=exu, variance_channels=(3,), outlier_scale=tol.upsample_scale(scale))
     gf.close(); gf_ddgi.close()
     rough = oracle.f16(lows[-1]["gb3"][..., 0])
     geo = lows[-1]["depth"] != 1.0

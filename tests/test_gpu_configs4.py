@@ -199,7 +199,7 @@ def test_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full, W, 
         tol.compare16(helpers.bits16(g_sh.output(hr.OUTPUT_UPSAMPLE)), sh, f"frame {f} shadows output", exclude=ex_sh, variance_channels=(1,))
         tol.compare16(helpers.bits16(g_ao.output(hr.OUTPUT_UPSAMPLE)), ao, f"frame {f} AO output", exclude=ex_ao)
         tol.compare16(helpers.bits16(g_gi.output()), gi, f"frame {f} DDGI sample", outlier_pixels=tol.DDGI_OUTLIERS)
-        tol.compare16(helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE)), rf, f"frame {f} reflections output", exclude=ex_rf, variance_channels=(3,))
+        tol.compare16(helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE)), rf, f"frame {f} reflections output", exclude=ex_rf, variance_channels=(3,), outlier_scale=tol.upsample_scale(1))
         got = helpers.bits16(g_df.output())
         # the composite of four images that are each within 2 ulp obeys the SAME image rule (measured: it also holds at 2 ulp, not only at 4)
         tol.compare16(got, ref, f"frame {f} final HDR image", exclude=ex_sh | ex_ao | ex_rf, outlier_pixels=tol.DDGI_OUTLIERS)
