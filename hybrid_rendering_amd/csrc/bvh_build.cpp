@@ -660,9 +660,12 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     for (int i = 0; i < n_tris; i++)
     {
         const float* p = positions + (size_t)i * 9;
+        bool finite = true;
+        for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
+        if (!finite) continue;   // see below: such a triangle is never hit and gets no reference
         all.add(p); all.add(p + 3); all.add(p + 6);
     }
-    if (n_tris == 0)
+    if (n_tris == 0 || !all.valid())
     {
         for (int a = 0; a < 3; a++) { all.lo[a] = 0; all.hi[a] = 0; }
     }
@@ -692,11 +695,25 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
     for (int i = 0; i < n_tris; i++)
     {
         const float* p = positions + (size_t)i * 9;
+        // A triangle with a NaN or infinite coordinate can never be hit (the watertight test's edge functions come out NaN / of mixed
+        // sign and its interval test fails on NaN), so it gets no reference at all: non-finite boxes would poison the SAH areas of every
+        // node above them (and made the reinsertion search quadratic: 15 s for 3000 triangles, two of them non-finite).
+        bool finite = true;
+        for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
+        if (!finite) continue;
         Box tb;
         tb.add(p); tb.add(p + 3); tb.add(p + 6);
         Poly poly;
         tri_poly(positions, i, poly);
         split_refs(poly, tb, i, limit, 0, refs);
+    }
+    if (refs.empty())
+    {
+        Node8 n;
+        std::memset(&n, 0, sizeof(n));
+        n.ex = n.ey = n.ez = 1;
+        out.nodes.push_back(n);
+        return;
     }
     // developer switches (A/B of the build steps; tests/test_bvh_host.py, tools/bvh_eval.cpp)
     B.bvh2_leaf = getenv("HR_BVH_GREEDY") ? kMaxLeaf : 1;

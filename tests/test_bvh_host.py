@@ -100,6 +100,24 @@ def test_build_is_deterministic(monkeypatch):
     assert api.bvh_selfcheck(big, 8) == 0
 
 
+def test_non_finite_triangles_get_no_reference(monkeypatch):
+    """a triangle with a NaN / infinite coordinate can never be hit (the watertight test fails on NaN): the builder leaves it out instead of
+    letting its box poison the SAH areas of every node above it; the scene bounds ignore it too"""
+    import time
+    rng = np.random.RandomState(0)
+    v = (rng.normal(size=(3000, 1, 3)) * 50 + rng.normal(size=(3000, 3, 3))).astype(np.float32)
+    w = v.copy()
+    w[5, 1, 2] = np.nan; w[77, 0, 0] = np.inf; w[200] = -np.inf
+    monkeypatch.setenv("HR_BVH_SBVH", "0")
+    t0 = time.time()
+    info, clean = api.bvh_build_info(w), api.bvh_build_info(np.delete(v, [5, 77, 200], axis=0))
+    assert time.time() - t0 < 5.0
+    assert info.tri_bytes == (3000 - 3) * 48 == clean.tri_bytes and info.n_nodes == clean.n_nodes
+    assert np.isfinite(list(info.bounds_lo) + list(info.bounds_hi)).all() and list(info.bounds_lo) == list(clean.bounds_lo)
+    nothing = api.bvh_build_info(np.full((4, 3, 3), np.nan, np.float32))
+    assert nothing.n_nodes == 1 and nothing.tri_bytes == 0
+
+
 def test_empty_and_single_triangle():
     assert api.bvh_build_info(np.zeros((0, 3, 3), np.float32)).n_nodes == 1
     one = api.bvh_build_info(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32))
