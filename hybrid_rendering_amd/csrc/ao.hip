@@ -536,7 +536,7 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     a.geo_hist = nullptr; a.geo_out = nullptr;
     if (!prm->exact && p->geo[0].p)
     {
-        if (p->geo_valid && !p->first_frame && pp != p->geo_pp && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3) a.geo_hist = p->geo[p->geo_parity].p;
+        if (p->geo_valid && !p->first_frame && pp != p->geo_pp && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3) a.geo_hist = p->geo[p->geo_parity].p;
         p->geo_parity ^= 1;
         a.geo_out = p->geo[p->geo_parity].p;
         p->geo_valid = true; p->geo_pp = pp; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;

@@ -615,7 +615,7 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     a.geo_hist = nullptr; a.geo_out = nullptr; p->geo_cur = nullptr;
     if (!prm->exact && p->geo[0].p)
     {
-        if (p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3) a.geo_hist = p->geo[p->geo_parity].p;
+        if (p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3) a.geo_hist = p->geo[p->geo_parity].p;
         p->geo_parity ^= 1;
         a.geo_out = p->geo[p->geo_parity].p;
         p->geo_cur = a.geo_out;

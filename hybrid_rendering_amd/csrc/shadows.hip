@@ -554,6 +554,7 @@ struct hr_shadows
     // the next frame reprojects.  They stand for the caller's PREVIOUS G-buffer exactly when the caller hands back, as in->prev, the
     // images it passed as in->cur in the previous call (the reference's ping-pong, g_buffer.cpp:208-211): then the reprojection reads
     // them (4 images, 16 gathers per pixel, full cache lines) instead of prev GB2 / GB3 (5 images, 21 gathers, half of every line).
+    // A previous G-buffer that ALIASES the current one (one buffer rewritten in place) is read as the caller passed it.
     bool          geo_history = true;       // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
     bool          geo_valid = false;        // `nd` half geo_parity holds the records of the last frame this pass rendered
     int           geo_parity = 0;
@@ -838,7 +839,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
         // the caller's images (its records cover the rows it computed, not the history apron its neighbours own)
         const size_t half = (size_t)p->w * p->h * 8;
         const bool   whole = p->y0 == 0 && p->y1 == p->h;
-        if (p->geo_history && p->geo_valid && whole && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3)
+        if (p->geo_history && p->geo_valid && whole && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3)
             a.geo_hist = (const char*)p->nd.p + (size_t)p->geo_parity * half;
         p->geo_parity ^= 1;
         a.nd = (float4*)((char*)p->nd.p + (size_t)p->geo_parity * half);

@@ -3,7 +3,7 @@ previous G-buffer (HR_GEO_HISTORY=0, what rounds 1-3 did).
 
 The records hold verbatim copies of the G-buffer words the reprojection reads (oct normal, mesh id; for AO also the AO history value),
 so every stage image must be equal BIT FOR BIT — through a history reset, a frame whose previous G-buffer arrives at other addresses
-(the pass must notice and read the caller's images), a switch to the parity mode and back, and a non-alternating ping_pong (AO: its
+(the pass must notice and read the caller's images), a frame whose previous G-buffer aliases the current one, a switch to the parity mode and back, and a non-alternating ping_pong (AO: its
 colour history then is NOT what the record holds).  reprojection.glsl:52-67,188-210."""
 import os
 
@@ -42,7 +42,7 @@ def _clone(g):
 
 
 # frame -> what happens before it: the script every pass below runs
-SCRIPT = {3: "reset", 5: "other_addresses", 7: "exact", 8: "fast_again", 10: "same_ping_pong"}
+SCRIPT = {3: "reset", 5: "other_addresses", 6: "aliased", 7: "exact", 8: "fast_again", 10: "same_ping_pong"}
 N = 12
 
 
@@ -60,6 +60,8 @@ def _drive(passes, render, images, frame_inputs, lows):
         prev = lows[f - 1] if f else lows[0]
         if what == "other_addresses":
             prev = _clone(prev)                       # same texels at other addresses: the records must NOT be trusted
+        if what == "aliased":
+            prev = None                                # the previous G-buffer IS the current one (one buffer rewritten in place)
         if what == "reset":
             for p in passes:
                 p.reset_history()
@@ -67,7 +69,7 @@ def _drive(passes, render, images, frame_inputs, lows):
             p.params.exact = 1 if what == "exact" else 0
         if what != "same_ping_pong":
             pp ^= 1
-        fi = frame_inputs(f, prev, pp)
+        fi = frame_inputs(f, prev, pp)   # prev None -> the current images
         for p in passes:
             render(p, fi, f)
         torch.cuda.synchronize()
@@ -87,7 +89,7 @@ def test_shadows_records_equal_the_callers_gbuffer(hr, ctx, name, W, H):
            lambda p, q, pp: [("temporal", p.image(p.IMG_TEMPORAL), q.image(q.IMG_TEMPORAL)), ("moments", p.image(p.IMG_MOMENTS1 if pp else p.IMG_MOMENTS0), q.image(q.IMG_MOMENTS1 if pp else q.IMG_MOMENTS0)),
                              ("a-trous output", p.output(hr.OUTPUT_ATROUS), q.output(hr.OUTPUT_ATROUS)), ("feedback image", p.image(p.IMG_PREV), q.image(q.IMG_PREV)),
                              ("tile classes", p.image(p.IMG_TILES), q.image(q.IMG_TILES))],
-           lambda f, prev, pp: hr.frame_inputs(gbs[f], prev, ubos[f], f, pp, sob_d, sr_d), lows)
+           lambda f, prev, pp: hr.frame_inputs(gbs[f], prev if prev is not None else gbs[f], ubos[f], f, pp, sob_d, sr_d), lows)
     a.close(); b.close(); gsc.close()
 
 
@@ -105,7 +107,7 @@ def test_ao_records_equal_the_callers_gbuffer(hr, ctx, name, W, H, spp):
            lambda p, q, pp: [("temporal AO", p.image(p.IMG_AO1 if pp else p.IMG_AO0), q.image(q.IMG_AO1 if pp else q.IMG_AO0)),
                              ("history length", p.image(p.IMG_LEN1 if pp else p.IMG_LEN0), q.image(q.IMG_LEN1 if pp else q.IMG_LEN0)),
                              ("blurred AO", p.image(p.IMG_BLUR1), q.image(q.IMG_BLUR1)), ("tile classes", p.image(p.IMG_TILES), q.image(q.IMG_TILES))],
-           lambda f, prev, pp: hr.frame_inputs(gbs[f], prev, ubos[f], f, pp, sob_d, sr_d, z_buffer_params=zbp), lows)
+           lambda f, prev, pp: hr.frame_inputs(gbs[f], prev if prev is not None else gbs[f], ubos[f], f, pp, sob_d, sr_d, z_buffer_params=zbp), lows)
     a.close(); b.close(); gsc.close()
 
 
@@ -140,5 +142,5 @@ def test_reflections_records_equal_the_callers_gbuffer(hr, ctx, W, H, scale):
                              ("moments", p.image(p.IMG_MOMENTS1 if pp else p.IMG_MOMENTS0), q.image(q.IMG_MOMENTS1 if pp else q.IMG_MOMENTS0)),
                              ("a-trous output", p.output(hr.OUTPUT_ATROUS), q.output(hr.OUTPUT_ATROUS)), ("output", p.output(hr.OUTPUT_UPSAMPLE), q.output(hr.OUTPUT_UPSAMPLE)),
                              ("tile classes", p.image(p.IMG_TILES), q.image(q.IMG_TILES))],
-           lambda f, prev, pp: hr.frame_inputs(lows[f], prev, ubos[f], f, pp, sob_d, sr_d, cur_full=gbs[f]), lows)
+           lambda f, prev, pp: hr.frame_inputs(lows[f], prev if prev is not None else lows[f], ubos[f], f, pp, sob_d, sr_d, cur_full=gbs[f]), lows)
     a.close(); b.close(); ddgi.close(); gsc.close()
