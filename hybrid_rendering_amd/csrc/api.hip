@@ -291,6 +291,11 @@ hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_inf
         set_last_error("hr_bvh_build_info: host allocation failed");
         return HR_ERR_OUT_OF_MEMORY;
     }
+    catch (const std::exception& e)   // nothing else is expected; no exception may cross the C ABI
+    {
+        set_last_error(std::string("hr_bvh_build_info: ") + e.what());
+        return HR_ERR_UNSUPPORTED;
+    }
 }
 
 // Host-only: builds the same BVH and checks that every triangle is found from every point of its surface (bvh.h
@@ -309,6 +314,11 @@ hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t sampl
     {
         set_last_error("hr_bvh_selfcheck: host allocation failed");
         return HR_ERR_OUT_OF_MEMORY;
+    }
+    catch (const std::exception& e)
+    {
+        set_last_error(std::string("hr_bvh_selfcheck: ") + e.what());
+        return HR_ERR_UNSUPPORTED;
     }
 }
 

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <future>
 #include <queue>
+#include <system_error>
 #include <thread>
 
 namespace hr {
@@ -244,9 +245,17 @@ struct Builder
             return;
         }
         Builder lc = child_context(), rc = child_context();
-        std::future<void> fut = std::async(std::launch::async, [&] { lc.build(AL, fl, cl, depth + 1, -1, bl); });
+        std::future<void> fut;
+        try
+        {
+            fut = std::async(std::launch::async, [&] { lc.build(AL, fl, cl, depth + 1, -1, bl); });
+        }
+        catch (const std::system_error&)   // no thread to be had: build the left subtree here (same result)
+        {
+            lc.build(AL, fl, cl, depth + 1, -1, bl);
+        }
         rc.build(AR, fr, cr, depth + 1, -1, br);
-        fut.get();
+        if (fut.valid()) fut.get();
         threads_left->fetch_add(1);
         l = (int32_t)n2.size();
         adopt(lc, me);
