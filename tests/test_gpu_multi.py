@@ -83,3 +83,16 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert len(j["comm"]["band_bounds"]) == 3 and j["comm"]["exchange_us_per_frame"] > 0
     assert "passes_error" not in j, j["passes_error"]
     assert j["hybrid_4k"]["n_gpus"] == 2 and set(j["hybrid_4k"]["comm_us_per_frame"]) >= {"shadows_exchange", "ao_exchange", "reflections_exchange", "ddgi_atlas_allgather"}
+    assert j["hybrid_4k"]["forked_streams"] is False and j["timed_repeats"] >= 1
+
+
+def test_bench_two_ranks_forked_hybrid_frame_gloo():
+    """HR_FRAME_FORKED=1: the N > 1 hybrid frame with its three chains on three torch streams (frame.py _render_forked) — must run (no
+    fall-back to the serial frame) and give the same ray counts as the serial one"""
+    if _n_devices() < 1:
+        pytest.skip("no GPU")
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    jf, _ = _launch(args, timeout=1500, env=dict(HR_DIST_BACKEND="gloo", HR_FORCE_DEVICE="0", HR_FRAME_FORKED="1"))
+    assert "passes_error" not in jf, jf["passes_error"]
+    assert jf["hybrid_4k"]["forked_streams"] is True and "forked_error" not in jf["hybrid_4k"], jf["hybrid_4k"]
+    assert jf["hybrid_4k"]["ms_per_frame"] > 0 and jf["hybrid_4k"]["Mrays_per_s"] > 0
