@@ -43,8 +43,11 @@ struct TraceArgs
 // wave ballot IS the packed mask (bit y*8+x of shadows_ray_trace.comp:126).
 #define TRACE_WAVES 1 // waves (8x8 tiles) per workgroup: 1 lets the dispatcher back-fill a CU wave by wave — tile
                       // costs differ by >10x, and with 4-wave groups the finished waves' slots idle until the slowest ends
+#ifndef SHADOWS_TRACE_EU
+#define SHADOWS_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for (A/B: see docs/EXPERIMENTS.md R4.3)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64 * TRACE_WAVES) void k_shadows_trace(TraceArgs a)
+__global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_trace(TraceArgs a)
 {
     __shared__ uint32_t s_stack[TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
