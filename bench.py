@@ -71,7 +71,7 @@ def kernel_of(pass_, stage, exact):
         return {"ray_trace": "k_ddgi_trace<false>", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
                 "sample_probe_grid": "k_ddgi_sample" if exact else "kf_ddgi_sample"}.get(stage)
     if pass_ == "reflections":
-        if stage == "ray_trace": return "k_refl_trace<false>"
+        if stage == "ray_trace": return "k_refl_trace<false, false>" if exact else "k_refl_trace<false, true>"   # <., FAST>: tolerance-mode irradiance gathers
         if stage == "temporal_accumulation": return "k_refl_temporal" if exact else "kf_refl_temporal<1>"
         if stage == "atrous_01": return "kf_refl_atrous01<16, true>"
         if stage in step: return "k_refl_atrous<1>" if exact else "kf_refl_atrous<%d, true>" % step[stage]

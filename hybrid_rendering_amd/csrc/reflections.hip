@@ -11,6 +11,7 @@
 #include "shading.h"
 #include "upsample.h"
 #include "pass_args.h"
+#include "ddgi_sample_fast.h"
 
 using namespace hr;
 
@@ -103,8 +104,12 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 #ifndef REFL_TRACE_EU
 #define REFL_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 216 / 226 / 235 us
 #endif
-// STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false>.
-template <bool STATS>
+// STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false, .>.
+// FAST (tolerance mode, hr_reflections_params.exact == 0): the DDGI irradiance gathers of the hit shading and of the rough pixels through
+// ddgi_sample_fast.h instead of shading.h's correctly rounded restatement.  The exact gather is ~3x the fast one (per-pixel sample kernel:
+// 225 vs 70 us) and was a third of this kernel: 339 k rough pixels + 350 k hit points of the 1080p bench frame.  Rays, hit points, ray
+// counts and tile classes do not depend on it; the trace IMAGE is then within the stated tolerance instead of bit-exact.
+template <bool STATS, bool FAST>
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)
 {
     __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
             else if (roughness > 0.75f && a.approximate_with_ddgi == 1)
             {
                 const f3 R = reflect3(neg3(Wo), N);
-                color      = scale3(sample_irradiance(a.d, P, R, Wo, a.irr, a.dep), a.rough_ddgi_intensity);
+                color      = scale3(FAST ? ddgi_fast::sample_irradiance<false>(a.d, P, R, Wo, a.irr, a.dep) : sample_irradiance(a.d, P, R, Wo, a.irr, a.dep), a.rough_ddgi_intensity);
             }
             else
             {
@@ -191,7 +196,8 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
                 float bx, by;
                 a.env.lut_fetch(ndv, s.roughness, bx, by);
                 const f3 specular = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), a.ibl_intensity);
-                const f3 diffuse  = mul3(scale3(c_diffuse, a.gi_intensity), sample_irradiance(a.d, s.P, s.N, hWo, a.irr, a.dep));
+                const f3 diffuse  = mul3(scale3(c_diffuse, a.gi_intensity),
+                                         FAST ? ddgi_fast::sample_irradiance<false>(a.d, s.P, s.N, hWo, a.irr, a.dep) : sample_irradiance(a.d, s.P, s.N, hWo, a.irr, a.dep));
                 Lo = add3(Lo, add3(mul3(kD, diffuse), specular));
             }
             color      = Lo;
@@ -430,6 +436,7 @@ struct hr_reflections
     // when the caller hands back as in->prev the images it passed as in->cur (the reference's ping-pong, g_buffer.cpp:208-211) — so does
     // the next frame's reprojection (see hr_shadows).
     bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
+    bool          fast_shading = true;  // tolerance mode: k_refl_trace<., FAST> (developer A/B switch HR_REFL_FAST_SHADING=0, read once at create)
     bool          geo_valid = false;
     int           geo_parity = 0;
     const void*   geo_gb2 = nullptr;
@@ -457,6 +464,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_REFL_FAST_SHADING")) p->fast_shading = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
@@ -560,12 +568,13 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
         // instrumented build of the same kernel (hr_reflections_trace_stats): counters + 8 .. 32
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 8, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 8);
-        hipLaunchKernelGGL(k_refl_trace<true>, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+        hipLaunchKernelGGL((k_refl_trace<true, false>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, px * 28);
-    hipLaunchKernelGGL(k_refl_trace<false>, dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+    if (prm->exact || !p->fast_shading) hipLaunchKernelGGL((k_refl_trace<false, false>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+    else hipLaunchKernelGGL((k_refl_trace<false, true>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -450,7 +450,9 @@ typedef struct
     int32_t feedback_iteration;              /* 1                                                 */
     float   camera_delta[3];                 /* CommonResources::camera_delta (main.cpp:1077-1079) */
     float   frame_time;                      /* CommonResources::frame_time (pushed, unused by the shader) */
-    int32_t exact;                           /* 1 (default) = bit-for-bit parity arithmetic, 0 = tolerance mode (see hr_shadows_params.exact) */
+    int32_t exact;                           /* 1 (default) = bit-for-bit parity arithmetic, 0 = tolerance mode (see hr_shadows_params.exact); in tolerance mode the
+                                                ray-trace stage keeps rays, hits, ray counts and the ray-length channel bit-exact and computes the hit shading's DDGI
+                                                irradiance gathers with the fast arithmetic: the trace image's colour is within the image rule */
 } hr_reflections_params;
 
 void      hr_reflections_default_params(hr_reflections_params* p);

@@ -199,10 +199,10 @@ def test_hybrid_frame_tolerance_mode_composite(oracle, hr, ctx, sponza_full, W, 
         tol.compare16(helpers.bits16(g_sh.output(hr.OUTPUT_UPSAMPLE)), sh, f"frame {f} shadows output", exclude=ex_sh, variance_channels=(1,))
         tol.compare16(helpers.bits16(g_ao.output(hr.OUTPUT_UPSAMPLE)), ao, f"frame {f} AO output", exclude=ex_ao)
         tol.compare16(helpers.bits16(g_gi.output()), gi, f"frame {f} DDGI sample", outlier_pixels=tol.DDGI_OUTLIERS)
-        tol.compare16(helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE)), rf, f"frame {f} reflections output", exclude=ex_rf, variance_channels=(3,), outlier_scale=tol.upsample_scale(1))
+        tol.compare16(helpers.bits16(g_rf.output(hr.OUTPUT_UPSAMPLE)), rf, f"frame {f} reflections output", exclude=ex_rf, variance_channels=(3,), outlier_scale=tol.upsample_scale(1), outlier_pixels=tol.REFL_OUTLIERS)
         got = helpers.bits16(g_df.output())
         # the composite of four images that are each within 2 ulp obeys the SAME image rule (measured: it also holds at 2 ulp, not only at 4)
-        tol.compare16(got, ref, f"frame {f} final HDR image", exclude=ex_sh | ex_ao | ex_rf, outlier_pixels=tol.DDGI_OUTLIERS)
+        tol.compare16(got, ref, f"frame {f} final HDR image", exclude=ex_sh | ex_ao | ex_rf, outlier_pixels=tol.REFL_OUTLIERS)
     img = oracle.f16(ref[..., :3])
     assert np.isfinite(img).all() and img.mean() > 0.01
     for g in (g_sh, g_ao, g_gi, g_rf, g_df):
