@@ -36,6 +36,8 @@ struct AABB
 void Scene::build(const float* verts, int n_tris)
 {
     tris.resize(n_tris);
+    order.clear();
+    order.reserve(n_tris);
     std::vector<AABB>  tb(n_tris);
     std::vector<float> cen((size_t)n_tris * 3);
     AABB               all;
@@ -51,23 +53,26 @@ void Scene::build(const float* verts, int n_tris)
         tb[i].grow(p + 3);
         tb[i].grow(p + 6);
         for (int a = 0; a < 3; a++) cen[(size_t)i * 3 + a] = 0.5f * (tb[i].lo[a] + tb[i].hi[a]);
-        all.grow(tb[i]);
+        // a triangle with a NaN / infinite coordinate is never hit (the watertight test fails on NaN): it stays in `tris` (indices are
+        // stable) but gets no place in the tree — its box would turn the bin index below into an out-of-range integer
+        bool finite = true;
+        for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
+        if (finite) { all.grow(tb[i]); order.push_back(i); }
     }
+    if (order.empty()) { const float z[3] = { 0.0f, 0.0f, 0.0f }; all.grow(z); }
     for (int a = 0; a < 3; a++) { lo[a] = all.lo[a]; hi[a] = all.hi[a]; }
     float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     pad      = 3e-5f * std::sqrt(dx * dx + dy * dy + dz * dz);
     for (int i = 0; i < n_tris; i++)
         for (int a = 0; a < 3; a++) { tb[i].lo[a] -= pad; tb[i].hi[a] += pad; }
 
-    order.resize(n_tris);
-    for (int i = 0; i < n_tris; i++) order[i] = i;
     nodes.clear();
     nodes.reserve((size_t)n_tris * 2);
     nodes.push_back(BVH2Node {});
 
     struct Job { int node, first, count; };
     std::vector<Job> stack;
-    stack.push_back({ 0, 0, n_tris });
+    stack.push_back({ 0, 0, (int)order.size() });
     const int NB = 16, MAX_LEAF = 4;
     while (!stack.empty())
     {
