@@ -11,6 +11,7 @@
 #include "mask_window.h"
 #include "upsample.h"
 #include "pass_args.h"
+#include "tile_order.h"
 
 using namespace hr;
 
@@ -47,6 +48,8 @@ struct AOTraceArgs
     float              bias, ray_length;
     uint32_t           num_frames;
     int                spp;
+    const uint32_t*    order;      // nullable: launch slot -> tile, last frame's heaviest tiles first (tile_order.h)
+    uint16_t*          cost;       // nullable: per tile, how long its wave lived (100 MHz ticks)
 };
 
 #ifdef HR_TRACE_DIVERGENCE
@@ -85,8 +88,10 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
     __shared__ CoopWave s_coop[AO_TRACE_WAVES];
 #endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * AO_TRACE_WAVES + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;
+    const int launch_slot = blockIdx.x * AO_TRACE_WAVES + wave;
+    if (launch_slot >= a.tiles_x * a.tiles_y) return;
+    const int tile = a.order ? (int)a.order[launch_slot] : launch_slot;
+    const unsigned long long t_begin = a.cost ? wall_clock64() : 0ull;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x + a.tile_y0;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool  active = false;
@@ -193,6 +198,11 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
     if (lane == 0)
     {
         a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint32_t)__popcll(fired) * (uint32_t)a.spp;
+        if (a.cost)
+        {
+            const unsigned long long ticks = wall_clock64() - t_begin;
+            a.cost[tile] = (uint16_t)(ticks > 65535ull ? 65535ull : ticks);
+        }
         if (STATS && a.stats)
         {
             atomicAdd(a.stats + 0, (unsigned long long)nn);
@@ -374,6 +384,7 @@ struct hr_ao
     int           geo_parity = 0, geo_pp = -1;
     const void*   geo_gb2 = nullptr;
     const void*   geo_gb3 = nullptr;
+    TileOrder     tile_order;           // heaviest-first launch order of the trace kernel (tile_order.h)
 };
 
 bool hr::profiling_enabled(const hr_ao* p) { return p && p->prof.enabled; }
@@ -393,6 +404,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
@@ -415,6 +427,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
     if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
 #undef A
+    if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     HR_HIP(hipMemset(p->mask.p, 0, p->mask.bytes));
@@ -481,6 +494,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     a.bias = prm->bias; a.ray_length = prm->ray_length; a.num_frames = in->num_frames; a.spp = prm->spp;
     const int n_tiles = a.tiles_x * a.tiles_y;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    a.order = p->tile_order.order_arg(n_tiles); a.cost = p->want_stats ? nullptr : p->tile_order.cost_arg(n_tiles);
     if (p->want_stats)
     {
         hipLaunchKernelGGL(k_ao_trace<true>, dim3(cdiv(n_tiles, AO_TRACE_WAVES)), dim3(64 * AO_TRACE_WAVES), 0, st, a);
@@ -491,6 +505,11 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     hipLaunchKernelGGL(k_ao_trace<false>, dim3(cdiv(n_tiles, AO_TRACE_WAVES)), dim3(64 * AO_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    if (a.cost)
+    {
+        const hr_status os = p->tile_order.update(n_tiles, st);
+        if (os != HR_OK) return os;
+    }
     return HR_OK;
 }
 

@@ -11,6 +11,7 @@
 #include "shading.h"
 #include "upsample.h"
 #include "pass_args.h"
+#include "tile_order.h"
 #include "ddgi_sample_fast.h"
 
 using namespace hr;
@@ -84,6 +85,8 @@ struct ReflTraceArgs
     int            sample_gi, approximate_with_ddgi;
     float          gi_intensity, rough_ddgi_intensity, ibl_intensity;
     unsigned long long* stats;   // instrumented build only (k_refl_trace<true>): [0] node steps, [1] triangle tests, [2] rays
+    const uint32_t* order;       // nullable: launch slot -> tile, last frame's heaviest tiles first (tile_order.h)
+    uint16_t*       cost;        // nullable: per tile, how long its wave lived (100 MHz ticks)
 };
 
 #ifdef HR_TRACE_DIVERGENCE
@@ -117,8 +120,10 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
     __shared__ CoopWave s_coop[REFL_TRACE_WAVES];
 #endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * REFL_TRACE_WAVES + wave;
-    if (tile >= a.tiles_x * a.tiles_y) return;   // wave-uniform
+    const int launch_slot = blockIdx.x * REFL_TRACE_WAVES + wave;
+    if (launch_slot >= a.tiles_x * a.tiles_y) return;   // wave-uniform
+    const int tile = a.order ? (int)a.order[launch_slot] : launch_slot;
+    const unsigned long long t_begin = a.cost ? wall_clock64() : 0ull;
     const int x = (tile % a.tiles_x) * 8 + (lane & 7), y = (tile / a.tiles_x + a.tile_y0) * 8 + (lane >> 3);
     uint32_t  rays = 0;
     HR_DIV(DivCounters dvp = {}, dvs = {};)
@@ -208,6 +213,11 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
     HR_DIV(div_flush(dvp, g_div_refl); div_flush(dvs, g_div_refl + 8);)
     for (int o2 = 32; o2 > 0; o2 >>= 1) rays += __shfl_down(rays, o2);
     if (lane == 0) a.ray_slots[tile] = rays;
+    if (lane == 0 && a.cost)
+    {
+        const unsigned long long ticks = wall_clock64() - t_begin;
+        a.cost[tile] = (uint16_t)(ticks > 65535ull ? 65535ull : ticks);
+    }
     if (STATS)
     {
         for (int o2 = 32; o2 > 0; o2 >>= 1) { st_n += __shfl_down(st_n, o2); st_t += __shfl_down(st_t, o2); }
@@ -442,6 +452,7 @@ struct hr_reflections
     const void*   geo_gb2 = nullptr;
     const void*   geo_gb3 = nullptr;
     const void*   geo_cur = nullptr;    // this frame's records (a-trous stages), nullptr in the parity mode / for bands
+    TileOrder     tile_order;           // heaviest-first launch order of the trace kernel (tile_order.h)
 };
 
 bool hr::profiling_enabled(const hr_reflections* p) { return p && p->prof.enabled; }
@@ -465,6 +476,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_REFL_FAST_SHADING")) p->fast_shading = atoi(e) != 0;
+    if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
@@ -481,6 +493,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     A(atrous[0], px * 8) A(atrous[1], px * 8) A(upsample, (size_t)full_width * full_height * 8) A(tile_class, (size_t)p->tiles_x * p->tiles_y) A(counters, 64) A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
     if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
 #undef A
+    if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
     *out = p;
@@ -563,8 +576,11 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     a.gi_intensity = prm->gi_intensity; a.rough_ddgi_intensity = prm->rough_ddgi_intensity; a.ibl_intensity = prm->ibl_indirect_specular_intensity;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     a.stats = nullptr;
+    const int n_tiles = a.tiles_x * a.tiles_y;
+    a.order = p->tile_order.order_arg(n_tiles); a.cost = p->tile_order.cost_arg(n_tiles);
     if (p->want_stats)
     {
+        a.cost = nullptr;
         // instrumented build of the same kernel (hr_reflections_trace_stats): counters + 8 .. 32
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 8, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 8);
@@ -577,6 +593,10 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     else hipLaunchKernelGGL((k_refl_trace<false, true>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    if (a.cost)
+    {
+        if ((s = p->tile_order.update(n_tiles, st)) != HR_OK) return s;
+    }
     return HR_OK;
 }
 

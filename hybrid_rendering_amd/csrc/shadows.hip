@@ -11,6 +11,7 @@
 #include "shading.h"
 #include "upsample.h"
 #include "pass_args.h"
+#include "tile_order.h"
 
 using namespace hr;
 
@@ -37,6 +38,8 @@ struct TraceArgs
     uint32_t        num_frames;
     uint32_t*       occluder;  // nullable: per pixel, the index (into tris) of the triangle that occluded its ray last frame (see k_shadows_trace)
     uint32_t        n_tri_refs;
+    const uint32_t* order;     // nullable: launch slot -> tile, heaviest tiles of the last frame first (tile_order.h)
+    uint16_t*       cost;      // nullable: per tile, how long its wave lived (100 MHz ticks)
 };
 
 // One wave = one 8x8 pixel tile = two 8x4 mask words; lane l -> pixel (l & 7, l >> 3), so the
@@ -51,15 +54,14 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
 {
     __shared__ uint32_t s_stack[TRACE_WAVES][HR_STACK_ENTRIES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * TRACE_WAVES + wave;
-    // Row-major tile order.  Measured alternatives (tools/timeline.py): stride permutations lose BVH
-    // locality in L2; heaviest-first order from the previous frame's per-tile wave lifetimes shortens the launch by
-    // ~1 us but needs a 13 us sort — the launch is bounded by its slowest single wave (~72 us with the GPU to itself).
-    if (slot >= a.tiles_x * a.tiles_y) return;
+    const int launch_slot = blockIdx.x * TRACE_WAVES + wave;
+    if (launch_slot >= a.tiles_x * a.tiles_y) return;
+    // Tile order: row-major, or last frame's heaviest tiles first (tile_order.h).  Stride permutations lose BVH locality in L2.
+    const int slot = a.order ? (int)a.order[launch_slot] : launch_slot;
     const int tx = slot % a.tiles_x, ty_local = slot / a.tiles_x, ty = ty_local + a.tile_y0;
     if (a.debug_only_tx >= 0 && (tx != a.debug_only_tx || ty != a.debug_only_ty)) return;
     unsigned long long t_begin = 0;
-    if (a.timeline) t_begin = wall_clock64();
+    if (a.timeline || a.cost) t_begin = wall_clock64();
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     bool      lit = false, fired = false;
     uint32_t  nn = 0, nt = 0, wave_max = 0;
@@ -136,6 +138,11 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
         if (my * 4 >= a.y0 && my * 4 < a.y1) a.mask[(size_t)my * a.mw + tx] = (uint32_t)(bits & 0xffffffffull);
         if ((my + 1) * 4 >= a.y0 && (my + 1) * 4 < a.y1 && (my + 1) * 4 < a.h) a.mask[(size_t)(my + 1) * a.mw + tx] = (uint32_t)(bits >> 32);
         a.ray_slots[(size_t)ty * a.tiles_x + tx] = (uint16_t)__popcll(fb);
+        if (a.cost)
+        {
+            const unsigned long long ticks = wall_clock64() - t_begin;
+            a.cost[slot] = (uint16_t)(ticks > 65535ull ? 65535ull : ticks);
+        }
         if (a.timeline)
         {
             const unsigned long long t_end = wall_clock64();
@@ -564,6 +571,7 @@ struct hr_shadows
     const void*   geo_gb2 = nullptr;        // in->cur.gb2 / gb3 of that frame
     const void*   geo_gb3 = nullptr;
     void*         nd_cur = nullptr;         // the side image of the frame in flight (a-trous stages)
+    TileOrder     tile_order;               // heaviest-first launch order of the trace kernel (tile_order.h)
 };
 
 bool hr::profiling_enabled(const hr_shadows* p) { return p && p->prof.enabled; }
@@ -588,6 +596,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
     p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
     p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
@@ -629,6 +638,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 2)
     A(occluder, px * 4)
 #undef A
+    if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->occluder.p, 0xff, p->occluder.bytes));   // no cached occluder
     HR_HIP(hipMemset(p->counters.p, 0, 64));
     HR_HIP(hipMemset(p->ray_slots.p, 0, p->ray_slots.bytes));
@@ -748,9 +758,11 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     const int n_slots = n_tiles;
     a.debug_only_tx = p->dbg_only_tx; a.debug_only_ty = p->dbg_only_ty;
     a.debug_skip_traversal = p->dbg_skip_traversal ? 1 : 0;
+    a.order = p->tile_order.order_arg(n_tiles); a.cost = p->tile_order.cost_arg(n_tiles);
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
     {
+        a.cost = nullptr;
         // instrumented build of the same kernel: counts node visits / triangle tests
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
@@ -780,6 +792,10 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
+    if (a.cost && !p->persistent_waves)
+    {
+        if ((s = p->tile_order.update(n_tiles, st)) != HR_OK) return s;
+    }
     return HR_OK;
 }
 

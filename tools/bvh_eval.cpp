@@ -474,6 +474,81 @@ int main(int argc, char** argv)
             }
         }
     }
+    if (getenv("DDGI_MAP_STUDY"))
+    {
+        // Which 64 rays should share a wave?  All 16x8x16 probes x 256 rays are walked once (probe rays + the hit points' light / sky rays),
+        // then the per-ray step counts are summed as max-over-lanes under several thread -> (probe, ray) mappings.
+        const int gx = 16, gy = 8, gz = 16, NP = gx * gy * gz, R = 256;
+        std::vector<Counts> c1((size_t)NP * R), c2((size_t)NP * R);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int p = 0; p < NP; p++)
+        {
+            const int ix = p % gx, iy = (p / gx) % gy, iz = p / (gx * gy);
+            const V3 o = mk(b.lo[0] + (b.hi[0] - b.lo[0]) * (ix + 0.5f) / gx, b.lo[1] + (b.hi[1] - b.lo[1]) * (iy + 0.5f) / gy, b.lo[2] + (b.hi[2] - b.lo[2]) * (iz + 0.5f) / gz);
+            for (int i = 0; i < R; i++)
+            {
+                const float phi = 6.2831853f * std::fmod(i * 0.61803398875f, 1.0f), ct = 1.0f - (2.0f * i + 1.0f) / 256.0f, st = std::sqrt(std::fmax(0.0f, 1.0f - ct * ct));
+                Ray s; s.o = o; s.d = mk(std::cos(phi) * st, std::sin(phi) * st, ct); s.tmin = 0.001f; s.tmax = 10000.0f;
+                float t;
+                Counts& a1 = c1[(size_t)p * R + i]; Counts& a2 = c2[(size_t)p * R + i];
+                const int hp = trace_closest(b, s, a1, t);
+                if (hp >= 0)
+                {
+                    const V3 hP = s.o + s.d * t, hN = tri_normal(hp, s.d * -1.0f);
+                    if (dot(hN, L) > 0)
+                    {
+                        Ray q; q.o = hP + hN * 0.1f; q.d = L; q.tmin = 0.01f; q.tmax = 10000.0f;
+                        g_any_mode ? trace_any_x(b, q, 0u, a2) : trace_any(b, q, 0u, a2);
+                    }
+                    V3 T = norm(cross(hN, std::fabs(hN.y) < 0.99f ? mk(0, 1, 0) : mk(1, 0, 0))), B = cross(hN, T);
+                    const float u1 = rnd(i * 31 + p, 5u), u2 = rnd(p, i + 77u), rr = std::sqrt(1.0f - u1), ph = 6.2831853f * u2;
+                    Ray q; q.o = hP + hN * 0.1f; q.d = norm(T * (rr * std::cos(ph)) + B * (rr * std::sin(ph)) + hN * std::sqrt(u1)); q.tmin = 0.01f; q.tmax = 10000.0f;
+                    Counts a3;
+                    g_any_mode ? trace_any_x(b, q, 0u, a3) : trace_any(b, q, 0u, a3);
+                    // the two any-hit traversals of a lane run one after the other, each as a wave-level loop: keep them apart
+                    a2.nodes |= a3.nodes << 16; a2.tris |= a3.tris << 16;
+                }
+            }
+        }
+        auto eval = [&](const char* name, auto&& lane_of) {
+            // lane_of(wave, lane) -> index into c1 / c2
+            double w1n = 0, w1t = 0, w2n = 0, w2t = 0, w3n = 0, w3t = 0;
+            const int n_waves = NP * R / 64;
+            for (int w = 0; w < n_waves; w++)
+            {
+                uint32_t m1n = 0, m1t = 0, m2n = 0, m2t = 0, m3n = 0, m3t = 0;
+                for (int l = 0; l < 64; l++)
+                {
+                    const size_t k = lane_of(w, l);
+                    m1n = std::max(m1n, c1[k].nodes); m1t = std::max(m1t, c1[k].tris);
+                    m2n = std::max(m2n, c2[k].nodes & 0xffffu); m2t = std::max(m2t, c2[k].tris & 0xffffu);
+                    m3n = std::max(m3n, c2[k].nodes >> 16); m3t = std::max(m3t, c2[k].tris >> 16);
+                }
+                w1n += m1n; w1t += m1t; w2n += m2n; w2t += m2t; w3n += m3n; w3t += m3t;
+            }
+            printf("%-28s probe rays: wave-max nodes %6.2f tris %6.2f | light rays %6.2f %6.2f | sky rays %6.2f %6.2f | wave cost %8.0f\n", name, w1n / n_waves, w1t / n_waves,
+                   w2n / n_waves, w2t / n_waves, w3n / n_waves, w3t / n_waves, ((w1n + w2n + w3n) * 230.0 + (w1t + w2t + w3t) * 80.0) / n_waves);
+        };
+        eval("probe-major (shipping)", [&](int w, int l) { return (size_t)w * 64 + l; });
+        eval("ray-major, 64 linear probes", [&](int w, int l) { const int i = w % R, pb = w / R; return (size_t)(pb * 64 + l) * R + i; });
+        eval("ray-major, 4x4x4 probes", [&](int w, int l) {
+            const int i = w % R, blk = w / R, bx = blk % (gx / 4), by = (blk / (gx / 4)) % (gy / 4), bz = blk / ((gx / 4) * (gy / 4));
+            const int px = bx * 4 + (l & 3), py = by * 4 + ((l >> 2) & 3), pz = bz * 4 + (l >> 4);
+            return (size_t)(px + gx * (py + gy * pz)) * R + i; });
+        eval("ray-major, 8x8x1 probes (xz)", [&](int w, int l) {
+            const int i = w % R, blk = w / R, bx = blk % (gx / 8), bz = (blk / (gx / 8)) % (gz / 8), py = blk / ((gx / 8) * (gz / 8));
+            const int px = bx * 8 + (l & 7), pz = bz * 8 + (l >> 3);
+            return (size_t)(px + gx * (py + gy * pz)) * R + i; });
+        eval("16 probes x 4 adjacent rays", [&](int w, int l) {
+            const int ig = w % (R / 4), pb = w / (R / 4); return (size_t)(pb * 16 + (l >> 2)) * R + ig * 4 + (l & 3); });
+        {
+            // lower bound: all rays sorted by cost
+            std::vector<size_t> idx((size_t)NP * R); for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
+            std::sort(idx.begin(), idx.end(), [&](size_t a_, size_t b_) { return c1[a_].nodes * 230 + c1[a_].tris * 80 < c1[b_].nodes * 230 + c1[b_].tris * 80; });
+            eval("all rays sorted by probe-ray cost", [&](int w, int l) { return idx[(size_t)w * 64 + l]; });
+        }
+        return 0;
+    }
     // DDGI: 16x8x16 probes over the scene box (ddgi.cpp:173-237 derives the grid from the extents), every 8th probe, 256 rays
     {
         const int gx = 16, gy = 8, gz = 16;

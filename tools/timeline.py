@@ -21,7 +21,9 @@ torch.cuda.synchronize()
 os.environ['HR_DEBUG_TIMELINE'] = path
 pt = hr.RayTracedShadows(ctx, W, H)
 del os.environ['HR_DEBUG_TIMELINE']
-pt.ray_trace(sc, fi)
+# every call rewrites the file: from the second call on the launch runs in last frame's heaviest-first order (csrc/tile_order.h; HR_TILE_ORDER=0: never)
+for _ in range(int(os.environ.get('TIMELINE_CALLS', '3'))):
+    pt.ray_trace(sc, fi)
 torch.cuda.synchronize()
 pt.close()
 t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
