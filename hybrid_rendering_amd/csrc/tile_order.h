@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t c)
 // representative sample of the image) and writes them to the launch slots of the same class — workgroups are dealt round-robin over
 // the 8 XCDs, so every XCD walks G / 8 interleaved heaviest-first lists.  Per wave a private histogram (plain LDS atomics: most tiles are
 // cheap and share a bucket — one LDS address per wave, not one for the workgroup), then an exclusive prefix in (bucket descending,
-// wave) order, then the scatter with returning LDS atomics.
+// wave) order (a shuffle scan), then the scatter with returning LDS atomics.
 #define HR_ORDER_GROUPS_MIN 8
 #define HR_ORDER_GROUPS_MAX 64
 static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __restrict__ cost, uint32_t* __restrict__ order, int n)
@@ -40,18 +40,17 @@ static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __re
     __syncthreads();
     for (int k = tid; k < n_g; k += 1024) atomicAdd(&s_cnt[wave][order_bucket(cost[(size_t)k * G + g])], 1u);
     __syncthreads();
-    if (tid < HR_ORDER_BUCKETS)
     {
-        uint32_t t = 0u;
-        for (int w = 0; w < 16; w++) t += s_cnt[w][tid];
-        s_tot[tid] = t;
-    }
-    __syncthreads();
-    if (tid < HR_ORDER_BUCKETS)
-    {
-        uint32_t base = 0u;
-        for (int b = HR_ORDER_BUCKETS - 1; b > tid; b--) base += s_tot[b];
-        for (int w = 0; w < 16; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = base; base += c; }
+        // exclusive prefix over the 16 x 64 counters in (bucket descending, wave ascending) order: thread i owns element i of that order
+        const int b = HR_ORDER_BUCKETS - 1 - (tid >> 4), w = tid & 15, lane = tid & 63;
+        const uint32_t v = s_cnt[w][b];
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) s_tot[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0u;
+        for (int k = 0; k < wave; k++) before += s_tot[k];
+        s_cnt[w][b] = before + inc - v;
     }
     __syncthreads();
     for (int k = tid; k < n_g; k += 1024)
