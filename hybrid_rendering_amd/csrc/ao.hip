@@ -494,6 +494,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     a.bias = prm->bias; a.ray_length = prm->ray_length; a.num_frames = in->num_frames; a.spp = prm->spp;
     const int n_tiles = a.tiles_x * a.tiles_y;
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
+    { const hr_status fs = p->tile_order.flush(st); if (fs != HR_OK) return fs; }   // last launch's costs, if no temporal stage took them along
     a.order = p->tile_order.order_arg(n_tiles); a.cost = p->want_stats ? nullptr : p->tile_order.cost_arg(n_tiles);
     if (p->want_stats)
     {
@@ -507,7 +508,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     HR_HIP(hipGetLastError());
     if (a.cost)
     {
-        const hr_status os = p->tile_order.update(n_tiles, st);
+        const hr_status os = p->tile_order.traced(n_tiles, st);
         if (os != HR_OK) return os;
     }
     return HR_OK;
@@ -563,10 +564,15 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     else p->geo_valid = false;
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
     int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);
     if (prm->exact && prm->spp > 1) hipLaunchKernelGGL(k_ao_temporal<true>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
     else if (prm->exact) hipLaunchKernelGGL(k_ao_temporal<false>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
-    else launch_ao_temporal_fast(a, a.tiles_x * a.tiles_y, st);
+    else
+    {
+        a.sort = p->tile_order.ride();   // the trace kernel's next launch order rides along (tile_order.h)
+        launch_ao_temporal_fast(a, a.tiles_x * a.tiles_y, st);
+    }
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

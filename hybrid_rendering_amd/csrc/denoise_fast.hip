@@ -19,6 +19,7 @@
 #include "fast_math.h"
 #include "mask_window.h"
 #include "block_map.h"
+#include "tile_order.h"
 #include "ddgi_sample_fast.h"
 
 #pragma clang fp contract(fast)
@@ -261,6 +262,7 @@ struct Reproj
 template <int GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
+    if (tile_order_rides<64 * FT_WAVES>(a.sort)) return;   // the trace kernel's next launch order, as extra grid rows (tile_order.h)
     const uint2 BLK = block_xy<0>();
     __shared__ uint32_t s_mask[FT_WAVES][1][18];
     __shared__ MaskRows s_rows[FT_WAVES];
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
 template <bool MULTI, int GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArgs a)
 {
+    if (tile_order_rides<64 * FT_WAVES>(a.sort)) return;   // the trace kernel's next launch order, as extra grid rows (tile_order.h)
     const uint2 BLK = block_xy<0>();
     __shared__ uint32_t s_mask[FT_WAVES][4][18];
     __shared__ MaskRows s_rows[FT_WAVES];
@@ -980,6 +983,7 @@ __global__ __launch_bounds__(256) void kf_ao_blur_generic(AOBlurArgs a)
 template <int GEO>
 __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs a)
 {
+    if (tile_order_rides<256>(a.sort)) return;   // the trace kernel's next launch order, as extra grid rows (tile_order.h)
     const uint2 BLK = block_xy<0>();
     constexpr int CW = FR_TW + 2 * FR_R, CH = FR_TH + 2 * FR_R;   // 48 x 24
 #if FR_ALIAS
@@ -1432,10 +1436,19 @@ __global__ __launch_bounds__(256) void kf_upsample(UpsampleArgs a)
 
 namespace hr {
 
-void launch_shadows_temporal_fast(const TemporalArgs& a, int n_tiles, hipStream_t st)
+// a riding sort (TileOrder::ride) goes behind the `rows` grid rows of a temporal launch of `grid_x` workgroups per row: the grid with it
+static dim3 grid_with_sort(TileSortArgs& t, int grid_x, int rows)
 {
-    if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<1>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
-    else hipLaunchKernelGGL(kf_shadows_temporal<0>, dim3(cdiv(a.tiles_x, FT_WAVES), a.tiles_y), dim3(64 * FT_WAVES), 0, st, a);
+    t.row0 = rows;
+    return dim3(grid_x, rows + (t.groups ? cdiv(t.groups, grid_x) : 0));
+}
+
+void launch_shadows_temporal_fast(const TemporalArgs& a_, int n_tiles, hipStream_t st)
+{
+    TemporalArgs a = a_;
+    const dim3 grid = grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
+    if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<1>, grid, dim3(64 * FT_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(kf_shadows_temporal<0>, grid, dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
@@ -1470,9 +1483,10 @@ bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, flo
     return true;
 }
 
-void launch_ao_temporal_fast(const AOTemporalArgs& a, int n_tiles, hipStream_t st)
+void launch_ao_temporal_fast(const AOTemporalArgs& a_, int n_tiles, hipStream_t st)
 {
-    const dim3 grid(cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
+    AOTemporalArgs a = a_;
+    const dim3 grid = grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
     if (a.geo_hist)
     {
         if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 2>), grid, dim3(64 * FT_WAVES), 0, st, a);
@@ -1499,10 +1513,12 @@ bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
     return true;
 }
 
-void launch_refl_temporal_fast(const ReflTemporalArgs& a, hipStream_t st)
+void launch_refl_temporal_fast(const ReflTemporalArgs& a_, hipStream_t st)
 {
-    if (a.geo_hist) hipLaunchKernelGGL(kf_refl_temporal<1>, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(kf_refl_temporal<0>, dim3(cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH)), dim3(256), 0, st, a);
+    ReflTemporalArgs a = a_;
+    const dim3 grid = grid_with_sort(a.sort, cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH));
+    if (a.geo_hist) hipLaunchKernelGGL(kf_refl_temporal<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(kf_refl_temporal<0>, grid, dim3(256), 0, st, a);
 }
 
 void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)

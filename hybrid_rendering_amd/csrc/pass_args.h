@@ -7,6 +7,16 @@
 
 namespace hr {
 
+// A sort of last launch's tile costs into the trace kernel's next launch order, riding along as extra grid rows of a temporal kernel
+// (tile_order.h).  groups == 0: none.
+struct TileSortArgs
+{
+    const uint16_t* cost;
+    uint32_t*       order;
+    int             n, groups;
+    int             row0;   // first grid row of the sort's workgroups
+};
+
 struct TemporalArgs
 {
     float           vpi[16];
@@ -30,6 +40,7 @@ struct TemporalArgs
                                     // band_y1) fell on a row of the image that is not resident on this GPU — the motion exceeded
                                     // hr_band.history_halo (the tap read as disoccluded).  Halo rows are the neighbour's to get right.
     int             band_y0, band_y1;
+    TileSortArgs    sort;           // rides along as extra grid rows (tolerance-mode kernel only)
 };
 
 struct AtrousArgs
@@ -63,6 +74,7 @@ struct AOTemporalArgs
     float           alpha;
     uint32_t*       apron_flag;     // see TemporalArgs
     int             band_y0, band_y1;
+    TileSortArgs    sort;           // rides along as extra grid rows (tolerance-mode kernel only)
 };
 
 struct AOBlurArgs
@@ -94,6 +106,7 @@ struct ReflTemporalArgs
     int         approximate_with_ddgi, moving;
     uint32_t*   apron_flag;         // see TemporalArgs
     int         band_y0, band_y1;
+    TileSortArgs sort;              // rides along as extra grid rows (tolerance-mode kernel only)
 };
 
 struct ReflAtrousArgs

@@ -577,6 +577,7 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     a.stats = nullptr;
     const int n_tiles = a.tiles_x * a.tiles_y;
+    if ((s = p->tile_order.flush(st)) != HR_OK) return s;   // last launch's costs, if no temporal stage took them along
     a.order = p->tile_order.order_arg(n_tiles); a.cost = p->tile_order.cost_arg(n_tiles);
     if (p->want_stats)
     {
@@ -595,7 +596,7 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
     HR_HIP(hipGetLastError());
     if (a.cost)
     {
-        if ((s = p->tile_order.update(n_tiles, st)) != HR_OK) return s;
+        if ((s = p->tile_order.traced(n_tiles, st)) != HR_OK) return s;
     }
     return HR_OK;
 }
@@ -654,9 +655,14 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     p->last_pp = pp;
     p->last_blur_as_input = prm->blur_as_input != 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
     int ev = p->prof.begin("temporal_accumulation", st, px * 80);
     if (prm->exact) hipLaunchKernelGGL(k_refl_temporal, dim3(cdiv(w, RT_TW), cdiv(y1 - y0, RT_TH)), dim3(256), 0, st, a);
-    else launch_refl_temporal_fast(a, st);
+    else
+    {
+        a.sort = p->tile_order.ride();   // the trace kernel's next launch order rides along (tile_order.h)
+        launch_refl_temporal_fast(a, st);
+    }
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -758,6 +758,7 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     const int n_slots = n_tiles;
     a.debug_only_tx = p->dbg_only_tx; a.debug_only_ty = p->dbg_only_ty;
     a.debug_skip_traversal = p->dbg_skip_traversal ? 1 : 0;
+    if ((s = p->tile_order.flush(st)) != HR_OK) return s;   // last launch's costs, if no temporal stage took them along
     a.order = p->tile_order.order_arg(n_tiles); a.cost = p->tile_order.cost_arg(n_tiles);
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     if (p->want_stats)
@@ -792,10 +793,7 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
     else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
-    if (a.cost && !p->persistent_waves)
-    {
-        if ((s = p->tile_order.update(n_tiles, st)) != HR_OK) return s;
-    }
+    if (a.cost && !p->persistent_waves && (s = p->tile_order.traced(n_tiles, st)) != HR_OK) return s;
     return HR_OK;
 }
 
@@ -875,8 +873,13 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
     if (prm->exact) hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, TEMPORAL_WAVES)), dim3(64 * TEMPORAL_WAVES), 0, st, a);
-    else launch_shadows_temporal_fast(a, a.tiles_x * a.tiles_y, st);
+    else
+    {
+        a.sort = p->tile_order.ride();   // the trace kernel's next launch order rides along (tile_order.h)
+        launch_shadows_temporal_fast(a, a.tiles_x * a.tiles_y, st);
+    }
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

@@ -9,6 +9,8 @@
 // the short ones fill the tail.  Every tile is still computed exactly once by the same code: results do not depend on the order.
 #pragma once
 #include "hr_internal.h"
+#include "pass_args.h"
+#include <cstdlib>
 
 namespace hr {
 
@@ -26,23 +28,24 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t c)
 // representative sample of the image) and writes them to the launch slots of the same class — workgroups are dealt round-robin over
 // the 8 XCDs, so every XCD walks G / 8 interleaved heaviest-first lists.  Per wave a private histogram (plain LDS atomics: most tiles are
 // cheap and share a bucket — one LDS address per wave, not one for the workgroup), then an exclusive prefix in (bucket descending,
-// wave) order (a shuffle scan), then the scatter with returning LDS atomics.
+// wave) order (a shuffle scan: one element per thread), then the scatter with returning LDS atomics.
+// THREADS = workgroup size of the kernel this runs in: 1024 alone (k_tile_order), 256 as extra workgroups of a pass's temporal kernel.
 #define HR_ORDER_GROUPS_MIN 8
-#define HR_ORDER_GROUPS_MAX 64
-static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __restrict__ cost, uint32_t* __restrict__ order, int n)
+template <int THREADS>
+__device__ __forceinline__ void tile_order_block(const uint16_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int g, int G)
 {
-    __shared__ uint32_t s_cnt[16][HR_ORDER_BUCKETS];
-    __shared__ uint32_t s_tot[HR_ORDER_BUCKETS];
-    const int g = blockIdx.x, G = gridDim.x;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t s_cnt[WAVES][HR_ORDER_BUCKETS];
+    __shared__ uint32_t s_tot[WAVES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_g = (n - g + G - 1) / G;
     (&s_cnt[0][0])[tid] = 0u;
     __syncthreads();
-    for (int k = tid; k < n_g; k += 1024) atomicAdd(&s_cnt[wave][order_bucket(cost[(size_t)k * G + g])], 1u);
+    for (int k = tid; k < n_g; k += THREADS) atomicAdd(&s_cnt[wave][order_bucket(cost[(size_t)k * G + g])], 1u);
     __syncthreads();
     {
-        // exclusive prefix over the 16 x 64 counters in (bucket descending, wave ascending) order: thread i owns element i of that order
-        const int b = HR_ORDER_BUCKETS - 1 - (tid >> 4), w = tid & 15, lane = tid & 63;
+        // thread i owns element i of the (bucket descending, wave ascending) order
+        const int b = HR_ORDER_BUCKETS - 1 - tid / WAVES, w = tid % WAVES;
         const uint32_t v = s_cnt[w][b];
         uint32_t inc = v;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
@@ -53,7 +56,7 @@ static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __re
         s_cnt[w][b] = before + inc - v;
     }
     __syncthreads();
-    for (int k = tid; k < n_g; k += 1024)
+    for (int k = tid; k < n_g; k += THREADS)
     {
         const uint32_t tile = (uint32_t)k * (uint32_t)G + (uint32_t)g;
         const uint32_t pos  = atomicAdd(&s_cnt[wave][order_bucket(cost[tile])], 1u);
@@ -61,39 +64,83 @@ static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __re
     }
 }
 
-// Host side of one pass: the two side buffers and whether last frame's order may be used.  The sort follows the trace kernel on the
-// caller's stream (capturable into a hipGraph like everything else).  Running it on a side stream beside the denoise kernels was
-// measured and is slower: two cross-stream event waits per frame cost more than the ~4 us kernel (docs/EXPERIMENTS.md R4.4).
+static __global__ __launch_bounds__(1024) void k_tile_order(const uint16_t* __restrict__ cost, uint32_t* __restrict__ order, int n)
+{
+    tile_order_block<1024>(cost, order, n, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Host side of one pass: the two side buffers, whether last frame's order may be used, and who runs the sort.  A launch of its own
+// costs ~6 us of stream time for ~1 us of work (launch, cold loads, kernel boundary), so the sort rides along as a few extra
+// workgroups of the pass's NEXT launch, the tolerance-mode temporal kernel (TileSortArgs in its argument block: the temporal stage
+// does not depend on it, the trace launch before it has finished, and the next trace launch must follow the temporal stage anyway —
+// it overwrites the mask that stage reads).  When no such launch comes (denoiser off, parity mode) the next trace call runs
+// k_tile_order first.  Running the sort on a side stream beside the denoise kernels was measured and is slower: two cross-stream
+// event waits per frame cost more than the kernel (docs/EXPERIMENTS.md R4.4).
 struct TileOrder
 {
     DevBuf cost, order;
     int    n       = 0;
     bool   enabled = true;    // developer A/B switch HR_TILE_ORDER=0 (read once at create)
-    bool   valid   = false;   // `order` holds a permutation of 0..n-1 built from a launch over the same tiles
+    bool   ride_along = true; // developer A/B switch HR_TILE_ORDER_FUSED=0: always a launch of its own
+    bool   valid   = false;   // `order` holds (in stream order) a permutation of 0..n-1 built from a launch over the same tiles
+    bool   pending = false;   // costs of a trace launch are waiting to be sorted
     hr_status init(int n_tiles)
     {
         n = n_tiles;
-        valid = false;
+        valid = pending = false;
+        if (const char* e = getenv("HR_TILE_ORDER_FUSED")) ride_along = atoi(e) != 0;
         if (!enabled) return HR_OK;
         hr_status s = cost.alloc((size_t)n_tiles * 2);
         if (s != HR_OK) return s;
         return order.alloc((size_t)n_tiles * 4);
     }
     bool active(int n_tiles) const { return enabled && n_tiles == n; }   // a pass asked to trace a different region keeps blockIdx order
-    // arguments of the trace launch (nullptr: blockIdx order / no cost record)
-    const uint32_t* order_arg(int n_tiles) const { return active(n_tiles) && valid ? (const uint32_t*)order.p : nullptr; }
-    uint16_t*       cost_arg(int n_tiles) const { return active(n_tiles) ? (uint16_t*)cost.p : nullptr; }
-    // after the trace launch, on the same stream: next frame's order
-    hr_status update(int n_tiles, hipStream_t st)
+    static int groups_for(int n, int threads)
     {
-        if (!active(n_tiles)) return HR_OK;
-        int groups = (n / 2048) & ~7;    // ~2000 tiles per workgroup: two rounds of its 1024 threads
-        groups = groups < HR_ORDER_GROUPS_MIN ? HR_ORDER_GROUPS_MIN : (groups > HR_ORDER_GROUPS_MAX ? HR_ORDER_GROUPS_MAX : groups);
-        hipLaunchKernelGGL(k_tile_order, dim3(groups), dim3(1024), 0, st, (const uint16_t*)cost.p, (uint32_t*)order.p, n);
+        int g = (n / (2 * threads)) & ~7;    // two rounds of the workgroup's threads
+        return g < HR_ORDER_GROUPS_MIN ? HR_ORDER_GROUPS_MIN : (g > 256 ? 256 : g);
+    }
+    // First thing in the pass's trace call: costs nobody has sorted yet get a launch of their own.
+    hr_status flush(hipStream_t st)
+    {
+        if (!pending) return HR_OK;
+        pending = false;
+        hipLaunchKernelGGL(k_tile_order, dim3(groups_for(n, 1024)), dim3(1024), 0, st, (const uint16_t*)cost.p, (uint32_t*)order.p, n);
         HR_HIP(hipGetLastError());
         valid = true;
         return HR_OK;
     }
+    // arguments of the trace launch (nullptr: blockIdx order / no cost record)
+    const uint32_t* order_arg(int n_tiles) const { return active(n_tiles) && valid ? (const uint32_t*)order.p : nullptr; }
+    uint16_t*       cost_arg(int n_tiles) const { return active(n_tiles) ? (uint16_t*)cost.p : nullptr; }
+    // after a trace launch that recorded costs
+    hr_status traced(int n_tiles, hipStream_t st)
+    {
+        if (!active(n_tiles)) return HR_OK;
+        pending = true;
+        return ride_along ? HR_OK : flush(st);
+    }
+    // For the pass's tolerance-mode temporal launch (256-thread workgroups): the sort as extra grid rows behind the launch's own (the
+    // launcher appends them and fills in row0).  groups == 0 when there is nothing to sort.
+    TileSortArgs ride()
+    {
+        TileSortArgs t { nullptr, nullptr, 0, 0, 0 };
+        if (!pending || !enabled) return t;
+        pending = false;
+        valid   = true;
+        t.cost = (const uint16_t*)cost.p; t.order = (uint32_t*)order.p; t.n = n; t.groups = groups_for(n, 256);
+        return t;
+    }
 };
+
+// at the top of a kernel whose argument block carries a TileSortArgs: true = this workgroup was one of the sort's (or a spare one)
+template <int THREADS>
+__device__ __forceinline__ bool tile_order_rides(const TileSortArgs& t)
+{
+    if (t.groups == 0 || (int)blockIdx.y < t.row0) return false;
+    const int g = ((int)blockIdx.y - t.row0) * (int)gridDim.x + (int)blockIdx.x;
+    if (g < t.groups) tile_order_block<THREADS>(t.cost, t.order, t.n, g, t.groups);
+    return true;
+}
 
 } // namespace hr
