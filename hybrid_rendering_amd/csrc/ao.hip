@@ -405,6 +405,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
+    p->tile_order.tag = "ao";
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
     p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
@@ -564,7 +565,7 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     else p->geo_valid = false;
     p->last_pp = pp;
     const uint64_t px = (uint64_t)w * (y1 - y0);
-    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0, 0 };
     int ev = p->prof.begin("temporal_accumulation", st, px * 48 + px * prm->spp / 8);
     if (prm->exact && prm->spp > 1) hipLaunchKernelGGL(k_ao_temporal<true>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);
     else if (prm->exact) hipLaunchKernelGGL(k_ao_temporal<false>, dim3(cdiv(a.tiles_x * a.tiles_y, 4)), dim3(256), 0, st, a);

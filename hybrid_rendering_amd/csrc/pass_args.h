@@ -15,6 +15,7 @@ struct TileSortArgs
     uint32_t*       order;
     int             n, groups;
     int             row0;   // first grid row of the sort's workgroups
+    int             min_spread;   // TileOrder::min_spread
 };
 
 struct TemporalArgs

@@ -477,6 +477,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_REFL_FAST_SHADING")) p->fast_shading = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
+    p->tile_order.tag = "reflections";
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
     if (band && band->band_y1 > band->band_y0)
     {
@@ -655,7 +656,7 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     p->last_pp = pp;
     p->last_blur_as_input = prm->blur_as_input != 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
-    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0, 0 };
     int ev = p->prof.begin("temporal_accumulation", st, px * 80);
     if (prm->exact) hipLaunchKernelGGL(k_refl_temporal, dim3(cdiv(w, RT_TW), cdiv(y1 - y0, RT_TH)), dim3(256), 0, st, a);
     else

@@ -597,6 +597,8 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
+    p->tile_order.tag = "shadows";
+    p->tile_order.min_spread = HR_ORDER_COHERENT_SPREAD;   // rays towards one light: coherent
     p->dbg_skip_traversal = getenv("HR_DEBUG_SKIP_TRAVERSAL") != nullptr;
     p->dbg_skip_reproject = getenv("HR_DEBUG_SKIP_REPROJECT") != nullptr;
     p->dbg_timeline_stats = getenv("HR_DEBUG_TIMELINE_STATS") != nullptr;
@@ -873,7 +875,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     p->last_ping_pong = in->ping_pong ? 1 : 0;
     const uint64_t px = (uint64_t)w * (y1 - y0);
     int ev = p->prof.begin("temporal_accumulation", st, px * 64 + px / 8);
-    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0 };
+    a.sort = TileSortArgs { nullptr, nullptr, 0, 0, 0, 0 };
     if (prm->exact) hipLaunchKernelGGL(k_shadows_temporal, dim3(cdiv(a.tiles_x * a.tiles_y, TEMPORAL_WAVES)), dim3(64 * TEMPORAL_WAVES), 0, st, a);
     else
     {
