@@ -3,7 +3,9 @@
 From the second frame on a trace launch maps blockIdx through a permutation sorted by how long each tile's wave lived in the previous
 frame.  Every tile is still traced exactly once by the same code, so the visibility masks, ray counts, trace images and everything the
 denoisers make of them must be equal BIT FOR BIT — on a ragged image (edge tiles), on a band (fewer tile rows than the image), through
-a history reset and through a statistics pass (which runs in the same order but must not disturb the recorded costs)."""
+a history reset and through a statistics pass (which runs in the same order but must not disturb the recorded costs).  Variants of the
+shadow pass: the sort as a launch of its own instead of riding along with the temporal kernel (HR_TILE_ORDER_FUSED=0), and the
+identity list the pass falls back to when its tile costs are narrowly spread (forced with HR_TILE_ORDER_SPREAD=64)."""
 import os
 
 import numpy as np
@@ -17,12 +19,16 @@ pytestmark = pytest.mark.gpu
 N = 7
 
 
-def _plain_order(make):
-    os.environ["HR_TILE_ORDER"] = "0"
+def _with_env(name, value, make):
+    os.environ[name] = value
     try:
         return make()
     finally:
-        del os.environ["HR_TILE_ORDER"]
+        del os.environ[name]
+
+
+def _plain_order(make):
+    return _with_env("HR_TILE_ORDER", "0", make)
 
 
 def _tables():
@@ -54,7 +60,8 @@ def test_shadows_and_ao_do_not_depend_on_the_launch_order(hr, ctx, name, W, H, b
     sob_d, sr_d = _tables()
     zbp = synth.z_buffer_params()
     kw = {} if band is None else {"band": band}
-    sh = [hr.RayTracedShadows(ctx, W, H, **kw), _plain_order(lambda: hr.RayTracedShadows(ctx, W, H, **kw))]
+    sh = [hr.RayTracedShadows(ctx, W, H, **kw), _plain_order(lambda: hr.RayTracedShadows(ctx, W, H, **kw)),
+          _with_env("HR_TILE_ORDER_FUSED", "0", lambda: hr.RayTracedShadows(ctx, W, H, **kw)), _with_env("HR_TILE_ORDER_SPREAD", "64", lambda: hr.RayTracedShadows(ctx, W, H, **kw))]
     ao = [hr.RayTracedAO(ctx, W, H, 0, **kw), _plain_order(lambda: hr.RayTracedAO(ctx, W, H, 0, **kw))]
     for p in sh + ao:
         p.params.exact = 0
@@ -69,13 +76,14 @@ def test_shadows_and_ao_do_not_depend_on_the_launch_order(hr, ctx, name, W, H, b
             p.render(gsc, fi)
         torch.cuda.synchronize()
         if f == 3:   # the instrumented kernel walks the same order and must leave the cost record alone
-            assert sh[0].trace_stats(gsc, fi) == sh[1].trace_stats(gsc, fi)
+            assert sh[0].trace_stats(gsc, fi) == sh[1].trace_stats(gsc, fi) == sh[2].trace_stats(gsc, fi) == sh[3].trace_stats(gsc, fi)
             assert ao[0].trace_stats(gsc, fi) == ao[1].trace_stats(gsc, fi)
-        a, b = sh
-        _same("shadow mask", f, a.image(a.IMG_MASK), b.image(b.IMG_MASK))
-        _same("shadows a-trous output", f, a.output(hr.OUTPUT_ATROUS), b.output(hr.OUTPUT_ATROUS))
-        _same("shadows moments", f, a.image(a.IMG_MOMENTS1 if f & 1 else a.IMG_MOMENTS0), b.image(b.IMG_MOMENTS1 if f & 1 else b.IMG_MOMENTS0))
-        assert a.ray_count() == b.ray_count()
+        b = sh[1]
+        for a in (sh[0], sh[2], sh[3]):
+            _same("shadow mask", f, a.image(a.IMG_MASK), b.image(b.IMG_MASK))
+            _same("shadows a-trous output", f, a.output(hr.OUTPUT_ATROUS), b.output(hr.OUTPUT_ATROUS))
+            _same("shadows moments", f, a.image(a.IMG_MOMENTS1 if f & 1 else a.IMG_MOMENTS0), b.image(b.IMG_MOMENTS1 if f & 1 else b.IMG_MOMENTS0))
+            assert a.ray_count() == b.ray_count()
         a, b = ao
         _same("AO mask planes", f, a.image(a.IMG_MASK), b.image(b.IMG_MASK))
         _same("blurred AO", f, a.image(a.IMG_BLUR1), b.image(b.IMG_BLUR1))
