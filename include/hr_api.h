@@ -273,7 +273,12 @@ hr_status hr_shadows_output(hr_shadows* p, hr_output_kind kind, hr_image_view* v
 hr_status hr_shadows_reset_history(hr_shadows* p);
 hr_status hr_shadows_destroy(hr_shadows* p);
 /* Stage-level entry points (the private methods ray_trace / temporal_accumulation / a_trous_filter /
- * upsample, ray_traced_shadows.cpp:972-1255) so a multi-GPU driver can exchange halos between them. */
+ * upsample, ray_traced_shadows.cpp:972-1255) so a multi-GPU driver can exchange halos between them.
+ * Launch order: the trace kernels of the shadows, AO and reflections passes record how long each 8x8 tile's wave lived and launch
+ * the next frame's tiles heaviest first (the sort runs inside the pass's tolerance-mode temporal launch, else at the start of the next
+ * trace call).  Outputs do not depend on it.  Like the visibility mask — which the next trace call overwrites and the temporal stage
+ * reads — this state asks for what a frame loop does anyway: a pass's next *_ray_trace call is stream-ordered after its last
+ * *_temporal call. */
 hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
 /* everything of render() after the trace: temporal + a-trous chain (+ upsample); hr_shadows_ray_trace + hr_shadows_denoise == hr_shadows_render.
  * In tolerance mode this (like render) launches a-trous iterations 0 and 1 as ONE kernel; the per-iteration entry point below stays. */
