@@ -248,7 +248,7 @@ typedef struct
                                    denoise / resolve kernels use the hardware's rcp / rsq / sqrt / exp / log and fused multiply-adds
                                    (2-4x faster);
                                    every fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels, with relative L2 error <= 1e-3 over
-                                   those texels and <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) additionally count
+                                   those texels and <= 1e-2 over ALL texels but the counted pixels of the hard cap below; variance channels (shadows .y, reflections .a) additionally count
                                    |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles.  HARD CAP per texel: outside the
                                    neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle, except
                                    for at most max(4, 1e-5 of the pixels) pixels per image (x 5 * 4^scale in a scaled pass's upsampled output) which — like the texels next to a flipped tile — stay
