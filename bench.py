@@ -547,6 +547,9 @@ def run(args, torch, dist, rank, world, local_rank):
                                + (f", same view as 1920x1080 with {world}x the pixels, row-tiled into {world} cost-balanced bands (rows {bounds})" if world > 1 else ""),
                    "math": ("exact = 1: every fp32 operation correctly rounded, all stage images bit-identical to the oracle" if exact else
                             "exact = 0 (shipping mode): visibility masks / ray counts bit-exact, fp16 images within 2 fp16 ulp (rel-L2 <= 1e-3) of the oracle — tests/test_gpu_tolerance.py"),
+                   "trace_launch_order": ("blockIdx order (HR_TILE_ORDER=0)" if os.environ.get("HR_TILE_ORDER") == "0" else
+                                          "last frame's heaviest 8x8 tiles first (csrc/tile_order.h: per-tile wave lifetimes, counting sort riding along with the temporal kernel; "
+                                          "every tile traced once, outputs bit-identical — tests/test_gpu_tile_order.py; valid from the second frame, i.e. inside the warm-up)"),
                    "rays_per_frame_per_gpu": int(rays_per_frame), "pixels_per_gpu": px, "bvh_nodes": int(scene.info.n_nodes),
                    "nodes_per_ray": round(nodes_per_ray, 2), "tris_per_ray": round(tris_per_ray, 2)},
         "timed_repeats": timing["timed_repeats"], "timed_region_ms": timing["timed_region_ms"], "timed_total_ms": timing["timed_total_ms"],
