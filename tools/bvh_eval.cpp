@@ -10,6 +10,7 @@
 //   ao        4 cosine-hemisphere any-hit rays per pixel, length 7, started at entry_node_for_box
 //   refl      one closest-hit mirror ray per pixel of the half-resolution tiles
 //   ddgi      256 spherical-Fibonacci closest-hit rays from every 8th probe of the 16x8x16 grid
+// AO_CANDIDATE_STUDY=1 / DDGI_MAP_STUDY=1 in the environment run one of the offline studies quoted in docs/EXPERIMENTS.md R4.4 instead.
 // and prints per set: node steps / ray, triangle tests / ray, and the same two summed as max-over-the-64-lanes-of-a-wave (what a SIMD
 // issues: the slowest lane of a wave sets its step count), plus the SAH cost of the tree and the build time.
 #include "bvh.h"
@@ -473,6 +474,63 @@ int main(int argc, char** argv)
                 pp.first->worst = std::max(pp.first->worst, pp.second->worst); pp.first->wc.insert(pp.first->wc.end(), pp.second->wc.begin(), pp.second->wc.end());
             }
         }
+    }
+    if (getenv("AO_CANDIDATE_STUDY"))
+    {
+        // How much geometry can the AO rays of one 8x8 tile reach?  Box of the tile's ray origins grown by the ray length, intersected with
+        // the tree: leaves / triangles inside (a per-tile candidate list would replace the per-ray walk: 3.1 node steps + 1.1 triangle tests).
+        std::vector<float> leaves, tris, visits;
+#pragma omp parallel
+        {
+            std::vector<float> ll, lt, lv;
+#pragma omp for schedule(dynamic, 16)
+            for (size_t ti = 0; ti < tile_list.size(); ti++)
+            {
+                const int tx = tile_list[ti] % tiles_x, ty = tile_list[ti] / tiles_x;
+                V3 lo = mk(1e30f, 1e30f, 1e30f), hi = mk(-1e30f, -1e30f, -1e30f);
+                int live = 0;
+                for (int l = 0; l < 64; l++)
+                {
+                    const Ray pr_ = primary((float)(tx * 8 + (l & 7)), (float)(ty * 8 + (l >> 3)));
+                    float t; Counts c;
+                    const int prim = trace_closest(b, pr_, c, t);
+                    if (prim < 0) continue;
+                    const V3 P = pr_.o + pr_.d * t, N = tri_normal(prim, pr_.d * -1.0f), o = P + N * 0.3f;
+                    lo = mk(std::fmin(lo.x, o.x), std::fmin(lo.y, o.y), std::fmin(lo.z, o.z)); hi = mk(std::fmax(hi.x, o.x), std::fmax(hi.y, o.y), std::fmax(hi.z, o.z));
+                    live++;
+                }
+                if (!live) continue;
+                lo = lo - mk(7, 7, 7); hi = hi + mk(7, 7, 7);
+                // box query
+                uint32_t stack[256]; int sp = 0; stack[sp++] = 0;
+                int nl = 0, nt = 0, nv = 0;
+                while (sp)
+                {
+                    const Node8& n = b.nodes[stack[--sp]];
+                    nv++;
+                    const float sc[3] = { std::ldexp(1.0f, (int)n.ex - 127), std::ldexp(1.0f, (int)n.ey - 127), std::ldexp(1.0f, (int)n.ez - 127) };
+                    const float oo[3] = { n.ox, n.oy, n.oz }, l3[3] = { lo.x, lo.y, lo.z }, h3[3] = { hi.x, hi.y, hi.z };
+                    const int nk = n.counts >> 4, ni = n.counts & 15;
+                    for (int i = 0; i < nk; i++)
+                    {
+                        bool in = true;
+                        for (int a = 0; a < 3; a++) in = in && std::fma((float)n.qlo[a][i], sc[a], oo[a]) <= h3[a] && std::fma((float)n.qhi[a][i], sc[a], oo[a]) >= l3[a];
+                        if (!in) continue;
+                        if (i < ni) { if (sp < 256) stack[sp++] = n.child_base + i; }
+                        else { nl++; nt += n.meta[i] >> 5; }
+                    }
+                }
+                ll.push_back((float)nl); lt.push_back((float)nt); lv.push_back((float)nv);
+            }
+#pragma omp critical
+            { leaves.insert(leaves.end(), ll.begin(), ll.end()); tris.insert(tris.end(), lt.begin(), lt.end()); visits.insert(visits.end(), lv.begin(), lv.end()); }
+        }
+        auto pct = [](std::vector<float> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0f : v[(size_t)((v.size() - 1) * q)]; };
+        printf("AO candidate study: %zu tiles; per tile (origins' box + ray length 7):\n", leaves.size());
+        printf("  leaves     p10 %6.0f  p50 %6.0f  p90 %6.0f  p99 %6.0f  max %6.0f\n", pct(leaves, 0.1), pct(leaves, 0.5), pct(leaves, 0.9), pct(leaves, 0.99), pct(leaves, 1.0));
+        printf("  triangles  p10 %6.0f  p50 %6.0f  p90 %6.0f  p99 %6.0f  max %6.0f\n", pct(tris, 0.1), pct(tris, 0.5), pct(tris, 0.9), pct(tris, 0.99), pct(tris, 1.0));
+        printf("  nodes the query visits  p50 %6.0f  p90 %6.0f  max %6.0f\n", pct(visits, 0.5), pct(visits, 0.9), pct(visits, 1.0));
+        return 0;
     }
     if (getenv("DDGI_MAP_STUDY"))
     {
