@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_bvh_selfcheck", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_bvh_selfcheck", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_stats_timed", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -382,10 +382,12 @@ class RayTracedShadows(_Pass):
         _check(lib().hr_shadows_tile_ray_counts(self.h, out.ctypes.data_as(C.POINTER(C.c_uint16)), None, None), "hr_shadows_tile_ray_counts")
         return out
 
-    def trace_stats(self, scene, inputs, stream=None):
-        """(rays, nodes visited, triangles tested) from the instrumented trace kernel."""
+    def trace_stats(self, scene, inputs, stream=None, timed=False):
+        """(rays, nodes visited, triangles tested) from the instrumented trace kernel.  timed=False: the full walk (occluder cache bypassed);
+        timed=True: the kernel render() launches in the pass's present state, cache on (hr_shadows_trace_stats_timed)"""
         out = (C.c_uint64 * 3)()
-        _check(lib().hr_shadows_trace_stats(self.h, scene.h, C.byref(inputs), C.byref(self.params), out, _stream_ptr(stream)), "hr_shadows_trace_stats")
+        fn = lib().hr_shadows_trace_stats_timed if timed else lib().hr_shadows_trace_stats
+        _check(fn(self.h, scene.h, C.byref(inputs), C.byref(self.params), out, _stream_ptr(stream)), "hr_shadows_trace_stats")
         return int(out[0]), int(out[1]), int(out[2])
 
 

@@ -806,14 +806,14 @@ hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps)
     return HR_OK;
 }
 
-hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
+static hr_status shadows_trace_stats_impl(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream, bool walk_only)
 {
     HR_CHECK_ARG(p && out3);
-    // the counts are those of the WALK (SURVEY 8d's BVH term, comparable between frames and builds): the occluder cache, whose
-    // contents depend on the previous frames, is bypassed for the statistics pass
+    // walk_only: the counts are those of the WALK (SURVEY 8d's BVH term, comparable between frames and builds): the occluder cache, whose
+    // contents depend on the previous frames, is bypassed for the statistics pass.  Otherwise: the counts of the kernel render() launches
     const bool cache = p->occluder_cache;
     p->want_stats = true;
-    p->occluder_cache = false;
+    if (walk_only) p->occluder_cache = false;
     hr_status s = hr_shadows_ray_trace(p, scene, in, prm, stream);
     p->want_stats = false;
     p->occluder_cache = cache;
@@ -826,6 +826,16 @@ hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_
     out3[1] = host[2]; out3[2] = host[3];
     p->last_wave_max_steps = host[4];
     return HR_OK;
+}
+
+hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
+{
+    return shadows_trace_stats_impl(p, scene, in, prm, out3, stream, true);
+}
+
+hr_status hr_shadows_trace_stats_timed(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, uint64_t* out3, void* stream)
+{
+    return shadows_trace_stats_impl(p, scene, in, prm, out3, stream, false);
 }
 
 hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream_)

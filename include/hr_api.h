@@ -48,7 +48,8 @@ const char* hr_version(void);
  * built against another revision must not call into this library: compare hr_api_revision() with HR_API_REVISION once at start-up
  * (hr::Context does).  Revision 3 = round 3: hr_*_denoise, hr_hybrid_frame, ticketed hr_comm, HR_ERR_TIMEOUT / HR_ERR_COMM. */
 /* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
-#define HR_API_REVISION 4
+/* revision 5 (round 5): + hr_shadows_trace_stats_timed; structs unchanged */
+#define HR_API_REVISION 5
 int32_t hr_api_revision(void);
 
 /* ---- formats -------------------------------------------------------------------------------- */
@@ -308,6 +309,11 @@ hr_status hr_shadows_tile_ray_counts(hr_shadows* p, uint16_t* out, int32_t* tile
  * returns out3 = { rays fired, BVH nodes visited, triangles tested } — the terms of the trace pass's
  * algorithmic-bytes figure.  Synchronises the stream. */
 hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
+/* hr_shadows_trace_stats counts the full WALK: it bypasses the occluder cache (the triangle that shadowed a pixel last frame is tested before
+ * the walk), whose contents depend on the previous frames.  This variant leaves the cache ON: the counts are those of the kernel a render()
+ * of `in` launches in the pass's present state (bench.py divides THESE by the timed kernel's duration).  It advances the cache exactly as
+ * that trace would; masks and every other output are the same either way. */
+hr_status hr_shadows_trace_stats_timed(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
 /* After hr_shadows_trace_stats: sum over waves of the slowest lane's (node + triangle) steps.  SIMD lane utilisation of
  * the traversal loop = (nodes + triangles) / (64 * wave_max_steps). */
 hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps);

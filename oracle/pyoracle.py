@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libhr_oracle.so")
+_REPLAY8_PATH = os.path.join(_HERE, "_build", "libhr_replay8.so")
 _lib = None
+_replay8 = None
 
 c_f32p = C.POINTER(C.c_float)
 c_u8p = C.POINTER(C.c_uint8)
@@ -26,10 +28,11 @@ c_u64p = C.POINTER(C.c_uint64)
 
 def build(force: bool = False) -> str:
     """Compile oracle/_build/libhr_oracle.so with the committed Makefile."""
-    if force or not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+    builder = [os.path.join(_HERE, "..", "hybrid_rendering_amd", "csrc", f) for f in ("bvh_build.cpp", "bvh.h")]   # compiled into libhr_replay8.so
+    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(_REPLAY8_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_REPLAY8_PATH))
         for f in os.listdir(_HERE) if f.endswith((".cpp", ".h", "Makefile"))
-    ):
+    ) or any(os.path.exists(b) and os.path.getmtime(b) > os.path.getmtime(_REPLAY8_PATH) for b in builder):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -98,6 +101,43 @@ def _p(a, t):
 def _ubo_ptr(ubo: np.ndarray):
     assert ubo.nbytes == 416
     return C.c_void_p(ubo.ctypes.data)
+
+
+class Replay8:
+    """CPU replay of the PRODUCT's 8-wide BVH (oracle/orc_replay8.cpp): the tree the GPU walks, built by the product's host builder, walked on
+    the host cores with the oracle's watertight triangle test.  bench.py's cpu_baseline.trace_replay_same_tree and the tests that pin it."""
+
+    def __init__(self, sd):
+        global _replay8
+        if _replay8 is None:
+            if not os.path.exists(_REPLAY8_PATH):
+                build()
+            _replay8 = C.CDLL(_REPLAY8_PATH)
+            _replay8.orc_replay8_create.restype = C.c_void_p
+            set_threads()
+        self.verts = np.ascontiguousarray(sd.verts, np.float32)
+        self.h = C.c_void_p(_replay8.orc_replay8_create(_p(self.verts, c_f32p), C.c_int(sd.n_tris)))
+
+    def num_nodes(self):
+        return int(_replay8.orc_replay8_num_nodes(self.h))
+
+    def num_refs(self):
+        return int(_replay8.orc_replay8_num_refs(self.h))
+
+    def any_hit(self, rays: np.ndarray, stats=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), np.uint8)
+        st = np.zeros(2, np.uint64) if stats else None
+        _replay8.orc_replay8_any_hit_batch(self.h, C.c_int(len(rays)), _p(rays, c_f32p), _p(out, c_u8p), _p(st, c_u64p))
+        return (out, st) if stats else out
+
+    def __del__(self):
+        try:
+            if self.h and _replay8 is not None:
+                _replay8.orc_replay8_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class Scene:

@@ -20,6 +20,39 @@ def _last_json(stdout):
     return json.loads(lines[0])
 
 
+def test_line_is_compact():
+    """BENCH_r04.parsed was null because the line had grown to 23 KB.  The stdout line is a pure function of the full record
+    (bench.compact_line); built from the round-4 record — and from one inflated well past it — it must stay under 7000 bytes (the driver keeps an
+    ~8 KB tail of stdout) and keep the contract's fields, `roofline` and `cpu_baseline`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_n", "bench.json")))
+    assert len(json.dumps(full)) > 20000          # the record that did not parse
+    for inflate in (False, True):
+        rec = json.loads(json.dumps(full))
+        if inflate:
+            rec["passes"]["note"] = "x" * 20000
+            rec["roofline"]["note"] = "y" * 5000
+            rec["config"]["workload"] += " " + "z" * 3000
+            rec["cpu_baseline"]["sample"] = "s" * 4000
+            rec["error"] = "e" * 4000
+            rec["stages"].update({f"extra_{i}": dict(rec["stages"]["ray_trace"]) for i in range(40)})
+        line = json.dumps(bench.compact_line(rec))
+        assert len(line.encode()) < bench.LINE_LIMIT <= 7000, len(line)
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in d, k
+        assert d["config"]["workload"].startswith("1920x1080")
+        assert d["roofline"]["bound"] in ("hbm", "mfma", "valu", "latency") and d["roofline"]["frac"] > 0 and d["roofline"]["peak"] == 8000.0 and "traffic" in d["roofline"]
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["sample"]
+        if not inflate:
+            assert set(d["passes"]["4k"]) == set(d["passes"]["1080p"]) == {"shadows", "ao", "reflections", "ddgi"}
+            assert all(set(v) >= {"ms", "frac", "bound"} for v in d["passes"]["4k"].values())
+            assert d["passes"]["hybrid_frame_ms"]["4k"]["serial"] > 0 and d["passes"]["hard_tier"]["ms_per_frame"] > 0
+    # a record with nothing in it (the watchdog's stub) goes through as well
+    assert json.loads(json.dumps(bench.compact_line({"metric": "m", "value": 0.0, "error": "boom"})))["error"] == "boom"
+
+
 def test_watchdog_prints_the_line_and_exits_nonzero():
     env = dict(os.environ, HR_BENCH_TIMEOUT_S="0.3")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
@@ -57,3 +90,25 @@ def test_gpu_two_ranks_on_one_gpu_report_comm_error():
     assert d["comm"]["error"], d
     if "watchdog" not in d["comm"]["error"]:
         assert d["requested_gpus"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0, d
+
+
+@pytest.mark.gpu
+def test_gpu_bench_line_as_the_driver_runs_it():
+    """the driver's own command (BENCH_rNN: `python3 bench.py --gpus 1 --steps 20 --warmup 5`): the LAST stdout line is one JSON object < 7000 bytes
+    with the contract's fields, a live `roofline` and a `cpu_baseline`; the full record sits in bench_detail.json"""
+    env = dict(os.environ, HR_BENCH_CPU_SECONDS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) < 7000, len(last)
+    d = _last_json(out.stdout)
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma", "valu", "latency") and 0 < r["frac"] and r["achieved"] > 0 and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["frac_is_requested_bytes"] is True
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["config"]["nodes_per_ray"] <= d["config"]["nodes_per_ray_full_walk"]      # the occluder cache only ever shortens the walk
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
+    assert set(d["passes"]["4k"]) == {"shadows", "ao", "reflections", "ddgi"}
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    assert detail["value"] == d["value"] and "kernels" in detail["passes"]["ao"]

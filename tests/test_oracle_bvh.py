@@ -56,3 +56,20 @@ def test_cornell_known_answers(oracle):
     assert abs(tuv[0, 0] - 50.0) < 1e-4                               # back wall
     # t_min is exclusive-ish: a hit closer than t_min is ignored
     r = ray((50, 0.005, 50), (0, -1, 0)); assert sc.any_hit(r)[0] == 0
+
+
+def test_replay8_walk_of_the_products_tree_gives_the_oracles_answers(oracle):
+    """oracle/orc_replay8.cpp (bench.py's cpu_baseline.trace_replay_same_tree): the PRODUCT's 8-wide tree, built by the product's builder and
+    walked on the host, must answer every any-hit query as the oracle's BVH2 / brute force does — and in far fewer node steps"""
+    for name, n in (("cornell", 50_000), ("sponza_small", 20_000)):
+        sd = helpers.scene_data(name)
+        sc, rp = oracle.Scene(sd), oracle.Replay8(sd)
+        assert rp.num_nodes() > 0 and rp.num_refs() >= sd.n_tris
+        r = _rays(sd, n, 21)
+        a = sc.any_hit(r)
+        b, st = rp.any_hit(r, stats=True)
+        assert np.array_equal(a, b)
+        assert np.array_equal(b, rp.any_hit(r))                       # the uninstrumented (timed) path
+        _, st2 = sc.any_hit(r[:4000], stats=True)
+        _, st8 = rp.any_hit(r[:4000], stats=True)
+        assert 0 < st8[0] < st2[0], (st8, st2)                        # an 8-wide node step replaces several BVH2 steps
