@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
-    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_bvh_selfcheck", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_stats_timed", "hr_shadows_trace_divergence", "hr_selftest_math",
+    "hr_gbuffer_mip_nearest", "hr_bvh_build_info", "hr_bvh_selfcheck", "hr_shadows_ray_count", "hr_shadows_tile_ray_counts", "hr_shadows_trace_stats", "hr_shadows_trace_stats_timed", "hr_shadows_launch_order", "hr_shadows_trace_divergence", "hr_selftest_math",
 ]
 
 _lib = None
@@ -328,6 +328,17 @@ class _Pass:
     def reset_history(self):
         _check(getattr(lib(), self._prefix + "_reset_history")(self.h), self._prefix + "_reset_history")
 
+    def launch_order(self) -> np.ndarray:
+        """the trace kernel's launch list (launch slot -> 8x8 tile) as its next launch will read it: always a permutation; the identity
+        until the first sort has run (hr_shadows_launch_order / hr_ao_launch_order)"""
+        fn = getattr(lib(), self._prefix + "_launch_order")
+        n = C.c_int32(0)
+        _check(fn(self.h, None, C.byref(n)), self._prefix + "_launch_order")
+        out = np.zeros(n.value, np.uint32)
+        if n.value:
+            _check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), None), self._prefix + "_launch_order")
+        return out
+
     def close(self):
         if self.h:
             getattr(lib(), self._prefix + "_destroy")(self.h)
@@ -437,4 +448,4 @@ class RayTracedAO(_Pass):
 
 ABI_SYMBOLS += ["hr_ao_default_params", "hr_ao_create", "hr_ao_render", "hr_ao_output", "hr_ao_reset_history", "hr_ao_destroy", "hr_ao_ray_trace",
                 "hr_ao_denoise", "hr_ao_temporal", "hr_ao_blur", "hr_ao_upsample", "hr_ao_image", "hr_ao_history_apron_exceeded", "hr_ao_set_profiling", "hr_ao_get_stage_times", "hr_ao_ray_count",
-                "hr_ao_trace_stats"]
+                "hr_ao_trace_stats", "hr_ao_launch_order"]

@@ -426,7 +426,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     A(tile_class, (size_t)p->tiles_x * p->tiles_y)
     A(counters, 64)
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
-    if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
+    if (p->geo_history) { A(geo[0], px * 8) A(geo[1], px * 8) }   // (round 5: bands too — see hr_ao_temporal)
 #undef A
     if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -444,7 +444,7 @@ hr_status hr_ao_destroy(hr_ao* p)
     delete p;
     return HR_OK;
 }
-hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; return HR_OK; }
+hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; p->tile_order.invalidate(); return HR_OK; }
 hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
 {
     HR_CHECK_ARG(p && exceeded);
@@ -515,6 +515,12 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     return HR_OK;
 }
 
+hr_status hr_ao_launch_order(hr_ao* p, uint32_t* out, int32_t* n_tiles)
+{
+    HR_CHECK_ARG(p);
+    return p->tile_order.read(out, n_tiles, p->last_stream);
+}
+
 hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, uint64_t* out3, void* stream)
 {
     HR_CHECK_ARG(p && out3);
@@ -554,9 +560,14 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
     a.w = w; a.h = p->h; a.y0 = y0; a.y1 = y1;
     a.tile_y0 = y0 / 8; a.tiles_x = p->tiles_x; a.tiles_y = cdiv(y1, 8) - a.tile_y0;
     a.alpha = prm->alpha;
-    a.geo_hist = nullptr; a.geo_out = nullptr;
+    a.geo_hist = nullptr; a.geo_out = nullptr; a.geo_band = 0;
     if (!prm->exact && p->geo[0].p)
     {
+        // A band (round 5) reprojects from the records as well, but takes only the GEOMETRY from them (a.geo_band: GEO = 1, the AO history stays
+        // with the R16F image): the rows next to a band boundary hold the neighbour's AO history after the per-frame exchange
+        // (hr_ao_exchange_history), the record's AO half there is this GPU's own redundant result.  The geometry half is a copy of the
+        // G-buffer either way, and a band computes — and so records — every row it reads history from (history_halo == halo for AO).
+        a.geo_band = (y0 > 0 || y1 < p->h) ? 1 : 0;
         if (p->geo_valid && !p->first_frame && pp != p->geo_pp && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3) a.geo_hist = p->geo[p->geo_parity].p;
         p->geo_parity ^= 1;
         a.geo_out = p->geo[p->geo_parity].p;

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
 #else
     HitRec h;
     h.prim = -1;
-    if (valid) h = trace_closest<STATS>(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp), &st_n, &st_t);
+    DivCounters* dvp_ptr = nullptr;   // (without HR_TRACE_DIVERGENCE the HR_DIV() argument vanished and &st_n slid into the `dv` slot)
+    HR_DIV(dvp_ptr = &dvp;)
+    if (valid) h = trace_closest<STATS>(a.nodes, a.tris, origin, dir, 0.001f, 10000.0f, s_stack[wave], lane, dvp_ptr, &st_n, &st_t);
 #endif
     if (valid)
     {

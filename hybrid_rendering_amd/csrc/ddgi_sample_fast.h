@@ -8,6 +8,7 @@
 #pragma once
 #include "fast_math.h"
 #include "shading.h"
+#include "exact_predicates.h"
 
 #pragma clang fp contract(fast)
 
@@ -45,8 +46,37 @@ HR_DEV Bilin bilin_setup(float x, float y, int w, int h)   // x, y in texel unit
 // (gi_common.glsl:299-320), NaN components replaced by 0.5 as the shader does.
 // UNROLL: the eight probes fully unrolled (their fetches overlap; 102 VGPRs — right for the stand-alone sample kernel) or as a rolled loop
 // (for the hit shading inside a trace kernel, whose occupancy the unrolled form would halve: shading.h sample_irradiance has the same note).
+//
+// WHERE THE FAST FORM IS NOT TRUSTED (round 5; tools/ddgi_pixel_terms.py and tools/ddgi_conditioning.py show the two cases on the CPU).  The
+// gather is a weighted mean whose weights span 17 orders of magnitude (an occluded probe is crushed to 2.5e-17), and two things in it are not
+// continuous:
+//   (a) the trilinear factor of a probe plane the shading point lies ON is exactly 0 in the parity arithmetic ((P - base) / step == 0: walls on
+//       the planes of a grid fitted to the scene's bounds) and ~1e-7 here (P, the quotient and the clamp each differ by an ulp).  When every
+//       probe that does count is crushed, that 1e-7 of an unoccluded probe on the "zero" plane outweighs them all: the pixel shows ANOTHER
+//       probe's irradiance.  Test: leak = 2e-7 x (largest weight before its trilinear factor) against 1e-3 x sum_w.
+//   (b) INFINITE second moments.  The depth atlas is RG16F (ddgi.cpp:197-201) and holds the squared hit distance: beyond 256 units it
+//       overflows to inf, and it stays inf (the hysteresis blend keeps it).  With var = inf the Chebyshev visibility
+//       `dist <= mean ? 1 : (var / (var + (dist - mean)^2))^3` (gi_common.glsl:262-273) is a STEP at dist == mean (inf / inf = NaN -> 0 through
+//       the max), and the bilinear fetch itself is discontinuous at every texel boundary next to an inf texel (mix(inf, x, t) is inf for
+//       t < 1 and x at t == 1): an ulp of dist, mean or of the atlas coordinate decides whether a probe weighs 1 or 1e-6.  Only possible
+//       when max_distance^2 overflows fp16 — a wave-uniform test on the uniforms, false for any grid whose probes are less than ~170 units
+//       apart (the bench grid: 47-75) — so the per-probe tests sit behind a uniform branch: |dist - mean| <= g with var not finite
+//       (g = 4e-6 (|P|_1 + |grid|_1 + dist + mean) >= 10x the error of the fast dist - mean), or the footprint within 2e-4 texels of a
+//       texel boundary (the fast coordinates are good to a few ulp of ~150).  In that regime a third of the waves take the redo: it is the
+//       regime in which the reference's own arithmetic is NaN-driven, and exactness is what can still be compared.
+//       (Measured and dropped: the same note wherever var < 2e-4 mean^2, "steep" — +19 % on the 1080p bench frame for no outlier it
+//       explained; every diagnosed outlier was (a) or an inf.)
+// A pixel that meets either is REDONE with the parity kernels' own gather (shading.h sample_irradiance_net on their operands: exact_inputs) —
+// a handful of pixels per frame on the bench scene (0.005 % of the pixels have sum_w < 1e-3), so the hot loop carries only the tests.
+// exact_inputs(P, N, Wo): fills in the PARITY kernels' operands of this shading point (only called by the redo); a caller whose P, N, Wo
+// already are those values passes them back (SameInputs).
+struct SameInputs
+{
+    f3 P, N, Wo;
+    HR_DEV void operator()(f3& p, f3& n, f3& wo) const { p = P; n = N; wo = Wo; }
+};
 template <bool UNROLL>
-HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irr, const AtlasRG& dep)
+HR_DEV f3 sample_irradiance_pass(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irr, const AtlasRG& dep, bool& redo, bool dbg = false)
 {
     const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]), g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
     const f3 igs = mk3(fm::rcp(gs.x), fm::rcp(gs.y), fm::rcp(gs.z));
@@ -69,6 +99,13 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
     const DivBy    Ddw = div_prepare((float)dep.w), Ddh = div_prepare((float)dep.h);
     f3    sum = mk3(0.0f, 0.0f, 0.0f);
     float sum_w = 0.0f;
+    // (b): the part of the guard that does not depend on the probe (probe positions lie inside the grid: |pp|_1 <= |grid|_1)
+    const float G = 4e-6f * (__builtin_fabsf(P.x) + __builtin_fabsf(P.y) + __builtin_fabsf(P.z)
+                             + fm::fmax_(__builtin_fabsf(g0.x), __builtin_fabsf(g0.x + gs.x * (float)(nx - 1))) + fm::fmax_(__builtin_fabsf(g0.y), __builtin_fabsf(g0.y + gs.y * (float)(ny - 1)))
+                             + fm::fmax_(__builtin_fabsf(g0.z), __builtin_fabsf(g0.z + gs.z * (float)(nz - 1))));
+    const bool wild_possible = !(d.max_distance * d.max_distance < 60000.0f);
+    bool  noted  = false;
+    float max_nt = 0.0f;   // (a): the largest weight before its trilinear factor
     auto probe = [&](const int i) {
         const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
         const int cx = clampi(bx + ox, 0, nx - 1), cy = clampi(by + oy, 0, ny - 1), cz = clampi(bz + oz, 0, nz - 1);
@@ -92,10 +129,17 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
             const float mean = fm::bilerp_rn(fm::lo(t00), fm::lo(t10), fm::lo(t01), fm::lo(t11), b.fx, b.fy);
             const float m2   = fm::bilerp_rn(fm::hi(t00), fm::hi(t10), fm::hi(t01), fm::hi(t11), b.fx, b.fy);
             const float variance = fm::cheb_variance_rn(mean, m2);
-            const float dm  = fm::fmax_(dist - mean, 0.0f);
+            const float dmr = dist - mean, dm = fm::fmax_(dmr, 0.0f);
             float che = variance * fm::rcp(variance + dm * dm);
             che       = fm::fmax_(che * che * che, 0.0f);
-            weight *= (dist <= mean) ? 1.0f : che;
+            const float vis = (dist <= mean) ? 1.0f : che;
+            if (wild_possible)   // wave-uniform (see (b) above)
+            {
+                const float g = G + 4e-6f * (dist + mean);
+                const bool  edge = (b.fx < 2e-4f) | (b.fx > 1.0f - 2e-4f) | (b.fy < 2e-4f) | (b.fy > 1.0f - 2e-4f);
+                noted = noted || edge || (!(variance < 3.0e38f) && __builtin_fabsf(dmr) <= g);
+            }
+            weight *= vis;
         }
         weight = fm::fmax_(0.000001f, weight);
         const uint32_t io = (uint32_t)((cz * (is + 2) + niy) * irr.w + col * (is + 2) + nix) * 8u;
@@ -104,9 +148,13 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
         const float ig = w00 * fm::hi(q00.x) + w10 * fm::hi(q10.x) + w01 * fm::hi(q01.x) + w11 * fm::hi(q11.x);
         const float ib = w00 * fm::lo(q00.y) + w10 * fm::lo(q10.y) + w01 * fm::lo(q01.y) + w11 * fm::lo(q11.y);
         if (weight < 0.2f) weight *= weight * weight * 25.0f;   // crush tiny weights (1 / 0.2^2)
+        max_nt = fm::fmax_(max_nt, weight);
         weight *= tri.x * tri.y * tri.z;
         sum.x += fm::sqrt1(ir) * weight; sum.y += fm::sqrt1(ig) * weight; sum.z += fm::sqrt1(ib) * weight;   // sqrt-space blending (LINEAR_BLENDING undefined)
         sum_w += weight;
+#ifdef HR_DEBUG_DDGI_PIXEL
+        if (dbg) printf("[ddgi dbg] probe %d cell (%d %d %d) tri %.9g %.9g %.9g weight %.9g sum_w %.9g max_nt %.9g noted %d ir %.9g\n", i, cx, cy, cz, tri.x, tri.y, tri.z, weight, sum_w, max_nt, (int)noted, ir);
+#endif
         };
     if constexpr (UNROLL)
     {
@@ -121,14 +169,36 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
     const float iw = fm::rcp(sum_w);
     f3 net = mk3(sum.x * iw, sum.y * iw, sum.z * iw);
     net.x = (net.x != net.x) ? 0.5f : net.x; net.y = (net.y != net.y) ? 0.5f : net.y; net.z = (net.z != net.z) ? 0.5f : net.z;
+    redo = noted || (2e-7f * max_nt > 1e-3f * sum_w);
+#ifdef HR_DEBUG_DDGI_PIXEL
+    if (dbg) printf("[ddgi dbg] P %.9g %.9g %.9g base %d %d %d alpha %.9g %.9g %.9g net %.9g %.9g %.9g redo %d\n", P.x, P.y, P.z, bx, by, bz, alpha.x, alpha.y, alpha.z, net.x, net.y, net.z, (int)redo);
+#endif
+    return net;
+}
+
+template <bool UNROLL, typename ExactInputs>
+HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irr, const AtlasRG& dep, const ExactInputs& exact_inputs, bool dbg = false)
+{
+    bool redo;
+    f3   net = sample_irradiance_pass<UNROLL>(d, P, N, Wo, irr, dep, redo, dbg);
+    if (redo)   // rare: the parity kernels' own gather for this shading point
+    {
+        f3 eP, eN, eWo;
+        exact_inputs(eP, eN, eWo);
+        net = hr::sample_irradiance_net(d, eP, eN, eWo, irr, dep);
+#ifdef HR_DEBUG_DDGI_PIXEL
+        if (dbg) printf("[ddgi dbg] redone: eP %.9g %.9g %.9g net %.9g %.9g %.9g\n", eP.x, eP.y, eP.z, net.x, net.y, net.z);
+#endif
+    }
     return net;
 }
 
 // the value gi_common.glsl's sample_irradiance returns: net^2 * energy_preservation * pi / 2
+// P, N, Wo: the parity kernels' operands (the hit shading computes them with the parity arithmetic in both modes)
 template <bool UNROLL>
 HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irr, const AtlasRG& dep)
 {
-    const f3    net = sample_irradiance_net<UNROLL>(d, P, N, Wo, irr, dep);
+    const f3    net = sample_irradiance_net<UNROLL>(d, P, N, Wo, irr, dep, SameInputs { P, N, Wo });
     const float k   = d.energy_preservation * (0.5f * HR_M_PI);
     return mk3(net.x * net.x * k, net.y * net.y * k, net.z * net.z * k);
 }

@@ -20,9 +20,17 @@
 #include "mask_window.h"
 #include "block_map.h"
 #include "tile_order.h"
+#include "exact_predicates.h"   // before any contract(fast): the knife-edge fallbacks keep the parity kernels' arithmetic
 #include "ddgi_sample_fast.h"
 
 #pragma clang fp contract(fast)
+
+#ifndef HR_TAP_REDO
+#define HR_TAP_REDO 1      // developer A/B: 0 = no second run of the pixel program (round 4's behaviour)
+#endif
+#ifndef HR_TAP_BAND
+#define HR_TAP_BAND 0.4f   // scale of the guard bands of Reproj::tap_valid (developer A/B; 0: never in doubt, the cold copy stays compiled in).  Measured at 1080p, shadows temporal: 0 -> +0 %, 0.3 -> +2.4 %, 1.0 -> +8 % (how often a wave runs twice); 0.4 keeps >= 3x the error bound of the fast operands
+#endif
 
 using namespace hr;
 
@@ -60,7 +68,8 @@ struct Reproj
     const void* __restrict__  geo;          // GEO: previous frame's {oct normal, mesh id | linear z} records
     HistGeom   g;
     f3         cur_pos, cur_n;
-    float      cur_id, hfx, hfy;
+    float      cur_id, hfx, hfy, band;
+    uint32_t   near13;       // resolve<NOTE>: bit s (< 4) = bilinear tap s on a knife edge, bit 4 + k = tap k of the 3x3 fallback
     int        hcx, hcy;
     bool       inb, lok, tok[4], apron_miss;   // apron_miss: the footprint touched an image row that is not resident (row bands)
     fm::Unproj hb;
@@ -68,14 +77,24 @@ struct Reproj
     uint32_t   mlen[4];
     float      td[4];
 
-    // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel; branch-free
-    HR_DEV bool tap_valid(uint32_t q2x, uint32_t q3y, float d) const
+    // texel (px, py) of the previous frame passes is_reprojection_valid (reprojection.glsl:52-67) for this pixel; branch-free.
+    // NOTE (shadows / AO): `near` = the tap sits inside a guard band around one of the two thresholds, where the fast operands cannot be
+    // trusted with the decision (they are good to ~3 ulp of the positions' coordinates; the parity kernels round every operation):
+    // |plane distance - 5| < band = HR_TAP_BAND (1e-4 + 3e-6 |p|_1) (cur_pos and the tap's position are each good to ~3 ulp of their
+    // coordinates, their difference along the normal to ~4e-7 |p|_1), |cos^2 - 0.1 |n'|^2| <= HR_TAP_BAND 4e-6 |n'|^2 (fast: ~1e-7).  Branch-free, 4 VALU per tap.  The bands decide how often a wave runs its pixels twice
+    // (first version, 0.01 + 1.6e-5 |p|_1 and 4e-4: shadows temporal +18 %, AO +15 % at 1080p; docs/EXPERIMENTS.md R5.1).
+    template <bool NOTE>
+    HR_DEV bool tap_valid(uint32_t q2x, uint32_t q3y, float d, bool& near) const
     {
         const f3    hn = fm::oct_raw(q2x);
-        const float dn = fm::dot(cur_n, hn);
+        const float dn = fm::dot(cur_n, hn), hh = fm::dot(hn, hn);
         const f3    hp = fm::unproject_at(hb, M, d);
-        const float pd = fm::dot(sub3(cur_pos, hp), cur_n);
-        return ((int)inb & (int)(cur_id == fm::lo(q3y)) & (int)!(__builtin_fabsf(pd) > 5.0f) & (int)(dn * dn > 0.1f * fm::dot(hn, hn))) != 0;
+        const float pd = __builtin_fabsf(fm::dot(sub3(cur_pos, hp), cur_n));
+        const float t  = dn * dn - 0.1f * hh;
+        const int   pre = (int)inb & (int)(cur_id == fm::lo(q3y));
+        near = false;
+        if constexpr (NOTE) near = (pre & ((int)(__builtin_fabsf(pd - 5.0f) < band) | (int)(__builtin_fabsf(t) <= (HR_TAP_BAND * 4e-6f) * hh))) != 0;
+        return (pre & (int)!(pd > 5.0f) & (int)(t > 0.0f)) != 0;
     }
     HR_DEV uint32_t tap_offset(int px, int py, bool& ok) const
     {
@@ -104,6 +123,7 @@ struct Reproj
         const float tu = ((float)x + 0.5f) * inv_w, tv = ((float)y + 0.5f) * inv_h;
         const float mvx = fm::lo(c2y), mvy = fm::hi(c2y);
         cur_pos = fm::unproject_at(fm::unproject_base(M, tu, tv), M, depth);
+        band    = HR_TAP_BAND * 1e-4f + (HR_TAP_BAND * 3e-6f) * (__builtin_fabsf(cur_pos.x) + __builtin_fabsf(cur_pos.y) + __builtin_fabsf(cur_pos.z));   // tap_valid<true>
         hfx = (float)x + mvx * fw; hfy = (float)y + mvy * fh;   // mv (fp16) * extent (<= 2^12) is exact: same texel as the exact mode
         if (REFL)
         {
@@ -172,11 +192,15 @@ struct Reproj
         else lraw = fm::ld<uint16_t>(hist_len, loff * 2u);
     }
 
-    HR_DEV bool resolve(ReprojOut& o) const
+    // NOTE = true (shadows, AO): taps on a knife edge are recorded in near13.  `known` (bit layout of near13): taps whose validity is
+    // taken from `ovr` — the parity kernels' verdicts of exact_bits() — instead of the fast test (and which are then not noted again).
+    template <bool NOTE = false>
+    HR_DEV bool resolve(ReprojOut& o, uint32_t ovr = 0u, uint32_t known = 0u)
     {
         const float fx = hfx - __builtin_floorf(hfx), fy = hfy - __builtin_floorf(hfy);
         const float wgt[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
         float sumw = 0.0f, col[NC], mom0 = 0.0f, mom1 = 0.0f;
+        uint32_t noted = 0u;
 #pragma unroll
         for (int c = 0; c < NC; c++) col[c] = 0.0f;
 #pragma unroll
@@ -184,7 +208,9 @@ struct Reproj
         {
             // an out-of-image texel reads as zeros (pinned rule) and is validated as such, as in the exact mode: its weight counts
             // in the normalisation, its (zero) values add nothing
-            const bool  v  = tap_valid(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f);
+            bool nr;
+            bool v = tap_valid<NOTE>(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f, nr);
+            if (NOTE) { if ((known >> s) & 1u) v = (ovr >> s) & 1u; else noted |= (uint32_t)nr << s; }
             const float ws = v ? wgt[s] : 0.0f, wv = ((int)v & (int)tok[s]) ? wgt[s] : 0.0f;
             float c3[NC];
             hist_decode(hx[s], hy[s], c3);
@@ -223,7 +249,10 @@ struct Reproj
                 if constexpr (GEO == 2) { qx = q3 >> 16; qy = 0u; }
                 else hist_load(qo, qx, qy);
                 const uint32_t qm = MOMENTS ? fm::ld<uint32_t>(hist_moments, qo * 8u) : 0u;
-                if (tap_valid(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f))
+                bool nr;
+                bool tv = tap_valid<NOTE>(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f, nr);
+                if (NOTE) { if ((known >> (4 + k)) & 1u) tv = (ovr >> (4 + k)) & 1u; else noted |= (uint32_t)nr << (4 + k); }
+                if (tv)
                 {
                     float c3[NC];
                     hist_decode(ok ? qx : 0u, ok ? qy : 0u, c3);
@@ -247,21 +276,63 @@ struct Reproj
         o.mom[0] = valid ? mom0 : 0.0f;
         o.mom[1] = valid ? mom1 : 0.0f;
         o.length = ((int)valid & (int)lok) ? fm::lo(lraw) : 0.0f;
+        near13 = noted;
         return valid;
     }
+
+    // The parity kernels' verdicts on the taps `which` of this pixel (bit layout of near13): their geometry is fetched again here (nothing of
+    // the hot path stays live across this), every verdict is exact::tap_valid.  Runs for the few waves that noted a tap on a knife edge.
+    // (x, y), depth, c2x, c2y: the pixel, its depth and its GB2 words as given to issue().
+    HR_DEV uint32_t exact_bits(uint32_t which, int x, int y, float depth, uint32_t c2x, uint32_t c2y) const
+    {
+        const int bx = (int)hfx, by = (int)hfy;
+        uint32_t  bits = 0u;
+#pragma unroll 1
+        while (which)
+        {
+            const int k = __builtin_ctz(which);
+            which &= which - 1u;
+            const int px = k < 4 ? bx + (k & 1) : hcx + (k - 4) % 3 - 1, py = k < 4 ? by + (k >> 1) : hcy + (k - 4) / 3 - 1;
+            bool           ok;
+            const uint32_t qo = tap_offset(px, py, ok);
+            uint32_t q2, q3;
+            if constexpr (GEO != 0) { const uint2 q = fm::ld<uint2>(geo, qo * 8u); q2 = q.x; q3 = q.y; }
+            else { q2 = fm::ld<uint32_t>(pgb2, qo * 8u); q3 = fm::ld<uint32_t>(pgb3, qo * 8u + 4u); }
+            const float qd = fm::ld<float>(pdepth, qo * 4u);
+            bits |= (uint32_t)exact::tap_valid(M, x, y, g.w, g.h, depth, c2x, c2y, cur_id, hcx, hcy, ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f) << k;
+        }
+        return bits;
+    }
 };
+
+// at the top of a temporal kernel whose argument block carries a GeoApronArgs: true = this workgroup was one of the apron's (pass_args.h)
+template <int THREADS>
+HR_DEV bool geo_apron_rides(const GeoApronArgs& g)
+{
+    if (g.row0 < 0 || (int)blockIdx.y < g.row0) return false;
+    const int      na = g.a1 - g.a0, total = (na + (g.b1 - g.b0)) * g.w;
+    const int      stride = (int)(gridDim.y - (unsigned)g.row0) * (int)gridDim.x * THREADS;
+    for (int i = (((int)blockIdx.y - g.row0) * (int)gridDim.x + (int)blockIdx.x) * THREADS + (int)threadIdx.x; i < total; i += stride)
+    {
+        const int      r = i / g.w, x = i - r * g.w, y = r < na ? g.a0 + r : g.b0 + (r - na);
+        const uint32_t o = (uint32_t)(y * g.w + x);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(g.out) + o * 8u) = make_uint2(fm::ld<uint32_t>(g.gb2, o * 8u), fm::ld<uint32_t>(g.gb3, o * 8u + 4u));
+    }
+    return true;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // shadows_denoise_reprojection.comp:196-293 (+ reset_args / tile classification), tolerance mode
 #define FT_WAVES 4
 #ifndef FT_SHADOWS_EU
-#define FT_SHADOWS_EU 5   // minimum waves per SIMD the register allocator must leave room for.  5 and 6 give the same 77 VGPRs (= 6 waves per SIMD), no
+#define FT_SHADOWS_EU 6   // minimum waves per SIMD the register allocator must leave room for (round 5: 6 — with the cold copy of the pixel program 5 lets the allocator take 88 VGPRs; 6 = 80 VGPRs, three spill stores on the hot path).  Round 4, without the cold copy: 5 and 6 give the same 77 VGPRs (= 6 waves per SIMD), no
                           // spill: 48-50 us at 1080p, 208 at 4K; 7 (72 VGPRs + 24 B of scratch) 58.7 / 252.8; 8 (64 VGPRs, more scratch) 81.4 / 362 — spills
                           // cost far more than waves buy
 #endif
 template <int GEO>
 __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_temporal(TemporalArgs a)
 {
+    if (geo_apron_rides<64 * FT_WAVES>(a.apron)) return;   // row bands: the records of the history apron, as extra grid rows behind the sort's
     if (tile_order_rides<64 * FT_WAVES>(a.sort)) return;   // the trace kernel's next launch order, as extra grid rows (tile_order.h)
     const uint2 BLK = block_xy<0>();
     __shared__ uint32_t s_mask[FT_WAVES][1][18];
@@ -281,54 +352,80 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_tempo
     const uint2 cg2_raw = fm::ld<uint2>(a.gb2.p, pix * 8u), cg3_raw = fm::ld<uint2>(a.gb3.p, pix * 8u);
     build_mask_rows<false>(s_rows[wave], s_mask[wave], a.mask, 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
     if (!tile_ok) return;
-    const float d   = edge ? 0.0f : d_raw;
-    const uint2 cg2 = edge ? make_uint2(0u, 0u) : cg2_raw, cg3 = edge ? make_uint2(0u, 0u) : cg3_raw;
-    const f3    cn  = fm::oct_unit(cg2.x);
-    const bool  live = (in_image || edge) && d != 1.0f;
-    Reproj<4, true, false, GEO> rp;
-    rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
-    rp.geo = a.geo_hist;
-    rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
-    const bool reproj = live && !a.debug_skip_reproject;
-    if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
-    if (a.apron_flag && __ballot(reproj && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
-    int sum, own;
-    mask_window<false>(s_rows[wave], lx, ly, sum, own);   // 17 bfe + bcnt pairs while the 21 history loads are in flight
-    const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f));
-
-    float out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
-    bool  flag = false;
-    if (live)
-    {
-        const float visibility = (float)own;
-        ReprojOut   r;
-        bool        success = false;
-        if (reproj) success = rp.resolve(r);
-        else { r.col[0] = 0.0f; r.mom[0] = r.mom[1] = 0.0f; r.length = 0.0f; }
-        hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
-        float hv = r.col[0];
-        if (success)
+    // The pixel's program, from its centre texels on.  It runs once; a wave in which some history tap sat on a knife edge of the validity
+    // test (Reproj::tap_valid notes it: a handful of pixels per frame) runs it a SECOND time — a second, cold copy of the code, entered with
+    // nothing of the first run live — in which the noted pixels take the parity kernels' verdicts on their taps (Reproj::exact_bits), and
+    // stores again.  Returns near13 (0: no tap of this pixel was in doubt); flag = the pixel's vote in the tile classification.
+    bool flag = false;
+    auto pixel = [&](const float d_in, const uint2 cg2_in, const uint2 cg3_in, const bool redo) -> uint32_t {
+        const float d   = edge ? 0.0f : d_in;
+        const uint2 cg2 = edge ? make_uint2(0u, 0u) : cg2_in, cg3 = edge ? make_uint2(0u, 0u) : cg3_in;
+        const f3    cn  = fm::oct_unit(cg2.x);
+        const bool  live = (in_image || edge) && d != 1.0f;
+        Reproj<4, true, false, GEO> rp;
+        rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
+        rp.geo = a.geo_hist;
+        rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+        const bool reproj = live && !a.debug_skip_reproject;
+        uint32_t ovr = 0u, known = 0u;
+        if (redo && reproj)
         {
-            const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
-            hv = fm::fmin_(fm::fmax_(hv, mean - 0.5f * sd), mean + 0.5f * sd);
+            // Which pixels were in doubt is found again the way the first run found it (the fast test is deterministic); such a pixel gets the
+            // parity kernels' verdicts on ALL 13 of its taps (a verdict may change which taps take part: the 3x3 fallback runs only when the
+            // four bilinear taps fail).  (Tried: verdicts for the noted taps only, repeated until nothing new is noted — 2x instead of 5x a
+            // normal wave per redo, but the loop made the allocator spill on the HOT path: +13 % whatever the bands.  docs/EXPERIMENTS.md R5.1)
+            rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
+            ReprojOut r0;
+            rp.template resolve<true>(r0);
+            if (rp.near13) { ovr = rp.exact_bits(0x1fffu, x, y, d, cg2.x, cg2.y); known = 0x1fffu; }
         }
-        const float ih = fm::rcp_nr(hlen);
-        const float al = success ? fm::fmax_(a.alpha, ih) : 1.0f;
-        const float am = success ? fm::fmax_(a.moments_alpha, ih) : 1.0f;
-        m0      = fm::mix_rn(r.mom[0], visibility, am);
-        m1      = fm::mix_rn(r.mom[1], visibility * visibility, am);
-        out_var = fm::fmax_(0.0f, fm::var_rn(m1, m0));
-        out_v   = fm::mix_rn(hv, visibility, al);
-        flag    = out_v > 0.0f;
-    }
-    if (in_image)
-    {
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + pix * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hlen, 0.0f));
-        // for the a-trous iterations: the centre's octahedral normal and linear depth, 8 bytes (copies of the G-buffer's fp16 values —
-        // the exact mode keeps 16 bytes of decoded fp32; decoding per tap is cheaper than the extra 8 B x 5 passes of HBM traffic)
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.nd) + pix * 8u)         = make_uint2(cg2.x, cg3.y);
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + pix * 4u)     = fm::pack2(out_v, out_var);
-    }
+        if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
+        if (!redo && a.apron_flag && __ballot(reproj && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
+        int sum, own;
+        mask_window<false>(s_rows[wave], lx, ly, sum, own);   // 17 bfe + bcnt pairs while the 21 history loads are in flight
+        const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f));
+
+        float out_v = 0.0f, out_var = 0.0f, m0 = 0.0f, m1 = 0.0f, hlen = 0.0f;
+        flag = false;
+        rp.near13 = 0u;
+        if (live)
+        {
+            const float visibility = (float)own;
+            ReprojOut   r;
+            bool        success = false;
+            if (reproj) success = rp.template resolve<true>(r, ovr, known);
+            else { r.col[0] = 0.0f; r.mom[0] = r.mom[1] = 0.0f; r.length = 0.0f; }
+            hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
+            float hv = r.col[0];
+            if (success)
+            {
+                const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
+                hv = fm::fmin_(fm::fmax_(hv, mean - 0.5f * sd), mean + 0.5f * sd);
+            }
+            const float ih = fm::rcp_nr(hlen);
+            const float al = success ? fm::fmax_(a.alpha, ih) : 1.0f;
+            const float am = success ? fm::fmax_(a.moments_alpha, ih) : 1.0f;
+            m0      = fm::mix_rn(r.mom[0], visibility, am);
+            m1      = fm::mix_rn(r.mom[1], visibility * visibility, am);
+            out_var = fm::fmax_(0.0f, fm::var_rn(m1, m0));
+            out_v   = fm::mix_rn(hv, visibility, al);
+            flag    = out_v > 0.0f;
+        }
+        if (in_image)
+        {
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_moments) + pix * 8u) = make_uint2(fm::pack2(m0, m1), fm::pack2(hlen, 0.0f));
+            // for the a-trous iterations: the centre's octahedral normal and linear depth, 8 bytes (copies of the G-buffer's fp16 values —
+            // the exact mode keeps 16 bytes of decoded fp32; decoding per tap is cheaper than the extra 8 B x 5 passes of HBM traffic)
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.nd) + pix * 8u)         = make_uint2(cg2.x, cg3.y);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out) + pix * 4u)     = fm::pack2(out_v, out_var);
+        }
+        return reproj ? rp.near13 : 0u;
+    };
+    const uint32_t doubt = pixel(d_raw, cg2_raw, cg3_raw, false);
+#if HR_TAP_REDO
+    if (__any(doubt != 0u))   // rare: the cold copy (re-reads the centre texels: nothing of the first run is kept)
+        pixel(fm::ld<float>(a.depth.p, pix * 4u), fm::ld<uint2>(a.gb2.p, pix * 8u), fm::ld<uint2>(a.gb3.p, pix * 8u), true);
+#endif
     const unsigned long long any = __ballot(flag);
     if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
 }
@@ -706,8 +803,11 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
 
 // ------------------------------------------------------------------------------------------------------------------------
 // ao_denoise_reprojection.comp:191-260, tolerance mode; spp = 1..4 sample planes (BASELINE configs[2]: 4)
+#ifndef FT_AO_EU
+#define FT_AO_EU 7   // 72 VGPRs; 8 (64 VGPRs) was right before the cold copy of the pixel program existed: with it the allocator spills in the hot path (+40 %)
+#endif
 template <bool MULTI, int GEO>
-__global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArgs a)
+__global__ __launch_bounds__(64 * FT_WAVES, FT_AO_EU) void kf_ao_temporal(AOTemporalArgs a)
 {
     if (tile_order_rides<64 * FT_WAVES>(a.sort)) return;   // the trace kernel's next launch order, as extra grid rows (tile_order.h)
     const uint2 BLK = block_xy<0>();
@@ -728,47 +828,66 @@ __global__ __launch_bounds__(64 * FT_WAVES, 8) void kf_ao_temporal(AOTemporalArg
     const uint32_t cg3y_raw = fm::ld<uint32_t>(a.gb3.p, pix * 8u + 4u);
     build_mask_rows<true>(s_rows[wave], s_mask[wave], a.mask, MULTI ? a.spp : 1, a.mw, a.mh, tx, ty, a.y0, a.y1, lane, tile_ok);
     if (!tile_ok) return;
-    const float    d    = edge ? 0.0f : d_raw;
-    const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_raw;
-    const uint32_t cg3y = edge ? 0u : cg3y_raw;
-    const bool     live = (in_image || edge) && d != 1.0f;
-    Reproj<2, false, false, GEO> rp;
-    rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = nullptr; rp.hist_len = a.hist_len.p;
-    rp.geo = a.geo_hist;
-    rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
-    if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
-    if (a.apron_flag && __ballot(live && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
-    int sum, own;
-    mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);   // popcounts while the history loads are in flight
-    const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f * (float)a.spp));
+    // the pixel's program, run once — and a second time (cold copy) by a wave that noted a history tap on a knife edge: kf_shadows_temporal
     bool flag = false;
-    if (in_image || edge)
-    {
-        float out = 1.0f, hlen = 0.0f;
-        if (live)
+    auto pixel = [&](const float d_in, const uint2 cg2_in, const uint32_t cg3y_in, const bool redo) -> uint32_t {
+        const float    d    = edge ? 0.0f : d_in;
+        const uint2    cg2  = edge ? make_uint2(0u, 0u) : cg2_in;
+        const uint32_t cg3y = edge ? 0u : cg3y_in;
+        const bool     live = (in_image || edge) && d != 1.0f;
+        Reproj<2, false, false, GEO> rp;
+        rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = nullptr; rp.hist_len = a.hist_len.p;
+        rp.geo = a.geo_hist;
+        rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+        uint32_t ovr = 0u, known = 0u;
+        if (redo && live)   // see kf_shadows_temporal
         {
-            const float ao = fm::div_by_inrange((float)own, div_prepare((float)a.spp));
-            ReprojOut   r;
-            const bool  success = rp.resolve(r);
-            hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
-            float hao = r.col[0];
-            if (success)
+            rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
+            ReprojOut r0;
+            rp.template resolve<true>(r0);
+            if (rp.near13) { ovr = rp.exact_bits(0x1fffu, x, y, d, cg2.x, cg2.y); known = 0x1fffu; }
+        }
+        if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
+        if (!redo && a.apron_flag && __ballot(live && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
+        int sum, own;
+        mask_window<MULTI>(s_rows[wave], lx, ly, sum, own);   // popcounts while the history loads are in flight
+        const float mean = fm::div_by_inrange((float)sum, div_prepare(289.0f * (float)a.spp));
+        flag = false;
+        rp.near13 = 0u;
+        if (in_image || edge)
+        {
+            float out = 1.0f, hlen = 0.0f;
+            if (live)
             {
-                const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
-                hao = fm::fmin_(fm::fmax_(hao, mean - 0.5f * sd), mean + 0.5f * sd);
+                const float ao = fm::div_by_inrange((float)own, div_prepare((float)a.spp));
+                ReprojOut   r;
+                const bool  success = rp.template resolve<true>(r, ovr, known);
+                hlen = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
+                float hao = r.col[0];
+                if (success)
+                {
+                    const float sd = fm::sqrt1(fm::fmax_(fm::var_rn(mean, mean), 0.0f));
+                    hao = fm::fmin_(fm::fmax_(hao, mean - 0.5f * sd), mean + 0.5f * sd);
+                }
+                const float al = success ? fm::fmax_(a.alpha, fm::rcp_nr(hlen)) : 1.0f;
+                out = fm::mix_rn(hao, ao, al);
             }
-            const float al = success ? fm::fmax_(a.alpha, fm::rcp_nr(hlen)) : 1.0f;
-            out = fm::mix_rn(hao, ao, al);
+            if (in_image)
+            {
+                *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + pix * 2u)     = fm::half_bits(out);
+                *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out_len) + pix * 2u) = fm::half_bits(hlen);
+                // next frame's reprojection record: this pixel's oct normal, mesh id and AO value (copies of what the images hold)
+                if (a.geo_out) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.geo_out) + pix * 8u) = make_uint2(cg2.x, (cg3y & 0xffffu) | ((uint32_t)fm::half_bits(out) << 16));
+            }
+            flag = out < 1.0f;
         }
-        if (in_image)
-        {
-            *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out) + pix * 2u)     = fm::half_bits(out);
-            *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.out_len) + pix * 2u) = fm::half_bits(hlen);
-            // next frame's reprojection record: this pixel's oct normal, mesh id and AO value (copies of what the images hold)
-            if (a.geo_out) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.geo_out) + pix * 8u) = make_uint2(cg2.x, (cg3y & 0xffffu) | ((uint32_t)fm::half_bits(out) << 16));
-        }
-        flag = out < 1.0f;
-    }
+        return live ? rp.near13 : 0u;
+    };
+    const uint32_t doubt = pixel(d_raw, cg2_raw, cg3y_raw, false);
+#if HR_TAP_REDO
+    if (__any(doubt != 0u))   // rare: the cold copy (re-reads the centre texels: nothing of the first run is kept)
+        pixel(fm::ld<float>(a.depth.p, pix * 4u), fm::ld<uint2>(a.gb2.p, pix * 8u), fm::ld<uint32_t>(a.gb3.p, pix * 8u + 4u), true);
+#endif
     const unsigned long long any = __ballot(flag);
     if (lane == 0) a.tile_class[(size_t)ty * a.tiles_x + tx] = any ? 1 : 0;
 }
@@ -1366,7 +1485,14 @@ __global__ __launch_bounds__(256) void kf_ddgi_sample(DDGISampleArgs a)
     f3       Wo = mk3(a.cam[0] - P.x, a.cam[1] - P.y, a.cam[2] - P.z);
     const float iwo = fm::rsq(fm::dot(Wo, Wo));
     Wo = mk3(Wo.x * iwo, Wo.y * iwo, Wo.z * iwo);
-    const f3 net = ddgi_fast::sample_irradiance_net<true>(d, P, N, Wo, a.irr, a.dep);
+    // the redo of a pixel with a probe on the Chebyshev knife edge needs k_ddgi_sample's own operands of this pixel (exact_predicates.h)
+    auto exact_inputs = [&](f3& eP, f3& eN, f3& eWo) { exact::pixel_inputs(a.vpi, a.cam, x, y, a.w, a.h, dp, fm::ld<uint32_t>(a.gb2, o * 8u), eP, eN, eWo); };
+#ifdef HR_DEBUG_DDGI_PIXEL   // developer build: -DHR_DEBUG_DDGI_PIXEL -DHR_DBG_X=.. -DHR_DBG_Y=.. -DHR_DBG_W=.. prints the gather's terms of one pixel
+    const bool dbg = x == HR_DBG_X && y == HR_DBG_Y && a.w == HR_DBG_W;
+#else
+    const bool dbg = false;
+#endif
+    const f3 net = ddgi_fast::sample_irradiance_net<true>(d, P, N, Wo, a.irr, a.dep, exact_inputs, dbg);
     const float k = d.energy_preservation * (0.5f * HR_M_PI) * a.gi_intensity;
     *outp = make_uint2(fm::pack2(net.x * net.x * k, net.y * net.y * k), fm::pack2(net.z * net.z * k, 1.0f));
 }
@@ -1442,11 +1568,19 @@ static dim3 grid_with_sort(TileSortArgs& t, int grid_x, int rows)
     t.row0 = rows;
     return dim3(grid_x, rows + (t.groups ? cdiv(t.groups, grid_x) : 0));
 }
+// ... and the history apron's records (GeoApronArgs) behind the sort: ~4 texels per thread
+static dim3 grid_with_apron(dim3 grid, GeoApronArgs& g, int threads)
+{
+    const int total = g.out ? ((g.a1 - g.a0) + (g.b1 - g.b0)) * g.w : 0;
+    if (total <= 0) { g.row0 = -1; return grid; }
+    g.row0 = (int)grid.y;
+    return dim3(grid.x, grid.y + (unsigned)cdiv(total, (int)grid.x * threads * 4));
+}
 
 void launch_shadows_temporal_fast(const TemporalArgs& a_, int n_tiles, hipStream_t st)
 {
     TemporalArgs a = a_;
-    const dim3 grid = grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
+    const dim3 grid = grid_with_apron(grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y), a.apron, 64 * FT_WAVES);
     if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<1>, grid, dim3(64 * FT_WAVES), 0, st, a);
     else hipLaunchKernelGGL(kf_shadows_temporal<0>, grid, dim3(64 * FT_WAVES), 0, st, a);
 }
@@ -1487,7 +1621,12 @@ void launch_ao_temporal_fast(const AOTemporalArgs& a_, int n_tiles, hipStream_t 
 {
     AOTemporalArgs a = a_;
     const dim3 grid = grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
-    if (a.geo_hist)
+    if (a.geo_hist && a.geo_band)
+    {
+        if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 1>), grid, dim3(64 * FT_WAVES), 0, st, a);
+        else hipLaunchKernelGGL((kf_ao_temporal<false, 1>), grid, dim3(64 * FT_WAVES), 0, st, a);
+    }
+    else if (a.geo_hist)
     {
         if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 2>), grid, dim3(64 * FT_WAVES), 0, st, a);
         else hipLaunchKernelGGL((kf_ao_temporal<false, 2>), grid, dim3(64 * FT_WAVES), 0, st, a);

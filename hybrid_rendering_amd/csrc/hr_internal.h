@@ -65,6 +65,17 @@ struct DevBuf
             p = nullptr;
             return HR_ERR_HIP;
         }
+        // hipMemset on device memory returns before the fill has run (it is queued on the NULL stream); a caller that renders straight away on
+        // a hipStreamNonBlocking stream is not ordered after it.  Creation is not a hot path: wait here, so that "created" means "zeroed"
+        // (hr_api.h: every hr_*_create returns with its images initialised)
+        e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+        {
+            set_last_error(std::string("hipStreamSynchronize after hipMemset failed: ") + hipGetErrorString(e));
+            (void)hipFree(p);
+            p = nullptr;
+            return HR_ERR_HIP;
+        }
         bytes = n;
         return HR_OK;
     }

@@ -18,6 +18,19 @@ struct TileSortArgs
     int             min_spread;   // TileOrder::min_spread
 };
 
+// Row bands, tolerance mode: the geometry records of the rows a band reads HISTORY from but does not compute — the part of
+// hr_band.history_halo beyond hr_band.halo.  A record is a copy of two words of the CURRENT G-buffer texel, which the caller keeps readable
+// on those rows (hr_api.h hr_band), so a few extra workgroups of the temporal launch (grid rows >= row0) write them: rows [a0, a1) above and
+// [b0, b1) below the computed rows.  row0 < 0: none.
+struct GeoApronArgs
+{
+    const void* gb2;
+    const void* gb3;
+    void*       out;      // this frame's records {GB2.x (oct normal), GB3.y (mesh id | linear z)}
+    int         w, a0, a1, b0, b1;
+    int         row0;
+};
+
 struct TemporalArgs
 {
     float           vpi[16];
@@ -42,6 +55,7 @@ struct TemporalArgs
                                     // hr_band.history_halo (the tap read as disoccluded).  Halo rows are the neighbour's to get right.
     int             band_y0, band_y1;
     TileSortArgs    sort;           // rides along as extra grid rows (tolerance-mode kernel only)
+    GeoApronArgs    apron;          // rides along behind the sort (tolerance-mode kernel, row bands only)
 };
 
 struct AtrousArgs
@@ -70,6 +84,7 @@ struct AOTemporalArgs
     const void*     geo_hist;       // tolerance mode: last frame's records {oct normal, mesh id | AO} when they stand for the caller's
                                     // previous G-buffer + the AO history (hr_ao_temporal decides), else nullptr
     void*           geo_out;        // tolerance mode: this frame's records, or nullptr
+    int             geo_band;       // 1: row band — only the geometry half of the records is read, the AO history comes from `hist` (hr_ao_temporal)
     int             w, h, y0, y1;
     int             tiles_x, tiles_y, tile_y0;
     float           alpha;

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
 #else
     HitRec hit;
     hit.prim = -1;
-    if (trace) hit = trace_closest<STATS>(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane HR_DIV(, &dvp), &st_n, &st_t);
+    DivCounters* dvp_ptr = nullptr;   // (without HR_TRACE_DIVERGENCE the HR_DIV() argument vanished and &st_n slid into the `dv` slot)
+    HR_DIV(dvp_ptr = &dvp;)
+    if (trace) hit = trace_closest<STATS>(a.nodes, a.tris, ray_origin, dir, 0.001f, 10000.0f, s_stack[wave], lane, dvp_ptr, &st_n, &st_t);
 #endif
     if (trace)
     {
@@ -492,7 +494,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
 #define A(buf, n) if ((s = p->buf.alloc(n)) != HR_OK) { delete p; return s; }
     A(trace, px * 8) A(color[0], px * 8) A(color[1], px * 8) A(moments[0], px * 8) A(moments[1], px * 8) A(prev_image, px * 8)
     A(atrous[0], px * 8) A(atrous[1], px * 8) A(upsample, (size_t)full_width * full_height * 8) A(tile_class, (size_t)p->tiles_x * p->tiles_y) A(counters, 64) A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
-    if (p->geo_history && p->y0 == 0 && p->y1 == p->h) { A(geo[0], px * 8) A(geo[1], px * 8) }   // a band keeps to the caller's images
+    if (p->geo_history) { A(geo[0], px * 8) A(geo[1], px * 8) }   // (round 5: bands too — a band computes, and so records, every row it reads history from: history_halo == halo)
 #undef A
     if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -509,7 +511,7 @@ hr_status hr_reflections_destroy(hr_reflections* p)
     delete p;
     return HR_OK;
 }
-hr_status hr_reflections_reset_history(hr_reflections* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; return HR_OK; }
+hr_status hr_reflections_reset_history(hr_reflections* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; p->tile_order.invalidate(); return HR_OK; }
 hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
 {
     HR_CHECK_ARG(p && exceeded);

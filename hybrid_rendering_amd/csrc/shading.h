@@ -219,8 +219,8 @@ HR_DEV void atlas_bilinear_rg(const AtlasRG& a, float u, float v, float& r0, flo
     r1 = mix1(mix1(h2f_hi(t00), h2f_hi(t10), fx), mix1(h2f_hi(t01), h2f_hi(t11), fx), fy);
 }
 
-// gi_common.glsl:188-320
-HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+// gi_common.glsl:188-316: the weighted sqrt-space mean `net` (NaN components replaced by 0.5), before the squaring and scaling of :317-320
+HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
 {
     const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]);
     const f3 g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
@@ -276,6 +276,12 @@ HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& 
     net.x = (net.x != net.x) ? 0.5f : net.x;
     net.y = (net.y != net.y) ? 0.5f : net.y;
     net.z = (net.z != net.z) ? 0.5f : net.z;
+    return net;
+}
+// gi_common.glsl:188-320
+HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+{
+    f3 net = sample_irradiance_net(d, P, N, Wo, irradiance, depth);
     net = mul3(net, net);
     net = scale3(net, d.energy_preservation);
     return scale3(net, 0.5f * HR_M_PI);

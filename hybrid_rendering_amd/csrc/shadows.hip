@@ -664,6 +664,7 @@ hr_status hr_shadows_reset_history(hr_shadows* p)
     HR_CHECK_ARG(p);
     p->first_frame = true;
     p->geo_valid = false;
+    p->tile_order.invalidate();   // costs of a frame that may never have run are not sorted (the launch list itself is always a permutation)
     return HR_OK;
 }
 
@@ -716,6 +717,12 @@ hr_status hr_shadows_tile_ray_counts(hr_shadows* p, uint16_t* out, int32_t* tile
     HR_HIP(hipStreamSynchronize(p->last_stream));
     HR_HIP(hipMemcpy(out, p->ray_slots.p, (size_t)p->tiles_x * p->tiles_y * 2, hipMemcpyDeviceToHost));
     return HR_OK;
+}
+
+hr_status hr_shadows_launch_order(hr_shadows* p, uint32_t* out, int32_t* n_tiles)
+{
+    HR_CHECK_ARG(p);
+    return p->tile_order.read(out, n_tiles, p->last_stream);
 }
 
 static hr_status check_inputs(const hr_shadows* p, const hr_frame_inputs* in, bool need_prev)
@@ -862,17 +869,21 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
     a.tile_class = (uint8_t*)p->tile_class.p;
     a.nd = (float4*)p->nd.p;
     a.geo_hist = nullptr;
+    a.apron = GeoApronArgs { nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, -1 };
     if (!prm->exact)
     {
         // the records of the last frame stand for in->prev when the caller hands back what it passed as in->cur then; a band keeps to
         // the caller's images (its records cover the rows it computed, not the history apron its neighbours own)
+        // (round 5: bands too — the records of the rows a band reads history from but does not compute, hr_band.history_halo beyond
+        // hr_band.halo, are copies of the current G-buffer as well, written by a few extra workgroups of the temporal launch: GeoApronArgs)
         const size_t half = (size_t)p->w * p->h * 8;
-        const bool   whole = p->y0 == 0 && p->y1 == p->h;
-        if (p->geo_history && p->geo_valid && whole && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3)
+        if (p->geo_history && p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3)
             a.geo_hist = (const char*)p->nd.p + (size_t)p->geo_parity * half;
         p->geo_parity ^= 1;
         a.nd = (float4*)((char*)p->nd.p + (size_t)p->geo_parity * half);
         p->geo_valid = true; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+        if (p->geo_history && (ry0 < y0 || ry1 > y1))
+            a.apron = GeoApronArgs { in->cur.gb2, in->cur.gb3, a.nd, w, ry0, y0, y1, ry1, -1 };
     }
     else p->geo_valid = false;   // the parity mode's float4 layout covers both halves
     p->nd_cur = a.nd;

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 namespace hr {
 
@@ -102,7 +103,7 @@ struct TileOrder
     int    n       = 0;
     bool   enabled = true;    // developer A/B switch HR_TILE_ORDER=0 (read once at create)
     bool   ride_along = true; // developer A/B switch HR_TILE_ORDER_FUSED=0: always a launch of its own
-    bool   valid   = false;   // `order` holds (in stream order) a permutation of 0..n-1 built from a launch over the same tiles
+    bool   valid   = false;   // a sort has been enqueued since creation (informational: `order` is a permutation either way, see identity())
     bool   pending = false;   // costs of a trace launch are waiting to be sorted
     int    min_spread = 0;    // > 0 (coherent rays: the shadow pass): sort only widely spread costs, see tile_order_block (developer switch HR_TILE_ORDER_SPREAD)
     std::string dump_path;    // developer switch HR_DEBUG_TILE_COSTS=<prefix>: every launch's costs go to <prefix>.<tag> (synchronises: never in a timed run)
@@ -124,8 +125,36 @@ struct TileOrder
         if (!enabled) return HR_OK;
         hr_status s = cost.alloc((size_t)n_tiles * 2);
         if (s != HR_OK) return s;
-        return order.alloc((size_t)n_tiles * 4);
+        if ((s = order.alloc((size_t)n_tiles * 4)) != HR_OK) return s;
+        return identity();
     }
+    // `order` ALWAYS holds a permutation of 0..n-1: the identity from creation until the first sort lands, a sorted list afterwards (a sort
+    // writes every slot of its residue class).  The trace launch therefore always takes the list — its arguments are the same from frame 0 on,
+    // so a hipGraph captured on the FIRST frame (whose temporal launch already carries the riding sort) replays with the launch order like
+    // one captured later, and a sort that never ran (a captured frame that was never launched, a failed launch) leaves a
+    // valid list behind instead of the zeros of a fresh buffer.  Synchronous: creation / reset, never inside a frame.
+    hr_status identity()
+    {
+        if (!enabled || !order.p || n <= 0) return HR_OK;
+        std::vector<uint32_t> id((size_t)n);
+        for (int i = 0; i < n; i++) id[(size_t)i] = (uint32_t)i;
+        HR_HIP(hipMemcpy(order.p, id.data(), id.size() * 4, hipMemcpyHostToDevice));
+        valid = false;
+        return HR_OK;
+    }
+    // hr_*_launch_order (introspection): the list as the next trace launch will read it
+    hr_status read(uint32_t* out, int32_t* n_tiles, hipStream_t st)
+    {
+        const bool on = enabled && order.p && n > 0;
+        if (n_tiles) *n_tiles = on ? n : 0;
+        if (!out || !on) return HR_OK;
+        HR_HIP(hipStreamSynchronize(st));
+        HR_HIP(hipMemcpy(out, order.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return HR_OK;
+    }
+    // hr_*_reset_history: forget costs nobody has sorted yet (they may belong to a frame that never ran).  The list itself stays — it is a
+    // permutation whatever happened — unless the caller asks for the image order back (device idle: reset is not called inside a frame)
+    void invalidate() { pending = false; }
     bool active(int n_tiles) const { return enabled && n_tiles == n; }   // a pass asked to trace a different region keeps blockIdx order
     static int groups_for(int n, int threads)
     {
@@ -143,7 +172,7 @@ struct TileOrder
         return HR_OK;
     }
     // arguments of the trace launch (nullptr: blockIdx order / no cost record)
-    const uint32_t* order_arg(int n_tiles) const { return active(n_tiles) && valid ? (const uint32_t*)order.p : nullptr; }
+    const uint32_t* order_arg(int n_tiles) const { return active(n_tiles) ? (const uint32_t*)order.p : nullptr; }
     uint16_t*       cost_arg(int n_tiles) const { return active(n_tiles) ? (uint16_t*)cost.p : nullptr; }
     // after a trace launch that recorded costs
     hr_status traced(int n_tiles, hipStream_t st)

@@ -160,6 +160,12 @@ class HybridFrame:
                 import torch
                 self.forked, self.forked_error = False, repr(e)[:200]
                 torch.cuda.synchronize()
+                # The forked attempt may have enqueued SOME passes of this frame already (shadows on its side stream, say, before AO raised): their
+                # ping-pong, first-frame and launch-order state has advanced once.  Rendering the same frame again serially would advance it twice
+                # and blend the frame into its own history, so every pass starts over — a disocclusion-like frame, never a corrupt one.
+                for t in (self.shadows, self.ao, self.refl):
+                    t.pass_.reset_history()
+                self.gi.pass_.restart_accumulation()
         if self.concurrent and only is None:
             self.gi.pass_.set_orientation(self._orients[k & 15])
             self._native.render(self.scene, self.env, fi, fi, fi, fl, mode=self.frame_mode)

@@ -48,7 +48,7 @@ const char* hr_version(void);
  * built against another revision must not call into this library: compare hr_api_revision() with HR_API_REVISION once at start-up
  * (hr::Context does).  Revision 3 = round 3: hr_*_denoise, hr_hybrid_frame, ticketed hr_comm, HR_ERR_TIMEOUT / HR_ERR_COMM. */
 /* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
-/* revision 5 (round 5): + hr_shadows_trace_stats_timed; structs unchanged */
+/* revision 5 (round 5): + hr_shadows_trace_stats_timed, hr_shadows_launch_order, hr_ao_launch_order; structs unchanged */
 #define HR_API_REVISION 5
 int32_t hr_api_revision(void);
 
@@ -313,6 +313,11 @@ hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_
  * the walk), whose contents depend on the previous frames.  This variant leaves the cache ON: the counts are those of the kernel a render()
  * of `in` launches in the pass's present state (bench.py divides THESE by the timed kernel's duration).  It advances the cache exactly as
  * that trace would; masks and every other output are the same either way. */
+/* The launch order of the trace kernel as its NEXT launch will read it (csrc/tile_order.h: launch slot -> 8x8 tile, last frame's heaviest tiles
+ * first; the identity list from creation until the first sort has run).  out = host array of *n_tiles words (nullable: only the count is
+ * returned; 0 when the launch order is switched off).  Always a permutation of 0 .. n_tiles - 1.  Synchronises the stream of the last render.
+ * Introspection for tests and tools (tests/test_gpu_tile_order.py: a hipGraph captured on the FIRST frame replays with the order too). */
+hr_status hr_shadows_launch_order(hr_shadows* p, uint32_t* out, int32_t* n_tiles);
 hr_status hr_shadows_trace_stats_timed(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
 /* After hr_shadows_trace_stats: sum over waves of the slowest lane's (node + triangle) steps.  SIMD lane utilisation of
  * the traversal loop = (nodes + triangles) / (64 * wave_max_steps). */
@@ -358,6 +363,8 @@ hr_status hr_ao_set_profiling(hr_ao* p, int32_t enable);
 hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out);
 hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays);
 hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, uint64_t* out3, void* stream);
+/* as hr_shadows_launch_order */
+hr_status hr_ao_launch_order(hr_ao* p, uint32_t* out, int32_t* n_tiles);
 
 /* ---- environment inputs (replace CommonResources::current_skybox_ds / IBL images) ------------------- */
 /* Cubemaps are [6][size][size] RGBA16F, faces +X -X +Y -Y +Z -Z, fetched NEAREST.

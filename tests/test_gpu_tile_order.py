@@ -127,3 +127,44 @@ def test_reflections_do_not_depend_on_the_launch_order(hr, ctx, W, H, scale):
         _same("tile classes", f, a.image(a.IMG_TILES), b.image(b.IMG_TILES))
         assert a.ray_count() == b.ray_count()
     a.close(); b.close(); ddgi.close(); gsc.close()
+
+
+def test_launch_list_is_always_a_permutation_and_a_first_frame_capture_replays_with_it(hr, ctx):
+    """VERDICT r4 weak #6 / ADVICE r4: the trace launch takes the launch list from the FIRST frame on (the identity until a sort has run), so
+    (a) right after creation and after reset_history the list is a valid permutation — never the zeros of a fresh buffer;
+    (b) a hipGraph captured on the very first frame (whose temporal launch carries the riding sort) re-sorts on every replay: after a few
+        replays the list is a non-identity permutation and the masks equal those of eager frames."""
+    import torch
+    name, W, H = "sponza_small", 320, 184
+    sd = helpers.scene_data(name)
+    gsc = hr.Scene(ctx, sd)
+    ubos, gbs = _frames(gsc, name, W, H)
+    sob_d, sr_d = _tables()
+    fi = hr.frame_inputs(gbs[1], gbs[0], ubos[1], 1, 1, sob_d, sr_d)
+    for make in (lambda: hr.RayTracedShadows(ctx, W, H), lambda: hr.RayTracedAO(ctx, W, H, hr.SCALE_FULL_RES)):
+        eager, graphed = make(), make()
+        for p in (eager, graphed):
+            p.params.exact = 0
+            if hasattr(p.params, "spp"):
+                p.params.spp = 2
+        n = len(graphed.launch_order())
+        ident = np.arange(n, dtype=np.uint32)
+        assert n > 0 and np.array_equal(graphed.launch_order(), ident)     # (a) at creation (n = the pass's own 8x8 tiles: AO defaults to half resolution)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            graphed.render(gsc, fi)                      # the pass's FIRST frame is the captured one
+        for _ in range(4):
+            g.replay()
+            eager.render(gsc, fi)
+        torch.cuda.synchronize()
+        lo = graphed.launch_order()
+        assert np.array_equal(np.sort(lo), ident), "the launch list must be a permutation"
+        if isinstance(graphed, hr.RayTracedAO):          # AO always sorts; the shadow pass keeps the image order when its costs are narrowly spread
+            assert not np.array_equal(lo, ident), "replays of a first-frame capture never sorted"
+            assert np.array_equal(np.sort(eager.launch_order()), ident) and not np.array_equal(eager.launch_order(), ident)
+        _same("mask (graph replays vs eager frames)", 1, graphed.image(graphed.IMG_MASK), eager.image(eager.IMG_MASK))
+        graphed.reset_history()
+        assert np.array_equal(np.sort(graphed.launch_order()), ident)                                      # (a) after a reset
+        eager.close(); graphed.close()
+    gsc.close()

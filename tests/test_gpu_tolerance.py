@@ -4,23 +4,21 @@ csrc/denoise_fast.hip) against the CPU oracle.
 Stated tolerance (north_star "AO / reflections / GI within a stated fp32 tolerance"):
   * visibility masks, ray counts: BIT-EXACT (the trace kernels have one mode);
   * every fp16 output image, EVERY channel: <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 error <= 1e-3 over those texels and
-    <= 1e-2 over ALL texels (other than the counted pixels beyond the hard cap below, which have their own bound); variance channels (shadows .y, reflections .a) also count |diff| <= 1e-4 as equal, the temporal stages'
+    <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) also count |diff| <= 1e-4 as equal, the temporal stages'
     intermediate images |diff| <= 2e-4 (both are differences of nearly equal numbers: m2 - m1^2, E[x^2] - E[x]^2).  The remaining <= 0.1 % are discrete decisions flipped by an fp32 ulp (a reprojection validity threshold, a truncation
     to a texel index, a tile whose only non-trivial pixel sits on the classification threshold) or 0/0 situations of the reference's
     own arithmetic (a DDGI pixel all of whose probe weights were crushed to the 1e-6 floor); their energy is bounded by the second
     L2 figure, not ignored;
-  * HARD CAPS on every single texel (round 4: the 0.1 % above had no per-texel bound): outside the neighbourhoods of flipped tiles
-    <= 32 fp16 ulp OR |diff| <= 2^-10, except for a COUNTED handful — at most max(4, 1e-5 of the pixels) pixels per image
-    (OUTLIER_PIXELS; twice that for the reflections' images, which meet both causes below; times 5 * 4^scale for the UPSAMPLED output of a scaled pass, whose 4-tap cross spreads one low-resolution texel over that
-    many full-resolution pixels) — which, like every texel inside a flipped-tile neighbourhood (a flipped tile is copied / cleared instead of
-    filtered), must stay within the value range of the reference image's channel.  The handful is what discrete decisions of the
-    REFERENCE's own formulas cost when an fp32 ulp flips them: (1) a reprojection tap's validity (plane distance > 5, (n.n')^2 > 0.1,
-    reprojection.glsl:11-67) or the truncation of a history coordinate onto a texel: the bilinear history is then re-weighted over other
-    texels (measured: 1 pixel of the half-resolution and 13 of the full-resolution 1080p reflections' temporal image, <= 80 ulp; none in
-    the shadows / AO images); (2) the DDGI probe-grid sample's `weight *= dist <= mean ? 1 : cheb^3` with cheb = var / (var + (dist -
-    mean)^2) (gi_common.glsl:262-282), which jumps from 1 to 0 where a probe's depth texels are flat (var == 0) and the pixel sits exactly
-    at the mean distance: a 1-ulp difference in `dist` moves one of the eight probe weights from 1 to the 1e-6 floor (measured: 3 pixels
-    of a 1080p frame, 9-16 of a 4K frame);
+  * HARD CAPS on every single texel: outside the neighbourhoods of flipped tiles <= 32 fp16 ulp OR |diff| <= 2^-10.  Round 5: NO counted
+    allowance any more for the shadows, AO and DDGI probe-grid-sample images and the reflections' trace image — the discrete decisions that
+    used to cost a handful of pixels per frame are now taken with the parity kernels' arithmetic wherever the fast operands cannot be
+    trusted with them (a history tap on a knife edge of the validity test, reprojection.glsl:52-67: Reproj::exact_bits in
+    csrc/denoise_fast.hip; a DDGI gather whose weights are ill-conditioned or NaN-driven, gi_common.glsl:262-320: the redo of
+    csrc/ddgi_sample_fast.h).  The reflections' DENOISED images keep one, tightly bounded (OUTLIER_* below): at most max(4, 2e-5 of the
+    pixels) pixels per image (x 5 * 4^scale for the upsampled output of a scaled pass), each within 512 fp16 ulp or 2^-5 of the oracle —
+    not "the channel's value range" of round 4 — because the reference's own luminance edge-stopping weight is ill-conditioned where the
+    variance estimate is 0 (see OUTLIER_PIXELS); texels inside a flipped-tile neighbourhood (a flipped tile is copied / cleared instead of
+    filtered) must stay within the value range of the reference image's channel;
   * tile classes: equal on >= 99.5 % of the tiles;
   * DDGI atlases are produced by the exact kernels in both modes (bit-exact); the per-pixel probe-grid sample obeys the image rule.
 The runs are several frames long with a moving camera, so the bound holds through the temporal feedback loops."""
@@ -50,13 +48,27 @@ def _key(bits):
 CAP_ULPS = int(os.environ.get("HR_TEST_CAP_ULPS", 32))     # hard per-texel cap (every texel outside flipped-tile neighbourhoods) ...
 CAP_ABS = float(os.environ.get("HR_TEST_CAP_ABS", 2.0 ** -10))   # ... OR this absolute difference
 REPORT = os.environ.get("HR_TEST_TOLERANCE_REPORT")          # print the achieved figures of every image
-OUTLIER_PIXELS = 1e-5   # share of the PIXELS of an image (at least 4) that may exceed the hard cap, bounded by the channel's value range (see above)
-DDGI_OUTLIERS = OUTLIER_PIXELS
-REFL_OUTLIERS = 2 * OUTLIER_PIXELS   # the reflections' images meet BOTH causes: reprojection taps and the DDGI gathers of their hit shading
+# Counted allowance of pixels beyond the hard cap (round 5: only the reflections' denoised images still have one, and it is bounded tightly):
+#   shadows, AO, DDGI probe-grid sample, reflections trace image: NONE.  Their discrete decisions are taken with the parity kernels' arithmetic
+#     wherever the fast operands cannot be trusted (history taps on a knife edge of the validity test: Reproj::exact_bits; DDGI gathers whose
+#     weights are ill-conditioned or NaN-driven: ddgi_sample_fast.h redo).
+#   reflections temporal / moments / a-trous / upsampled output: at most max(4, 2e-5 of the pixels) pixels per image (x 5 * 4^scale for an
+#     upsampled output), each within OUTLIER_ULPS fp16 ulp or OUTLIER_ABS of the oracle — NOT the channel's value range of round 4.  Cause, shown
+#     by tools/refl_outlier_probe.py on frame 0 of two fuzz configurations (trace and temporal images bit-identical, variance channel 0): the
+#     reference's luminance edge-stopping weight is exp(-|dl| / (phi_color sqrt(1e-10 + var))) (reflections_denoise_atrous.comp:113-125,
+#     edge_stopping.glsl:31-62): with var == 0 (first frames, disocclusions) the exponent changes by ~0.6 per fp16 ulp of an input texel, so ONE
+#     fp16 ulp of difference in the stored intermediate of a-trous iteration i (inside the 2-ulp rule) re-weights a tap of iteration i + 1 by
+#     e^0.6 — the reference's own filter is ill-conditioned there, any arithmetic that is not bit-identical meets it (measured over 200 random
+#     configurations: 9 images, 1-4 texels each, <= 134 ulp / 1.1e-2).  The reflections' temporal kernel also keeps the fast history-tap test.
+OUTLIER_PIXELS = float(os.environ.get("HR_TEST_OUTLIER_PIXELS", 0.0))
+DDGI_OUTLIERS = float(os.environ.get("HR_TEST_DDGI_OUTLIERS", 0.0))
+REFL_OUTLIERS = float(os.environ.get("HR_TEST_REFL_OUTLIERS", 2e-5))
+OUTLIER_ULPS = int(os.environ.get("HR_TEST_OUTLIER_ULPS", 512))
+OUTLIER_ABS = float(os.environ.get("HR_TEST_OUTLIER_ABS", 2.0 ** -5))
 
 
 def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, exclude=None, variance_channels=(), variance_floor=VARIANCE_FLOOR,
-              cap_ulps=None, cap_abs=None, outlier_pixels=OUTLIER_PIXELS, outlier_scale=1):
+              cap_ulps=None, cap_abs=None, outlier_pixels=None, outlier_scale=1):
     """got / ref: uint16 fp16 bit patterns, ALL channels of the image.  abs_floor: differences below it count as equal (intermediate
     images whose small values are differences of nearly equal numbers, e.g. variance = m2 - m1^2).  exclude: bool [H, W] of texels
     left out of the per-texel bound (neighbourhoods of tiles whose classification differs — a discrete decision; they stay in the L2
@@ -65,6 +77,7 @@ def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, ex
     — the quantity the next a-trous iteration reads them for is phi * sqrt(variance) (shadows_denoise_atrous.comp:65-88), on which
     a 1e-4 absolute slip is far below the 2-ulp bound of the filtered channel; the L2 bounds cover them like every other channel."""
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    outlier_pixels = OUTLIER_PIXELS if outlier_pixels is None else outlier_pixels
     g, r = got.view(np.float16).astype(np.float64), ref.view(np.float16).astype(np.float64)
     assert np.isfinite(g).all(), f"{what}: non-finite values"
     num, den = np.sqrt(((g - r) ** 2).sum()), np.sqrt((r ** 2).sum())
@@ -94,9 +107,10 @@ def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, ex
     allowed = int(max(4, outlier_pixels * n_pixels) * outlier_scale) if outlier_pixels > 0 else 0
     beyond_px = (~outside).reshape(ok.shape[0], ok.shape[1], -1).any(axis=2)
     if allowed and 0 < beyond_px.sum() <= allowed:
-        # the counted allowance: these pixels are bounded by the channel's value range instead
-        rngc = (r.max(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None) - r.min(axis=tuple(range(r.ndim - 1)) if r.ndim == 3 else None)) + cap_abs
-        assert not (abs_d > rngc).any(), f"{what}: an outlier pixel differs by more than the channel's value range (max {abs_d.max():.3e})"
+        # the counted allowance: these pixels answer to the outlier bound (OUTLIER_ULPS fp16 ulp or OUTLIER_ABS), not to the hard cap
+        wild = ~outside & ~((ulp_d <= OUTLIER_ULPS) | (abs_d <= OUTLIER_ABS))
+        assert not wild.any(), (f"{what}: an outlier pixel differs by more than {OUTLIER_ULPS} fp16 ulp and {OUTLIER_ABS:.2e} "
+                                f"(worst {int(ulp_d[wild].max())} ulp / {abs_d[wild].max():.3e})")
         if REPORT:
             print(f"[tolerance] {what}: {int(beyond_px.sum())} pixels beyond the hard cap, inside the allowance of {allowed}", flush=True)
     elif not outside.all():
@@ -114,13 +128,7 @@ def compare16(got, ref, what, rel_l2=1e-3, ulps=2, frac=0.999, abs_floor=0.0, ex
     sel = ok if exclude is None else (ok & ~(exclude if ok.ndim == 2 else np.broadcast_to(exclude[..., None], ok.shape)))
     rl2_in = np.sqrt(((g - r)[sel] ** 2).sum()) / max(np.sqrt((r[sel] ** 2).sum()), 1e-30)
     assert rl2_in <= rel_l2, f"{what}: relative L2 error over the texels inside the ulp bound {rl2_in:.2e} > {rel_l2:.0e}"
-    # over ALL texels — except the counted pixels beyond the hard cap, which answer to their own bound (the channel's value range, above):
-    # in a small image ONE such pixel outweighs everything else (tools/fuzz_tolerance.py 777, configuration 26: a 70x32 quarter-resolution
-    # reflections trace image, one pixel of 2240 off by 0.34 where the DDGI Chebyshev branch flipped: 1.1e-2 over all texels, 1e-5 without it)
-    if allowed and 0 < beyond_px.sum() <= allowed:
-        keep = ~np.broadcast_to(beyond_px.reshape(beyond_px.shape + (1,) * (g.ndim - 2)), g.shape)
-        num_a, den_a = np.sqrt(((g - r)[keep] ** 2).sum()), np.sqrt((r[keep] ** 2).sum())
-        rl2 = num_a / den_a if den_a > 0 else num_a
+    # over ALL texels (round 5: the counted pixels included again — bounded by OUTLIER_ABS they cannot outweigh even a 70x32 image)
     assert rl2 <= 10 * rel_l2, f"{what}: relative L2 error over all texels {rl2:.2e} > {10 * rel_l2:.0e}"
     assert f >= frac, f"{what}: only {f * 100:.3f} % of the texels within {ulps} fp16 ulp ({len(bad)} outside, max abs diff {np.abs(g - r).max():.3e}){where}"
     return rl2, f
@@ -130,7 +138,7 @@ def compare_trace(got, ref, what):
     """the reflections' ray-trace image in tolerance mode (round 4: its DDGI irradiance gathers run through ddgi_sample_fast.h): the ray
     length channel (.a — traversal: hit distance / -1 for a miss) BIT-EXACT, the colour under the image rule with the DDGI outlier allowance"""
     assert np.array_equal(got[..., 3], ref[..., 3]), f"{what}: ray lengths (channel a) must be bit-exact — the traversal has one mode"
-    return compare16(got[..., :3], ref[..., :3], what + " (rgb)", outlier_pixels=REFL_OUTLIERS)
+    return compare16(got[..., :3], ref[..., :3], what + " (rgb)", outlier_pixels=DDGI_OUTLIERS)
 
 
 def upsample_scale(scale):

@@ -1,6 +1,6 @@
 """The tolerance-mode image rule itself (tests/test_gpu_tolerance.py compare16) on synthetic images, no GPU: what it accepts and
-what it refuses — in particular the counted allowance for pixels beyond the hard cap and its interplay with the all-texel L2 bound
-on small images (one allowed outlier pixel must not fail a 70x32 image through the L2 figure; nine must fail it)."""
+what it refuses — in particular that there is no counted allowance by default (round 5), and how the reflections' bounded allowance
+interacts with the all-texel L2 bound."""
 import numpy as np
 import pytest
 
@@ -25,23 +25,37 @@ def test_identical_and_one_ulp_images_pass_a_uniform_bias_does_not():
         T.compare16((_bits(ref).astype(np.int32) + 2).astype(np.uint16), _bits(ref), "two ulp bias")
 
 
-def test_one_counted_outlier_in_a_small_image_passes_and_is_range_bounded():
+def test_no_outlier_is_allowed_by_default_and_the_reflections_allowance_is_tightly_bounded():
+    """round 5: shadows / AO / DDGI images have NO counted allowance; the reflections' denoised images keep max(4, 2e-5 px) pixels, each within
+    OUTLIER_ULPS fp16 ulp or OUTLIER_ABS (not the channel's value range), and the all-texel L2 bound covers those pixels again"""
     ref = _image()
     got = ref.copy()
-    got[5, 7, 1] = np.float16(float(ref[5, 7, 1]) + 0.3)        # inside the channel's value range
-    T.compare16(_bits(got), _bits(ref), "one outlier", outlier_pixels=T.REFL_OUTLIERS)
-    got[5, 7, 1] = np.float16(5.0)                              # far outside it
-    with pytest.raises(AssertionError, match="value range"):
+    got[5, 7, 1] = np.float16(float(ref[5, 7, 1]) + 0.02)       # beyond the hard cap (32 ulp / 2^-10), inside the outlier bound (2^-5)
+    with pytest.raises(AssertionError, match="beyond the hard cap"):
+        T.compare16(_bits(got), _bits(ref), "one outlier, default rule")
+    T.compare16(_bits(got), _bits(ref), "one outlier, reflections rule", outlier_pixels=T.REFL_OUTLIERS)
+    got[5, 7, 1] = np.float16(float(ref[5, 7, 1]) + 0.3)        # inside the channel's value range — round 4 accepted it — but beyond the outlier bound
+    with pytest.raises(AssertionError, match="outlier pixel differs by more than"):
         T.compare16(_bits(got), _bits(ref), "one wild outlier", outlier_pixels=T.REFL_OUTLIERS)
+    assert T.OUTLIER_PIXELS == 0.0 and T.DDGI_OUTLIERS == 0.0 and 0 < T.REFL_OUTLIERS <= 2e-5 and T.OUTLIER_ABS <= 2.0 ** -5 and T.OUTLIER_ULPS <= 512
 
 
 def test_more_outliers_than_the_allowance_fail():
     ref = _image()
     got = ref.copy()
     for k in range(9):
-        got[3 + k, 9, 0] = np.float16(0.9)
+        got[3 + k, 9, 0] = np.float16(float(ref[3 + k, 9, 0]) + 0.02)
     with pytest.raises(AssertionError, match="beyond the hard cap"):
         T.compare16(_bits(got), _bits(ref), "nine outliers", outlier_pixels=T.REFL_OUTLIERS)
+
+
+def test_allowed_outliers_count_in_the_all_texel_l2_bound_again():
+    ref = (_image(8, 12) * 0.02).astype(np.float16)            # a small, dark image: four allowed outliers of 0.03 outweigh everything else
+    got = ref.copy()
+    for k in range(4):
+        got[1 + k, 3, 0] = np.float16(float(ref[1 + k, 3, 0]) + 0.03)
+    with pytest.raises(AssertionError, match="over all texels"):
+        T.compare16(_bits(got), _bits(ref), "outliers that dominate the image", outlier_pixels=T.REFL_OUTLIERS)
 
 
 def test_many_small_errors_fail_the_share_or_the_l2_bound():

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from hybrid_rendering_amd import build as hb
 
 with tempfile.TemporaryDirectory() as td:
-    flags = [f for f in hb.FLAGS if f not in ("-shared",)]
+    flags = [f for f in hb.FLAGS if f not in ("-shared",)] + os.environ.get("HR_CFLAGS", "").split()
     subprocess.check_call([hb.hipcc()] + flags + ["-c", "-x", "hip", src, "-o", os.path.join(td, "o.o"), "-save-temps=obj"], stderr=subprocess.DEVNULL)
     asm = [f for f in os.listdir(td) if f.endswith(".s") and "amdgcn" in f][0]
     text = open(os.path.join(td, asm)).read()
