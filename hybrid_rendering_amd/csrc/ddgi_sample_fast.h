@@ -61,7 +61,8 @@ HR_DEV Bilin bilin_setup(float x, float y, int w, int h)   // x, y in texel unit
 //       t < 1 and x at t == 1): an ulp of dist, mean or of the atlas coordinate decides whether a probe weighs 1 or 1e-6.  Only possible
 //       when max_distance^2 overflows fp16 — a wave-uniform test on the uniforms, false for any grid whose probes are less than ~170 units
 //       apart (the bench grid: 47-75) — so the per-probe tests sit behind a uniform branch: |dist - mean| <= g with var not finite
-//       (g = 4e-6 (|P|_1 + |grid|_1 + dist + mean) >= 10x the error of the fast dist - mean), or the footprint within 2e-4 texels of a
+//       (g = 4e-6 (|P|_1 + |grid|_1 + dist + mean) + 4e-5 (max - min of the footprint's four mean texels) >= 4x the error of the fast
+//       dist - mean), or the footprint within 2e-4 texels of a
 //       texel boundary (the fast coordinates are good to a few ulp of ~150).  In that regime a third of the waves take the redo: it is the
 //       regime in which the reference's own arithmetic is NaN-driven, and exactness is what can still be compared.
 //       (Measured and dropped: the same note wherever var < 2e-4 mean^2, "steep" — +19 % on the 1080p bench frame for no outlier it
@@ -135,7 +136,11 @@ HR_DEV f3 sample_irradiance_pass(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasR
             const float vis = (dist <= mean) ? 1.0f : che;
             if (wild_possible)   // wave-uniform (see (b) above)
             {
-                const float g = G + 4e-6f * (dist + mean);
+                // ... + the error of `mean` itself: the fast atlas coordinate is good to ~1e-5 texels, and the four texels of a footprint can
+                // differ by hundreds of units (a probe that sees a near wall beside the far end of the hall)
+                const float m00 = fm::lo(t00), m10 = fm::lo(t10), m01 = fm::lo(t01), m11 = fm::lo(t11);
+                const float spread = fm::fmax_(fm::fmax_(m00, m10), fm::fmax_(m01, m11)) - fm::fmin_(fm::fmin_(m00, m10), fm::fmin_(m01, m11));
+                const float g = G + 4e-6f * (dist + mean) + 4e-5f * spread;
                 const bool  edge = (b.fx < 2e-4f) | (b.fx > 1.0f - 2e-4f) | (b.fy < 2e-4f) | (b.fy > 1.0f - 2e-4f);
                 noted = noted || edge || (!(variance < 3.0e38f) && __builtin_fabsf(dmr) <= g);
             }

@@ -119,8 +119,11 @@ struct Reproj
     {
         cur_id = cur_id_; cur_n = cur_n_;
         const float fw = (float)g.w, fh = (float)g.h;
-        const float inv_w = fm::rcp(fw), inv_h = fm::rcp(fh);
-        const float tu = ((float)x + 0.5f) * inv_w, tv = ((float)y + 0.5f) * inv_h;
+        // (x + 0.5) / w correctly rounded (round 5): the clip -> world products below cancel 3-4 digits, so ONE ulp of tu moved a world
+        // position by up to ~1e-3 — 20 ulp of its coordinates — and the plane distance of a history tap with it (measured: the guard band of
+        // tap_valid had to be 10x wider than the error of everything else).  With the parity kernels' tu / tv the products are theirs
+        // bit for bit (same operation order, fast_math.h) and only the perspective divide differs (rcp_nr: ~1 ulp).  ~10 VALU per pixel.
+        const float tu = fm::div_by_inrange((float)x + 0.5f, div_prepare(fw)), tv = fm::div_by_inrange((float)y + 0.5f, div_prepare(fh));
         const float mvx = fm::lo(c2y), mvy = fm::hi(c2y);
         cur_pos = fm::unproject_at(fm::unproject_base(M, tu, tv), M, depth);
         band    = HR_TAP_BAND * 1e-4f + (HR_TAP_BAND * 3e-6f) * (__builtin_fabsf(cur_pos.x) + __builtin_fabsf(cur_pos.y) + __builtin_fabsf(cur_pos.z));   // tap_valid<true>
@@ -130,7 +133,7 @@ struct Reproj
             if (ray_length > 0.0f && curvature == 0.0f)
             {
                 // virtual_point_reprojection (reprojection.glsl:71-111): NB current_coord / size without the half-pixel offset
-                const f3    ro  = fm::unproject_at(fm::unproject_base(M, (float)x * inv_w, (float)y * inv_h), M, depth);
+                const f3    ro  = fm::unproject_at(fm::unproject_base(M, fm::div_by_inrange((float)x, div_prepare(fw)), fm::div_by_inrange((float)y, div_prepare(fh))), M, depth);
                 f3          cr  = sub3(ro, cam_pos);
                 const float l2  = fm::dot(cr, cr);
                 const float il  = fm::rsq(l2), crl = l2 * il;
@@ -1479,7 +1482,9 @@ __global__ __launch_bounds__(256) void kf_ddgi_sample(DDGISampleArgs a)
     const float dp = fm::ld<float>(a.depth, o * 4u);
     if (dp == 1.0f) { *outp = make_uint2(0u, 0u); return; }
     const DDGIU& d = a.d;
-    const float tu = ((float)x + 0.5f) * fm::rcp((float)a.w), tv = ((float)y + 0.5f) * fm::rcp((float)a.h);
+    // (x + 0.5) / w correctly rounded (round 5, as in Reproj::issue): the clip -> world products cancel 3-4 digits, one ulp of tu moved P by up
+    // to ~1e-3 (20 ulp of its coordinates) — more than the whole guard of the gather's knife-edge tests
+    const float tu = fm::div_by_inrange((float)x + 0.5f, div_prepare((float)a.w)), tv = fm::div_by_inrange((float)y + 0.5f, div_prepare((float)a.h));
     const f3 P  = fm::unproject_at(fm::unproject_base(a.vpi, tu, tv), a.vpi, dp);
     const f3 N  = fm::oct_unit(fm::ld<uint32_t>(a.gb2, o * 8u));
     f3       Wo = mk3(a.cam[0] - P.x, a.cam[1] - P.y, a.cam[2] - P.z);

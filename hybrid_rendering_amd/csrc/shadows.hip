@@ -46,6 +46,9 @@ struct TraceArgs
 // wave ballot IS the packed mask (bit y*8+x of shadows_ray_trace.comp:126).
 #define TRACE_WAVES 1 // waves (8x8 tiles) per workgroup: 1 lets the dispatcher back-fill a CU wave by wave — tile
                       // costs differ by >10x, and with 4-wave groups the finished waves' slots idle until the slowest ends
+#ifndef SHADOWS_SHARE
+#define SHADOWS_SHARE 0   // developer A/B (round 5): 1 = wave-level walk that hands pending subtrees of the last live lanes to idle lanes (traverse.h trace_any_share)
+#endif
 #ifndef SHADOWS_TRACE_EU
 #define SHADOWS_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for (A/B: see docs/EXPERIMENTS.md R4.3)
 #endif
@@ -73,6 +76,57 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
     const uint2    g2_pre = a.gb2[pix];
     const uint32_t bn_pre = blue_noise_texel(x, y, a.sr);
     const uint32_t occ_pre = a.occluder ? a.occluder[pix] : 0xffffffffu;
+#if SHADOWS_SHARE
+    // wave-level traversal with work sharing in the tail (traverse.h trace_any_share): every lane prepares its ray (or none), then the WAVE walks
+    f3    ro = mk3(0.0f, 0.0f, 0.0f), Wi = mk3(0.0f, 0.0f, 1.0f);
+    float t_max = 0.0f;
+    bool  walk = false, occluded = false;
+    uint32_t hit_tri = 0xffffffffu;
+    if (kind)
+    {
+        const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
+        if (d != 1.0f)
+        {
+            const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
+            const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
+            const uint2 g2 = kind == 1 ? g2_pre : make_uint2(0u, 0u);
+            const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
+            ro = add3(P, scale3(N, a.bias));
+            const float r0 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 0, a.sobol);
+            const float r1 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 1, a.sobol);
+            float att;
+            fetch_light_shadow(a.light, P, N, r0, r1, Wi, t_max, att);
+            if (att > 0.0f)
+            {
+                fired = true;
+                if (a.occluder && kind == 1 && !a.debug_skip_traversal)   // occluder cache: see the per-lane form below
+                {
+                    const uint32_t c = occ_pre;
+                    if (c < a.n_tri_refs)
+                    {
+                        const RayPre rp = ray_prepare(ro, Wi);
+                        float t, u, v;
+                        occluded = ray_tri_raw<false>(rp, load_tri_raw(a.tris, c), 0.01f, t_max, t, u, v);
+                        if (STATS) nt++;
+                        hit_tri = c;
+                    }
+                }
+                if (a.debug_skip_traversal) lit = (ro.x + Wi.y > -1e30f);
+                else walk = !occluded;
+            }
+        }
+    }
+    {
+        uint32_t walked_tri = 0xffffffffu;
+        const bool wo = trace_any_share<STATS>(walk, a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt, &walked_tri);
+        if (walk) { occluded = wo; hit_tri = walked_tri; }
+    }
+    if (fired && !a.debug_skip_traversal)
+    {
+        lit = !occluded;
+        if (a.occluder && kind == 1 && hit_tri != occ_pre) a.occluder[pix] = hit_tri;
+    }
+#else
     if (kind)
     {
         const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
@@ -122,6 +176,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
             }
         }
     }
+#endif
     const unsigned long long bits = __ballot(lit);
     const unsigned long long fb   = __ballot(fired);
     if (STATS)

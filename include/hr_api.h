@@ -48,7 +48,8 @@ const char* hr_version(void);
  * built against another revision must not call into this library: compare hr_api_revision() with HR_API_REVISION once at start-up
  * (hr::Context does).  Revision 3 = round 3: hr_*_denoise, hr_hybrid_frame, ticketed hr_comm, HR_ERR_TIMEOUT / HR_ERR_COMM. */
 /* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
-/* revision 5 (round 5): + hr_shadows_trace_stats_timed, hr_shadows_launch_order, hr_ao_launch_order; structs unchanged */
+/* revision 5 (round 5): + hr_shadows_trace_stats_timed, hr_shadows_launch_order, hr_ao_launch_order; structs unchanged; every hr_*_create
+ * returns with its images zero-filled (it waits for the fills), so a first render() on any stream is ordered after them */
 #define HR_API_REVISION 5
 int32_t hr_api_revision(void);
 
@@ -249,13 +250,19 @@ typedef struct
                                    denoise / resolve kernels use the hardware's rcp / rsq / sqrt / exp / log and fused multiply-adds
                                    (2-4x faster);
                                    every fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels, with relative L2 error <= 1e-3 over
-                                   those texels and <= 1e-2 over ALL texels but the counted pixels of the hard cap below; variance channels (shadows .y, reflections .a) additionally count
+                                   those texels and <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) additionally count
                                    |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles.  HARD CAP per texel: outside the
-                                   neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle, except
-                                   for at most max(4, 1e-5 of the pixels) pixels per image (x 5 * 4^scale in a scaled pass's upsampled output) which — like the texels next to a flipped tile — stay
-                                   within the value range of the channel: discrete decisions of the reference's own formulas (a reprojection
-                                   tap's validity, the DDGI Chebyshev branch over a flat depth texel) that one fp32 ulp flips
-                                   (tests/test_gpu_tolerance.py compare16; measured figures: profiles/r4_d);
+                                   neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle.  Round 5:
+                                   no counted exceptions for the shadows, AO, DDGI-sample and reflections-trace images — where the reference's
+                                   formulas are discontinuous (a history tap's validity thresholds, reprojection.glsl:52-67; the DDGI gather's
+                                   trilinear zero on a probe plane and its NaN-driven Chebyshev term where the fp16 depth moments overflow,
+                                   gi_common.glsl:188-320) the tolerance-mode kernels detect the shading points at which their fast operands
+                                   cannot be trusted and take the decision with the parity arithmetic.  The reflections' DENOISED images (temporal,
+                                   a-trous, upsampled output) may exceed the cap on at most max(4, 2e-5 of the pixels) pixels per image (x 5 * 4^scale
+                                   in a scaled pass's upsampled output), each within 512 fp16 ulp or 2^-5: the reference's luminance edge-stopping
+                                   weight exp(-|dl| / (phi sqrt(1e-10 + var))) moves by e^0.6 per fp16 ulp of its input where var == 0, so a 1-ulp
+                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration
+                                   (tests/test_gpu_tolerance.py compare16; fuzz logs: profiles/r5_*);
                                    visibility masks, ray counts and traversal are identical in both modes.
                                    Tolerance mode also reprojects from the pass's own copy of the previous frame's geometry (normal, mesh id,
                                    linear z — written by its temporal kernel) instead of in->prev.gb2 / gb3 whenever in->prev.gb2 / gb3 are the
