@@ -348,7 +348,7 @@ class _Pass:
 class RayTracedShadows(_Pass):
     """src/ray_traced_shadows.h:7-142.  ``render(scene, frame_inputs)`` = RayTracedShadows::render(cmd_buf)."""
     _prefix = "hr_shadows"
-    IMG_MASK, IMG_TEMPORAL, IMG_MOMENTS0, IMG_MOMENTS1, IMG_PREV, IMG_ATROUS0, IMG_ATROUS1, IMG_UPSAMPLE, IMG_TILES = range(9)
+    IMG_MASK, IMG_TEMPORAL, IMG_MOMENTS0, IMG_MOMENTS1, IMG_PREV, IMG_ATROUS0, IMG_ATROUS1, IMG_UPSAMPLE, IMG_TILES, IMG_GEO = range(10)   # IMG_GEO: tolerance mode, the geometry records of the last temporal stage
 
     def __init__(self, ctx: Context, width: int, height: int, scale: int = SCALE_FULL_RES, band=None):
         self.ctx = ctx

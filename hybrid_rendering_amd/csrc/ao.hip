@@ -381,6 +381,7 @@ struct hr_ao
     // instead of 5 images, 17 gathers with half of every G-buffer line unused.
     bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
     bool          geo_valid = false;
+    bool          dbg_require_geo = false;   // HR_DEBUG_REQUIRE_GEO (tests)
     int           geo_parity = 0, geo_pp = -1;
     const void*   geo_gb2 = nullptr;
     const void*   geo_gb3 = nullptr;
@@ -404,6 +405,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_DEBUG_REQUIRE_GEO")) p->dbg_require_geo = atoi(e) != 0;   // test switch, see hr_shadows
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->tile_order.tag = "ao";
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
@@ -568,10 +570,12 @@ hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params
         // (hr_ao_exchange_history), the record's AO half there is this GPU's own redundant result.  The geometry half is a copy of the
         // G-buffer either way, and a band computes — and so records — every row it reads history from (history_halo == halo for AO).
         a.geo_band = (y0 > 0 || y1 < p->h) ? 1 : 0;
+        const bool had_records = p->geo_valid;
         if (p->geo_valid && !p->first_frame && pp != p->geo_pp && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3) a.geo_hist = p->geo[p->geo_parity].p;
         p->geo_parity ^= 1;
         a.geo_out = p->geo[p->geo_parity].p;
         p->geo_valid = true; p->geo_pp = pp; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+        if (p->dbg_require_geo && had_records && !a.geo_hist) { hr::set_last_error("hr_ao_temporal: HR_DEBUG_REQUIRE_GEO is set and the record path was not taken"); return HR_ERR_INVALID_ARG; }
     }
     else p->geo_valid = false;
     p->last_pp = pp;

@@ -450,6 +450,7 @@ struct hr_reflections
     bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
     bool          fast_shading = true;  // tolerance mode: k_refl_trace<., FAST> (developer A/B switch HR_REFL_FAST_SHADING=0, read once at create)
     bool          geo_valid = false;
+    bool          dbg_require_geo = false;   // HR_DEBUG_REQUIRE_GEO (tests)
     int           geo_parity = 0;
     const void*   geo_gb2 = nullptr;
     const void*   geo_gb3 = nullptr;
@@ -477,6 +478,7 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_DEBUG_REQUIRE_GEO")) p->dbg_require_geo = atoi(e) != 0;   // test switch, see hr_shadows
     if (const char* e = getenv("HR_REFL_FAST_SHADING")) p->fast_shading = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->tile_order.tag = "reflections";
@@ -648,11 +650,13 @@ hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, 
     a.geo_hist = nullptr; a.geo_out = nullptr; p->geo_cur = nullptr;
     if (!prm->exact && p->geo[0].p)
     {
+        const bool had_records = p->geo_valid;
         if (p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3) a.geo_hist = p->geo[p->geo_parity].p;
         p->geo_parity ^= 1;
         a.geo_out = p->geo[p->geo_parity].p;
         p->geo_cur = a.geo_out;
         p->geo_valid = true; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
+        if (p->dbg_require_geo && had_records && !a.geo_hist) { hr::set_last_error("hr_reflections_temporal: HR_DEBUG_REQUIRE_GEO is set and the record path was not taken"); return HR_ERR_INVALID_ARG; }
     }
     else p->geo_valid = false;
     p->last_pp = pp;

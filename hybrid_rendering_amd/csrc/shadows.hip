@@ -46,9 +46,6 @@ struct TraceArgs
 // wave ballot IS the packed mask (bit y*8+x of shadows_ray_trace.comp:126).
 #define TRACE_WAVES 1 // waves (8x8 tiles) per workgroup: 1 lets the dispatcher back-fill a CU wave by wave — tile
                       // costs differ by >10x, and with 4-wave groups the finished waves' slots idle until the slowest ends
-#ifndef SHADOWS_SHARE
-#define SHADOWS_SHARE 0   // developer A/B (round 5): 1 = wave-level walk that hands pending subtrees of the last live lanes to idle lanes (traverse.h trace_any_share)
-#endif
 #ifndef SHADOWS_TRACE_EU
 #define SHADOWS_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for (A/B: see docs/EXPERIMENTS.md R4.3)
 #endif
@@ -76,57 +73,6 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
     const uint2    g2_pre = a.gb2[pix];
     const uint32_t bn_pre = blue_noise_texel(x, y, a.sr);
     const uint32_t occ_pre = a.occluder ? a.occluder[pix] : 0xffffffffu;
-#if SHADOWS_SHARE
-    // wave-level traversal with work sharing in the tail (traverse.h trace_any_share): every lane prepares its ray (or none), then the WAVE walks
-    f3    ro = mk3(0.0f, 0.0f, 0.0f), Wi = mk3(0.0f, 0.0f, 1.0f);
-    float t_max = 0.0f;
-    bool  walk = false, occluded = false;
-    uint32_t hit_tri = 0xffffffffu;
-    if (kind)
-    {
-        const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
-        if (d != 1.0f)
-        {
-            const float tu = __fdiv_rn((float)x + 0.5f, (float)a.w), tv = __fdiv_rn((float)y + 0.5f, (float)a.h);
-            const f3    P  = world_pos_from_depth(tu, tv, d, a.vpi);
-            const uint2 g2 = kind == 1 ? g2_pre : make_uint2(0u, 0u);
-            const f3    N  = oct_decode(h2f_lo(g2.x), h2f_hi(g2.x));
-            ro = add3(P, scale3(N, a.bias));
-            const float r0 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 0, a.sobol);
-            const float r1 = sample_blue_noise_t(bn_pre, (int)a.num_frames, 1, a.sobol);
-            float att;
-            fetch_light_shadow(a.light, P, N, r0, r1, Wi, t_max, att);
-            if (att > 0.0f)
-            {
-                fired = true;
-                if (a.occluder && kind == 1 && !a.debug_skip_traversal)   // occluder cache: see the per-lane form below
-                {
-                    const uint32_t c = occ_pre;
-                    if (c < a.n_tri_refs)
-                    {
-                        const RayPre rp = ray_prepare(ro, Wi);
-                        float t, u, v;
-                        occluded = ray_tri_raw<false>(rp, load_tri_raw(a.tris, c), 0.01f, t_max, t, u, v);
-                        if (STATS) nt++;
-                        hit_tri = c;
-                    }
-                }
-                if (a.debug_skip_traversal) lit = (ro.x + Wi.y > -1e30f);
-                else walk = !occluded;
-            }
-        }
-    }
-    {
-        uint32_t walked_tri = 0xffffffffu;
-        const bool wo = trace_any_share<STATS>(walk, a.nodes, a.tris, ro, Wi, 0.01f, t_max, s_stack[wave], lane, nn, nt, &walked_tri);
-        if (walk) { occluded = wo; hit_tri = walked_tri; }
-    }
-    if (fired && !a.debug_skip_traversal)
-    {
-        lit = !occluded;
-        if (a.occluder && kind == 1 && hit_tri != occ_pre) a.occluder[pix] = hit_tri;
-    }
-#else
     if (kind)
     {
         const float d = kind == 1 ? d_pre : 0.0f;      // edge thread: out-of-image fetches read 0
@@ -176,7 +122,6 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
             }
         }
     }
-#endif
     const unsigned long long bits = __ballot(lit);
     const unsigned long long fb   = __ballot(fired);
     if (STATS)
@@ -622,6 +567,7 @@ struct hr_shadows
     // A previous G-buffer that ALIASES the current one (one buffer rewritten in place) is read as the caller passed it.
     bool          geo_history = true;       // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
     bool          geo_valid = false;        // `nd` half geo_parity holds the records of the last frame this pass rendered
+    bool          dbg_require_geo = false;  // HR_DEBUG_REQUIRE_GEO (tests): from the second frame on, a tolerance-mode temporal stage must take the record path
     int           geo_parity = 0;
     const void*   geo_gb2 = nullptr;        // in->cur.gb2 / gb3 of that frame
     const void*   geo_gb3 = nullptr;
@@ -651,6 +597,7 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
+    if (const char* e = getenv("HR_DEBUG_REQUIRE_GEO")) p->dbg_require_geo = atoi(e) != 0;   // test switch: a temporal stage that cannot reproject from the records fails
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->tile_order.tag = "shadows";
     p->tile_order.min_spread = HR_ORDER_COHERENT_SPREAD;   // rays towards one light: coherent
@@ -932,6 +879,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
         // (round 5: bands too — the records of the rows a band reads history from but does not compute, hr_band.history_halo beyond
         // hr_band.halo, are copies of the current G-buffer as well, written by a few extra workgroups of the temporal launch: GeoApronArgs)
         const size_t half = (size_t)p->w * p->h * 8;
+        const bool   had_records = p->geo_history && p->geo_valid;
         if (p->geo_history && p->geo_valid && !p->first_frame && in->prev.gb2 == p->geo_gb2 && in->prev.gb3 == p->geo_gb3 && in->prev.gb2 != in->cur.gb2 && in->prev.gb3 != in->cur.gb3)
             a.geo_hist = (const char*)p->nd.p + (size_t)p->geo_parity * half;
         p->geo_parity ^= 1;
@@ -939,6 +887,7 @@ hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr
         p->geo_valid = true; p->geo_gb2 = in->cur.gb2; p->geo_gb3 = in->cur.gb3;
         if (p->geo_history && (ry0 < y0 || ry1 > y1))
             a.apron = GeoApronArgs { in->cur.gb2, in->cur.gb3, a.nd, w, ry0, y0, y1, ry1, -1 };
+        if (p->dbg_require_geo && had_records && !a.geo_hist) { set_last_error("hr_shadows_temporal: HR_DEBUG_REQUIRE_GEO is set and the record path was not taken"); return HR_ERR_INVALID_ARG; }
     }
     else p->geo_valid = false;   // the parity mode's float4 layout covers both halves
     p->nd_cur = a.nd;
@@ -1114,6 +1063,9 @@ hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* v)
         case 6: fill_view(v, p->atrous[1].p, p->w, p->h, 4, HR_FORMAT_RG16F); break;
         case 7: fill_view(v, p->upsample.p, p->full_w, p->full_h, 2, HR_FORMAT_R16F); break;
         case 8: fill_view(v, p->tile_class.p, p->tiles_x, p->tiles_y, 1, (hr_format)0); break;
+        case 9:   // tolerance mode: the geometry records {GB2.x, GB3.y} the last temporal stage wrote — tests / tools
+            if (!p->nd_cur || p->latched_exact != 0) { set_last_error("hr_shadows_image(9): no geometry records (parity mode, or no temporal stage yet)"); return HR_ERR_INVALID_ARG; }
+            fill_view(v, p->nd_cur, p->w, p->h, 8, HR_FORMAT_RGBA16F); break;
         default: set_last_error("hr_shadows_image: unknown image index"); return HR_ERR_INVALID_ARG;
     }
     return HR_OK;

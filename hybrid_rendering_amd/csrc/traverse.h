@@ -224,9 +224,8 @@ struct LaneStack
     uint32_t* lds;   // &wave_region[lane]
     uint32_t* spill; // private overflow array, HR_SPILL_ENTRIES entries
     int       sp;
-    int       bot;   // entries [bot, sp) are live: trace_any_share gives entries away from the BOTTOM (the largest pending subtrees); 0 everywhere else
-    HR_DEV void init(uint32_t* wave_region, int lane, uint32_t* spill_array) { lds = wave_region + lane; spill = spill_array; sp = 0; bot = 0; }
-    HR_DEV bool empty() const { return sp == bot; }
+    HR_DEV void init(uint32_t* wave_region, int lane, uint32_t* spill_array) { lds = wave_region + lane; spill = spill_array; sp = 0; }
+    HR_DEV bool empty() const { return sp == 0; }
     // The walk keeps one entry per BVH level and hr_scene_create refuses trees deeper than kMaxTraversalDepth (bvh.h; the
     // builder caps the depth, bvh_build.cpp kSahDepth), so `sp` never reaches the capacity.  Belt and braces: a push beyond
     // it is dropped WITHOUT advancing sp — push and pop stay paired and no index ever leaves the arrays.
@@ -411,135 +410,6 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
 
 HR_DEV void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 HR_DEV uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
-
-// ---- any-hit with work sharing in the tail of a wave ------------------------------------------------------------------------------
-// One ray per lane, as trace_any — but the wave is the unit: once it has thinned out to HR_SHARE_BELOW live lanes, a live lane whose
-// stack holds pending entries gives the BOTTOM one (the siblings nearest the root: its largest pending subtree) to an idle lane, which
-// takes over the owner's ray (17 ds_bpermute) and walks that subtree on its own LDS stack column.  "Is any triangle hit" is the OR over the
-// subtrees, so the pieces need no ordering: whoever finds a hit marks the OWNER's ray dead (a wave-uniform 64-bit mask), the owner and every
-// lane helping it stop, and the answer is that bit.  Decisions per node / triangle are those of trace_any (same tests, same operands), so the
-// masks are bit-identical; which triangle is reported as the occluder (hit_tri: only a hint for the next frame's occluder cache) may differ.
-// Built for the stragglers of the shadow trace (docs/EXPERIMENTS.md R5.3): a ray grazing finely tessellated geometry
-// keeps dozens of sibling subtrees pending while the other 60 lanes of its wave idle.
-// All lanes of the wave must call it (active = this lane has a ray).
-#ifndef HR_SHARE_BELOW
-#define HR_SHARE_BELOW 16
-#endif
-template <bool STATS, int ORDER = HR_ANY_ORDER>
-HR_DEV bool trace_any_share(bool active, const Node8* __restrict__ nodes, const TriGPU* __restrict__ tris, f3 o, f3 d, float t_min, float t_max,
-                            uint32_t* wave_stack, int lane, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* hit_tri = nullptr)
-{
-    RayPre    r = ray_prepare(o, d);
-    uint32_t  spill_array[HR_SPILL_ENTRIES];
-    LaneStack st;
-    st.init(wave_stack, lane, spill_array);
-    uint32_t cur = 1u;               // root = "child 0 of child_base 0"
-    int      owner = lane;           // whose ray this lane is walking
-    unsigned long long dead = 0ull;  // rays (by owner lane) that are known to be occluded — wave-uniform
-    uint32_t found_tri = 0xffffffffu;
-    // the axis permutation of the triangle test, if the rays of the wave share one (lanes without a ray do not vote; helpers walk copies of
-    // the same rays, so a wave-uniform permutation stays one)
-    int pcode = -1;
-    {
-        const unsigned long long am = __ballot(active);
-        if (am)
-        {
-            const int c = perm_code(r), c0 = __builtin_amdgcn_readlane(c, __builtin_ctzll(am));
-            if (__ballot(active && c != c0) == 0ull) pcode = c0;
-        }
-    }
-    for (;;)
-    {
-        const unsigned long long act = __ballot(active);
-        if (!act) break;
-        bool     hit_now = false;
-        uint32_t hit_idx = 0u;
-        if (active)
-        {
-            uint32_t ni;
-            if (((dead >> owner) & 1ull) || !walk_next<ORDER != HR_ORDER_SLOTS>(cur, st, ni)) active = false;
-            else
-            {
-                const NodeHits h = test_node<ORDER>(load_node(nodes, ni), r, t_min, t_max);
-                if (STATS) n_nodes++;
-                uint32_t trimask = walk_expand(h, cur, st);
-                while (trimask)
-                {
-                    const uint32_t i0 = (uint32_t)__builtin_ctz(trimask);
-                    trimask &= trimask - 1u;
-                    const bool     two = trimask != 0u;
-                    const uint32_t i1  = two ? (uint32_t)__builtin_ctz(trimask) : i0;
-                    trimask &= trimask - 1u;   // no-op on 0
-                    const TriRaw ta = load_tri_raw(tris, h.tri_base + i0), tb = load_tri_raw(tris, h.tri_base + i1);
-                    if (STATS) n_tris += two ? 2u : 1u;
-                    float t, u, v;
-                    const bool ha = ray_tri_raw_uniform<false>(r, pcode, ta, t_min, t_max, t, u, v);
-                    const bool hb = ray_tri_raw_uniform<false>(r, pcode, tb, t_min, t_max, t, u, v);
-                    if (ha || hb) { hit_now = true; hit_idx = h.tri_base + (ha ? i0 : i1); break; }
-                }
-                if (hit_now) active = false;
-            }
-        }
-        // a hit answers the OWNER's ray
-        unsigned long long hb = __ballot(hit_now);
-        while (hb)
-        {
-            const int l = __builtin_ctzll(hb);
-            hb &= hb - 1ull;
-            const int      ow = __builtin_amdgcn_readlane(owner, l);
-            const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)hit_idx, l);
-            dead |= 1ull << ow;
-            if (lane == ow) found_tri = ti;
-        }
-        // sharing: the wave has thinned out, some live lane has pending entries, some lane idles
-        const unsigned long long live = __ballot(active);
-        if (live && __popcll(live) <= HR_SHARE_BELOW)
-        {
-            const bool               offer  = active && !((dead >> owner) & 1ull) && st.sp > st.bot && st.bot < HR_STACK_ENTRIES;
-            const unsigned long long donors = __ballot(offer), idle = ~live;
-            int n = __popcll(donors);
-            const int n_idle = __popcll(idle);
-            n = n < n_idle ? n : n_idle;
-            if (n > 0)
-            {
-                const int  drank = (int)lanes_below(donors), irank = (int)lanes_below(idle);
-                const bool gives = offer && drank < n, takes = !active && irank < n;
-                // the irank-th idle lane takes from the irank-th donor
-                int src = lane;
-                {
-                    unsigned long long dm = donors;
-                    for (int i = 0; i < n; i++)
-                    {
-                        const int dl = __builtin_ctzll(dm);
-                        dm &= dm - 1ull;
-                        if (takes && irank == i) src = dl;
-                    }
-                }
-                const uint32_t entry = gives ? st.lds[st.bot * 64] : 0u;
-                if (gives) st.bot++;
-                const uint32_t g_entry = (uint32_t)__shfl((int)entry, src);
-                const int      g_owner = __shfl(owner, src);
-                RayPre q;
-                q.o.x = __shfl(r.o.x, src); q.o.y = __shfl(r.o.y, src); q.o.z = __shfl(r.o.z, src);
-                q.Sx  = __shfl(r.Sx, src);  q.Sy  = __shfl(r.Sy, src);  q.Sz  = __shfl(r.Sz, src);
-                q.idx = __shfl(r.idx, src); q.idy = __shfl(r.idy, src); q.idz = __shfl(r.idz, src);
-                const int kp = __shfl(r.kx | (r.ky << 2) | (r.kz << 4) | ((int)r.sel << 6), src);
-                const float q_max = __shfl(t_max, src);
-                if (takes)
-                {
-                    r.o = q.o; r.Sx = q.Sx; r.Sy = q.Sy; r.Sz = q.Sz; r.idx = q.idx; r.idy = q.idy; r.idz = q.idz;
-                    r.kx = kp & 3; r.ky = (kp >> 2) & 3; r.kz = (kp >> 4) & 3; r.sel = (uint32_t)(kp >> 6);
-                    t_max = q_max;
-                    cur = g_entry; st.sp = 0; st.bot = 0;
-                    owner = g_owner;
-                    active = true;
-                }
-            }
-        }
-    }
-    if (hit_tri && ((dead >> lane) & 1ull)) *hit_tri = found_tri;
-    return (dead >> lane) & 1ull;
-}
 
 // ---- lane-sequential any-hit rays ---------------------------------------------------------------------------------------------
 // NB rays per lane (the sample rays of one AO pixel), walked back to back INSIDE one wave-level loop: a lane whose ray is done

@@ -233,3 +233,55 @@ def test_history_apron_guard(oracle, hr, ctx, exact):
     for p in (gp, ao, whole):
         p.close()
     gsc.close()
+
+
+def test_bands_reproject_from_their_geometry_records(oracle, hr, ctx, monkeypatch):
+    """Round 5: with the reference's G-buffer ping-pong (in->prev is what the previous render() received as in->cur) a BAND of
+    a row-tiled frame reprojects from its own geometry records in tolerance mode, like a whole frame.  HR_DEBUG_REQUIRE_GEO makes
+    a temporal stage FAIL if it does not take the record path from the second frame on, so that this test cannot pass on the caller's images;
+    band rows and history aprons stay bit-identical to the un-tiled frame, and the shadow pass's records of the history rows it does not
+    compute (history_halo 40 beyond halo 24: written by extra workgroups of the temporal launch) are copies of the current G-buffer."""
+    import torch
+    monkeypatch.setenv("HR_DEBUG_REQUIRE_GEO", "1")
+    name, W, H, n_frames, world = "sponza_small", 192, 264, 5, 3
+    sd = helpers.scene_data(name)
+    osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
+    frames = helpers.make_frames(oracle, osc, name, W, H, n_frames, 2.0)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    # two persistent device G-buffers, written alternately: frame f reads cur = slot f & 1, prev = the other slot (what it was given as cur last frame)
+    slots = [helpers.to_cuda(frames[0]["gb"]), helpers.to_cuda(frames[0]["gb"])]
+    sh_whole, ao_whole = hr.RayTracedShadows(ctx, W, H), hr.RayTracedAO(ctx, W, H, 0)
+    sh_bands = [tiling.TiledShadows(ctx, W, H, r, world) for r in range(world)]
+    ao_bands = [tiling.TiledAO(ctx, W, H, r, world, scale=0) for r in range(world)]
+    for p in [sh_whole, ao_whole] + sh_bands + ao_bands:
+        p.params.exact = 0
+        if hasattr(p.params, "spp"):
+            p.params.spp = 2
+    for b in sh_bands + ao_bands:
+        b.world = 1   # exchange emulated with device copies
+    ping = False
+    for f in range(n_frames):
+        cur = slots[f & 1]
+        for k, v in helpers.to_cuda(frames[f]["gb"]).items():
+            cur[k].copy_(v)
+        prev = slots[(f + 1) & 1] if f else cur
+        fi = hr.frame_inputs(cur, prev, frames[f]["ubo"], f, ping, sob_d, sr_d, z_buffer_params=synth.z_buffer_params())
+        sh_whole.render(gsc, fi); ao_whole.render(gsc, fi)
+        for b in sh_bands + ao_bands:
+            b.render(gsc, fi)                  # raises (HR_DEBUG_REQUIRE_GEO) if a band falls back to the caller's previous G-buffer
+        _emulate_exchange(sh_bands, H, ping); _emulate_exchange(ao_bands, H, ping)
+        torch.cuda.synchronize()
+        ref, ref_prev = helpers.bits16(sh_whole.output(hr.OUTPUT_ATROUS)), helpers.bits16(sh_whole.image(sh_whole.IMG_PREV))
+        ref_ao = helpers.bits16(ao_whole.output(hr.OUTPUT_UPSAMPLE))
+        g2, g3 = cur["gb2"].contiguous().view(torch.int32).cpu().numpy(), cur["gb3"].contiguous().view(torch.int32).cpu().numpy()
+        for r, b in enumerate(sh_bands):
+            assert np.array_equal(helpers.bits16(b.pass_.output(hr.OUTPUT_ATROUS))[b.b0:b.b1], ref[b.b0:b.b1]), f"frame {f} band {r}: shadows output differs"
+            lo, hi = max(0, b.b0 - tiling.HISTORY_HALO), min(H, b.b1 + tiling.HISTORY_HALO)
+            assert np.array_equal(helpers.bits16(b.pass_.image(b.pass_.IMG_PREV))[lo:hi], ref_prev[lo:hi]), f"frame {f} band {r}: history halo differs"
+            rec = b.pass_.image(b.pass_.IMG_GEO).contiguous().view(torch.int32).cpu().numpy().reshape(H, W, 2)
+            assert np.array_equal(rec[lo:hi, :, 0], g2.reshape(H, W, 2)[lo:hi, :, 0]) and np.array_equal(rec[lo:hi, :, 1], g3.reshape(H, W, 2)[lo:hi, :, 1]), \
+                f"frame {f} band {r}: records of the rows [{lo}, {hi}) (band + history apron) are not copies of the G-buffer words"
+        for r, b in enumerate(ao_bands):
+            assert np.array_equal(helpers.bits16(b.pass_.output(hr.OUTPUT_UPSAMPLE))[b.b0:b.b1], ref_ao[b.b0:b.b1]), f"frame {f} band {r}: AO output differs"
+        ping = not ping
