@@ -15,7 +15,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH=(python $R/bench.py --steps 100 --warmup 20 --exact $EXACT)
 if [ -z "$SKIP_BENCH" ]; then
-    python $R/bench.py --exact $EXACT 2>/dev/null | tail -1 > $OUT/bench.json
+    python $R/bench.py --exact $EXACT 2>/dev/null | tail -1 > $OUT/bench.json          # the compact stdout line (what the driver parses)
+    cp $R/bench_detail.json $OUT/bench_detail.json 2>/dev/null                          # the full record (per-kernel blocks, notes)
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- "${BENCH[@]}" --no-cpu-baseline --no-passes > /dev/null 2> $OUT/kt.err
     cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 fi
