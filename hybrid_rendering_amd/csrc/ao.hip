@@ -50,7 +50,37 @@ struct AOTraceArgs
     int                spp;
     const uint32_t*    order;      // nullable: launch slot -> tile, last frame's heaviest tiles first (tile_order.h)
     uint16_t*          cost;       // nullable: per tile, how long its wave lived (100 MHz ticks)
+    // nullable: table of traversal entry nodes over a grid of cells of edge 1 / grid_inv_c from grid_lo (AoEntryGrid below)
+    const uint32_t*    grid;
+    float              grid_lo[3], grid_inv_c;
+    int                grid_n[3];
 };
+
+// Entry-node table (round 5).  Every sample ray of a pixel stays within ray_length of its origin, so the traversals may start at the deepest
+// BVH node that holds all the geometry of that ball (entry_node_for_box) — until round 4 found per pixel by a descent from the root: 3.5
+// dependent node tests per pixel, 5 for the slowest lane of a wave, ~18 % of the kernel.  The descent only depends on WHERE the ball is, so it
+// is done once per CELL of a grid over the scene (cell box grown by the ray length: a superset of the ball of every origin in the cell — any
+// node whose subtree holds all geometry touching a superset is a valid entry, so the hit set and the masks are unchanged) and a pixel looks
+// its cell up: one load instead of the descent, for an entry node that is on average 0.2-0.3 node steps per ray shallower
+// (tools/bvh_eval.cpp AO_ENTRY_CELL study: cells of 3.5 / 7 / 14 units at ray length 7: +0.17 / +0.30 / +0.48 node steps per ray against
+// 3.45 descent tests per pixel saved).  The table belongs to the pass, is rebuilt (one thread per cell, in-stream) when the scene or the ray
+// length changes, and has a fixed capacity so that nothing is allocated inside a frame (a frame may be under hipGraph capture).
+#ifndef HR_AO_GRID_CELLS
+#define HR_AO_GRID_CELLS (1 << 22)      // 16 MB (developer A/B: -DHR_AO_GRID_CELLS=...)
+#endif
+constexpr int kAoGridCells = HR_AO_GRID_CELLS;
+__global__ __launch_bounds__(256) void k_ao_entry_grid(const Node8* __restrict__ nodes, uint32_t* __restrict__ cells, float lox, float loy, float loz, float c, int nx, int ny, int nz, float grow)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nx * ny * nz) return;
+    const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+    // the cell's box in the arithmetic the lookup uses (lo + index * c), grown by the ray length and by a sliver of the cell for the
+    // rounding of the lookup's (o - lo) / c
+    const float g  = grow + 1e-3f * c;
+    const f3    bl = mk3(lox + (float)ix * c - g, loy + (float)iy * c - g, loz + (float)iz * c - g);
+    const f3    bh = mk3(lox + (float)(ix + 1) * c + g, loy + (float)(iy + 1) * c + g, loz + (float)(iz + 1) * c + g);
+    cells[i] = entry_node_for_box(nodes, bl, bh);
+}
 
 #ifdef HR_TRACE_DIVERGENCE
 static __device__ unsigned long long g_div_ao[8];
@@ -119,7 +149,18 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
     if (active)
     {
         const float r = a.ray_length * 1.0001f + 1e-4f;
-        entry = entry_node_for_box(a.nodes, mk3(ro.x - r, ro.y - r, ro.z - r), mk3(ro.x + r, ro.y + r, ro.z + r));
+        bool looked_up = false;
+        if (a.grid)   // wave-uniform
+        {
+            const float gx = (ro.x - a.grid_lo[0]) * a.grid_inv_c, gy = (ro.y - a.grid_lo[1]) * a.grid_inv_c, gz = (ro.z - a.grid_lo[2]) * a.grid_inv_c;
+            const int   ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+            if (ix >= 0 && iy >= 0 && iz >= 0 && ix < a.grid_n[0] && iy < a.grid_n[1] && iz < a.grid_n[2])   // an origin outside the scene's box (bias): the descent
+            {
+                entry     = a.grid[((size_t)iz * a.grid_n[1] + iy) * a.grid_n[0] + ix];
+                looked_up = true;
+            }
+        }
+        if (!looked_up) entry = entry_node_for_box(a.nodes, mk3(ro.x - r, ro.y - r, ro.z - r), mk3(ro.x + r, ro.y + r, ro.z + r));
     }
 #if AO_SEQ
     if (!STATS)
@@ -386,6 +427,12 @@ struct hr_ao
     const void*   geo_gb2 = nullptr;
     const void*   geo_gb3 = nullptr;
     TileOrder     tile_order;           // heaviest-first launch order of the trace kernel (tile_order.h)
+    // entry-node table of the trace kernel (AoEntryGrid above): built for (scene, ray_length), rebuilt in-stream when either changes
+    DevBuf        entry_grid;
+    bool          grid_enabled = true;  // developer A/B switch HR_AO_ENTRY_GRID=0 (read once at create)
+    uint64_t      grid_scene = 0;       // hr_scene::uid the table was built for (0: none)
+    float         grid_ray_length = -1.0f, grid_lo[3] = { 0, 0, 0 }, grid_c = 0.0f;
+    int           grid_n[3] = { 0, 0, 0 };
 };
 
 bool hr::profiling_enabled(const hr_ao* p) { return p && p->prof.enabled; }
@@ -406,6 +453,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_DEBUG_REQUIRE_GEO")) p->dbg_require_geo = atoi(e) != 0;   // test switch, see hr_shadows
+    if (const char* e = getenv("HR_AO_ENTRY_GRID")) p->grid_enabled = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->tile_order.tag = "ao";
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale;
@@ -429,6 +477,7 @@ hr_status hr_ao_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_
     A(counters, 64)
     A(ray_slots, (size_t)p->tiles_x * p->tiles_y * 4)
     if (p->geo_history) { A(geo[0], px * 8) A(geo[1], px * 8) }   // (round 5: bands too — see hr_ao_temporal)
+    if (p->grid_enabled) { A(entry_grid, (size_t)kAoGridCells * 4) }
 #undef A
     if ((s = p->tile_order.init(p->tiles_x * (cdiv(p->y1, 8) - p->y0 / 8))) != HR_OK) { delete p; return s; }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -499,6 +548,43 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     const uint64_t px = (uint64_t)p->w * (p->y1 - p->y0);
     { const hr_status fs = p->tile_order.flush(st); if (fs != HR_OK) return fs; }   // last launch's costs, if no temporal stage took them along
     a.order = p->tile_order.order_arg(n_tiles); a.cost = p->want_stats ? nullptr : p->tile_order.cost_arg(n_tiles);
+    a.grid = nullptr;
+    if (p->grid_enabled && p->entry_grid.p && prm->ray_length > 0.0f)
+    {
+        if (p->grid_scene != scene->uid || p->grid_ray_length != prm->ray_length)
+        {
+            // cells of half the ray length, no finer than 1/256 of the longest extent, coarsened until the table fits its fixed capacity
+            const float* lo = scene->info.bounds_lo; const float* hi = scene->info.bounds_hi;
+            const float ext[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
+            const float longest = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
+            float c = 0.5f * prm->ray_length;
+            if (c < longest / 256.0f) c = longest / 256.0f;
+            if (!(c > 0.0f) || !(longest < 1e30f)) c = 0.0f;
+            int n[3] = { 0, 0, 0 };
+            for (int it = 0; it < 64 && c > 0.0f; it++)
+            {
+                bool fits = true;
+                for (int k = 0; k < 3; k++) { const double q = std::floor((double)ext[k] / c) + 1.0; n[k] = q < 1.0 ? 1 : (q > 4096.0 ? 4096 : (int)q); if (q > 4096.0) fits = false; }
+                if (fits && (long long)n[0] * n[1] * n[2] <= (long long)kAoGridCells) break;
+                c *= 1.26f;
+            }
+            p->grid_scene = 0;
+            if (c > 0.0f && (long long)n[0] * n[1] * n[2] <= (long long)kAoGridCells)
+            {
+                const int cells = n[0] * n[1] * n[2];
+                hipLaunchKernelGGL(k_ao_entry_grid, dim3(cdiv(cells, 256)), dim3(256), 0, st, (const Node8*)scene->nodes.p, (uint32_t*)p->entry_grid.p,
+                                   lo[0], lo[1], lo[2], c, n[0], n[1], n[2], prm->ray_length * 1.0001f + 1e-4f);
+                HR_HIP(hipGetLastError());
+                p->grid_scene = scene->uid; p->grid_ray_length = prm->ray_length; p->grid_c = c;
+                for (int k = 0; k < 3; k++) { p->grid_lo[k] = lo[k]; p->grid_n[k] = n[k]; }
+            }
+        }
+        if (p->grid_scene == scene->uid)
+        {
+            a.grid = (const uint32_t*)p->entry_grid.p; a.grid_inv_c = 1.0f / p->grid_c;
+            for (int k = 0; k < 3; k++) { a.grid_lo[k] = p->grid_lo[k]; a.grid_n[k] = p->grid_n[k]; }
+        }
+    }
     if (p->want_stats)
     {
         hipLaunchKernelGGL(k_ao_trace<true>, dim3(cdiv(n_tiles, AO_TRACE_WAVES)), dim3(64 * AO_TRACE_WAVES), 0, st, a);

@@ -1,5 +1,6 @@
 // C-ABI glue: context, scene (BVH build + upload), raw ray queries, G-buffer synthesis.
 #include "hr_internal.h"
+#include <atomic>
 #include <memory>
 #include <new>
 #include "traverse.h"
@@ -417,6 +418,7 @@ static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene
     }
 #undef UP
     s->n_materials      = d->materials ? d->n_materials : 0;
+    { static std::atomic<uint64_t> next_uid { 1 }; s->uid = next_uid.fetch_add(1); }
     s->info.n_tris      = d->n_tris;
     s->info.n_nodes     = (int32_t)b.nodes.size();
     s->info.max_depth   = b.max_depth;

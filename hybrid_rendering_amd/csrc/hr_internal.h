@@ -213,6 +213,7 @@ struct hr_scene
     hr::DevBuf    tri_uvs, tri_tangents, mat_tex, tex_table, tex_data;          // textured materials (optional)
     bool          has_uvs = false, has_tangents = false, has_textures = false;
     hr_scene_info info;
+    uint64_t      uid = 0;   // unique per hr_scene_create (a destroyed scene's device addresses may be handed out again): key of per-scene caches in the passes
     int           n_materials = 0;
     bool          has_normals = false, has_material = false, has_mesh_id = false;
 };

@@ -239,11 +239,16 @@ static int trace_closest(const BuiltBVH& b, const Ray& r, Counts& c, float& tbes
     return best;
 }
 
+static double g_entry_levels = 0, g_entry_calls = 0;   // AO entry study (round 5): node tests of the per-pixel descent
 static uint32_t entry_node_for_box(const BuiltBVH& b, V3 lo, V3 hi)
 {
     uint32_t ni = 0;
+#pragma omp atomic
+    g_entry_calls += 1;
     for (int depth = 0; depth < 24; depth++)
     {
+#pragma omp atomic
+        g_entry_levels += 1;
         const Node8& n = b.nodes[ni];
         const float s[3] = { std::ldexp(1.0f, (int)n.ex - 127), std::ldexp(1.0f, (int)n.ey - 127), std::ldexp(1.0f, (int)n.ez - 127) };
         const float o[3] = { n.ox, n.oy, n.oz }, l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
@@ -432,7 +437,16 @@ int main(int argc, char** argv)
                 }
                 {
                     const V3 o = P + N * 0.3f;
-                    const uint32_t entry = entry_node_for_box(b, mk(o.x - 7, o.y - 7, o.z - 7), mk(o.x + 7, o.y + 7, o.z + 7));
+                    // AO_ENTRY_CELL=<c> (round 5 study): the entry node of the grid cell of edge c that holds the origin, grown by the ray length —
+                    // what a per-scene table of entry nodes would hand every pixel of the cell instead of the per-pixel descent
+                    static const float cell = getenv("AO_ENTRY_CELL") ? (float)atof(getenv("AO_ENTRY_CELL")) : 0.0f;
+                    V3 blo = mk(o.x - 7, o.y - 7, o.z - 7), bhi = mk(o.x + 7, o.y + 7, o.z + 7);
+                    if (cell > 0.0f)
+                    {
+                        const V3 c0 = mk(std::floor(o.x / cell) * cell, std::floor(o.y / cell) * cell, std::floor(o.z / cell) * cell);
+                        blo = mk(c0.x - 7, c0.y - 7, c0.z - 7); bhi = mk(c0.x + cell + 7, c0.y + cell + 7, c0.z + cell + 7);
+                    }
+                    const uint32_t entry = entry_node_for_box(b, blo, bhi);
                     V3 T = norm(cross(N, std::fabs(N.y) < 0.99f ? mk(0, 1, 0) : mk(1, 0, 0))), B = cross(N, T);
                     for (int s4 = 0; s4 < 4; s4++)
                     {
@@ -659,6 +673,7 @@ int main(int argc, char** argv)
               gi.rays += l.rays; gi.nodes += l.nodes; gi.tris += l.tris; gi.wnodes += l.wnodes; gi.wtris += l.wtris; gi.waves += l.waves; gi.hits += l.hits; }
         }
     }
+    printf("AO entry descent: %.2f node tests per pixel (%.0f pixels)\n", g_entry_levels / std::max(1.0, g_entry_calls), g_entry_calls);
     report("primary", pr); report("shadows", sh); report("ao", ao); report("refl", rf); report("ddgi", gi);
     report("refl-vis", r2); report("ddgi-vis", g2);
     return 0;
