@@ -239,6 +239,7 @@ static int trace_closest(const BuiltBVH& b, const Ray& r, Counts& c, float& tbes
     return best;
 }
 
+static double g_lit_nodes = 0, g_occ_nodes = 0, g_lit_rays = 0, g_occ_rays = 0, g_wave_cost = 0, g_wave_cost_no_lit = 0, g_waves_lit_slowest = 0, g_waves_n = 0;   // SHADOW_LIT_STUDY
 static double g_entry_levels = 0, g_entry_calls = 0;   // AO entry study (round 5): node tests of the per-pixel descent
 static uint32_t entry_node_for_box(const BuiltBVH& b, V3 lo, V3 hi)
 {
@@ -416,6 +417,7 @@ int main(int argc, char** argv)
         {
             const int tx = tile_list[ti] % tiles_x, ty = tile_list[ti] / tiles_x;
             Counts cp[64], cs[64], ca[64], cr[64], c2[64];
+            bool   lit_lane[64] = {};
             for (int l = 0; l < 64; l++)
             {
                 const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
@@ -433,7 +435,17 @@ int main(int argc, char** argv)
                     V3 T = norm(cross(L, std::fabs(L.y) < 0.99f ? mk(0, 1, 0) : mk(1, 0, 0))), B = cross(L, T);
                     Ray s; s.o = P + N * 0.5f; s.d = norm(L + T * (r1 * std::cos(a1)) + B * (r1 * std::sin(a1))); s.tmin = 0.01f; s.tmax = 10000.0f;
                     lsh.rays++;
-                    lsh.hits += g_any_mode ? trace_any_x(b, s, 0u, cs[l]) : trace_any(b, s, 0u, cs[l]);
+                    const bool occ = g_any_mode ? trace_any_x(b, s, 0u, cs[l]) : trace_any(b, s, 0u, cs[l]);
+                    lsh.hits += occ;
+                    // round-5 study (SHADOW_LIT_STUDY): how much of the walk belongs to rays that turn out LIT (they walk to the end of the scene)
+                    if (getenv("SHADOW_LIT_STUDY"))
+                    {
+#pragma omp atomic
+                        (occ ? g_occ_nodes : g_lit_nodes) += cs[l].nodes;
+#pragma omp atomic
+                        (occ ? g_occ_rays : g_lit_rays) += 1;
+                        lit_lane[l] = !occ;
+                    }
                 }
                 {
                     const V3 o = P + N * 0.3f;
@@ -476,6 +488,25 @@ int main(int argc, char** argv)
                         }
                     }
                 }
+            }
+            if (getenv("SHADOW_LIT_STUDY"))
+            {
+                // the wave's slowest lane: a lit ray or an occluded one?  and what the wave would cost if its lit rays were free
+                uint32_t mx = 0, mx_occ = 0; bool mx_lit = false;
+                for (int l = 0; l < 64; l++)
+                {
+                    const uint32_t c = cs[l].nodes * 230u + cs[l].tris * 80u;
+                    if (c > mx) { mx = c; mx_lit = lit_lane[l]; }
+                    if (!lit_lane[l] && c > mx_occ) mx_occ = c;
+                }
+#pragma omp atomic
+                g_wave_cost += mx;
+#pragma omp atomic
+                g_wave_cost_no_lit += mx_occ;
+#pragma omp atomic
+                g_waves_lit_slowest += mx_lit ? 1 : 0;
+#pragma omp atomic
+                g_waves_n += mx > 0 ? 1 : 0;
             }
             add_wave(lpr, cp, 64); add_wave(lsh, cs, 64); add_wave(lao, ca, 64); add_wave(lrf, cr, 64); add_wave(l2, c2, 64);
         }
@@ -673,6 +704,10 @@ int main(int argc, char** argv)
               gi.rays += l.rays; gi.nodes += l.nodes; gi.tris += l.tris; gi.wnodes += l.wnodes; gi.wtris += l.wtris; gi.waves += l.waves; gi.hits += l.hits; }
         }
     }
+    if (getenv("SHADOW_LIT_STUDY"))
+        printf("shadow rays: lit %.0f rays, %.2f nodes/ray; occluded %.0f rays, %.2f nodes/ray; waves whose slowest lane is a LIT ray: %.1f %%; wave cost if lit rays were free: %.1f %% of today's\n",
+               g_lit_rays, g_lit_nodes / std::max(1.0, g_lit_rays), g_occ_rays, g_occ_nodes / std::max(1.0, g_occ_rays), 100.0 * g_waves_lit_slowest / std::max(1.0, g_waves_n),
+               100.0 * g_wave_cost_no_lit / std::max(1.0, g_wave_cost));
     printf("AO entry descent: %.2f node tests per pixel (%.0f pixels)\n", g_entry_levels / std::max(1.0, g_entry_calls), g_entry_calls);
     report("primary", pr); report("shadows", sh); report("ao", ao); report("refl", rf); report("ddgi", gi);
     report("refl-vis", r2); report("ddgi-vis", g2);
