@@ -70,6 +70,7 @@ struct Reproj
     f3         cur_pos, cur_n;
     float      cur_id, hfx, hfy, band;
     uint32_t   near13;       // resolve<NOTE>: bit s (< 4) = bilinear tap s on a knife edge, bit 4 + k = tap k of the 3x3 fallback
+    uint32_t   valid13;      // resolve<NOTE>: the verdicts used (same layout); bit 13 = the 3x3 fallback was evaluated
     int        hcx, hcy;
     bool       inb, lok, tok[4], apron_miss;   // apron_miss: the footprint touched an image row that is not resident (row bands)
     fm::Unproj hb;
@@ -203,7 +204,7 @@ struct Reproj
         const float fx = hfx - __builtin_floorf(hfx), fy = hfy - __builtin_floorf(hfy);
         const float wgt[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
         float sumw = 0.0f, col[NC], mom0 = 0.0f, mom1 = 0.0f;
-        uint32_t noted = 0u;
+        uint32_t noted = 0u, used = 0u;
 #pragma unroll
         for (int c = 0; c < NC; c++) col[c] = 0.0f;
 #pragma unroll
@@ -213,7 +214,7 @@ struct Reproj
             // in the normalisation, its (zero) values add nothing
             bool nr;
             bool v = tap_valid<NOTE>(tok[s] ? g2x[s] : 0u, tok[s] ? g3y[s] : 0u, tok[s] ? td[s] : 0.0f, nr);
-            if (NOTE) { if ((known >> s) & 1u) v = (ovr >> s) & 1u; else noted |= (uint32_t)nr << s; }
+            if (NOTE) { if ((known >> s) & 1u) v = (ovr >> s) & 1u; else noted |= (uint32_t)nr << s; used |= (uint32_t)v << s; }
             const float ws = v ? wgt[s] : 0.0f, wv = ((int)v & (int)tok[s]) ? wgt[s] : 0.0f;
             float c3[NC];
             hist_decode(hx[s], hy[s], c3);
@@ -254,7 +255,7 @@ struct Reproj
                 const uint32_t qm = MOMENTS ? fm::ld<uint32_t>(hist_moments, qo * 8u) : 0u;
                 bool nr;
                 bool tv = tap_valid<NOTE>(ok ? q2 : 0u, ok ? q3 : 0u, ok ? qd : 0.0f, nr);
-                if (NOTE) { if ((known >> (4 + k)) & 1u) tv = (ovr >> (4 + k)) & 1u; else noted |= (uint32_t)nr << (4 + k); }
+                if (NOTE) { if ((known >> (4 + k)) & 1u) tv = (ovr >> (4 + k)) & 1u; else noted |= (uint32_t)nr << (4 + k); used |= ((uint32_t)tv << (4 + k)) | (1u << 13); }
                 if (tv)
                 {
                     float c3[NC];
@@ -279,7 +280,7 @@ struct Reproj
         o.mom[0] = valid ? mom0 : 0.0f;
         o.mom[1] = valid ? mom1 : 0.0f;
         o.length = ((int)valid & (int)lok) ? fm::lo(lraw) : 0.0f;
-        near13 = noted;
+        near13 = noted; valid13 = used;
         return valid;
     }
 
@@ -373,14 +374,25 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_SHADOWS_EU) void kf_shadows_tempo
         uint32_t ovr = 0u, known = 0u;
         if (redo && reproj)
         {
-            // Which pixels were in doubt is found again the way the first run found it (the fast test is deterministic); such a pixel gets the
-            // parity kernels' verdicts on ALL 13 of its taps (a verdict may change which taps take part: the 3x3 fallback runs only when the
-            // four bilinear taps fail).  (Tried: verdicts for the noted taps only, repeated until nothing new is noted — 2x instead of 5x a
-            // normal wave per redo, but the loop made the allocator spill on the HOT path: +13 % whatever the bands.  docs/EXPERIMENTS.md R5.1)
+            // Which taps were in doubt is found again the way the first run found it (the fast test is deterministic); THOSE taps get the parity
+            // kernels' verdicts (typically one tap: ~250 VALU instead of 3250 for all 13).  If that changes the verdict of a bilinear tap, the
+            // 3x3 fallback may run where it did not before (or the other way round) and its taps were never tested for doubt: then all nine
+            // get exact verdicts as well.  Straight-line code on purpose: as a loop ("until nothing new is noted") the allocator spilled on
+            // the HOT path (+13 %, docs/EXPERIMENTS.md R5.1).
             rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
             ReprojOut r0;
             rp.template resolve<true>(r0);
-            if (rp.near13) { ovr = rp.exact_bits(0x1fffu, x, y, d, cg2.x, cg2.y); known = 0x1fffu; }
+            if (rp.near13)
+            {
+                known = rp.near13;
+                ovr   = rp.exact_bits(known, x, y, d, cg2.x, cg2.y);
+                if ((((ovr ^ rp.valid13) & known) & 0xfu) != 0u)   // a bilinear verdict flipped
+                {
+                    const uint32_t rest = 0x1ff0u & ~known;
+                    ovr |= rp.exact_bits(rest, x, y, d, cg2.x, cg2.y);
+                    known |= rest;
+                }
+            }
         }
         if (reproj) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), 0.0f, cn, mk3(0, 0, 0), nullptr, 0.0f);
         if (!redo && a.apron_flag && __ballot(reproj && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
@@ -848,7 +860,17 @@ __global__ __launch_bounds__(64 * FT_WAVES, FT_AO_EU) void kf_ao_temporal(AOTemp
             rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
             ReprojOut r0;
             rp.template resolve<true>(r0);
-            if (rp.near13) { ovr = rp.exact_bits(0x1fffu, x, y, d, cg2.x, cg2.y); known = 0x1fffu; }
+            if (rp.near13)
+            {
+                known = rp.near13;
+                ovr   = rp.exact_bits(known, x, y, d, cg2.x, cg2.y);
+                if ((((ovr ^ rp.valid13) & known) & 0xfu) != 0u)
+                {
+                    const uint32_t rest = 0x1ff0u & ~known;
+                    ovr |= rp.exact_bits(rest, x, y, d, cg2.x, cg2.y);
+                    known |= rest;
+                }
+            }
         }
         if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3y), 0.0f, fm::oct_unit(cg2.x), mk3(0, 0, 0), nullptr, 0.0f);
         if (!redo && a.apron_flag && __ballot(live && in_image && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) && lane == 0) atomicOr(a.apron_flag, 1u);
