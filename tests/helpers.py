@@ -16,6 +16,10 @@ def scene_data(name: str):
         return synth.sponza_like(0.25)
     if name == "sponza":
         return synth.sponza_like(1.0)
+    if name == "sponza_hard":            # bench.py --tier hard: ~2.5 M triangles, layered fabric and foliage cards
+        return synth.sponza_like(1.0, tier="hard")
+    if name == "sponza_hard_small":
+        return synth.sponza_like(0.5, tier="hard")
     if name.startswith("one_triangle"):
         return one_triangle_scene(int(name[len("one_triangle_x"):]) if name.startswith("one_triangle_x") else 1)
     raise KeyError(name)
@@ -54,6 +58,8 @@ def cameras(name: str, aspect: float, n_frames: int, dolly: float):
 def light_for(name: str, kind: str = "default"):
     if _cornell_setup(name):
         return synth.cornell_light(hard=(kind != "soft"))
+    if kind == "grazing":
+        return synth.sponza_hard_light()
     if kind == "point":
         return synth.make_light(synth.LIGHT_POINT, position=(100.0, 300.0, 20.0), radius=4.0, intensity=50000.0)
     if kind == "spot":

@@ -1,7 +1,8 @@
 """GPU developer tool: the tolerance-mode runners of tests/test_gpu_tolerance.py (exact = 0 against the oracle within the stated
 tolerance — masks bit-exact, >= 99.9 % of the texels within 2 fp16 ulp, rel-L2 <= 1e-3) on random image sizes,
 scenes, lights, camera speeds, resolution scales (full / half / quarter) and pass parameters; `frames` > the tests' 5-6 checks that the
-bound holds once the temporal feedback has run to its steady state.   python tools/fuzz_tolerance.py [seed] [n_configs] [frames]"""
+bound holds once the temporal feedback has run to its steady state.   python tools/fuzz_tolerance.py [seed] [n_configs] [frames] [hard]
+(a 4th argument "hard" draws the scenes from bench.py's hard-tier geometry — layered fabric, foliage cards — and adds its grazing sun)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,14 +15,15 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 kw = dict(n_frames=n_frames) if n_frames else {}
+hard = len(sys.argv) > 4 and sys.argv[4] == "hard"
 rng = np.random.RandomState(seed)
 ctx = hr.Context(0)
 bad = 0
 for trial in range(n):
-    name = str(rng.choice(["cornell", "sponza_small"]))
+    name = str(rng.choice(["sponza_hard_small", "sponza_hard_small", "sponza_small"] if hard else ["cornell", "sponza_small"]))
     # large enough that 0.1 % of the texels is a population, not two pixels
     W, H = int(rng.randint(160, 360)), int(rng.randint(120, 220))
-    light = str(rng.choice(["default", "point", "spot"]) if name != "cornell" else rng.choice(["default", "soft"]))
+    light = str(rng.choice(["default", "point", "spot"] + (["grazing", "grazing"] if hard else [])) if name != "cornell" else rng.choice(["default", "soft"]))
     dolly = float(rng.uniform(0.2, 2.5))
     scale = int(rng.choice([0, 1, 1, 2]))
     sp = ap = rp = None
