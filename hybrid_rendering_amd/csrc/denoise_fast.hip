@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous_lds(AtrousArgs a)
     __shared__ float4   s_nz[TH * TW];   // unit normal, linear z
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * 8;
+    if (bx0 >= a.w) return;   // a padding column of the launch (block_map.h grid_cols)
     const int x = bx0 + lx, y = by0 + ly;
     const bool inside = x < a.w && y < a.y1;
     const uint32_t cls = inside ? a.tile_class[(size_t)(y >> 3) * a.tiles_x + (x >> 3)] : 0u;
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(256) void kf_shadows_atrous01(AtrousArgs a, uint32_
     __shared__ float4   s_nz[AH * AW];   // unit normal, linear z
     __shared__ uint32_t s_mid[BH * BW];  // iteration 0, as the RG16F image would hold it
     const int bx0 = (int)BLK.x * 32, by0 = a.y0 + (int)BLK.y * TH;
+    if (bx0 >= a.w) return;   // a padding column of the launch (block_map.h grid_cols)
     const int ry0 = a.y0 > 0 ? a.y0 : 0, ry1 = a.y1 < a.h ? a.y1 : a.h;
     // tile classes of this workgroup's own tiles: all shadow => every output is 0 and nothing is staged
     int any_cls = 0;
@@ -1142,6 +1144,7 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
 #endif
     __shared__ int    s_flag[4];
     const int bx0 = BLK.x * FR_TW, by0 = a.y0 + BLK.y * FR_TH;
+    if (bx0 >= a.w) return;   // a padding column of the launch (block_map.h grid_cols)
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int x = bx0 + lx, y = by0 + ly;
     const bool have = x < a.w && y < a.y1;
@@ -1607,14 +1610,14 @@ static dim3 grid_with_apron(dim3 grid, GeoApronArgs& g, int threads)
 void launch_shadows_temporal_fast(const TemporalArgs& a_, int n_tiles, hipStream_t st)
 {
     TemporalArgs a = a_;
-    const dim3 grid = grid_with_apron(grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y), a.apron, 64 * FT_WAVES);
+    const dim3 grid = grid_with_apron(grid_with_sort(a.sort, grid_cols(cdiv(a.tiles_x, FT_WAVES), 4), a.tiles_y), a.apron, 64 * FT_WAVES);
     if (a.geo_hist) hipLaunchKernelGGL(kf_shadows_temporal<1>, grid, dim3(64 * FT_WAVES), 0, st, a);
     else hipLaunchKernelGGL(kf_shadows_temporal<0>, grid, dim3(64 * FT_WAVES), 0, st, a);
 }
 
 void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
 {
-    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
+    const dim3 grid(grid_cols(cdiv(a.w, 32), (a.step >= 4 || !FT_ATROUS_LDS) ? 0 : 7), cdiv(a.y1 - a.y0, 8));
     const bool n32 = a.phi_normal == 32.0f;
 #define HR_LAUNCH_ATROUS(K, S) \
     do { if (n32) hipLaunchKernelGGL((K<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((K<S, false>), grid, dim3(256), 0, st, a); } while (0)
@@ -1638,7 +1641,7 @@ void launch_shadows_atrous_fast(const AtrousArgs& a, hipStream_t st)
 bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, float power1, hipStream_t st)
 {
     if (a.radius != 1 || a.step != 1) return false;
-    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_ATROUS01_TH));
+    const dim3 grid(grid_cols(cdiv(a.w, 32), 7), cdiv(a.y1 - a.y0, FT_ATROUS01_TH));
     if (a.phi_normal == 32.0f) hipLaunchKernelGGL((kf_shadows_atrous01<FT_ATROUS01_TH, true>), grid, dim3(256), 0, st, a, out_first2, power1);
     else hipLaunchKernelGGL((kf_shadows_atrous01<FT_ATROUS01_TH, false>), grid, dim3(256), 0, st, a, out_first2, power1);
     return true;
@@ -1647,7 +1650,7 @@ bool launch_shadows_atrous01_fast(const AtrousArgs& a, uint32_t* out_first2, flo
 void launch_ao_temporal_fast(const AOTemporalArgs& a_, int n_tiles, hipStream_t st)
 {
     AOTemporalArgs a = a_;
-    const dim3 grid = grid_with_sort(a.sort, cdiv(a.tiles_x, FT_WAVES), a.tiles_y);
+    const dim3 grid = grid_with_sort(a.sort, grid_cols(cdiv(a.tiles_x, FT_WAVES), 5), a.tiles_y);
     if (a.geo_hist && a.geo_band)
     {
         if (a.spp > 1) hipLaunchKernelGGL((kf_ao_temporal<true, 1>), grid, dim3(64 * FT_WAVES), 0, st, a);
@@ -1682,14 +1685,14 @@ bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
 void launch_refl_temporal_fast(const ReflTemporalArgs& a_, hipStream_t st)
 {
     ReflTemporalArgs a = a_;
-    const dim3 grid = grid_with_sort(a.sort, cdiv(a.w, FR_TW), cdiv(a.y1 - a.y0, FR_TH));
+    const dim3 grid = grid_with_sort(a.sort, grid_cols(cdiv(a.w, FR_TW), 6), cdiv(a.y1 - a.y0, FR_TH));
     if (a.geo_hist) hipLaunchKernelGGL(kf_refl_temporal<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(kf_refl_temporal<0>, grid, dim3(256), 0, st, a);
 }
 
 void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)
 {
-    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8));
+    const dim3 grid(grid_cols(cdiv(a.w, 32), 1), cdiv(a.y1 - a.y0, 8));
     const bool n32 = a.phi_normal == 32.0f;
 #define HR_LAUNCH_RATROUS(S) \
     do { if (n32) hipLaunchKernelGGL((kf_refl_atrous<S, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((kf_refl_atrous<S, false>), grid, dim3(256), 0, st, a); } while (0)
@@ -1715,12 +1718,12 @@ bool launch_refl_atrous01_fast(const ReflAtrousArgs& a, uint2* out_first2, hipSt
 
 void launch_ddgi_sample_fast(const DDGISampleArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(kf_ddgi_sample, dim3(cdiv(a.w, 32), cdiv(a.y1 - a.y0, 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kf_ddgi_sample, dim3(grid_cols(cdiv(a.w, 32), 3), cdiv(a.y1 - a.y0, 8)), dim3(256), 0, st, a);
 }
 
 void launch_upsample_fast(const UpsampleArgs& a, hipStream_t st)
 {
-    const dim3 grid(cdiv(a.W, 32), cdiv(a.H, 8));
+    const dim3 grid(grid_cols(cdiv(a.W, 32), 2), cdiv(a.H, 8));
     if (a.channels == 4) hipLaunchKernelGGL(kf_upsample<4>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(kf_upsample<1>, grid, dim3(256), 0, st, a);
 }

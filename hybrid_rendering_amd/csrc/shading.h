@@ -11,6 +11,16 @@
 #include "../../include/hr_api.h"
 #include "traverse.h"
 
+#ifdef HR_PROBE_FAST_HIT
+// developer probe (docs/EXPERIMENTS.md R5.6): an UPPER BOUND on what tolerance-mode hit shading could save — every correctly rounded
+// quotient / root / normalisation of this header through the hardware approximations, for every kernel that includes it (the exact mode of
+// such a build is NOT bit-exact; never shipped)
+namespace hr { HR_DEV f3 probe_normalize3(f3 a) { return scale3(a, __builtin_amdgcn_rsqf(dot3(a, a))); } }
+#define __fdiv_rn(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define hr_sqrt(x) __builtin_amdgcn_sqrtf(x)
+#define normalize3(v) probe_normalize3(v)
+#endif
+
 namespace hr {
 
 #define HR_EPSILON 0.0001f
@@ -549,3 +559,9 @@ HR_DEV DirectSplit direct_lighting_split(const hr_light& light, f3 Wo, f3 N, f3 
 }
 
 } // namespace hr
+
+#ifdef HR_PROBE_FAST_HIT
+#undef __fdiv_rn
+#undef hr_sqrt
+#undef normalize3
+#endif

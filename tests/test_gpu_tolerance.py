@@ -345,10 +345,23 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
         mo = helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0))
         compare16(mo, st["moments"], f"frame {f} moments (m1, m2, history length, 0)", outlier_pixels=REFL_OUTLIERS)
         at = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
+        # Stage-wise, no allowance at all: the ORACLE's a-trous chain run on the GPU's own temporal image and tile classes.  The reference's
+        # luminance weight exp(-|dl| / (phi sqrt(1e-10 + var))) is ill-conditioned where var == 0, so the end-to-end comparison below also measures
+        # how far the reference's filter spreads the (tolerated) differences of its INPUT; this one measures the a-trous kernels alone
+        # (tools/refl_outlier_probe.py, docs/EXPERIMENTS.md R5.1 / R5.8).
+        gt = gp.image(gp.IMG_TILES).cpu().numpy()
+        chain = tc
+        for i in range(op.p["filter_iterations"]):
+            chain = orf.atrous(chain, cur, np.ascontiguousarray(gt.reshape(st["tiles"].shape).astype(st["tiles"].dtype)), 1 << i, op.p["radius"], op.p["phi_color"],
+                               op.p["phi_normal"], op.p["sigma_depth"], op.p["approximate_with_ddgi"])
+        compare16(at, chain, f"frame {f} a-trous kernels against the oracle's chain on the same temporal image", variance_channels=(3,), outlier_pixels=0)
         compare16(at, st["atrous"][-1], f"frame {f} a-trous colour + variance", exclude=ex, variance_channels=(3,), outlier_pixels=REFL_OUTLIERS)
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         if scale:
             ex = upscale_mask(ex, scale, H, W)
+            # stage-wise, no allowance: the oracle's upsample of the GPU's own a-trous output
+            compare16(out, oracle.upsample(full, cur, at, channels=4, sky_value=0.0, power=0.0), f"frame {f} upsample kernel against the oracle's upsample of the same image",
+                      variance_channels=(3,), outlier_pixels=0)
         compare16(out, st["output"], f"frame {f} reflections output", exclude=ex, variance_channels=(3,), outlier_scale=upsample_scale(scale), outlier_pixels=REFL_OUTLIERS)
     gp.close(); g_ddgi.close(); gsc.close()
 

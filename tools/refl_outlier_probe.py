@@ -85,3 +85,24 @@ for label, got, ref in imgs:
         print(f"{label} ch{c}: max |got-ref| in 3x3 = {d:.3e}")
         print("  got", g[..., c].ravel())
         print("  ref", r[..., c].ravel())
+
+# ---- whole-image view: where do the inputs of the a-trous chain differ, and is the chain itself faithful?
+def ulps(a, b):
+    k = lambda v: np.where(v & 0x8000, 0x8000 - (v & 0x7fff).astype(np.int32), 0x8000 + (v & 0x7fff).astype(np.int32))
+    return np.abs(k(a.astype(np.int32)) - k(b.astype(np.int32)))
+g_tmp = helpers.bits16(gp.image(gp.IMG_COLOR1 if f & 1 else gp.IMG_COLOR0))
+for label, got, ref in imgs[:3]:
+    u = ulps(got, ref)
+    w_ = np.argwhere(u > 0)
+    print(f"[whole image] {label}: {len(w_)} of {u.size} values differ, {int((u > 2).sum())} by more than 2 ulp, worst {int(u.max())} ulp; first: {w_[:8].tolist()}")
+# the ORACLE's a-trous chain run on the GPU's temporal image: what is left against the GPU's a-trous output is the a-trous kernels' own arithmetic,
+# what it differs by from the oracle's output is the reference's filter amplifying the (tolerated) input differences
+p = op.p
+img = g_tmp.copy()
+for i in range(p["filter_iterations"]):
+    img = orf.atrous(img, cur, st["tiles"], 1 << i, p["radius"], p["phi_color"], p["phi_normal"], p["sigma_depth"], p["approximate_with_ddgi"])
+g_out = helpers.bits16(gp.output(hr.OUTPUT_ATROUS))
+for label, a, b in (("GPU a-trous output vs ORACLE chain on the GPU's temporal image", g_out, img), ("ORACLE chain on the GPU's temporal image vs oracle output", img, st["atrous"][-1]),
+                    ("GPU a-trous output vs oracle output", g_out, st["atrous"][-1])):
+    u = ulps(a, b)
+    print(f"[whole image] {label}: {int((u > 0).sum())} values differ, {int((u > 2).sum())} by more than 2 ulp ({100.0 * (u > 2).mean():.3f} %), worst {int(u.max())} ulp")
