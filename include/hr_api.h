@@ -261,7 +261,11 @@ typedef struct
                                    a-trous, upsampled output) may exceed the cap on at most max(4, 2e-5 of the pixels) pixels per image (x 5 * 4^scale
                                    in a scaled pass's upsampled output), each within 512 fp16 ulp or 2^-5: the reference's luminance edge-stopping
                                    weight exp(-|dl| / (phi sqrt(1e-10 + var))) moves by e^0.6 per fp16 ulp of its input where var == 0, so a 1-ulp
-                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration
+                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration.  For the same reason the
+                                   99.9 % population bound, end to end, is a property of the SEQUENCE for the reflections' a-trous and output
+                                   images: where var == 0 over a region (a spot light's dark surround in the first frames) 2 of 1054 fuzzed
+                                   sequences measured 99.83 / 99.87 %; stage by stage — the a-trous and upsample kernels against the oracle's
+                                   stage run on the SAME input image — the bound holds with no counted exception at all
                                    (tests/test_gpu_tolerance.py compare16; fuzz logs: profiles/r5_*);
                                    visibility masks, ray counts and traversal are identical in both modes.
                                    Tolerance mode also reprojects from the pass's own copy of the previous frame's geometry (normal, mesh id,
