@@ -328,6 +328,12 @@ HR_DEV bool geo_apron_rides(const GeoApronArgs& g)
 // ------------------------------------------------------------------------------------------------------------------------
 // shadows_denoise_reprojection.comp:196-293 (+ reset_args / tile classification), tolerance mode
 #define FT_WAVES 4
+#ifndef FT_AO_BLUR_ROWS
+#define FT_AO_BLUR_ROWS 1      // block_map.h block_xy<R>: tile rows per XCD run for the fused AO blur (0: identity, then HR_COLS8 bit 8 applies)
+#endif
+#ifndef FT_RATROUS01_ROWS
+#define FT_RATROUS01_ROWS 1    // ... and for the fused reflections a-trous 0 + 1 (0: identity, HR_COLS8 bit 9)
+#endif
 #ifndef FT_SHADOWS_EU
 #define FT_SHADOWS_EU 6   // minimum waves per SIMD the register allocator must leave room for (round 5: 6 — with the cold copy of the pixel program 5 lets the allocator take 88 VGPRs; 6 = 80 VGPRs, three spill stores on the hot path).  Round 4, without the cold copy: 5 and 6 give the same 77 VGPRs (= 6 waves per SIMD), no
                           // spill: 48-50 us at 1080p, 208 at 4K; 7 (72 VGPRs + 24 B of scratch) 58.7 / 252.8; 8 (64 VGPRs, more scratch) 81.4 / 362 — spills
@@ -994,7 +1000,8 @@ __global__ __launch_bounds__(256) void kf_ao_blur(AOBlurArgs a)
 template <int RADIUS, int TH>
 __global__ __launch_bounds__(256) void kf_ao_blur_xy(AOBlurArgs a)
 {
-    const uint2 BLK = block_xy<1>();
+    const uint2 BLK = block_xy<FT_AO_BLUR_ROWS>();
+    if ((int)BLK.x * 32 >= a.w) return;   // a padding column of the launch (block_map.h grid_cols)
     constexpr int SW = 32 + 2 * RADIUS, SH = TH + 2 * RADIUS;
     __shared__ float4  s_nz[SH * SW];      // unit normal, linear eye depth
     __shared__ float   s_ao[SH * SW];
@@ -1406,7 +1413,8 @@ __global__ __launch_bounds__(256) void kf_refl_atrous(ReflAtrousArgs a)
 template <int TH, bool N32>
 __global__ __launch_bounds__(256) void kf_refl_atrous01(ReflAtrousArgs a, uint2* out_first2)
 {
-    const uint2 BLK = block_xy<1>();
+    const uint2 BLK = block_xy<FT_RATROUS01_ROWS>();
+    if ((int)BLK.x * 32 >= a.w) return;   // a padding column of the launch (block_map.h grid_cols)
     constexpr int AW = 38, AH = TH + 6, BW = 36, BH = TH + 4;   // A = tile + 3 all round, B = tile + 2 (round-3 advisor: one ring too many each)
     __shared__ uint2  s_in[AH * AW];
     __shared__ float4 s_nz[AH * AW];    // unit normal (0 outside the image), linear z
@@ -1678,7 +1686,7 @@ void launch_ao_blur_fast(const AOBlurArgs& a, hipStream_t st)
 bool launch_ao_blur_xy_fast(const AOBlurArgs& a, hipStream_t st)
 {
     if (a.radius != 4) return false;   // other radii keep the two-launch form
-    hipLaunchKernelGGL((kf_ao_blur_xy<4, FT_AO_BLUR_TH>), dim3(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_AO_BLUR_TH)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((kf_ao_blur_xy<4, FT_AO_BLUR_TH>), dim3(grid_cols(cdiv(a.w, 32), 8), cdiv(a.y1 - a.y0, FT_AO_BLUR_TH)), dim3(256), 0, st, a);
     return true;
 }
 
@@ -1710,7 +1718,7 @@ void launch_refl_atrous_fast(const ReflAtrousArgs& a, hipStream_t st)
 bool launch_refl_atrous01_fast(const ReflAtrousArgs& a, uint2* out_first2, hipStream_t st)
 {
     if (a.radius != 1 || a.step != 1) return false;
-    const dim3 grid(cdiv(a.w, 32), cdiv(a.y1 - a.y0, FT_RATROUS01_TH));
+    const dim3 grid(grid_cols(cdiv(a.w, 32), 9), cdiv(a.y1 - a.y0, FT_RATROUS01_TH));
     if (a.phi_normal == 32.0f) hipLaunchKernelGGL((kf_refl_atrous01<FT_RATROUS01_TH, true>), grid, dim3(256), 0, st, a, out_first2);
     else hipLaunchKernelGGL((kf_refl_atrous01<FT_RATROUS01_TH, false>), grid, dim3(256), 0, st, a, out_first2);
     return true;
