@@ -300,6 +300,35 @@ def compact_line(full):
     return c
 
 
+_LINE_FD = None   # isolate_stdout(): the descriptor the ONE line goes to
+
+
+def isolate_stdout():
+    """stdout must carry exactly one line, and it must be the last thing on it.  Libraries write there behind Python's back — RCCL prints a five-line
+    banner through C stdio at its first communicator, which sits in libc's buffer until the process EXITS, i.e. lands after the JSON line of a
+    `--gpus N` run (and every other rank's copy lands in the launcher's merged stdout whenever that rank exits).  So every rank points descriptor 1
+    at stderr for the whole run and keeps the real stdout aside for emit()."""
+    global _LINE_FD
+    if _LINE_FD is not None:
+        return
+    try:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+    except OSError:
+        _LINE_FD = None
+
+
+def flush_c_stdio():
+    """whatever libraries have written through C stdio so far leaves libc's buffer NOW (before the line), not when the process exits (after it) —
+    for a driver that reads stdout and stderr as one stream"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def emit(out):
     """prints the bench line once per process: the full record goes to bench_detail.json (next to this script and, when that directory exists,
     under gpurun_out/) and to stderr; stdout gets ONE compact line (compact_line)"""
@@ -320,7 +349,11 @@ def emit(out):
     except Exception as e:   # never lose the line to its own summariser
         line = json.dumps({**stub_line_from(out), "error": f"compact_line failed: {e!r}"[:300]})
     sys.stdout.flush()
-    print(line, flush=True)
+    flush_c_stdio()
+    if _LINE_FD is not None:
+        os.write(_LINE_FD, (line + "\n").encode())
+    else:
+        print(line, flush=True)
 
 
 def stub_line_from(out):
@@ -392,6 +425,10 @@ def pass_roofline(kernels):
 
 def main():
     args = parse()
+    isolate_stdout()
+    if os.environ.get("HR_BENCH_TEST_C_STDOUT"):   # test hook (tests/test_bench_robustness.py): what a library's C stdio does — buffered, flushed when the process exits
+        import ctypes
+        ctypes.CDLL(None).printf(b"a library's banner, written through C stdio\n")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -448,6 +485,12 @@ def main():
         out["comm"] = {"error": comm_error, "ranks_seen": seen, "backend": os.environ.get("HR_DIST_BACKEND", "nccl"),
                        "note": "the distributed run could not start / complete; `value` and everything else on this line are rank 0's LOCAL single-GPU numbers (n_gpus = 1)"}
     wd.cancel()
+    flush_c_stdio()
+    if world > 1 and comm_error is None:
+        try:
+            dist.barrier()   # every rank has emptied its C stdio buffer before rank 0 writes the line
+        except Exception:
+            pass
     if rank == 0:
         emit(out)
     if world > 1 and comm_error is None:

@@ -53,6 +53,18 @@ def test_line_is_compact():
     assert json.loads(json.dumps(bench.compact_line({"metric": "m", "value": 0.0, "error": "boom"})))["error"] == "boom"
 
 
+def test_stdout_carries_only_the_line(tmp_path):
+    """what a library writes to stdout behind Python's back — through C stdio, where it sits in libc's buffer until the process exits (RCCL's
+    banner in a --gpus N run) — must not follow the JSON line: bench.isolate_stdout() points descriptor 1 at stderr and emit() writes the line to
+    the real stdout"""
+    code = ("import sys, ctypes\nsys.path.insert(0, %r)\nimport bench\nbench.ROOT = %r\nbench.isolate_stdout()\n"
+            "ctypes.CDLL(None).printf(b'banner via C stdio\\n')\nprint('a python print')\nbench.emit({'metric': 'm', 'value': 1.0})\n" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert out.stdout.count("\n") == 1 and json.loads(out.stdout)["value"] == 1.0, out.stdout
+    assert "banner via C stdio" in out.stderr and "a python print" in out.stderr
+
+
 def test_watchdog_prints_the_line_and_exits_nonzero():
     env = dict(os.environ, HR_BENCH_TIMEOUT_S="0.3")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
@@ -96,9 +108,13 @@ def test_gpu_two_ranks_on_one_gpu_report_comm_error():
 def test_gpu_bench_line_as_the_driver_runs_it():
     """the driver's own command (BENCH_rNN: `python3 bench.py --gpus 1 --steps 20 --warmup 5`): the LAST stdout line is one JSON object < 7000 bytes
     with the contract's fields, a live `roofline` and a `cpu_baseline`; the full record sits in bench_detail.json"""
-    env = dict(os.environ, HR_BENCH_CPU_SECONDS="2")
+    env = dict(os.environ, HR_BENCH_CPU_SECONDS="2", HR_BENCH_TEST_C_STDOUT="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    # stdout is the line and nothing else: what libraries write through C stdio (RCCL's banner sits in libc's buffer until the process exits,
+    # i.e. AFTER the line) goes to stderr (bench.isolate_stdout)
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[-1500:]
+    assert "a library's banner" in out.stderr
     last = out.stdout.strip().splitlines()[-1]
     assert len(last.encode()) < 7000, len(last)
     d = _last_json(out.stdout)
