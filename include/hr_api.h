@@ -261,9 +261,10 @@ typedef struct
                                    a-trous, upsampled output) may exceed the cap on at most max(4, 2e-5 of the pixels) pixels per image (x 5 * 4^scale
                                    in a scaled pass's upsampled output), each within 512 fp16 ulp or 2^-5: the reference's luminance edge-stopping
                                    weight exp(-|dl| / (phi sqrt(1e-10 + var))) moves by e^0.6 per fp16 ulp of its input where var == 0, so a 1-ulp
-                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration.  For the same reason the
-                                   99.9 % population bound, end to end, is a property of the SEQUENCE for the reflections' a-trous and output
-                                   images: where var is 0 or tiny over a region (a spot light's dark surround, the first frames of a history) 6 of 1214 fuzzed
+                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration.  The 99.9 % population bound, end to end, is likewise a property of
+                                   the SEQUENCE for the reflections' a-trous and output images — var is m2 - m1^2 of two stored fp16 moments, so one
+                                   ulp of a stored moment moves a small variance by more than its size and re-weights every tap around it: where
+                                   var is 0 or tiny over a region (a spot light's dark surround, the first frames of a history) 6 of 1214 fuzzed
                                    sequences measured 99.83 - 99.89 % (all 1214 >= 99.8 %); stage by stage — the a-trous and upsample kernels against the oracle's
                                    stage run on the SAME input image — the bound holds with no counted exception at all
                                    (tests/test_gpu_tolerance.py compare16; fuzz logs: profiles/r5_*);
