@@ -25,6 +25,9 @@
 
 #pragma clang fp contract(fast)
 
+#ifndef HR_REFL_VP_EXACT
+#define HR_REFL_VP_EXACT 1   // the reflections' virtual-point history coordinate in the parity arithmetic (0: rsq / rcp, as rounds 2-5)
+#endif
 #ifndef HR_TAP_REDO
 #define HR_TAP_REDO 1      // developer A/B: 0 = no second run of the pixel program (round 4's behaviour)
 #endif
@@ -133,6 +136,11 @@ struct Reproj
         {
             if (ray_length > 0.0f && curvature == 0.0f)
             {
+#if HR_REFL_VP_EXACT
+                // virtual_point_reprojection with the parity kernels' operations (exact_predicates.h: the weights of the history taps — and so the
+                // interpolated moments — are then the oracle's; round 5, late)
+                exact::virtual_point(M, prev_vp, cam_pos, x, y, g.w, g.h, depth, ray_length, hfx, hfy);
+#else
                 // virtual_point_reprojection (reprojection.glsl:71-111): NB current_coord / size without the half-pixel offset
                 const f3    ro  = fm::unproject_at(fm::unproject_base(M, fm::div_by_inrange((float)x, div_prepare(fw)), fm::div_by_inrange((float)y, div_prepare(fh))), M, depth);
                 f3          cr  = sub3(ro, cam_pos);
@@ -146,6 +154,7 @@ struct Reproj
                 const float py  = (prev_vp[1] * hp.x + prev_vp[5] * hp.y + prev_vp[9] * hp.z + prev_vp[13]) * ipw;
                 hfx = (px * 0.5f + 0.5f) * fw;
                 hfy = (py * 0.5f + 0.5f) * fh;
+#endif
             }
             hcx = (int)hfx; hcy = (int)hfy;
         }
@@ -220,7 +229,10 @@ struct Reproj
             hist_decode(hx[s], hy[s], c3);
 #pragma unroll
             for (int c = 0; c < NC; c++) col[c] += wv * c3[c];
-            if (MOMENTS) { mom0 += wv * fm::lo(mm[s]); mom1 += wv * fm::hi(mm[s]); }
+            // the moments keep the parity kernels' two roundings per term (no FMA): the variance downstream is m2 - m1^2, and where it is tiny
+            // (<= 1e-8: a sixth of the surface texels of a young history) ONE fp32 ulp of a moment is a multiple of it — and the a-trous
+            // chain divides luminance differences by its square root (docs/EXPERIMENTS.md R5.8)
+            if (MOMENTS) { mom0 = fm::mad_rn(wv, fm::lo(mm[s]), mom0); mom1 = fm::mad_rn(wv, fm::hi(mm[s]), mom1); }
             sumw += ws;
         }
         // Normalisations are correctly rounded divisions (one shared denominator: fast_math.h div_by_inrange): a history of
@@ -1272,7 +1284,7 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
                 }
             }
             const float max_acc = a.moving ? 8.0f : hl;
-            const float ia = fm::rcp_nr(max_acc);
+            const float ia = fm::div_by_inrange(1.0f, div_prepare(max_acc));   // correctly rounded (1 <= max_acc <= 32): the moments' blend factor, see Reproj::resolve
             const float al = success ? fm::fmax_(a.alpha, ia) : 1.0f;
             const float am = success ? fm::fmax_(a.moments_alpha, ia) : 1.0f;
             const float lum = luminance(color);

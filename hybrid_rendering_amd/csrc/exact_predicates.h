@@ -38,6 +38,28 @@ HR_DEV bool tap_valid(const float* __restrict__ M, int x, int y, int w, int h, f
     return reprojection_valid(hcx, hcy, cur_pos, hp, cur_n, hn, cur_id, h2f_lo(q3y), w, h);
 }
 
+// virtual_point_reprojection (reprojection.glsl:71-111, reproject.h:115-129) with the parity kernels' operations: the history coordinate of a mirror-like
+// pixel (ray length > 0 on a flat surface).  The tolerance-mode reflections temporal kernel used rsq / rcp here; the coordinate then differed from the
+// oracle's by a few ulp, the bilinear weights of the four history taps by ~1e-4 — enough to move an interpolated fp16 MOMENT across a rounding boundary
+// in one of ~10 such texels, and the variance m2 - m1^2 of two stored moments is what the a-trous chain is sensitive to (docs/EXPERIMENTS.md R5.8,
+// tools/refl_atrous_conditioning.py).  With this coordinate the weights, and so the history colour and moments, are the parity kernels' wherever
+// the history images are.
+HR_DEV void virtual_point(const float* __restrict__ M, const float* __restrict__ prev_vp, f3 cam_pos, int x, int y, int w, int h, float depth, float ray_length,
+                          float& rx, float& ry)
+{
+    const float fw = (float)w, fh = (float)h;
+    const float vu = __fdiv_rn((float)x, fw), vv = __fdiv_rn((float)y, fh);   // NB without the half-pixel offset, as the reference
+    const f3    ro = world_pos_from_depth(vu, vv, depth, M);
+    f3          cr = sub3(ro, cam_pos);
+    const float crl = len3(cr);
+    cr = normalize3(cr);
+    const f3 hp = add3(cam_pos, scale3(cr, crl + ray_length));
+    const f4 rp = mul_m4(prev_vp, hp.x, hp.y, hp.z, 1.0f);
+    const float px = __fdiv_rn(rp.x, rp.w), py = __fdiv_rn(rp.y, rp.w);
+    rx = (px * 0.5f + 0.5f) * fw;
+    ry = (py * 0.5f + 0.5f) * fh;
+}
+
 // the operands k_ddgi_sample (ddgi.hip) derives for pixel (x, y): world position, normal, direction to the camera
 HR_DEV void pixel_inputs(const float* __restrict__ vpi, const float* __restrict__ cam, int x, int y, int w, int h, float depth, uint32_t g2x, f3& P, f3& N, f3& Wo)
 {
