@@ -264,8 +264,9 @@ typedef struct
                                    difference in a stored a-trous intermediate re-weights a tap of the next iteration.  The 99.9 % population bound, end to end, is likewise a property of
                                    the SEQUENCE for the reflections' a-trous and output images — var is m2 - m1^2 of two stored fp16 moments, so one
                                    ulp of a stored moment moves a small variance by more than its size and re-weights every tap around it: where
-                                   var is 0 or tiny over a region (the first frames of a history) and the 17x17 neighbourhood clamp is nearly degenerate, 5 of
-                                   1214 fuzzed sequences measure 99.86 - 99.89 % (all 1214 >= 99.8 %; the moment path itself keeps the parity arithmetic); stage by stage — the a-trous and upsample kernels against the oracle's
+                                   var is tiny over a region (the first frames of a history), the 1-ulp colours the trace image's fast DDGI gathers are
+                                   allowed reach it through the next frame's moments: 5 of 1214 fuzzed sequences measure 99.86 - 99.89 % (all 1214
+                                   >= 99.8 %; the temporal kernel's own moment path keeps the parity arithmetic); stage by stage — the a-trous and upsample kernels against the oracle's
                                    stage run on the SAME input image — the bound holds with no counted exception at all
                                    (tests/test_gpu_tolerance.py compare16; fuzz logs: profiles/r5_*);
                                    visibility masks, ray counts and traversal are identical in both modes.

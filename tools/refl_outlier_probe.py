@@ -106,3 +106,13 @@ for label, a, b in (("GPU a-trous output vs ORACLE chain on the GPU's temporal i
                     ("GPU a-trous output vs oracle output", g_out, st["atrous"][-1])):
     u = ulps(a, b)
     print(f"[whole image] {label}: {int((u > 0).sum())} values differ, {int((u > 2).sum())} by more than 2 ulp ({100.0 * (u > 2).mean():.3f} %), worst {int(u.max())} ulp")
+
+# ---- which temporal texels are off by more than 2 ulp, and what do their moments / history lengths say?
+g_mom = helpers.bits16(gp.image(gp.IMG_MOMENTS1 if f & 1 else gp.IMG_MOMENTS0))
+u = ulps(g_tmp, st["temporal"])
+bad = np.argwhere((u > 2).any(axis=2))
+f16 = lambda v: v.view(np.float16).astype(np.float32)
+print(f"[temporal texels beyond 2 ulp] {len(bad)} texels")
+for (yy, xx) in bad[:24]:
+    print(f"  ({yy:3d},{xx:3d}) roughness {float(f16(cur['gb3'][yy, xx, 0:1])[0]):.3f} curv {float(f16(cur['gb3'][yy, xx, 1:2])[0]):.3f} ray_len {float(f16(st['trace'][yy, xx, 3:4])[0]):8.3f} | "
+          f"got {np.round(f16(g_tmp[yy, xx]), 6).tolist()} ref {np.round(f16(st['temporal'][yy, xx]), 6).tolist()} | moments got {np.round(f16(g_mom[yy, xx, :3]), 5).tolist()} ref {np.round(f16(st['moments'][yy, xx, :3]), 5).tolist()}")
