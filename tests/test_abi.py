@@ -81,6 +81,20 @@ def test_product_does_not_reference_the_oracle():
                 assert "pyoracle" not in txt and "orc_" not in txt and "libhr_oracle" not in txt, f
 
 
+def test_oracle_study_switches_are_never_set_by_the_checkers():
+    """the oracle has study switches (ORC_STUDY_*: tools/refl_clamp_order_study.py) that change its arithmetic on purpose; nothing that CHECKS with the
+    oracle — tests/, bench.py, __graft_entry__.py — nor the product may set or mention them, and the environment the tests run in must not carry one"""
+    assert not [k for k in os.environ if k.startswith("ORC_STUDY_")]
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for top in ("tests", "hybrid_rendering_amd"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp"))]
+    for f in files:
+        if os.path.abspath(f) == os.path.abspath(__file__):
+            continue
+        assert "ORC_STUDY_" not in open(f, errors="replace").read(), f
+
+
 def test_cpp_shims_compile():
     """include/hr/passes.hpp (the C++ mirror of the reference's pass classes) is valid C++14 against hr_api.h."""
     import subprocess
