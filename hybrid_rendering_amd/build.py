@@ -67,7 +67,30 @@ def build(force: bool = False, verbose: bool = False, variant: str = None) -> st
         build_comm(False, verbose)
         return LIB
     extra = os.environ.get("HR_CFLAGS", "").split()
-    cmd = [hipcc()] + FLAGS + extra + ["-x", "hip"] + sources() + ["-o", out + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
+    # one object per translation unit, compiled in parallel and cached by (source, headers, flags): a one-file change rebuilds in seconds
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(HERE, "_obj", variant or "product")
+    os.makedirs(obj_dir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "hr_api.h"), __file__]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+    tag = hashlib.sha1(" ".join(cflags).encode()).hexdigest()[:10]
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src) + "." + tag + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [hipcc()] + cflags + ["-x", "hip", "-c", src, "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

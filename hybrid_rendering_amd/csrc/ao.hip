@@ -495,7 +495,15 @@ hr_status hr_ao_destroy(hr_ao* p)
     delete p;
     return HR_OK;
 }
-hr_status hr_ao_reset_history(hr_ao* p) { HR_CHECK_ARG(p); p->first_frame = true; p->geo_valid = false; p->tile_order.invalidate(); return HR_OK; }
+// Also forgets the entry-node table: it is marked built when its kernel is ENQUEUED, and this is the path a frame whose capture / launch
+// failed takes (frame.hip reset_after_failed_frame) — the table may never have been written.
+hr_status hr_ao_reset_history(hr_ao* p)
+{
+    HR_CHECK_ARG(p);
+    p->first_frame = true; p->geo_valid = false; p->tile_order.invalidate();
+    p->grid_scene = 0; p->grid_ray_length = -1.0f;
+    return HR_OK;
+}
 hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded)   // see hr_shadows_history_apron_exceeded
 {
     HR_CHECK_ARG(p && exceeded);
@@ -551,6 +559,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     a.grid = nullptr;
     if (p->grid_enabled && p->entry_grid.p && prm->ray_length > 0.0f)
     {
+        bool enqueued = false;
         if (p->grid_scene != scene->uid || p->grid_ray_length != prm->ray_length)
         {
             // cells of half the ray length, no finer than 1/256 of the longest extent, coarsened until the table fits its fixed capacity
@@ -575,9 +584,19 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
                 hipLaunchKernelGGL(k_ao_entry_grid, dim3(cdiv(cells, 256)), dim3(256), 0, st, (const Node8*)scene->nodes.p, (uint32_t*)p->entry_grid.p,
                                    lo[0], lo[1], lo[2], c, n[0], n[1], n[2], prm->ray_length * 1.0001f + 1e-4f);
                 HR_HIP(hipGetLastError());
+                enqueued = true;
                 p->grid_scene = scene->uid; p->grid_ray_length = prm->ray_length; p->grid_c = c;
                 for (int k = 0; k < 3; k++) { p->grid_lo[k] = lo[k]; p->grid_n[k] = n[k]; }
             }
+        }
+        // Under stream capture (HR_FRAME_GRAPH) the kernel node is recorded EVERY frame — over zero cells when the table is up to date — so that a
+        // frame that rebuilds it (an animated ray_length) has the topology of the frames around it and hipGraphExecUpdate keeps the instantiated
+        // graph (the extra node used to force the synchronise + re-instantiate path).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (!enqueued && st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive)
+        {
+            hipLaunchKernelGGL(k_ao_entry_grid, dim3(1), dim3(256), 0, st, (const Node8*)scene->nodes.p, (uint32_t*)p->entry_grid.p, 0.0f, 0.0f, 0.0f, 1.0f, 0, 0, 0, 0.0f);
+            HR_HIP(hipGetLastError());
         }
         if (p->grid_scene == scene->uid)
         {

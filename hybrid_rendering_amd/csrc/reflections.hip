@@ -108,10 +108,13 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 #define REFL_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 216 / 226 / 235 us
 #endif
 // STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false, .>.
-// FAST (tolerance mode, hr_reflections_params.exact == 0): the DDGI irradiance gathers of the hit shading and of the rough pixels through
-// ddgi_sample_fast.h instead of shading.h's correctly rounded restatement.  The exact gather is ~3x the fast one (per-pixel sample kernel:
-// 225 vs 70 us) and was a third of this kernel: 339 k rough pixels + 350 k hit points of the 1080p bench frame.  Rays, hit points, ray
-// counts and tile classes do not depend on it; the trace IMAGE is then within the stated tolerance instead of bit-exact.
+// FAST: the DDGI irradiance gathers of the hit shading and of the rough pixels through ddgi_sample_fast.h instead of shading.h's
+// correctly rounded restatement (a third of this kernel: 339 k rough pixels + 350 k hit points of the 1080p bench frame; 149 vs 185 us
+// at 1080p, 382 vs 488 us at 4K).  NOT what ships (round 6): the fast gather leaves ~0.02 % of the trace image's colours one fp16 ulp
+// off, and one frame later `m2 - m1^2` of the stored luminance moments turns that into 0.4-100 % of a small variance, which normalises
+// the a-trous luminance weights (docs/EXPERIMENTS.md R5.8, R6.1): six fuzzed sequences missed the 99.9 % population bound because of
+// it, none does with the parity gather.  Both modes therefore launch <., false>: the trace image is bit-exact in tolerance mode too.
+// The template parameter stays for the developer A/B switch HR_REFL_FAST_SHADING=1.
 template <bool STATS, bool FAST>
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)
 {
@@ -448,7 +451,7 @@ struct hr_reflections
     // when the caller hands back as in->prev the images it passed as in->cur (the reference's ping-pong, g_buffer.cpp:208-211) — so does
     // the next frame's reprojection (see hr_shadows).
     bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
-    bool          fast_shading = true;  // tolerance mode: k_refl_trace<., FAST> (developer A/B switch HR_REFL_FAST_SHADING=0, read once at create)
+    bool          fast_shading = false; // developer A/B switch HR_REFL_FAST_SHADING=1 (read once at create): k_refl_trace<., FAST> in tolerance mode
     bool          geo_valid = false;
     bool          dbg_require_geo = false;   // HR_DEBUG_REQUIRE_GEO (tests)
     int           geo_parity = 0;

@@ -148,7 +148,10 @@ struct TileOrder
         const bool on = enabled && order.p && n > 0;
         if (n_tiles) *n_tiles = on ? n : 0;
         if (!out || !on) return HR_OK;
-        HR_HIP(hipStreamSynchronize(st));
+        // the DEVICE, not `st`: under HR_FRAME_GRAPH the pass's last stream is the internal capture stream, while the riding sort that writes
+        // `order` runs on whatever stream the graph was launched on
+        (void)st;
+        HR_HIP(hipDeviceSynchronize());
         HR_HIP(hipMemcpy(out, order.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         return HR_OK;
     }

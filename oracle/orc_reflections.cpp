@@ -200,29 +200,6 @@ void orc_reflections_temporal(const void* ubo_, int w, int h, const uint16_t* in
                             const float wgt = 289.0f;
                             vec3 mean = m1 / wgt;
                             vec3 var  = (m2 / wgt) - (mean * mean);
-                            // STUDY SWITCH, never set by tests / bench / smoke (tools/refl_clamp_order_study.py, docs/EXPERIMENTS.md R5.8): the same statistics
-                            // summed SEPARABLY (rows first, then the 17 row sums; mean = sum * (1 / 289)) — the association the tolerance-mode GPU kernel
-                            // uses — to measure how much of the temporal image depends on nothing but the order of these fp32 sums
-                            static const bool separable_study = std::getenv("ORC_STUDY_SEPARABLE_STATS") != nullptr;
-                            if (separable_study)
-                            {
-                                m1 = v3(0, 0, 0); m2 = v3(0, 0, 0);
-                                for (int dy = -8; dy <= 8; dy++)
-                                {
-                                    vec3 r1 = v3(0, 0, 0), r2 = v3(0, 0, 0);
-                                    for (int dx = -8; dx <= 8; dx++)
-                                    {
-                                        vec3 s = v3(in.fetch(x + dx, y + dy, 0), in.fetch(x + dx, y + dy, 1), in.fetch(x + dx, y + dy, 2));
-                                        r1 = r1 + s;
-                                        r2 = r2 + s * s;
-                                    }
-                                    m1 = m1 + r1;
-                                    m2 = m2 + r2;
-                                }
-                                const float inv = 1.0f / 289.0f;
-                                mean = inv * m1;
-                                var  = (inv * m2) - (mean * mean);
-                            }
                             vec3 sd   = v3(std::sqrt(fmax2(var.x, 0.0f)), std::sqrt(fmax2(var.y, 0.0f)), std::sqrt(fmax2(var.z, 0.0f)));
                             vec3 amin = mean - sd, amax = mean + sd;
                             // clip_aabb

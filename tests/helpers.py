@@ -114,3 +114,33 @@ def unpack_mask(mask, w, h):
         for lx in range(8):
             bits[ly::4, lx::8] = (mask >> np.uint32(ly * 8 + lx)) & 1
     return bits[:h, :w]
+
+
+def fuzz_configs(seed: int, n: int, hard: bool = False):
+    """The random configurations of tools/fuzz_tolerance.py, as a generator of dicts — ONE place for the draws, so that a sequence a fuzz
+    campaign found can be named (seed, trial) in a test (tests/test_gpu_tolerance.py FUZZ_SEQUENCES) and replayed by tools/fuzz_one.py."""
+    rng = np.random.RandomState(seed)
+    for trial in range(n):
+        name = str(rng.choice(["sponza_hard_small", "sponza_hard_small", "sponza_small"] if hard else ["cornell", "sponza_small"]))
+        # large enough that 0.1 % of the texels is a population, not two pixels
+        W, H = int(rng.randint(160, 360)), int(rng.randint(120, 220))
+        light = str(rng.choice(["default", "point", "spot"] + (["grazing", "grazing"] if hard else [])) if name != "cornell" else rng.choice(["default", "soft"]))
+        dolly = float(rng.uniform(0.2, 2.5))
+        scale = int(rng.choice([0, 1, 1, 2]))
+        sp = ap = rp = None
+        if trial % 2:
+            sp = dict(alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)), phi_visibility=float(rng.uniform(1, 20)),
+                      phi_normal=float(rng.choice([8.0, 32.0, 64.0, 12.5])), sigma_depth=float(rng.uniform(0.3, 3)), power=float(rng.choice([0.0, 1.2, 2.0])),
+                      radius=int(rng.choice([1, 2])), filter_iterations=int(rng.choice([1, 3, 5])), feedback_iteration=int(rng.choice([0, 1])))
+            ap = dict(blur_radius=int(rng.choice([2, 4, 6])), alpha=float(rng.uniform(0.005, 0.3)), ray_length=float(rng.uniform(5, 60)))
+            rp = dict(alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)), phi_color=float(rng.uniform(1, 20)),
+                      phi_normal=float(rng.choice([32.0, 8.0, 12.5])), sigma_depth=float(rng.uniform(0.3, 3)), radius=int(rng.choice([1, 2])),
+                      filter_iterations=int(rng.choice([1, 3, 5])), feedback_iteration=int(rng.choice([0, 1])))
+        ao_spp = int(rng.randint(1, 5))
+        yield dict(trial=trial, name=name, W=W, H=H, light=light, dolly=dolly, scale=scale, shadows=sp, ao=ap, reflections=rp, ao_spp=ao_spp)
+
+
+def fuzz_config(seed: int, trial: int, hard: bool = False):
+    for c in fuzz_configs(seed, trial + 1, hard):
+        pass
+    return c

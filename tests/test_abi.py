@@ -81,18 +81,22 @@ def test_product_does_not_reference_the_oracle():
                 assert "pyoracle" not in txt and "orc_" not in txt and "libhr_oracle" not in txt, f
 
 
-def test_oracle_study_switches_are_never_set_by_the_checkers():
-    """the oracle has study switches (ORC_STUDY_*: tools/refl_clamp_order_study.py) that change its arithmetic on purpose; nothing that CHECKS with the
-    oracle — tests/, bench.py, __graft_entry__.py — nor the product may set or mention them, and the environment the tests run in must not carry one"""
+def test_the_oracle_has_no_behaviour_switches():
+    """the oracle is the trust root of every parity and tolerance test: no environment variable may change its arithmetic (round 5 had a
+    study switch ORC_STUDY_SEPARABLE_STATS read through getenv — removed with the study); neither the checkers nor the product mention one"""
     assert not [k for k in os.environ if k.startswith("ORC_STUDY_")]
     files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
-    for top in ("tests", "hybrid_rendering_amd"):
-        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+    for top in ("tests", "hybrid_rendering_amd", "oracle"):
+        for dp, ds, fs in os.walk(os.path.join(ROOT, top)):
+            ds[:] = [d for d in ds if d not in ("_build", "_ref", "__pycache__")]
             files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp"))]
     for f in files:
         if os.path.abspath(f) == os.path.abspath(__file__):
             continue
         assert "ORC_STUDY_" not in open(f, errors="replace").read(), f
+    for f in os.listdir(os.path.join(ROOT, "oracle")):
+        if f.startswith("orc_") and f.endswith((".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "oracle", f)).read(), f"oracle/{f} reads the environment"
 
 
 def test_cpp_shims_compile():

@@ -63,3 +63,25 @@ def test_many_small_errors_fail_the_share_or_the_l2_bound():
     got = (_bits(ref).astype(np.int32) + 8).astype(np.uint16)   # every texel 8 ulp up: inside the cap, outside the 2-ulp share
     with pytest.raises(AssertionError):
         T.compare16(got, _bits(ref), "eight ulp everywhere")
+
+
+def test_thresholds_are_constants():
+    """every threshold of the tolerance rule is a constant of tests/test_gpu_tolerance.py: no environment variable can loosen it (round 5 had
+    HR_TEST_* overrides for strict fuzz campaigns); the one switch left prints a report"""
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_tolerance.py")).read()
+    assert re.findall(r"environ[^\n]*?(HR_TEST_\w+)", src) == ["HR_TEST_TOLERANCE_REPORT"]
+    assert not [k for k in os.environ if k.startswith("HR_TEST_") and k != "HR_TEST_TOLERANCE_REPORT"]
+    assert (T.CAP_ULPS, T.CAP_ABS, T.INTERMEDIATE_FLOOR, T.VARIANCE_FLOOR) == (32, 2.0 ** -10, 2e-4, 1e-4)
+    assert (T.OUTLIER_PIXELS, T.DDGI_OUTLIERS, T.REFL_OUTLIERS, T.OUTLIER_ULPS, T.OUTLIER_ABS) == (0.0, 0.0, 2e-5, 512, 2.0 ** -5)
+
+
+def test_fuzz_sequences_name_the_recorded_draws():
+    """the six sequences of test_reflections_fuzz_sequences_that_missed_the_population_bound are the configurations the round-5 campaigns printed
+    (profiles/r5_f/fuzz_tolerance_8088x160.txt, profiles/r5_g/fuzz_one_six_v2.txt)"""
+    import helpers
+    got = {(s, t): helpers.fuzz_config(s, t) for s, t in T.FUZZ_SEQUENCES}
+    want = {(8088, 21): ("sponza_small", 283, 147, "point", 2), (8088, 61): ("sponza_small", 160, 124, "default", 1), (8088, 84): ("sponza_small", 339, 136, "default", 2),
+            (8088, 159): ("sponza_small", 177, 136, "default", 2), (555, 66): ("sponza_small", 336, 138, "spot", 1), (31337, 206): ("sponza_small", 181, 159, "spot", 1)}
+    for k, c in got.items():
+        assert (c["name"], c["W"], c["H"], c["light"], c["scale"]) == want[k], (k, c)

@@ -16,28 +16,14 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 kw = dict(n_frames=n_frames) if n_frames else {}
 hard = len(sys.argv) > 4 and sys.argv[4] == "hard"
-rng = np.random.RandomState(seed)
+import helpers
 ctx = hr.Context(0)
 bad = 0
-for trial in range(n):
-    name = str(rng.choice(["sponza_hard_small", "sponza_hard_small", "sponza_small"] if hard else ["cornell", "sponza_small"]))
-    # large enough that 0.1 % of the texels is a population, not two pixels
-    W, H = int(rng.randint(160, 360)), int(rng.randint(120, 220))
-    light = str(rng.choice(["default", "point", "spot"] + (["grazing", "grazing"] if hard else [])) if name != "cornell" else rng.choice(["default", "soft"]))
-    dolly = float(rng.uniform(0.2, 2.5))
-    scale = int(rng.choice([0, 1, 1, 2]))
-    sp = ap = rp = None
-    if trial % 2:
-        sp = dict(alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)), phi_visibility=float(rng.uniform(1, 20)),
-                  phi_normal=float(rng.choice([8.0, 32.0, 64.0, 12.5])), sigma_depth=float(rng.uniform(0.3, 3)), power=float(rng.choice([0.0, 1.2, 2.0])),
-                  radius=int(rng.choice([1, 2])), filter_iterations=int(rng.choice([1, 3, 5])), feedback_iteration=int(rng.choice([0, 1])))
-        ap = dict(blur_radius=int(rng.choice([2, 4, 6])), alpha=float(rng.uniform(0.005, 0.3)), ray_length=float(rng.uniform(5, 60)))
-        rp = dict(alpha=float(rng.uniform(0.005, 0.3)), moments_alpha=float(rng.uniform(0.05, 0.5)), phi_color=float(rng.uniform(1, 20)),
-                  phi_normal=float(rng.choice([32.0, 8.0, 12.5])), sigma_depth=float(rng.uniform(0.3, 3)), radius=int(rng.choice([1, 2])),
-                  filter_iterations=int(rng.choice([1, 3, 5])), feedback_iteration=int(rng.choice([0, 1])))
+for c in helpers.fuzz_configs(seed, n, hard):
+    trial, name, W, H, light, dolly, scale, sp, ap, rp = (c[k] for k in ("trial", "name", "W", "H", "light", "dolly", "scale", "shadows", "ao", "reflections"))
     res = []
     for label, fn in (("shadows", lambda: tol.test_shadows_tolerance(oracle, hr, ctx, name, W, H, dolly, light, sp, **kw)),
-                      ("ao", lambda: tol.test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, int(rng.randint(1, 5)), ap, **kw)),
+                      ("ao", lambda: tol.test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, c["ao_spp"], ap, **kw)),
                       ("reflections+ddgi", lambda: tol.test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, min(scale, 1), dolly, rp, **kw))):
         try:
             fn()
