@@ -164,13 +164,9 @@ int main(int argc, char** argv)
         env.prefiltered = upload(pre); env.prefiltered_size = SK; env.prefiltered_levels = LV;
         env.brdf_lut = upload(lut); env.brdf_lut_size = 16;
 
-        // ---- DDGI grid 5 x 5 x 5 over the room (ddgi.cpp:150-169, :197-201) -----------------------------------------
-        hr_ddgi_uniforms g {};
-        for (int a = 0; a < 3; a++) { g.grid_start_position[a] = 0.0f; g.grid_step[a] = S / 3.0f; g.probe_counts[a] = 5; }
-        g.max_distance = g.grid_step[0] * 1.5f; g.depth_sharpness = 50.0f; g.hysteresis = 0.98f; g.normal_bias = 1.0f; g.energy_preservation = 0.85f;
-        g.irradiance_probe_side_length = 8; g.depth_probe_side_length = 16; g.rays_per_probe = 64; g.visibility_test = 1;
-        g.irradiance_texture_width = 10 * 25 + 2; g.irradiance_texture_height = 10 * 5 + 2;
-        g.depth_texture_width = 18 * 25 + 2; g.depth_texture_height = 18 * 5 + 2;
+        // ---- DDGI: the probe grid is derived from the scene's extents by the pass itself (DDGI::initialize_probe_grid, ddgi.cpp:150-169):
+        // probe distance S / 3 over the S-sized room -> ivec3(3) + 2 = 5 x 5 x 5 probes, the presets' normal bias 1.0 (main.cpp:1094-1095) ----
+        auto configure_ddgi = [&](hr::DDGI& d) { d.set_normal_bias(1.0f); d.set_probe_distance(S / 3.0f); d.set_rays_per_probe(64); };
 
         // ---- passes, created like main.cpp:1150-1159: every pass keeps non-owning pointers to the application's CommonResources
         // and GBuffer (ray_traced_shadows.h:127-129) and reads them at render() --------------------------------------------------
@@ -180,7 +176,8 @@ int main(int argc, char** argv)
         g_buffer.current[0].width = W; g_buffer.current[0].height = H;   // the extent is read at construction, the images every frame
         hr::RayTracedShadows      shadows(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         hr::RayTracedAO           ao(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::DDGI                  ddgi(ctx, &common, &g_buffer, g);
+        hr::DDGI                  ddgi(ctx, &common, &g_buffer);   // the reference's four constructor arguments (ddgi.h:12)
+        configure_ddgi(ddgi);
         hr::RayTracedReflections  reflections(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         hr::DeferredShading       deferred(ctx, &common, &g_buffer);
         hr::TemporalAA            taa(ctx, W, H);
@@ -189,7 +186,8 @@ int main(int argc, char** argv)
         // Two more sets of passes (each keeps its own temporal history) so that their outputs can be compared with the serial calls.
         hr::RayTracedShadows      shadows_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), shadows_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         hr::RayTracedAO           ao_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), ao_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
-        hr::DDGI                  ddgi_s(ctx, &common, &g_buffer, g), ddgi_g(ctx, &common, &g_buffer, g);
+        hr::DDGI                  ddgi_s(ctx, &common, &g_buffer), ddgi_g(ctx, &common, &g_buffer);
+        configure_ddgi(ddgi_s); configure_ddgi(ddgi_g);
         hr::RayTracedReflections  reflections_s(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES), reflections_g(ctx, &common, &g_buffer, hr::RAY_TRACE_SCALE_FULL_RES);
         hr::HybridFrame           frame_streams(ctx, &common, &g_buffer, &shadows_s, &ao_s, &ddgi_s, &reflections_s);
         hr::HybridFrame           frame_graph(ctx, &common, &g_buffer, &shadows_g, &ao_g, &ddgi_g, &reflections_g);
@@ -293,6 +291,8 @@ int main(int argc, char** argv)
         int inst = 0, upd = 0;
         frame_graph.graph_stats(inst, upd);
         std::printf("hr::HybridFrame GRAPH: %d graph instantiated, %d in-place updates; %d mismatching frames\n", inst, upd, forked_mismatches);
+        std::printf("hr::DDGI(ctx, common, g_buffer): probe grid %d x %d x %d derived from the scene's extents at probe distance %.3f, normal bias %.2f\n",
+                    ddgi.probe_counts()[0], ddgi.probe_counts()[1], ddgi.probe_counts()[2], ddgi.probe_distance(), ddgi.normal_bias());
         std::printf("hybrid_frame: %d triangles, %dx%d, all passes ran\n", n_tris, W, H);
         const bool ok = forked_mismatches == 0 && inst >= 1 && m_shadow > 0.05 && m_shadow < 1.0 && m_ao > 0.2 && m_ao <= 1.0 && m_gi > 0.0 && m_final > 0.0 && m_taa > 0.0 && m_gt > 0.0 &&
                         std::isfinite(m_refl) && std::isfinite(m_final) && m_ldr > 0.02 && m_ldr < 0.98;

@@ -91,7 +91,7 @@ SCALE_FULL_RES, SCALE_HALF_RES, SCALE_QUARTER_RES = 0, 1, 2
 
 # every symbol include/hr_api.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info",
+    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info", "hr_scene_id",
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
@@ -119,6 +119,8 @@ def lib():
         _lib.hr_status_string.restype = C.c_char_p
         _lib.hr_last_error.restype = C.c_char_p
         _lib.hr_version.restype = C.c_char_p
+        _lib.hr_scene_id.restype = C.c_uint64
+        _lib.hr_scene_id.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -183,6 +185,11 @@ class Scene:
         _check(lib().hr_scene_create(ctx.h, C.byref(d), C.byref(self.h)), "hr_scene_create")
         self.info = hr_scene_info()
         _check(lib().hr_scene_get_info(self.h, C.byref(self.info)), "hr_scene_get_info")
+
+    @property
+    def id(self) -> int:
+        """dw::Scene::id() (hr_scene_id)"""
+        return int(lib().hr_scene_id(self.h))
 
     def close(self):
         if self.h:

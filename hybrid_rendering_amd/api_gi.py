@@ -40,6 +40,18 @@ def environment(sky, prefiltered=None, prefiltered_size=0, prefiltered_levels=0,
     return e
 
 
+def grid_from_extents(lo, hi, probe_distance: float, rays_per_probe: int = 256) -> np.ndarray:
+    """hr_ddgi_grid_from_extents = DDGI::initialize_probe_grid + atlas sizing + uniform constants (ddgi.cpp:150-169, :197-201, :738-763); host only.
+    Returns the 88-byte block as a numpy record (synth_env.DDGI_DTYPE)."""
+    from . import synth_env
+    u = hr_ddgi_uniforms()
+    a, b = (C.c_float * 3)(*[float(v) for v in lo]), (C.c_float * 3)(*[float(v) for v in hi])
+    _check(lib().hr_ddgi_grid_from_extents(a, b, C.c_float(probe_distance), C.c_int32(rays_per_probe), C.byref(u)), "hr_ddgi_grid_from_extents")
+    out = np.zeros((), synth_env.DDGI_DTYPE)
+    C.memmove(out.ctypes.data, C.byref(u), 88)
+    return out
+
+
 def make_uniforms(np_ddgi: np.ndarray) -> hr_ddgi_uniforms:
     assert np_ddgi.nbytes == 88
     u = hr_ddgi_uniforms()
@@ -60,6 +72,11 @@ class DDGI(_Pass):
         self.h = C.c_void_p()
         _check(lib().hr_ddgi_create(ctx.h, C.c_int32(width), C.c_int32(height), C.c_int(scale), C.byref(self.uniforms), C.byref(self.h)), "hr_ddgi_create")
         self.width, self.height = width >> scale, height >> scale
+
+    def set_normal_bias(self, v: float):
+        """DDGI::set_normal_bias (ddgi.h:29)"""
+        _check(lib().hr_ddgi_set_normal_bias(self.h, C.c_float(v)), "hr_ddgi_set_normal_bias")
+        self.uniforms.normal_bias = float(v)
 
     def set_orientation(self, m9):
         for i in range(9):
@@ -118,4 +135,5 @@ class DDGI(_Pass):
 
 api.ABI_SYMBOLS += ["hr_ddgi_default_params", "hr_ddgi_create", "hr_ddgi_render", "hr_ddgi_output", "hr_ddgi_current_read",
                     "hr_ddgi_restart_accumulation", "hr_ddgi_destroy", "hr_ddgi_ray_trace", "hr_ddgi_probe_update", "hr_ddgi_sample_probe_grid",
-                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count", "hr_ddgi_set_shard", "hr_ddgi_current_write", "hr_ddgi_trace_stats"]
+                    "hr_ddgi_end_frame", "hr_ddgi_image", "hr_ddgi_get_uniforms", "hr_ddgi_set_profiling", "hr_ddgi_get_stage_times", "hr_ddgi_ray_count", "hr_ddgi_set_shard", "hr_ddgi_current_write", "hr_ddgi_trace_stats",
+                    "hr_ddgi_grid_from_extents", "hr_ddgi_set_normal_bias"]

@@ -459,6 +459,8 @@ hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info)
     return HR_OK;
 }
 
+uint64_t hr_scene_id(const hr_scene* scene) { return scene ? scene->uid : 0; }
+
 hr_status hr_scene_destroy(hr_scene* scene)
 {
     if (scene)

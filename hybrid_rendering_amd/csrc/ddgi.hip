@@ -478,6 +478,34 @@ void hr_ddgi_default_params(hr_ddgi_params* p)
     p->exact = 1;
 }
 
+// DDGI::initialize_probe_grid (ddgi.cpp:150-169), create_images' atlas sizes (:197-201), update_properties_ubo (:738-763); member defaults ddgi.h:54-56,71-75,92-95
+hr_status hr_ddgi_grid_from_extents(const float* lo, const float* hi, float probe_distance, int32_t rays_per_probe, hr_ddgi_uniforms* out)
+{
+    HR_CHECK_ARG(lo && hi && out && probe_distance > 0.0f && rays_per_probe > 0);
+    hr_ddgi_uniforms u = {};
+    for (int k = 0; k < 3; k++)
+    {
+        HR_CHECK_ARG(hi[k] >= lo[k] && hi[k] - lo[k] < 1e30f);
+        const float q = (hi[k] - lo[k]) / probe_distance;   // glm: vec3 / float, then ivec3() truncates
+        HR_CHECK_ARG(q < 65536.0f);
+        u.probe_counts[k]        = (int32_t)q + 2;           // "Add 2 more probes to fully cover scene."
+        u.grid_start_position[k] = lo[k];
+        u.grid_step[k]           = probe_distance;
+    }
+    u.max_distance = probe_distance * 1.5f;
+    u.depth_sharpness = 50.0f; u.hysteresis = 0.98f; u.normal_bias = 0.25f; u.energy_preservation = 0.85f;
+    u.irradiance_probe_side_length = 8; u.depth_probe_side_length = 16;
+    const long long cols = (long long)u.probe_counts[0] * u.probe_counts[1];
+    HR_CHECK_ARG((u.depth_probe_side_length + 2) * cols + 2 < (1ll << 30));
+    u.irradiance_texture_width  = (u.irradiance_probe_side_length + 2) * (int32_t)cols + 2;
+    u.irradiance_texture_height = (u.irradiance_probe_side_length + 2) * u.probe_counts[2] + 2;
+    u.depth_texture_width       = (u.depth_probe_side_length + 2) * (int32_t)cols + 2;
+    u.depth_texture_height      = (u.depth_probe_side_length + 2) * u.probe_counts[2] + 2;
+    u.rays_per_probe = rays_per_probe; u.visibility_test = 1;
+    *out = u;
+    return HR_OK;
+}
+
 hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_ddgi_uniforms* grid, hr_ddgi** out)
 {
     HR_CHECK_ARG(ctx && out && grid && full_width > 0 && full_height > 0 && (int)scale >= 0 && (int)scale <= 2);
@@ -537,6 +565,7 @@ hr_status hr_ddgi_set_shard(hr_ddgi* p, int32_t probe_z0, int32_t probe_z1, int3
 }
 
 hr_status hr_ddgi_restart_accumulation(hr_ddgi* p) { HR_CHECK_ARG(p); p->first_frame = true; return HR_OK; }
+hr_status hr_ddgi_set_normal_bias(hr_ddgi* p, float v) { HR_CHECK_ARG(p && v == v); p->d.normal_bias = v; return HR_OK; }
 hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t e) { HR_CHECK_ARG(p); p->prof.enabled = e != 0; return HR_OK; }
 hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out) { HR_CHECK_ARG(p && out); p->prof.collect(out); return HR_OK; }
 hr_status hr_ddgi_get_uniforms(hr_ddgi* p, hr_ddgi_uniforms* out) { HR_CHECK_ARG(p && out); *out = p->d; return HR_OK; }

@@ -223,25 +223,44 @@ private:
 class DDGI
 {
 public:
+    // explicit grid (tests, tools, BASELINE configs[4]'s fixed 16 x 8 x 16): the probe grid never re-derives itself
     DDGI(Context& ctx, uint32_t width, uint32_t height, const hr_ddgi_uniforms& grid, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
-        m_scale(scale), m_width(width >> scale), m_height(height >> scale)
+        m_ctx(&ctx), m_scale(scale), m_full_width(width), m_full_height(height), m_width(width >> scale), m_height(height >> scale), m_grid(grid), m_explicit_grid(true)
     {
         hr_ddgi_default_params(&params);
+        m_probe_distance = grid.grid_step[0]; m_normal_bias = grid.normal_bias;
         check(hr_ddgi_create(ctx.handle(), (int32_t)width, (int32_t)height, (hr_scale)scale, &grid, &m_pass), "hr_ddgi_create");
     }
-    // the reference's constructor shape: DDGI(backend, common_resources, g_buffer, scale) — non-owning pointers, read at render()
     DDGI(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, const hr_ddgi_uniforms& grid, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
         DDGI(ctx, g_buffer->width(), g_buffer->height(), grid, scale)
     {
         m_common_resources = common_resources; m_g_buffer = g_buffer;
+    }
+    // The reference's constructor, argument for argument (ddgi.h:12, ddgi.cpp:61-76): DDGI(backend, common_resources, g_buffer, scale).  The probe
+    // grid is derived from the extents of common_resources->scene by the first render() and again whenever the scene's id changes
+    // (ddgi.cpp:93-95 -> initialize_probe_grid :150-169 -> recreate_probe_grid_resources :723-734), with the probe distance / normal bias the
+    // setters hold at that moment (main.cpp:1094-1136 sets both just before it swaps the scene).
+    DDGI(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTraceScale scale = RAY_TRACE_SCALE_FULL_RES) :
+        m_ctx(&ctx), m_common_resources(common_resources), m_g_buffer(g_buffer), m_scale(scale), m_full_width(g_buffer->width()), m_full_height(g_buffer->height()),
+        m_width(g_buffer->width() >> scale), m_height(g_buffer->height() >> scale)
+    {
+        hr_ddgi_default_params(&params);
     }
     ~DDGI() { hr_ddgi_destroy(m_pass); }
     DDGI(const DDGI&) = delete;
     DDGI& operator=(const DDGI&) = delete;
 
     void render(Stream cmd_buf) { render(cmd_buf, make_frame(*providers(), *m_g_buffer, (int)m_scale)); }   // ddgi.h:15
+    // "If the scene has changed re-initialize the probe grid" (ddgi.cpp:93-95); render() calls it, and so does whoever needs handle() before the
+    // first render (hr::HybridFrame)
+    void prepare(const Scene& scene)
+    {
+        if (!m_explicit_grid && m_last_scene_id != hr_scene_id(scene.handle())) initialize_probe_grid(scene);
+    }
     void render(Stream cmd_buf, const Frame& frame)
     {
+        if (frame.scene) prepare(*frame.scene);
+        if (!m_pass) throw Error(HR_ERR_INVALID_ARG, "DDGI::render: no scene to derive the probe grid from");
         check(hr_ddgi_render(m_pass, frame.scene->handle(), &frame.inputs, frame.environment, &params, cmd_buf), "DDGI::render");
     }
     ImageView output_ds()
@@ -255,12 +274,24 @@ public:
     uint32_t      width() const { return m_width; }
     uint32_t      height() const { return m_height; }
     RayTraceScale scale() const { return m_scale; }
+    // ddgi.h:24-33
+    const int32_t* probe_counts() const { return m_grid.probe_counts; }   // glm::ivec3 in the reference; {0, 0, 0} before the first render()
+    float         normal_bias() const { return m_normal_bias; }
+    float         probe_distance() const { return m_probe_distance; }
     float         infinite_bounce_intensity() const { return params.infinite_bounce_intensity; }
     float         gi_intensity() const { return params.gi_intensity; }
+    void          set_normal_bias(float v)   // takes effect with the next render (update_properties_ubo, ddgi.cpp:747)
+    {
+        m_normal_bias = v; m_grid.normal_bias = v;
+        if (m_pass) check(hr_ddgi_set_normal_bias(m_pass, v), "DDGI::set_normal_bias");
+    }
+    void          set_probe_distance(float v) { m_probe_distance = v; }   // takes effect when the scene changes, as in the reference
     void          set_infinite_bounce_intensity(float v) { params.infinite_bounce_intensity = v; }
     void          set_gi_intensity(float v) { params.gi_intensity = v; }
-    void          restart_accumulation() { check(hr_ddgi_restart_accumulation(m_pass), "DDGI::restart_accumulation"); }
-    hr_ddgi*      handle() const { return m_pass; }
+    void          set_rays_per_probe(int32_t n) { m_rays_per_probe = n; }  // RayTrace::rays_per_probe = 256 (ddgi.h:56); read when the grid is (re)derived
+    void          restart_accumulation() { if (m_pass) check(hr_ddgi_restart_accumulation(m_pass), "DDGI::restart_accumulation"); }
+    const hr_ddgi_uniforms& uniforms() const { return m_grid; }   // what update_properties_ubo uploads
+    hr_ddgi*      handle() const { return m_pass; }               // NULL until the first render() of a scene-derived grid
 
     hr_ddgi_params params; // incl. this frame's probe-ray rotation (std::mt19937 in the reference, ddgi.cpp:788)
 
@@ -270,11 +301,30 @@ private:
         if (!m_common_resources || !m_g_buffer) throw Error(HR_ERR_INVALID_ARG, "DDGI::render(cmd_buf): constructed without CommonResources / GBuffer");
         return m_common_resources;
     }
+    void initialize_probe_grid(const Scene& scene)   // ddgi.cpp:150-169 + recreate_probe_grid_resources :723-734 (waits for the device, restarts the accumulation)
+    {
+        hr_scene_info info;
+        check(hr_scene_get_info(scene.handle(), &info), "hr_scene_get_info");
+        hr_ddgi_uniforms g;
+        check(hr_ddgi_grid_from_extents(info.bounds_lo, info.bounds_hi, m_probe_distance, m_rays_per_probe, &g), "hr_ddgi_grid_from_extents");
+        g.normal_bias = m_normal_bias;
+        hr_ddgi* fresh = nullptr;
+        check(hr_ddgi_create(m_ctx->handle(), (int32_t)m_full_width, (int32_t)m_full_height, (hr_scale)m_scale, &g, &fresh), "hr_ddgi_create");
+        hr_ddgi_destroy(m_pass);   // synchronises the device (backend->wait_idle())
+        m_pass = fresh; m_grid = g; m_last_scene_id = hr_scene_id(scene.handle());
+    }
+    Context*         m_ctx = nullptr;
     CommonResources* m_common_resources = nullptr;   // non-owning, like the reference's raw pointers
     GBuffer*         m_g_buffer = nullptr;
     hr_ddgi*      m_pass = nullptr;
     RayTraceScale m_scale;
-    uint32_t      m_width, m_height;
+    uint32_t      m_full_width, m_full_height, m_width, m_height;
+    hr_ddgi_uniforms m_grid {};
+    bool          m_explicit_grid = false;
+    uint64_t      m_last_scene_id = ~0ull;             // m_last_scene_id = UINT32_MAX (ddgi.h:117)
+    float         m_probe_distance = 1.0f;             // ProbeGrid::probe_distance = 1.0 (ddgi.h:73)
+    float         m_normal_bias = 0.25f;               // ProbeUpdate::normal_bias = 0.25 (ddgi.h:95)
+    int32_t       m_rays_per_probe = 256;              // RayTrace::rays_per_probe = 256 (ddgi.h:56)
 };
 
 class RayTracedReflections
@@ -352,10 +402,10 @@ public:
     enum Mode { SERIAL = HR_FRAME_SERIAL, STREAMS = HR_FRAME_STREAMS, GRAPH = HR_FRAME_GRAPH };
 
     HybridFrame(Context& ctx, CommonResources* common_resources, GBuffer* g_buffer, RayTracedShadows* shadows, RayTracedAO* ao, DDGI* ddgi, RayTracedReflections* reflections) :
-        m_common_resources(common_resources), m_g_buffer(g_buffer), m_shadows(shadows), m_ao(ao), m_ddgi(ddgi), m_reflections(reflections)
+        m_ctx(&ctx), m_common_resources(common_resources), m_g_buffer(g_buffer), m_shadows(shadows), m_ao(ao), m_ddgi(ddgi), m_reflections(reflections)
     {
-        check(hr_hybrid_frame_create(ctx.handle(), shadows ? shadows->handle() : nullptr, ao ? ao->handle() : nullptr, ddgi ? ddgi->handle() : nullptr,
-                                     reflections ? reflections->handle() : nullptr, &m_frame), "hr_hybrid_frame_create");
+        if (m_ddgi && m_common_resources->scene) m_ddgi->prepare(*m_common_resources->scene);
+        create();
     }
     ~HybridFrame() { hr_hybrid_frame_destroy(m_frame); }
     HybridFrame(const HybridFrame&) = delete;
@@ -364,6 +414,11 @@ public:
     void render(Stream cmd_buf, Mode mode = STREAMS)
     {
         const CommonResources& c = *m_common_resources;
+        if (m_ddgi)   // a scene-derived probe grid re-creates its pass when the scene changes (ddgi.cpp:93-95): the frame object follows
+        {
+            m_ddgi->prepare(*c.scene);
+            if (m_ddgi->handle() != m_ddgi_handle) { hr_hybrid_frame_destroy(m_frame); m_frame = nullptr; create(); }
+        }
         Frame fs, fa, fg, fr;
         hr_hybrid_frame_desc d {};
         d.environment = c.environment;
@@ -383,6 +438,14 @@ public:
     hr_hybrid_frame* handle() const { return m_frame; }
 
 private:
+    void create()
+    {
+        m_ddgi_handle = m_ddgi ? m_ddgi->handle() : nullptr;
+        check(hr_hybrid_frame_create(m_ctx->handle(), m_shadows ? m_shadows->handle() : nullptr, m_ao ? m_ao->handle() : nullptr, m_ddgi_handle,
+                                     m_reflections ? m_reflections->handle() : nullptr, &m_frame), "hr_hybrid_frame_create");
+    }
+    Context*              m_ctx;
+    hr_ddgi*              m_ddgi_handle = nullptr;
     CommonResources*      m_common_resources;
     GBuffer*              m_g_buffer;
     RayTracedShadows*     m_shadows;

@@ -50,7 +50,9 @@ const char* hr_version(void);
 /* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
 /* revision 5 (round 5): + hr_shadows_trace_stats_timed, hr_shadows_launch_order, hr_ao_launch_order; structs unchanged; every hr_*_create
  * returns with its images zero-filled (it waits for the fills), so a first render() on any stream is ordered after them */
-#define HR_API_REVISION 5
+/* revision 6 (round 6): + hr_scene_id, hr_ddgi_grid_from_extents, hr_ddgi_set_normal_bias, hr_scene_create_instanced,
+ * hr_scene_update_instances; structs unchanged */
+#define HR_API_REVISION 6
 int32_t hr_api_revision(void);
 
 /* ---- formats -------------------------------------------------------------------------------- */
@@ -169,6 +171,9 @@ typedef struct
  * depth, so no triangle soup reaches it); HR_ERR_OUT_OF_MEMORY: host or device allocation failed.  Never throws. */
 hr_status hr_scene_create(hr_ctx* ctx, const hr_scene_desc* desc, hr_scene** out);
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info);
+/* dw::Scene::id(): unique per hr_scene_create within the process, never 0 (0: NULL scene) — DDGI::render re-derives its probe grid when it
+ * changes (ddgi.cpp:93-95) */
+uint64_t  hr_scene_id(const hr_scene* scene);
 /* Host only (no device needed): the shape of the BVH hr_scene_create would build over `positions` ([n_tris][3][3] floats). */
 hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_info* info);
 /* Host only: builds the same BVH and descends it from `samples_per_triangle` points of every triangle (corners, edge midpoints,
@@ -422,6 +427,11 @@ typedef struct
 } hr_ddgi_params;
 
 void      hr_ddgi_default_params(hr_ddgi_params* p);
+/* DDGI::initialize_probe_grid (ddgi.cpp:150-169) + the atlas sizing of create_images (:197-201) + the constants update_properties_ubo uploads
+ * (:738-763, member defaults ddgi.h:54-56,71-75,92-95): probe_counts = ivec3((max - min) / probe_distance) + 2, grid_start_position = min_extents,
+ * grid_step = probe_distance, max_distance = 1.5 * probe_distance, hysteresis 0.98, depth_sharpness 50, normal_bias 0.25, energy preservation
+ * 0.85, octahedral sides 8 / 16, visibility test on.  Host only (no device).  probe_distance > 0, rays_per_probe > 0 (the reference: 256). */
+hr_status hr_ddgi_grid_from_extents(const float min_extents[3], const float max_extents[3], float probe_distance, int32_t rays_per_probe, hr_ddgi_uniforms* out);
 /* DDGI(backend, common, g_buffer, scale) + initialize_probe_grid/recreate_probe_grid_resources
  * (ddgi.cpp:61-76,150-237): the grid description is passed in (probe counts, atlas sizes). */
 hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, hr_scale scale, const hr_ddgi_uniforms* grid, hr_ddgi** out);
@@ -437,6 +447,8 @@ hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_v
  * slab rows of hr_ddgi_current_write() between hr_ddgi_probe_update and hr_ddgi_sample_probe_grid. */
 hr_status hr_ddgi_set_shard(hr_ddgi* p, int32_t probe_z0, int32_t probe_z1, int32_t row_y0, int32_t row_y1);
 hr_status hr_ddgi_current_write(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
+/* DDGI::set_normal_bias (ddgi.h:29): read by the next render's uniform upload (ddgi.cpp:747); hr_ddgi_get_uniforms reads it back */
+hr_status hr_ddgi_set_normal_bias(hr_ddgi* p, float normal_bias);
 /* DDGI::restart_accumulation (ddgi.h:33) */
 hr_status hr_ddgi_restart_accumulation(hr_ddgi* p);
 hr_status hr_ddgi_destroy(hr_ddgi* p);

@@ -108,3 +108,32 @@ def test_cpp_shims_compile():
         f.write(src)
     subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])
     os.unlink(f.name)
+
+
+def test_ddgi_grid_from_extents_follows_initialize_probe_grid():
+    """hr_ddgi_grid_from_extents = DDGI::initialize_probe_grid (ddgi.cpp:150-169: counts = ivec3(extent / probe_distance) + 2, start = min extents,
+    max_distance = 1.5 * probe_distance) + the atlas sizes of create_images (:197-201) + the member defaults update_properties_ubo uploads
+    (ddgi.h:54-56,71-75,92-95).  Host only.  Checked on the Sponza preset (main.cpp:1125-1126: normal bias 0.1, probe distance 50) over extents of
+    the size SURVEY.md §8(d) quotes for Sponza (~1100 x 450 x 700), on the procedural stand-in's own bounds, and against the Python derivation."""
+    import numpy as np
+    from hybrid_rendering_amd import api_gi, synth, synth_env
+    u = api_gi.grid_from_extents((-550.0, 0.0, -350.0), (550.0, 450.0, 350.0), 50.0)
+    assert tuple(u["probe_counts"]) == (24, 11, 16) and tuple(u["grid_start_position"]) == (-550.0, 0.0, -350.0) and tuple(u["grid_step"]) == (50.0, 50.0, 50.0)
+    assert float(u["max_distance"]) == 75.0 and int(u["rays_per_probe"]) == 256 and int(u["visibility_test"]) == 1
+    assert (float(u["hysteresis"]), float(u["depth_sharpness"]), float(u["normal_bias"]), float(u["energy_preservation"])) == (np.float32(0.98), 50.0, 0.25, np.float32(0.85))
+    assert (int(u["irradiance_probe_side_length"]), int(u["depth_probe_side_length"])) == (8, 16)
+    assert (int(u["irradiance_texture_width"]), int(u["irradiance_texture_height"])) == (10 * 24 * 11 + 2, 10 * 16 + 2)
+    assert (int(u["depth_texture_width"]), int(u["depth_texture_height"])) == (18 * 24 * 11 + 2, 18 * 16 + 2)
+    lo, hi = synth.sponza_like(0.25).bounds()
+    for dist, rays in ((50.0, 256), (4.0, 64), (37.5, 128)):
+        a = api_gi.grid_from_extents(lo, hi, dist, rays)
+        b = synth_env.ddgi_uniforms(lo, hi, probe_distance=dist, rays_per_probe=rays)
+        assert a.tobytes() == b.tobytes(), (dist, a, b)
+    # a truncation case: 100 / (100 / 3) = 3.0000002 -> 3 + 2 probes per axis (examples/hybrid_frame.cpp)
+    assert tuple(api_gi.grid_from_extents((0, 0, 0), (100, 100, 100), np.float32(100.0) / np.float32(3.0), 64)["probe_counts"]) == (5, 5, 5)
+    L = api_gi.lib()
+    import ctypes as C
+    f3 = (C.c_float * 3)(0, 0, 0)
+    assert L.hr_ddgi_grid_from_extents(f3, f3, C.c_float(0.0), C.c_int32(256), C.byref(api_gi.hr_ddgi_uniforms())) == 1   # HR_ERR_INVALID_ARG
+    assert L.hr_ddgi_grid_from_extents(None, f3, C.c_float(1.0), C.c_int32(256), None) == 1
+    assert L.hr_scene_id(None) == 0

@@ -200,7 +200,7 @@ def test_arithmetic_mode_is_latched_at_the_temporal_stage(hr, ctx):
     p.params.exact = 0
     p.atrous_iteration(fi, 0)
     torch.cuda.synchronize()
-    assert hr.lib().hr_api_revision() == 5
+    assert hr.lib().hr_api_revision() == 6
     p.close(); gsc.close()
 
 
