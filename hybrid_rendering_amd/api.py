@@ -91,7 +91,7 @@ SCALE_FULL_RES, SCALE_HALF_RES, SCALE_QUARTER_RES = 0, 1, 2
 
 # every symbol include/hr_api.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info", "hr_scene_id",
+    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info", "hr_scene_id", "hr_scene_create_instanced", "hr_scene_update_instances", "hr_scene_instance_count", "hr_scene_read_bvh",
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
@@ -150,6 +150,19 @@ def _stream_ptr(stream=None):
 # ------------------------------------------------------------------------------ context / scene
 
 
+class hr_mesh_desc(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("tri_material", C.c_void_p), ("uvs", C.c_void_p), ("tangents", C.c_void_p), ("n_tris", C.c_int32)]
+
+
+class hr_instance(C.Structure):
+    _fields_ = [("model_matrix", C.c_float * 16), ("mesh_idx", C.c_uint32), ("mesh_id", C.c_uint32)]
+
+
+class hr_instanced_scene_desc(C.Structure):
+    _fields_ = [("meshes", C.POINTER(hr_mesh_desc)), ("n_meshes", C.c_int32), ("instances", C.POINTER(hr_instance)), ("n_instances", C.c_int32),
+                ("materials", C.c_void_p), ("n_materials", C.c_int32), ("material_textures", C.c_void_p), ("textures", C.c_void_p), ("n_textures", C.c_int32)]
+
+
 class Context:
     def __init__(self, device: int = 0):
         self.h = C.c_void_p()
@@ -196,6 +209,17 @@ class Scene:
             lib().hr_scene_destroy(self.h)
             self.h = C.c_void_p()
 
+    def read_bvh(self):
+        """(nodes [n][80] uint8, triangle references [m][48] uint8): host copies of the device BVH (csrc/bvh.h layouts)"""
+        self.refresh_info()
+        nodes, tris = np.zeros((self.info.n_nodes, 80), np.uint8), np.zeros((int(self.info.tri_bytes) // 48, 48), np.uint8)
+        _check(lib().hr_scene_read_bvh(self.h, C.c_void_p(nodes.ctypes.data), C.c_void_p(tris.ctypes.data)), "hr_scene_read_bvh")
+        return nodes, tris
+
+    def refresh_info(self):
+        _check(lib().hr_scene_get_info(self.h, C.byref(self.info)), "hr_scene_get_info")
+        return self.info
+
     def any_hit(self, rays, stats=False, stream=None):
         """rays: cuda float32 [n,8] (origin, t_max, dir, t_min) -> uint8 [n] (1 = occluded)."""
         import torch
@@ -224,6 +248,43 @@ class Scene:
         _check(lib().hr_gbuffer_raycast(self.h, C.byref(u), C.c_int32(w), C.c_int32(h), _ptr(gb1), _ptr(gb2), _ptr(gb3), _ptr(depth), _stream_ptr(stream)),
                "hr_gbuffer_raycast")
         return dict(gb1=gb1, gb2=gb2, gb3=gb3, depth=depth)
+
+
+class InstancedScene(Scene):
+    """dw::RayTracedScene as the reference holds it — meshes + instances — with the per-frame update of main.cpp:74 (build_tlas):
+    hr_scene_create_instanced / hr_scene_update_instances.  ``isd``: synth.InstancedSceneData.  Every pass takes it like a Scene."""
+
+    def __init__(self, ctx: Context, isd):
+        self.ctx, self.isd = ctx, isd
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        keep, meshes = [], (hr_mesh_desc * len(isd.meshes))()
+        for k, m in enumerate(isd.meshes):
+            arrs = [f32(m.verts), f32(m.normals), np.ascontiguousarray(m.tri_material, np.uint32), f32(m.uvs), f32(m.tangents)]
+            keep.append(arrs)
+            meshes[k] = hr_mesh_desc(*[(a.ctypes.data if a is not None else None) for a in arrs], m.n_tris)
+        inst = (hr_instance * len(isd.instances))()
+        for i, (mat, mesh_idx, mesh_id) in enumerate(isd.instances):
+            inst[i].model_matrix[:] = [float(v) for v in np.asarray(mat, np.float32).reshape(16)]
+            inst[i].mesh_idx, inst[i].mesh_id = int(mesh_idx), int(mesh_id)
+        mats = np.ascontiguousarray(isd.materials, np.float32)
+        d = hr_instanced_scene_desc(meshes, len(isd.meshes), inst, len(isd.instances), mats.ctypes.data, len(mats), None, None, 0)
+        if isd.material_textures is not None:
+            mt = np.ascontiguousarray(isd.material_textures, np.int32)
+            tex = [np.ascontiguousarray(t, np.uint8) for t in isd.textures]
+            arr = (hr_texture * len(tex))(*[hr_texture(t.ctypes.data, t.shape[1], t.shape[0]) for t in tex])
+            keep += [mt, tex, arr]
+            d.material_textures, d.textures, d.n_textures = mt.ctypes.data, C.cast(arr, C.c_void_p), len(tex)
+        self._keep = [keep, meshes, inst, mats]
+        self.h = C.c_void_p()
+        _check(lib().hr_scene_create_instanced(ctx.h, C.byref(d), C.byref(self.h)), "hr_scene_create_instanced")
+        self.info = hr_scene_info()
+        self.refresh_info()
+
+    def update(self, matrices, stream=None):
+        """hr_scene_update_instances: matrices [n_instances][16] column-major (host); enqueued on ``stream`` (default: torch's current stream)"""
+        m = np.ascontiguousarray(np.asarray(matrices, np.float32).reshape(-1, 16))
+        assert m.shape[0] == lib().hr_scene_instance_count(self.h)
+        _check(lib().hr_scene_update_instances(self.h, m.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(stream)), "hr_scene_update_instances")
 
 
 def bvh_build_info(verts) -> hr_scene_info:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhybrid_rendering_amd.so")
 SOURCES = ["api.hip", "shadows.hip", "bvh_build.cpp"]
-OPTIONAL = ["denoise_fast.hip", "ao.hip", "reflections.hip", "ddgi.hip", "deferred.hip", "ground_truth.hip", "taa.hip", "frame.hip"]
+OPTIONAL = ["denoise_fast.hip", "ao.hip", "reflections.hip", "ddgi.hip", "deferred.hip", "ground_truth.hip", "taa.hip", "frame.hip", "instances.hip"]
 # -ffp-contract=off: every fp32 op is individually rounded; FMAs are explicit.
 # -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 operations into v_pk_mul / v_pk_add / v_pk_fma_f32.  On gfx950 a packed
 # fp32 instruction issues at half rate, and pairing costs v_mov / v_pk_mov shuffles and hazard s_nops on top (kf_ddgi_sample: 305 packed

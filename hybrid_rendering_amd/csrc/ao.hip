@@ -431,6 +431,7 @@ struct hr_ao
     DevBuf        entry_grid;
     bool          grid_enabled = true;  // developer A/B switch HR_AO_ENTRY_GRID=0 (read once at create)
     uint64_t      grid_scene = 0;       // hr_scene::uid the table was built for (0: none)
+    uint64_t      grid_epoch = 0;       // ... and its geometry_epoch (an instanced scene moves: hr_scene_update_instances)
     float         grid_ray_length = -1.0f, grid_lo[3] = { 0, 0, 0 }, grid_c = 0.0f;
     int           grid_n[3] = { 0, 0, 0 };
 };
@@ -560,10 +561,10 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
     if (p->grid_enabled && p->entry_grid.p && prm->ray_length > 0.0f)
     {
         bool enqueued = false;
-        if (p->grid_scene != scene->uid || p->grid_ray_length != prm->ray_length)
+        if (p->grid_scene != scene->uid || p->grid_epoch != scene->geometry_epoch || p->grid_ray_length != prm->ray_length)
         {
             // cells of half the ray length, no finer than 1/256 of the longest extent, coarsened until the table fits its fixed capacity
-            const float* lo = scene->info.bounds_lo; const float* hi = scene->info.bounds_hi;
+            const float* lo = scene->grid_lo; const float* hi = scene->grid_hi;   // no read-back: conservative bounds for an instanced scene
             const float ext[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
             const float longest = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
             float c = 0.5f * prm->ray_length;
@@ -585,7 +586,7 @@ hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs
                                    lo[0], lo[1], lo[2], c, n[0], n[1], n[2], prm->ray_length * 1.0001f + 1e-4f);
                 HR_HIP(hipGetLastError());
                 enqueued = true;
-                p->grid_scene = scene->uid; p->grid_ray_length = prm->ray_length; p->grid_c = c;
+                p->grid_scene = scene->uid; p->grid_epoch = scene->geometry_epoch; p->grid_ray_length = prm->ray_length; p->grid_c = c;
                 for (int k = 0; k < 3; k++) { p->grid_lo[k] = lo[k]; p->grid_n[k] = n[k]; }
             }
         }

@@ -425,7 +425,7 @@ static hr_status scene_create_impl(hr_ctx* ctx, const hr_scene_desc* d, hr_scene
     s->info.node_bytes  = b.nodes.size() * sizeof(Node8);
     s->info.tri_bytes   = b.tris.size() * sizeof(TriGPU);
     s->info.box_pad     = b.pad;
-    for (int a = 0; a < 3; a++) { s->info.bounds_lo[a] = b.lo[a]; s->info.bounds_hi[a] = b.hi[a]; }
+    for (int a = 0; a < 3; a++) { s->info.bounds_lo[a] = s->grid_lo[a] = b.lo[a]; s->info.bounds_hi[a] = s->grid_hi[a] = b.hi[a]; }
     *out = guard.release();
     return HR_OK;
 }
@@ -455,11 +455,26 @@ extern "C" hr_status hr_gbuffer_mip_nearest(const hr_gbuffer_level* src, const h
 hr_status hr_scene_get_info(const hr_scene* scene, hr_scene_info* info)
 {
     HR_CHECK_ARG(scene && info);
+    if (scene->n_instances > 0)
+    {
+        const hr_status s = instanced_scene_refresh_bounds(scene);   // the exact bounds of the last hr_scene_update_instances, read back on demand
+        if (s != HR_OK) return s;
+    }
     *info = scene->info;
     return HR_OK;
 }
 
 uint64_t hr_scene_id(const hr_scene* scene) { return scene ? scene->uid : 0; }
+
+hr_status hr_scene_read_bvh(const hr_scene* scene, void* nodes_out, void* tris_out)
+{
+    HR_CHECK_ARG(scene);
+    HR_HIP(hipSetDevice(scene->ctx->device));
+    HR_HIP(hipDeviceSynchronize());
+    if (nodes_out) HR_HIP(hipMemcpy(nodes_out, scene->nodes.p, (size_t)scene->info.node_bytes, hipMemcpyDeviceToHost));
+    if (tris_out) HR_HIP(hipMemcpy(tris_out, scene->tris.p, (size_t)scene->info.tri_bytes, hipMemcpyDeviceToHost));
+    return HR_OK;
+}
 
 hr_status hr_scene_destroy(hr_scene* scene)
 {

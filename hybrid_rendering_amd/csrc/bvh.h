@@ -41,6 +41,18 @@ struct alignas(16) TriGPU
 };
 static_assert(sizeof(TriGPU) == 48, "TriGPU must be 48 bytes");
 
+// One instance of an instanced scene (instances.hip; scene_descriptor_set.glsl:30-34 Instance { mat4 model_matrix; uint mesh_idx; }): the
+// hit shading maps a global triangle index to the mesh's object-space attributes and applies `m` (shading.h surface_at).
+struct alignas(16) InstanceRec
+{
+    float    m[16];          // column-major object -> world
+    uint32_t first_tri;      // global index of the instance's first triangle
+    uint32_t mesh_tri_base;  // index of the mesh's first triangle in the concatenated per-mesh attribute arrays
+    uint32_t mesh_id;        // GB3.z of the instance's pixels
+    uint32_t n_tris;
+};
+static_assert(sizeof(InstanceRec) == 80, "InstanceRec must be 80 bytes");
+
 // deepest 8-wide tree the traversal's per-lane stack can walk (one entry per level, traverse.h LaneStack)
 constexpr int kMaxTraversalDepth = 64;
 
@@ -52,6 +64,11 @@ struct BuiltBVH
     float               pad;
     int                 max_depth;
     int                 n_refs = 0;   // triangle references after splitting (== tris.size())
+    // want_child_boxes (set before build_bvh8): child_boxes[(node * 8 + slot) * 6 ..] = lo xyz, hi xyz of the slot's box as the builder had it
+    // (padded, not yet quantised).  A LEAF's box may be smaller than the bounds of its triangles: the builder splits references spatially
+    // (SBVH), and a leaf then bounds only the pieces inside its cell.  The instanced scenes' refit needs these cells (instances.hip).
+    bool                want_child_boxes = false;
+    std::vector<float>  child_boxes;
 };
 
 // positions: [n][3][3].  Deterministic: the result does not depend on the number of builder threads (HR_BVH_THREADS, default min(hardware, 16)).

@@ -661,6 +661,7 @@ inline uint8_t exponent_for(float extent)
 void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
 {
     out.nodes.clear();
+    out.child_boxes.clear();
     out.tris.clear();
     out.max_depth = 0;
     Builder B;
@@ -983,6 +984,16 @@ void build_bvh8(const float* positions, int n_tris, BuiltBVH& out)
         size_t base = out.nodes.size();
         out.nodes.resize(base + n_internal);
         out.nodes[pd.n8] = n;
+        if (out.want_child_boxes)
+        {
+            if (out.child_boxes.size() < out.nodes.size() * 48) out.child_boxes.resize(out.nodes.size() * 48, 0.0f);
+            for (int i = 0; i < nk; i++)
+                for (int a = 0; a < 3; a++)
+                {
+                    out.child_boxes[((size_t)pd.n8 * 8 + i) * 6 + a]     = B.n2[kids[i]].box.lo[a];
+                    out.child_boxes[((size_t)pd.n8 * 8 + i) * 6 + 3 + a] = B.n2[kids[i]].box.hi[a];
+                }
+        }
         int slot = 0;
         for (int i = 0; i < nk; i++)
             if (i < n_int_kids) q.push({ kids[i], (int32_t)(base + slot++), pd.depth + 1 });

@@ -39,6 +39,8 @@ bool profiling_enabled(const hr_shadows* p);
 bool profiling_enabled(const hr_ao* p);
 bool profiling_enabled(const hr_ddgi* p);
 bool profiling_enabled(const hr_reflections* p);
+// instances.hip: brings info.bounds_* of an instanced scene up to date with its last update (synchronises the device when they lag)
+hr_status instanced_scene_refresh_bounds(const hr_scene* scene);
 
 struct DevBuf
 {
@@ -216,4 +218,19 @@ struct hr_scene
     uint64_t      uid = 0;   // unique per hr_scene_create (a destroyed scene's device addresses may be handed out again): key of per-scene caches in the passes
     int           n_materials = 0;
     bool          has_normals = false, has_material = false, has_mesh_id = false;
+    // ---- instanced scenes (instances.hip); n_instances == 0: a flattened scene from hr_scene_create.  `nodes` / `tris` / `positions` /
+    // `tri_normals` are then REWRITTEN by hr_scene_update_instances (world space); the mesh_* arrays hold the object-space attributes the
+    // hit shading interpolates (meshes concatenated), tri_instance / inst_records map a global triangle to them
+    int           n_instances = 0;
+    uint64_t      geometry_epoch = 0;   // bumped by every update: with `uid` the key of geometry-dependent caches of the passes (AO entry table)
+    hr::DevBuf    inst_records, tri_instance, mesh_positions, mesh_normals, mesh_uvs, mesh_tangents, mesh_material;
+    hr::DevBuf    level_nodes, node_box, bounds_bits, leaf_cells, node_inst, inst_dirty_dev;
+    std::vector<uint32_t> inst_dirty;             // per instance: its matrix changed in the update being enqueued
+    std::vector<int32_t>  level_offsets;          // level_nodes[level_offsets[d] .. level_offsets[d + 1]): the nodes of depth d
+    std::vector<uint32_t> inst_mesh;              // per instance: mesh index
+    std::vector<hr::InstanceRec> inst_host;       // host copy of inst_records (matrices of the last update)
+    std::vector<float>    mesh_bounds;            // per mesh: object-space lo xyz, hi xyz
+    float         grid_lo[3] = { 0, 0, 0 }, grid_hi[3] = { 0, 0, 0 };   // bounds a pass may read WITHOUT synchronising: exact for a flattened scene, the
+                                                                         // host's conservative bounds (transformed mesh boxes) for an instanced one
+    mutable bool  bounds_stale = false;           // info.bounds_* lag the last update until hr_scene_get_info reads them back
 };

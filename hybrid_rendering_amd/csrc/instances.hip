@@ -1,0 +1,667 @@
+// Instanced scenes with a per-frame acceleration-structure update — the MI355X replacement for dw::RayTracedScene's instance list
+// (scene_descriptor_set.glsl:30-34 Instance, :102-131 fetch_hit_info / fetch_triangle through instance.mesh_idx, :150-160
+// transform_vertex) and for main.cpp:74 build_tlas(cmd_buf), which the reference runs every frame.
+//
+// Layout (hr_api.h hr_scene_create_instanced): ONE world-space 8-wide BVH.  The topology of a mesh is built once, in object space, by the
+// host builder (bvh_build.cpp); every instance gets a private copy of it (nodes + triangle references: HBM is 288 GB, a traversal
+// that never leaves world space is worth the copies) under a top level over the instance roots:
+//
+//   nodes:  [ top level, root = 0 | the instance roots, grouped by eight under their top-level node | instance 0's other nodes | ... ]
+//   tris:   [ instance 0's references | instance 1's references | ... ]       prim = global triangle index (instance order, then mesh order)
+//
+// hr_scene_update_instances (all on the caller's stream, no host synchronisation):
+//   k_instances_transform   one thread per triangle: world vertices = model_matrix * (p, 1) (the hit records, the G-buffer synthesiser and
+//                           the references read them), world vertex normals for the G-buffer synthesiser, per-instance bounds by atomic min / max
+//   k_instances_gather      one thread per triangle reference: the 36 vertex bytes of its TriGPU
+//   k_instances_refit       one launch per tree level, deepest first: a thread per node recomputes the boxes of its eight children (internal
+//                           children: the box their own thread stored one launch earlier; leaves: the bounds of their triangles CUT to the
+//                           leaf's cell — the builder splits references spatially (SBVH), so a leaf of a mesh with long triangles bounds
+//                           only the pieces inside its object-space cell: the cell goes through the instance's matrix (centre + |M| extent,
+//                           in double, rounded outwards) and is intersected with the triangles' world bounds; without the cells the bench
+//                           building traced 1.8x slower after a refit than as built), the node's origin / scale exponents, and
+//                           requantises — the encoding rules of bvh_build.cpp, in double like there.
+//                           Launch boundaries are the only ordering used: the per-XCD L2s are not coherent with each other, and a
+//                           bottom-up walk with arrival counters inside one launch would need an agent-scope release per node.
+// Only instances whose matrix CHANGED are touched: the kernels drop the triangles, references and nodes of the others on a 4-byte flag, so
+// an update costs what moved (a static building under a few hundred movers: the movers), plus the top level.
+// The topology (which triangles share a leaf, which nodes share a parent) never changes, so a query's ANSWER is the one a fresh build over
+// the same world-space vertices would give — any-hit is a function of the geometry, closest hit is the smallest t with ties to the
+// smallest triangle index — while the boxes stay as tight as the moved geometry allows: a rigidly moving instance keeps its own subtree.
+#include "hr_internal.h"
+#include "device_math.h"
+#include <atomic>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+using namespace hr;
+
+namespace {
+
+struct RefitArgs
+{
+    Node8*             nodes;
+    const TriGPU*      tris;
+    float*             node_box;     // [n_nodes][8]: lo xyz, pad, hi xyz, pad
+    const uint32_t*    list;         // the nodes of this level
+    const float*       cells;        // [n_nodes][8][6]: object-space cell of every LEAF slot (the builder's box of it), lo xyz hi xyz
+    const int32_t*     node_inst;    // instance a node belongs to, -1: top level
+    const InstanceRec* inst;
+    const uint32_t*    dirty;        // per instance: matrix changed in this update
+    int                count;
+    float              pad;
+};
+
+__device__ uint8_t exponent_for_dev(float extent)
+{
+    // smallest e with extent <= 255 * 2^(e - 127) (bvh_build.cpp exponent_for; the answer is unique, so the starting guess is free)
+    if (!(extent > 0.0f)) return 1;
+    int e = (int)((__float_as_uint(extent) >> 23) & 0xffu) - 7;
+    if (e < 1) e = 1;
+    if (e > 254) e = 254;
+    while (e > 1 && ldexp(255.0, e - 1 - 127) >= (double)extent) e--;
+    while (e < 254 && ldexp(255.0, e - 127) < (double)extent) e++;
+    return (uint8_t)e;
+}
+__device__ float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
+__device__ float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
+
+__global__ __launch_bounds__(64) void k_instances_refit(RefitArgs a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.count) return;
+    const uint32_t ni = a.list[i];
+    const int      in = a.node_inst[ni];
+    if (in >= 0 && !a.dirty[in]) return;   // the instance did not move: its subtree stands
+    Node8 n = a.nodes[ni];
+    const int n_internal = n.counts & 15, n_children = n.counts >> 4;
+    float clo[8][3], chi[8][3];
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int c = 0; c < n_children; c++)
+    {
+        if (c < n_internal)
+        {
+            const float* b = a.node_box + (size_t)(n.child_base + c) * 8;
+            for (int k = 0; k < 3; k++) { clo[c][k] = b[k]; chi[c][k] = b[4 + k]; }
+        }
+        else
+        {
+            const uint32_t m = n.meta[c], cnt = m >> 5, off = m & 31u;
+            float l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (uint32_t t = 0; t < cnt; t++)
+            {
+                const TriGPU& tr = a.tris[n.tri_base + off + t];
+                for (int k = 0; k < 3; k++)
+                {
+                    l[k] = fminf(l[k], fminf(tr.v0[k], fminf(tr.v1[k], tr.v2[k])));
+                    h[k] = fmaxf(h[k], fmaxf(tr.v0[k], fmaxf(tr.v1[k], tr.v2[k])));
+                }
+            }
+            if (in >= 0)
+            {
+                // the leaf's object-space cell through the instance's matrix: centre c' = M c, half extent e' = |mat3(M)| e, rounded outwards
+                const float*       cell = a.cells + ((size_t)ni * 8 + c) * 6;
+                const float*       M    = a.inst[in].m;
+                const double cx = 0.5 * ((double)cell[0] + cell[3]), cy = 0.5 * ((double)cell[1] + cell[4]), cz = 0.5 * ((double)cell[2] + cell[5]);
+                const double ex = 0.5 * ((double)cell[3] - cell[0]), ey = 0.5 * ((double)cell[4] - cell[1]), ez = 0.5 * ((double)cell[5] - cell[2]);
+                for (int k = 0; k < 3; k++)
+                {
+                    const double wc = ((double)M[k] * cx + (double)M[4 + k] * cy) + ((double)M[8 + k] * cz + (double)M[12 + k]);
+                    const double we = (fabs((double)M[k]) * ex + fabs((double)M[4 + k]) * ey) + fabs((double)M[8 + k]) * ez;
+                    const double sl = 1e-12 * (fabs(wc) + we);   // the double arithmetic's own rounding, generously
+                    l[k] = fmaxf(l[k], round_down(wc - we - sl));
+                    h[k] = fminf(h[k], round_up(wc + we + sl));
+                }
+            }
+            for (int k = 0; k < 3; k++)
+            {
+                if (h[k] < l[k]) h[k] = l[k];   // (cell and triangles disjoint up to rounding: cannot happen for a builder cell, harmless if it did)
+                clo[c][k] = l[k] - a.pad; chi[c][k] = h[k] + a.pad;   // bvh_build.cpp finalise(pad)
+            }
+        }
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], clo[c][k]); hi[k] = fmaxf(hi[k], chi[c][k]); }
+    }
+    if (n_children == 0) { for (int k = 0; k < 3; k++) { lo[k] = 0.0f; hi[k] = 0.0f; } }
+    float* nb = a.node_box + (size_t)ni * 8;
+    nb[0] = lo[0]; nb[1] = lo[1]; nb[2] = lo[2]; nb[3] = 0.0f; nb[4] = hi[0]; nb[5] = hi[1]; nb[6] = hi[2]; nb[7] = 0.0f;
+    n.ox = lo[0]; n.oy = lo[1]; n.oz = lo[2];
+    n.ex = exponent_for_dev(hi[0] - lo[0]); n.ey = exponent_for_dev(hi[1] - lo[1]); n.ez = exponent_for_dev(hi[2] - lo[2]);
+    const uint8_t eb[3] = { n.ex, n.ey, n.ez };
+    for (int c = 0; c < 8; c++)
+        for (int k = 0; k < 3; k++)
+        {
+            uint8_t ql = 0, qh = 0;
+            if (c < n_children)
+            {
+                // child box = origin + q * 2^(e - 127), lo floored / hi ceiled => conservative (bvh.h)
+                const double s = ldexp(1.0, (int)eb[k] - 127), o = (double)lo[k];
+                double l = floor(((double)clo[c][k] - o) / s), h = ceil(((double)chi[c][k] - o) / s);
+                if (!(l > 0.0)) l = 0.0;
+                if (l > 255.0) l = 255.0;
+                if (!(h < 255.0)) h = 255.0;
+                if (h < l) h = l;
+                ql = (uint8_t)l; qh = (uint8_t)h;
+            }
+            n.qlo[k][c] = ql; n.qhi[k][c] = qh;
+        }
+    a.nodes[ni] = n;
+}
+
+// ordered-integer image of a float: unsigned comparison == float comparison
+__device__ uint32_t ordered_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+float ordered_float(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct TransformArgs
+{
+    const InstanceRec* inst;
+    const uint32_t*    tri_instance;
+    const uint32_t*    dirty;           // per instance
+    const float*       mesh_positions;
+    const float*       mesh_normals;    // or null
+    float*             positions;       // world, by global triangle
+    float*             normals;         // world mat3(model) * n (NOT normalised: the synthesiser normalises the interpolated sum), or null
+    uint32_t*          bounds_bits;     // [n_instances][6] ordered-integer min xyz, max xyz of the instance's world vertices
+    int                n_tris;
+};
+
+__global__ __launch_bounds__(256) void k_instances_reset_bounds(uint32_t* bounds_bits, const uint32_t* dirty, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !dirty[i]) return;
+    for (int k = 0; k < 3; k++) { bounds_bits[(size_t)i * 6 + k] = 0xffffffffu; bounds_bits[(size_t)i * 6 + 3 + k] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void k_instances_transform(TransformArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    int   ii = -1;
+    if (t < a.n_tris)
+    {
+        const uint32_t in = a.tri_instance[t];
+        if (a.dirty[in])
+        {
+            ii = (int)in;
+            const InstanceRec& r = a.inst[in];
+            const size_t q = (size_t)r.mesh_tri_base + ((uint32_t)t - r.first_tri);
+            const float* p = a.mesh_positions + q * 9;
+            float*       w = a.positions + (size_t)t * 9;
+            for (int v = 0; v < 3; v++)
+            {
+                // model_matrix * vec4(p, 1): ((m0 x + m1 y) + m2 z) + m3 w per row (scene_descriptor_set.glsl:155; device_math.h mul_m4)
+                const f4 x = mul_m4(r.m, p[v * 3], p[v * 3 + 1], p[v * 3 + 2], 1.0f);
+                w[v * 3] = x.x; w[v * 3 + 1] = x.y; w[v * 3 + 2] = x.z;
+                const float c[3] = { x.x, x.y, x.z };
+                for (int k = 0; k < 3; k++) { if (c[k] < lo[k]) lo[k] = c[k]; if (c[k] > hi[k]) hi[k] = c[k]; }
+            }
+            if (a.mesh_normals)
+            {
+                const float* n = a.mesh_normals + q * 9;
+                float*       o = a.normals + (size_t)t * 9;
+                for (int v = 0; v < 3; v++)
+                {
+                    const float x = n[v * 3], y = n[v * 3 + 1], z = n[v * 3 + 2];
+                    o[v * 3]     = (r.m[0] * x + r.m[4] * y) + r.m[8] * z;
+                    o[v * 3 + 1] = (r.m[1] * x + r.m[5] * y) + r.m[9] * z;
+                    o[v * 3 + 2] = (r.m[2] * x + r.m[6] * y) + r.m[10] * z;
+                }
+            }
+        }
+    }
+    // per-instance bounds: one atomic pair per axis per WAVE when the wave's live lanes share the instance (big meshes), per lane otherwise
+    const int  first = __builtin_amdgcn_readfirstlane(ii);
+    const bool same  = __all(ii == first);
+    if (same)
+    {
+        if (first < 0) return;
+        for (int k = 0; k < 3; k++)
+        {
+            float l = lo[k], h = hi[k];
+            for (int o = 32; o > 0; o >>= 1) { l = fminf(l, __shfl_xor(l, o)); h = fmaxf(h, __shfl_xor(h, o)); }
+            if ((threadIdx.x & 63) == 0 && l <= h) { atomicMin(a.bounds_bits + (size_t)first * 6 + k, ordered_bits(l)); atomicMax(a.bounds_bits + (size_t)first * 6 + 3 + k, ordered_bits(h)); }
+        }
+    }
+    else if (ii >= 0)
+        for (int k = 0; k < 3; k++)
+            if (lo[k] <= hi[k]) { atomicMin(a.bounds_bits + (size_t)ii * 6 + k, ordered_bits(lo[k])); atomicMax(a.bounds_bits + (size_t)ii * 6 + 3 + k, ordered_bits(hi[k])); }
+}
+
+__global__ __launch_bounds__(256) void k_instances_gather(TriGPU* tris, const float* positions, const uint32_t* tri_instance, const uint32_t* dirty, int n_refs)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_refs) return;
+    TriGPU t = tris[r];
+    if (!dirty[tri_instance[t.prim]]) return;
+    const float* p = positions + (size_t)t.prim * 9;
+    t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2];
+    t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5];
+    t.v2[0] = p[6]; t.v2[1] = p[7]; t.v2[2] = p[8];
+    tris[r] = t;
+}
+
+bool finite16(const float* m)
+{
+    for (int i = 0; i < 16; i++)
+        if (!std::isfinite(m[i])) return false;
+    return true;
+}
+
+// conservative world bounds of the instances (the eight corners of every mesh box through its matrix, in double, widened by an ulp-scale
+// margin) — what the box padding and the passes' grids are sized from without reading anything back
+void conservative_bounds(const hr_scene* s, float* lo, float* hi)
+{
+    double l[3] = { 1e300, 1e300, 1e300 }, h[3] = { -1e300, -1e300, -1e300 };
+    for (int i = 0; i < s->n_instances; i++)
+    {
+        const float* m  = s->inst_host[(size_t)i].m;
+        const float* mb = &s->mesh_bounds[(size_t)s->inst_mesh[(size_t)i] * 6];
+        if (!(mb[0] <= mb[3])) continue;   // empty mesh
+        for (int c = 0; c < 8; c++)
+        {
+            const double x = mb[(c & 1) ? 3 : 0], y = mb[(c & 2) ? 4 : 1], z = mb[(c & 4) ? 5 : 2];
+            for (int k = 0; k < 3; k++)
+            {
+                const double v = (double)m[k] * x + (double)m[4 + k] * y + (double)m[8 + k] * z + (double)m[12 + k];
+                const double e = 1e-6 * (std::fabs((double)m[k] * x) + std::fabs((double)m[4 + k] * y) + std::fabs((double)m[8 + k] * z) + std::fabs((double)m[12 + k]));
+                l[k] = std::min(l[k], v - e); h[k] = std::max(h[k], v + e);
+            }
+        }
+    }
+    for (int k = 0; k < 3; k++)
+    {
+        if (!(l[k] <= h[k])) { l[k] = 0.0; h[k] = 0.0; }
+        lo[k] = (float)l[k]; hi[k] = (float)h[k];
+        if ((double)lo[k] > l[k]) lo[k] = std::nextafter(lo[k], -INFINITY);
+        if ((double)hi[k] < h[k]) hi[k] = std::nextafter(hi[k], INFINITY);
+    }
+}
+
+hr_status update_impl(hr_scene* s, const float* matrices, hipStream_t st, bool all_dirty)
+{
+    const int m = s->n_instances;
+    for (int i = 0; i < m; i++)
+    {
+        if (!finite16(matrices + (size_t)i * 16)) { set_last_error("hr_scene_update_instances: model_matrices[" + std::to_string(i) + "] is not finite"); return HR_ERR_INVALID_ARG; }
+    }
+    // which instances moved: their subtrees are refitted, the others stand
+    s->inst_dirty.resize((size_t)m);
+    bool any = false;
+    for (int i = 0; i < m; i++)
+    {
+        const bool d = all_dirty || std::memcmp(s->inst_host[(size_t)i].m, matrices + (size_t)i * 16, 64) != 0;
+        s->inst_dirty[(size_t)i] = d ? 1u : 0u;
+        any = any || d;
+        std::memcpy(s->inst_host[(size_t)i].m, matrices + (size_t)i * 16, 64);
+    }
+    if (!any) return HR_OK;
+    HR_HIP(hipSetDevice(s->ctx->device));
+    // the records are small (80 B per instance); the copies are ordered on `st` and read the scene's own host arrays, which live until the next update
+    HR_HIP(hipMemcpyAsync(s->inst_records.p, s->inst_host.data(), (size_t)m * sizeof(InstanceRec), hipMemcpyHostToDevice, st));
+    HR_HIP(hipMemcpyAsync(s->inst_dirty_dev.p, s->inst_dirty.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    conservative_bounds(s, s->grid_lo, s->grid_hi);
+    {
+        const double dx = (double)s->grid_hi[0] - s->grid_lo[0], dy = (double)s->grid_hi[1] - s->grid_lo[1], dz = (double)s->grid_hi[2] - s->grid_lo[2];
+        float pad = (float)(3e-5 * std::sqrt(dx * dx + dy * dy + dz * dz));   // bvh_build.cpp: well above the fp32 error of the triangle test
+        if (!(pad > 0.0f)) pad = 1e-6f;
+        // subtrees that stand keep the pad they were refitted with; the refitted ones never get a smaller one (250x the fp32 epsilon of the
+        // scene's diagonal: a scene that doubles in size still leaves the standing boxes a margin of two orders of magnitude)
+        if (all_dirty || pad > s->info.box_pad) s->info.box_pad = pad;
+    }
+    const uint32_t* dirty = (const uint32_t*)s->inst_dirty_dev.p;
+    hipLaunchKernelGGL(k_instances_reset_bounds, dim3(cdiv(m, 256)), dim3(256), 0, st, (uint32_t*)s->bounds_bits.p, dirty, m);
+    const int n_tris = s->info.n_tris, n_refs = (int)(s->tris.bytes / sizeof(TriGPU));
+    if (n_tris > 0)
+    {
+        TransformArgs t;
+        t.inst = (const InstanceRec*)s->inst_records.p; t.tri_instance = (const uint32_t*)s->tri_instance.p; t.dirty = dirty;
+        t.mesh_positions = (const float*)s->mesh_positions.p; t.mesh_normals = s->has_normals ? (const float*)s->mesh_normals.p : nullptr;
+        t.positions = (float*)s->positions.p; t.normals = s->has_normals ? (float*)s->tri_normals.p : nullptr;
+        t.bounds_bits = (uint32_t*)s->bounds_bits.p; t.n_tris = n_tris;
+        hipLaunchKernelGGL(k_instances_transform, dim3(cdiv(n_tris, 256)), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(k_instances_gather, dim3(cdiv(n_refs, 256)), dim3(256), 0, st, (TriGPU*)s->tris.p, (const float*)s->positions.p, (const uint32_t*)s->tri_instance.p, dirty, n_refs);
+    }
+    RefitArgs r;
+    r.nodes = (Node8*)s->nodes.p; r.tris = (const TriGPU*)s->tris.p; r.node_box = (float*)s->node_box.p; r.pad = s->info.box_pad;
+    r.cells = (const float*)s->leaf_cells.p; r.node_inst = (const int32_t*)s->node_inst.p; r.inst = (const InstanceRec*)s->inst_records.p; r.dirty = dirty;
+    for (int d = (int)s->level_offsets.size() - 2; d >= 0; d--)
+    {
+        r.list = (const uint32_t*)s->level_nodes.p + s->level_offsets[(size_t)d];
+        r.count = s->level_offsets[(size_t)d + 1] - s->level_offsets[(size_t)d];
+        if (r.count > 0) hipLaunchKernelGGL(k_instances_refit, dim3(cdiv(r.count, 64)), dim3(64), 0, st, r);
+    }
+    HR_HIP(hipGetLastError());
+    s->geometry_epoch++;
+    s->bounds_stale = true;
+    return HR_OK;
+}
+
+hr_status create_impl(hr_ctx* ctx, const hr_instanced_scene_desc* d, hr_scene** out)
+{
+    HR_CHECK_ARG(ctx && d && out && d->n_meshes > 0 && d->meshes && d->n_instances > 0 && d->instances);
+    HR_CHECK_ARG(d->n_materials >= 0 && (d->materials || d->n_materials == 0));
+    const int M = d->n_meshes, I = d->n_instances;
+    bool all_normals = true, any_normals = false, all_mat = true, any_mat = false, all_uv = true, all_tan = true;
+    for (int k = 0; k < M; k++)
+    {
+        const hr_mesh_desc& me = d->meshes[k];
+        HR_CHECK_ARG(me.n_tris >= 0 && (me.positions || me.n_tris == 0));
+        all_normals = all_normals && me.normals; any_normals = any_normals || me.normals;
+        all_mat = all_mat && me.tri_material; any_mat = any_mat || me.tri_material;
+        all_uv = all_uv && me.uvs; all_tan = all_tan && me.tangents;
+        if (me.tri_material)
+        {
+            if (!d->materials) { set_last_error("hr_scene_create_instanced: tri_material given without materials"); return HR_ERR_INVALID_ARG; }
+            for (int i = 0; i < me.n_tris; i++)
+                if (me.tri_material[i] >= (uint32_t)d->n_materials) { set_last_error("hr_scene_create_instanced: a tri_material entry >= n_materials"); return HR_ERR_INVALID_ARG; }
+        }
+    }
+    if (any_normals && !all_normals) { set_last_error("hr_scene_create_instanced: vertex normals on some meshes only"); return HR_ERR_INVALID_ARG; }
+    if (any_mat && !all_mat) { set_last_error("hr_scene_create_instanced: tri_material on some meshes only"); return HR_ERR_INVALID_ARG; }
+    for (int i = 0; i < I; i++)
+    {
+        if (d->instances[i].mesh_idx >= (uint32_t)M) { set_last_error("hr_scene_create_instanced: instances[" + std::to_string(i) + "].mesh_idx >= n_meshes"); return HR_ERR_INVALID_ARG; }
+        if (!finite16(d->instances[i].model_matrix)) { set_last_error("hr_scene_create_instanced: instances[" + std::to_string(i) + "].model_matrix is not finite"); return HR_ERR_INVALID_ARG; }
+    }
+    HR_HIP(hipSetDevice(ctx->device));
+
+    // ---- per-mesh topologies (object space) ------------------------------------------------------------------------------------------
+    std::vector<BuiltBVH> blas((size_t)M);
+    std::vector<std::vector<int>> blas_depth((size_t)M);
+    std::vector<uint32_t> mesh_tri_base((size_t)M + 1, 0u);
+    std::unique_ptr<hr_scene> guard(new hr_scene());
+    hr_scene* s = guard.get();
+    s->ctx = ctx;
+    s->mesh_bounds.assign((size_t)M * 6, 0.0f);
+    for (int k = 0; k < M; k++)
+    {
+        blas[(size_t)k].want_child_boxes = true;
+        build_bvh8(d->meshes[k].positions, d->meshes[k].n_tris, blas[(size_t)k]);
+        blas[(size_t)k].child_boxes.resize(blas[(size_t)k].nodes.size() * 48, 0.0f);
+        const BuiltBVH& b = blas[(size_t)k];
+        mesh_tri_base[(size_t)k + 1] = mesh_tri_base[(size_t)k] + (uint32_t)d->meshes[k].n_tris;
+        for (int a = 0; a < 3; a++) { s->mesh_bounds[(size_t)k * 6 + a] = b.lo[a]; s->mesh_bounds[(size_t)k * 6 + 3 + a] = b.hi[a]; }
+        if (d->meshes[k].n_tris == 0) { s->mesh_bounds[(size_t)k * 6] = 1.0f; s->mesh_bounds[(size_t)k * 6 + 3] = 0.0f; }   // empty: lo > hi
+        // depth of every node (children follow their parent in the builder's breadth-first order)
+        std::vector<int>& dep = blas_depth[(size_t)k];
+        dep.assign(b.nodes.size(), 0);
+        for (size_t j = 0; j < b.nodes.size(); j++)
+            for (int c = 0; c < (b.nodes[j].counts & 15); c++) dep[(size_t)b.nodes[j].child_base + c] = dep[j] + 1;
+    }
+
+    // ---- top level: instances in Morton order of their (initial) world box centres, grouped by eight, level by level --------------------
+    s->n_instances = I;
+    s->inst_mesh.resize((size_t)I);
+    s->inst_host.resize((size_t)I);
+    uint64_t total_tris = 0, total_refs = 0, total_sub_nodes = 0;
+    for (int i = 0; i < I; i++)
+    {
+        const uint32_t k = d->instances[i].mesh_idx;
+        s->inst_mesh[(size_t)i] = k;
+        InstanceRec& r = s->inst_host[(size_t)i];
+        std::memcpy(r.m, d->instances[i].model_matrix, 64);
+        r.first_tri = (uint32_t)total_tris; r.mesh_tri_base = mesh_tri_base[k]; r.mesh_id = d->instances[i].mesh_id; r.n_tris = (uint32_t)d->meshes[k].n_tris;
+        total_tris += (uint64_t)d->meshes[k].n_tris; total_refs += blas[k].tris.size(); total_sub_nodes += blas[k].nodes.size() - 1;
+    }
+    if (total_tris >= (1ull << 31) || total_refs >= (1ull << 26)) { set_last_error("hr_scene_create_instanced: more than 2^26 triangle references"); return HR_ERR_UNSUPPORTED; }
+    conservative_bounds(s, s->grid_lo, s->grid_hi);
+    std::vector<int> order((size_t)I);
+    for (int i = 0; i < I; i++) order[(size_t)i] = i;
+    if (I > 1)
+    {
+        std::vector<uint64_t> code((size_t)I);
+        for (int i = 0; i < I; i++)
+        {
+            const float* m  = s->inst_host[(size_t)i].m;
+            const float* mb = &s->mesh_bounds[(size_t)s->inst_mesh[(size_t)i] * 6];
+            const double c[3] = { 0.5 * ((double)mb[0] + mb[3]), 0.5 * ((double)mb[1] + mb[4]), 0.5 * ((double)mb[2] + mb[5]) };
+            uint64_t key = 0;
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++)
+            {
+                const double w   = (double)m[a] * c[0] + (double)m[4 + a] * c[1] + (double)m[8 + a] * c[2] + (double)m[12 + a];
+                const double ext = (double)s->grid_hi[a] - s->grid_lo[a];
+                double       u   = ext > 0.0 ? (w - s->grid_lo[a]) / ext : 0.0;
+                u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+                q[a] = (uint32_t)(u * 1048575.0);
+            }
+            for (int b = 19; b >= 0; b--)
+                for (int a = 0; a < 3; a++) key = (key << 1) | ((q[a] >> b) & 1u);
+            code[(size_t)i] = key;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return code[(size_t)x] < code[(size_t)y]; });
+    }
+    // level sizes from the bottom (groups of eight instance roots) to a single root
+    std::vector<int> tl_sizes;   // bottom first
+    if (I > 1)
+    {
+        int n = I;
+        do { n = (n + 7) / 8; tl_sizes.push_back(n); } while (n > 1);
+    }
+    const int tl_levels = (int)tl_sizes.size();
+    int n_top = 0;
+    for (int v : tl_sizes) n_top += v;
+    const uint64_t n_nodes64 = (uint64_t)n_top + (uint64_t)I + total_sub_nodes;
+    if (n_nodes64 >= (1ull << 23)) { set_last_error("hr_scene_create_instanced: more than 2^23 BVH nodes"); return HR_ERR_UNSUPPORTED; }
+    const size_t n_nodes = (size_t)n_nodes64;
+    std::vector<Node8>  nodes(n_nodes);
+    std::vector<int>    depth(n_nodes, 0);
+    std::vector<float>   cells(n_nodes * 48, 0.0f);     // object-space cell of every leaf slot
+    std::vector<int32_t> node_inst(n_nodes, -1);
+    std::vector<TriGPU> tris((size_t)total_refs);
+    std::memset(nodes.data(), 0, n_nodes * sizeof(Node8));
+    // top-level nodes, top-down: level L (0 = root) starts at tl_start[L]; its node g has the children [8 g, 8 g + 8) of the level below
+    std::vector<int> tl_start((size_t)tl_levels + 1, 0);
+    for (int L = 0; L < tl_levels; L++) tl_start[(size_t)L + 1] = tl_start[(size_t)L] + tl_sizes[(size_t)(tl_levels - 1 - L)];
+    const int roots_at = n_top;   // the instance roots, in `order`
+    for (int L = 0; L < tl_levels; L++)
+    {
+        const int count = tl_sizes[(size_t)(tl_levels - 1 - L)];
+        const int below = L + 1 < tl_levels ? tl_sizes[(size_t)(tl_levels - 2 - L)] : I;
+        const int below_at = L + 1 < tl_levels ? tl_start[(size_t)L + 1] : roots_at;
+        for (int g = 0; g < count; g++)
+        {
+            Node8& n = nodes[(size_t)tl_start[(size_t)L] + g];
+            const int nk = std::min(8, below - 8 * g);
+            n.ex = n.ey = n.ez = 1;
+            n.counts = (uint8_t)(nk | (nk << 4));
+            n.child_base = (uint32_t)(below_at + 8 * g);
+            n.tri_base = 0;
+            for (int c = 0; c < nk; c++) n.meta[c] = 0x10;   // slot 0's low bits: the axis the children are sorted along (0: the order is Morton, not sorted — only a hint)
+            depth[(size_t)tl_start[(size_t)L] + g] = L;
+        }
+    }
+    // instance subtrees
+    size_t node_at = (size_t)roots_at + (size_t)I, ref_at = 0;
+    int    max_depth = 0;
+    std::vector<uint32_t> tri_instance((size_t)total_tris);
+    for (int oi = 0; oi < I; oi++)
+    {
+        const int       i = order[(size_t)oi];
+        const uint32_t  k = s->inst_mesh[(size_t)i];
+        const BuiltBVH& b = blas[k];
+        const size_t    root = I > 1 ? (size_t)roots_at + (size_t)oi : 0;
+        const size_t    base = node_at;   // mesh node j >= 1 -> base + j - 1
+        for (size_t j = 0; j < b.nodes.size(); j++)
+        {
+            Node8 n = b.nodes[j];
+            if (n.counts & 15) n.child_base = (uint32_t)(base + n.child_base - 1);
+            n.tri_base += (uint32_t)ref_at;
+            const size_t at = j == 0 ? root : base + j - 1;
+            nodes[at] = n;
+            node_inst[at] = i;
+            std::memcpy(&cells[at * 48], &b.child_boxes[j * 48], 48 * sizeof(float));
+            depth[at] = tl_levels + blas_depth[k][j];
+            max_depth = std::max(max_depth, depth[at]);
+        }
+        const InstanceRec& r = s->inst_host[(size_t)i];
+        for (size_t t = 0; t < b.tris.size(); t++)
+        {
+            TriGPU tg = b.tris[t];
+            tg.prim += r.first_tri;
+            tris[ref_at + t] = tg;
+        }
+        for (uint32_t t = 0; t < r.n_tris; t++) tri_instance[(size_t)r.first_tri + t] = (uint32_t)i;
+        node_at += b.nodes.size() - 1; ref_at += b.tris.size();
+    }
+    if (max_depth + 1 >= kMaxTraversalDepth) { set_last_error("hr_scene_create_instanced: BVH depth exceeds the traversal stack"); return HR_ERR_UNSUPPORTED; }
+    // nodes by depth
+    s->level_offsets.assign((size_t)max_depth + 2, 0);
+    for (size_t j = 0; j < n_nodes; j++) s->level_offsets[(size_t)depth[j] + 1]++;
+    for (size_t dd = 0; dd + 1 < s->level_offsets.size(); dd++) s->level_offsets[dd + 1] += s->level_offsets[dd];
+    std::vector<uint32_t> level_nodes(n_nodes);
+    {
+        std::vector<int32_t> cur(s->level_offsets.begin(), s->level_offsets.end() - 1);
+        for (size_t j = 0; j < n_nodes; j++) level_nodes[(size_t)cur[(size_t)depth[j]]++] = (uint32_t)j;
+    }
+
+    // ---- attributes --------------------------------------------------------------------------------------------------------------------
+    const size_t MT = mesh_tri_base[(size_t)M], N = (size_t)total_tris;
+    std::vector<float> mpos(MT * 9), mnor(all_normals ? MT * 9 : 0), muv(all_uv ? MT * 6 : 0), mtan(all_tan ? MT * 9 : 0);
+    std::vector<uint32_t> mmat(all_mat ? MT : 0), gmat(all_mat ? N : 0), gid(N);
+    for (int k = 0; k < M; k++)
+    {
+        const hr_mesh_desc& me = d->meshes[k];
+        const size_t o = mesh_tri_base[(size_t)k], n = (size_t)me.n_tris;
+        if (n == 0) continue;
+        std::memcpy(&mpos[o * 9], me.positions, n * 36);
+        if (all_normals) std::memcpy(&mnor[o * 9], me.normals, n * 36);
+        if (all_uv) std::memcpy(&muv[o * 6], me.uvs, n * 24);
+        if (all_tan) std::memcpy(&mtan[o * 9], me.tangents, n * 36);
+        if (all_mat) std::memcpy(&mmat[o], me.tri_material, n * 4);
+    }
+    for (int i = 0; i < I; i++)
+    {
+        const InstanceRec& r = s->inst_host[(size_t)i];
+        for (uint32_t t = 0; t < r.n_tris; t++)
+        {
+            gid[(size_t)r.first_tri + t] = r.mesh_id;
+            if (all_mat) gmat[(size_t)r.first_tri + t] = mmat[(size_t)r.mesh_tri_base + t];
+        }
+    }
+    hr_status st;
+#define UP(buf, src, nbytes)                                                                     \
+    if ((st = s->buf.alloc(nbytes)) != HR_OK) return st;                                         \
+    if ((nbytes) > 0) { hipError_t e_ = hipMemcpy(s->buf.p, src, nbytes, hipMemcpyHostToDevice); \
+        if (e_ != hipSuccess) { set_last_error(std::string("hipMemcpy H2D failed: ") + hipGetErrorString(e_)); return HR_ERR_HIP; } }
+    UP(nodes, nodes.data(), n_nodes * sizeof(Node8))
+    UP(tris, tris.data(), tris.size() * sizeof(TriGPU))
+    UP(level_nodes, level_nodes.data(), n_nodes * 4)
+    UP(leaf_cells, cells.data(), cells.size() * 4)
+    UP(node_inst, node_inst.data(), n_nodes * 4)
+    UP(tri_instance, tri_instance.data(), N * 4)
+    UP(mesh_positions, mpos.data(), MT * 36)
+    UP(materials, d->materials, d->materials ? (size_t)d->n_materials * 32 : 0)
+    if (all_normals) { UP(mesh_normals, mnor.data(), MT * 36) s->has_normals = true; if ((st = s->tri_normals.alloc(N * 36)) != HR_OK) return st; }
+    if (all_mat) { UP(mesh_material, mmat.data(), MT * 4) UP(tri_material, gmat.data(), N * 4) s->has_material = true; }
+    UP(tri_mesh_id, gid.data(), N * 4)
+    s->has_mesh_id = true;
+    if ((st = s->positions.alloc(N * 36)) != HR_OK) return st;
+    if ((st = s->node_box.alloc(n_nodes * 32)) != HR_OK) return st;
+    if ((st = s->bounds_bits.alloc((size_t)I * 24)) != HR_OK) return st;
+    if ((st = s->inst_dirty_dev.alloc((size_t)I * 4)) != HR_OK) return st;
+    if ((st = s->inst_records.alloc((size_t)I * sizeof(InstanceRec))) != HR_OK) return st;
+    if (d->material_textures && d->materials && d->n_textures > 0 && d->textures)
+    {
+        std::vector<uint32_t> table;
+        std::vector<uint8_t>  texels;
+        for (int i = 0; i < d->n_textures; i++)
+        {
+            const hr_texture& t = d->textures[i];
+            if (!t.rgba8 || t.width <= 0 || t.height <= 0) { set_last_error("hr_scene_create_instanced: empty texture"); return HR_ERR_INVALID_ARG; }
+            table.insert(table.end(), { (uint32_t)(texels.size() / 4), (uint32_t)t.width, (uint32_t)t.height, 0u });
+            texels.insert(texels.end(), t.rgba8, t.rgba8 + (size_t)t.width * t.height * 4);
+        }
+        for (int i = 0; i < d->n_materials * 4; i++)
+            if (d->material_textures[(i / 4) * 6 + (i % 4)] >= d->n_textures) { set_last_error("hr_scene_create_instanced: material texture index out of range"); return HR_ERR_INVALID_ARG; }
+        UP(mat_tex, d->material_textures, (size_t)d->n_materials * 24)
+        UP(tex_table, table.data(), table.size() * 4)
+        UP(tex_data, texels.data(), texels.size())
+        if (all_uv) { UP(mesh_uvs, muv.data(), MT * 24) s->has_uvs = true; }
+        if (all_tan) { UP(mesh_tangents, mtan.data(), MT * 36) s->has_tangents = true; }
+        s->has_textures = true;
+    }
+#undef UP
+    s->n_materials = d->materials ? d->n_materials : 0;
+    { static std::atomic<uint64_t> next_uid { 1ull << 40 }; s->uid = next_uid.fetch_add(1); }   // disjoint from hr_scene_create's counter
+    s->info.n_tris     = (int32_t)N;
+    s->info.n_nodes    = (int32_t)n_nodes;
+    s->info.max_depth  = max_depth;
+    s->info.node_bytes = n_nodes * sizeof(Node8);
+    s->info.tri_bytes  = tris.size() * sizeof(TriGPU);
+    // first update: the instances' own matrices, then wait (creation is synchronous like hr_scene_create)
+    std::vector<float> mats((size_t)I * 16);
+    for (int i = 0; i < I; i++) std::memcpy(&mats[(size_t)i * 16], d->instances[i].model_matrix, 64);
+    if ((st = update_impl(s, mats.data(), nullptr, true)) != HR_OK) return st;
+    HR_HIP(hipStreamSynchronize(nullptr));
+    s->geometry_epoch = 0;
+    hr_scene_info tmp;
+    if ((st = hr_scene_get_info(s, &tmp)) != HR_OK) return st;
+    *out = guard.release();
+    return HR_OK;
+}
+
+} // namespace
+
+// hr_scene_get_info of an instanced scene: the exact bounds of the last update, read back on demand (synchronises the device)
+hr_status hr::instanced_scene_refresh_bounds(const hr_scene* scene)
+{
+    if (!scene->bounds_stale) return HR_OK;
+    hr_scene* s = const_cast<hr_scene*>(scene);
+    HR_HIP(hipSetDevice(s->ctx->device));
+    HR_HIP(hipDeviceSynchronize());
+    std::vector<uint32_t> bits((size_t)s->n_instances * 6);
+    HR_HIP(hipMemcpy(bits.data(), s->bounds_bits.p, bits.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t lo[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, hi[3] = { 0u, 0u, 0u };
+    for (int i = 0; i < s->n_instances; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], bits[(size_t)i * 6 + k]); hi[k] = std::max(hi[k], bits[(size_t)i * 6 + 3 + k]); }
+    for (int k = 0; k < 3; k++)
+    {
+        const bool any = lo[k] <= hi[k] && lo[k] != 0xffffffffu;
+        s->info.bounds_lo[k] = any ? ordered_float(lo[k]) : 0.0f;
+        s->info.bounds_hi[k] = any ? ordered_float(hi[k]) : 0.0f;
+    }
+    s->bounds_stale = false;
+    return HR_OK;
+}
+
+extern "C" {
+
+hr_status hr_scene_create_instanced(hr_ctx* ctx, const hr_instanced_scene_desc* desc, hr_scene** out)
+{
+    try
+    {
+        return create_impl(ctx, desc, out);
+    }
+    catch (const std::bad_alloc&)
+    {
+        set_last_error("hr_scene_create_instanced: host allocation failed");
+        return HR_ERR_OUT_OF_MEMORY;
+    }
+    catch (const std::exception& e)
+    {
+        set_last_error(std::string("hr_scene_create_instanced: ") + e.what());
+        return HR_ERR_UNSUPPORTED;
+    }
+}
+
+hr_status hr_scene_update_instances(hr_scene* scene, const float* model_matrices, void* stream)
+{
+    HR_CHECK_ARG(scene && model_matrices);
+    if (scene->n_instances <= 0) { set_last_error("hr_scene_update_instances: not an instanced scene (hr_scene_create_instanced)"); return HR_ERR_INVALID_ARG; }
+    return update_impl(scene, model_matrices, (hipStream_t)stream, false);
+}
+
+int32_t hr_scene_instance_count(const hr_scene* scene) { return scene ? scene->n_instances : 0; }
+
+} // extern "C"

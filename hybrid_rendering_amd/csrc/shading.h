@@ -310,16 +310,23 @@ struct SceneShading
     const int32_t*  mat_tex;     // [m][6]: albedo, normal, roughness, metallic texture (-1 none), roughness channel, metallic channel
     const uint4*    tex_table;   // per texture: texel offset, width, height
     const uint32_t* tex_data;    // RGBA8 texels
+    // instanced scenes (null otherwise): positions / normals / uvs / tangents / tri_material are then the OBJECT-space per-mesh arrays,
+    // indexed by inst[tri_instance[prim]].mesh_tri_base + (prim - first_tri)
+    const uint32_t*    tri_instance;
+    const InstanceRec* inst;
 };
 // fills the members above from a scene (host)
 static inline void scene_shading_from(const hr_scene* scene, SceneShading& sh)
 {
-    sh.positions    = (const float*)scene->positions.p;
-    sh.normals      = scene->has_normals ? (const float*)scene->tri_normals.p : nullptr;
-    sh.tri_material = scene->has_material ? (const uint32_t*)scene->tri_material.p : nullptr;
+    const bool inst = scene->n_instances > 0;
+    sh.tri_instance = inst ? (const uint32_t*)scene->tri_instance.p : nullptr;
+    sh.inst         = inst ? (const InstanceRec*)scene->inst_records.p : nullptr;
+    sh.positions    = (const float*)(inst ? scene->mesh_positions.p : scene->positions.p);
+    sh.normals      = scene->has_normals ? (const float*)(inst ? scene->mesh_normals.p : scene->tri_normals.p) : nullptr;
+    sh.tri_material = scene->has_material ? (const uint32_t*)(inst ? scene->mesh_material.p : scene->tri_material.p) : nullptr;
     sh.materials    = scene->n_materials ? (const float*)scene->materials.p : nullptr;
-    sh.uvs          = scene->has_uvs ? (const float*)scene->tri_uvs.p : nullptr;
-    sh.tangents     = scene->has_tangents ? (const float*)scene->tri_tangents.p : nullptr;
+    sh.uvs          = scene->has_uvs ? (const float*)(inst ? scene->mesh_uvs.p : scene->tri_uvs.p) : nullptr;
+    sh.tangents     = scene->has_tangents ? (const float*)(inst ? scene->mesh_tangents.p : scene->tri_tangents.p) : nullptr;
     sh.mat_tex      = scene->has_textures ? (const int32_t*)scene->mat_tex.p : nullptr;
     sh.tex_table    = scene->has_textures ? (const uint4*)scene->tex_table.p : nullptr;
     sh.tex_data     = scene->has_textures ? (const uint32_t*)scene->tex_data.p : nullptr;
@@ -355,23 +362,36 @@ HR_DEV void sample_texture(const SceneShading& s, int tex, float u, float v, flo
 // interpolated_vertex + transform_vertex (identity model) + fetch_albedo / fetch_roughness / fetch_metallic / fetch_normal
 // (scene_descriptor_set.glsl:133-220).  Quirk kept: the hit shaders call fetch_normal(material, tangent, TANGENT, normal, uv)
 // (reflections_ray_trace.rchit:134, gi_ray_trace.rchit:112, ground_truth_path_trace.rchit:131): TBN = (T, T, N).
+// mat3(model_matrix) * v and model_matrix * vec4(p, 1), each row summed left to right (transform_vertex, scene_descriptor_set.glsl:150-160)
+HR_DEV f3 inst_mul3(const float* __restrict__ m, f3 v)
+{
+    return mk3((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z, (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+HR_DEV f3 inst_point(const float* __restrict__ m, f3 p)
+{
+    return mk3(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12] * 1.0f, ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13] * 1.0f, ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f);
+}
 HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
 {
     SurfaceHit o;
-    const float* p = s.positions + (size_t)h.prim * 9;
+    // instanced scene: the attributes live per MESH in object space; interpolate there, then transform_vertex with the instance's matrix
+    const InstanceRec* ir = s.tri_instance ? s.inst + s.tri_instance[h.prim] : nullptr;
+    const size_t       q  = ir ? (size_t)ir->mesh_tri_base + ((uint32_t)h.prim - ir->first_tri) : (size_t)h.prim;
+    const float* p = s.positions + q * 9;
     const f3 v0 = mk3(p[0], p[1], p[2]), v1 = mk3(p[3], p[4], p[5]), v2 = mk3(p[6], p[7], p[8]);
     const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
     o.P = add3(add3(scale3(v0, b0), scale3(v1, b1)), scale3(v2, b2));
+    if (ir) o.P = inst_point(ir->m, o.P);
     f3 n;
     if (s.normals)
     {
-        const float* q = s.normals + (size_t)h.prim * 9;
-        n = add3(add3(scale3(mk3(q[0], q[1], q[2]), b0), scale3(mk3(q[3], q[4], q[5]), b1)), scale3(mk3(q[6], q[7], q[8]), b2));
+        const float* qn = s.normals + q * 9;
+        n = add3(add3(scale3(mk3(qn[0], qn[1], qn[2]), b0), scale3(mk3(qn[3], qn[4], qn[5]), b1)), scale3(mk3(qn[6], qn[7], qn[8]), b2));
     }
     else
         n = cross3(sub3(v1, v0), sub3(v2, v0));
-    o.N = normalize3(normalize3(n));
-    const uint32_t mat = s.tri_material ? s.tri_material[h.prim] : 0u;
+    o.N = ir ? normalize3(inst_mul3(ir->m, normalize3(n))) : normalize3(normalize3(n));
+    const uint32_t mat = s.tri_material ? s.tri_material[q] : 0u;
     if (s.materials)
     {
         const float* m = s.materials + (size_t)mat * 8;
@@ -384,9 +404,9 @@ HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
         float tu = 0.0f, tv = 0.0f;
         if (s.uvs)
         {
-            const float* q = s.uvs + (size_t)h.prim * 6;
-            tu = (q[0] * b0 + q[2] * b1) + q[4] * b2;
-            tv = (q[1] * b0 + q[3] * b1) + q[5] * b2;
+            const float* qu = s.uvs + q * 6;
+            tu = (qu[0] * b0 + qu[2] * b1) + qu[4] * b2;
+            tv = (qu[1] * b0 + qu[3] * b1) + qu[5] * b2;
         }
         float c[4];
         if (mt[0] >= 0) { sample_texture(s, mt[0], tu, tv, c); o.albedo = mk3(c[0], c[1], c[2]); }
@@ -397,10 +417,10 @@ HR_DEV SurfaceHit surface_at(const SceneShading& s, const HitRec& h)
             f3 tg = mk3(1.0f, 0.0f, 0.0f);
             if (s.tangents)
             {
-                const float* q = s.tangents + (size_t)h.prim * 9;
-                tg = add3(add3(scale3(mk3(q[0], q[1], q[2]), b0), scale3(mk3(q[3], q[4], q[5]), b1)), scale3(mk3(q[6], q[7], q[8]), b2));
+                const float* qt = s.tangents + q * 9;
+                tg = add3(add3(scale3(mk3(qt[0], qt[1], qt[2]), b0), scale3(mk3(qt[3], qt[4], qt[5]), b1)), scale3(mk3(qt[6], qt[7], qt[8]), b2));
             }
-            tg = normalize3(normalize3(tg));                       // interpolated_vertex, then transform_vertex
+            tg = ir ? normalize3(inst_mul3(ir->m, normalize3(tg))) : normalize3(normalize3(tg));   // interpolated_vertex, then transform_vertex
             const f3 T = normalize3(tg), Nn = normalize3(o.N);     // get_normal_from_map: TBN = (T, T, N)
             sample_texture(s, mt[1], tu, tv, c);
             const f3 tn = normalize3(sub3(scale3(mk3(c[0], c[1], c[2]), 2.0f), one3()));

@@ -47,6 +47,102 @@ class SceneData:
         return v.min(0), v.max(0)
 
 
+@dataclass
+class InstancedSceneData:
+    """A scene as the reference holds it (scene_descriptor_set.glsl:30-34): meshes in OBJECT space + instances {model_matrix, mesh_idx}.
+    meshes: SceneData whose verts / normals / uvs / tangents are object space and whose tri_material indexes `materials` (their
+    tri_mesh_id / materials members are unused).  instances: (matrix16 column-major float32, mesh_idx, mesh_id)."""
+    meshes: list
+    instances: list
+    materials: np.ndarray
+    name: str = "instanced"
+    material_textures: np.ndarray = None
+    textures: list = None
+
+    def matrices(self) -> np.ndarray:
+        return np.ascontiguousarray(np.stack([np.asarray(m, np.float32).reshape(16) for m, _, _ in self.instances]), np.float32)
+
+    def layout(self):
+        """per instance: first_tri, mesh_tri_base, mesh_id, n_tris (uint32 arrays) — instance i's triangles follow instance i - 1's"""
+        base = np.cumsum([0] + [m.n_tris for m in self.meshes]).astype(np.uint32)
+        n = np.array([self.meshes[k].n_tris for _, k, _ in self.instances], np.uint32)
+        first = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.uint32)
+        return first, np.array([base[k] for _, k, _ in self.instances], np.uint32), np.array([i for _, _, i in self.instances], np.uint32), n
+
+    def mesh_arrays(self):
+        cat = lambda xs: None if any(x is None for x in xs) else np.ascontiguousarray(np.concatenate(xs), xs[0].dtype)
+        return dict(positions=cat([np.asarray(m.verts, np.float32) for m in self.meshes]), normals=cat([m.normals for m in self.meshes]),
+                    material=cat([np.asarray(m.tri_material, np.uint32) for m in self.meshes]), uvs=cat([m.uvs for m in self.meshes]),
+                    tangents=cat([m.tangents for m in self.meshes]))
+
+    def flatten(self, matrices=None) -> "SceneData":
+        """World-space SceneData in the pinned arithmetic of transform_vertex (numpy float32, one rounding per operation:
+        ((m0 x + m1 y) + m2 z) + m3) — the arithmetic of csrc/instances.hip k_instances_transform; normals = mat3(model) * n."""
+        mats = self.matrices() if matrices is None else np.asarray(matrices, np.float32).reshape(-1, 16)
+        V, Nn, M, I, U, T = [], [], [], [], [], []
+        for (m0, k, mid), m in zip(self.instances, mats):
+            me = self.meshes[k]
+            p = np.asarray(me.verts, np.float32).reshape(-1, 3)
+            w = np.stack([((m[r] * p[:, 0] + m[4 + r] * p[:, 1]) + m[8 + r] * p[:, 2]) + m[12 + r] * np.float32(1.0) for r in range(3)], 1)
+            V.append(w.reshape(-1, 3, 3).astype(np.float32))
+            q = np.asarray(me.normals, np.float32).reshape(-1, 3)
+            Nn.append(np.stack([(m[r] * q[:, 0] + m[4 + r] * q[:, 1]) + m[8 + r] * q[:, 2] for r in range(3)], 1).reshape(-1, 3, 3).astype(np.float32))
+            M.append(np.asarray(me.tri_material, np.uint32)); I.append(np.full(me.n_tris, mid, np.uint32))
+            U.append(me.uvs); T.append(me.tangents)
+        cat = lambda xs: None if any(x is None for x in xs) else np.ascontiguousarray(np.concatenate(xs))
+        return SceneData(verts=cat(V), normals=cat(Nn), tri_material=cat(M), tri_mesh_id=cat(I), materials=np.asarray(self.materials, np.float32), name=self.name + "_flat",
+                         uvs=cat(U), tangents=cat(T), material_textures=self.material_textures, textures=self.textures)
+
+
+def model_matrix(translate=(0.0, 0.0, 0.0), axis=(0.0, 1.0, 0.0), angle=0.0, scale=1.0) -> np.ndarray:
+    """column-major mat4 = T * R(axis, angle) * S (float32), the shape of Instance::model_matrix"""
+    a = np.asarray(axis, np.float64)
+    a = a / max(np.linalg.norm(a), 1e-30)
+    x, y, z = a
+    c, s_ = math.cos(angle), math.sin(angle)
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                  [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                  [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]])
+    sc = np.broadcast_to(np.asarray(scale, np.float64), (3,))
+    M = np.eye(4)
+    M[:3, :3] = R * sc[None, :]
+    M[:3, 3] = translate
+    return np.ascontiguousarray(M.T.reshape(16), np.float32)   # column-major
+
+
+def instanced_cornell(n_boxes: int = 5, seed: int = 3, frame: int = 0) -> InstancedSceneData:
+    """The Cornell room as ONE mesh (identity instance) + a unit-cube mesh and a small pyramid mesh instanced `n_boxes` times with
+    rotations, non-uniform scales and translations; `frame` moves every second instance (a per-frame TLAS update, main.cpp:74)."""
+    room = _Builder()
+    S = 100.0
+    room.box((0, 0, 0), (S, S, S), 0, faces="yYz", inward=True)
+    room.box((0, 0, 0), (S, S, S), 1, faces="x", inward=True)
+    room.box((0, 0, 0), (S, S, S), 2, faces="X", inward=True)
+    room.quad((35, S - 0.5, 35), (65, S - 0.5, 35), (65, S - 0.5, 65), (35, S - 0.5, 65), 4)
+    mats = cornell32().materials
+    cube = _Builder()
+    cube.box((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), 0, faces="xXyYzZ")
+    pyr = _Builder()
+    apex, b0, b1, b2, b3 = (0, 1, 0), (-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5)
+    pyr.add(np.array([[b0, apex, b1], [b1, apex, b2], [b2, apex, b3], [b3, apex, b0], [b0, b1, b2], [b0, b2, b3]], np.float32), None, 3)
+    meshes = [room.finish(mats, "room"), cube.finish(mats, "cube"), pyr.finish(mats, "pyramid")]
+    return InstancedSceneData(meshes=meshes, instances=instanced_cornell_instances(n_boxes, seed, frame), materials=mats, name="instanced_cornell")
+
+
+def instanced_cornell_instances(n_boxes: int = 5, seed: int = 3, frame: int = 0):
+    rng = np.random.RandomState(seed)
+    inst = [(model_matrix(), 0, 1)]
+    for i in range(n_boxes):
+        pos = np.array([rng.uniform(15, 85), rng.uniform(8, 40), rng.uniform(15, 85)])
+        axis, ang = rng.uniform(-1, 1, 3), rng.uniform(0, 2 * math.pi)
+        sc = rng.uniform(8, 28, 3)
+        if i % 2 == 1:   # the moving ones
+            pos = pos + np.array([1.7, 0.9, -1.3]) * frame
+            ang = ang + 0.11 * frame
+        inst.append((model_matrix(pos, axis, ang, sc), 1 + (i % 2), 2 + i))
+    return inst
+
+
 class _Builder:
     def __init__(self):
         self.v, self.n, self.mat, self.mid = [], [], [], []

@@ -61,6 +61,12 @@ class Scene
 {
 public:
     Scene(Context& ctx, const hr_scene_desc& desc) { check(hr_scene_create(ctx.handle(), &desc, &m_scene), "hr_scene_create"); }
+    // meshes + instances, as the reference's scene holds them (scene_descriptor_set.glsl:30-34); update_instances() every frame an instance
+    // moved replaces main.cpp:74 build_tlas(cmd_buf)
+    Scene(Context& ctx, const hr_instanced_scene_desc& desc) { check(hr_scene_create_instanced(ctx.handle(), &desc, &m_scene), "hr_scene_create_instanced"); }
+    void     update_instances(const float* model_matrices, Stream cmd_buf) { check(hr_scene_update_instances(m_scene, model_matrices, cmd_buf), "hr_scene_update_instances"); }
+    int      instance_count() const { return hr_scene_instance_count(m_scene); }
+    uint64_t id() const { return hr_scene_id(m_scene); }   // dw::Scene::id()
     ~Scene() { hr_scene_destroy(m_scene); }
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;

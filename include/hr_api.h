@@ -180,6 +180,63 @@ hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_inf
  * centroid, then pseudo-random interior points); *uncovered = the (triangle, point) pairs that reach no leaf holding the triangle.
  * 0 for a correct tree: the builder references a triangle from several leaves (spatial splits) and the pieces must cover it. */
 hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t samples_per_triangle, int64_t* uncovered);
+
+/* ---- instanced scenes: dw::RayTracedScene as the reference holds it (scene_descriptor_set.glsl:30-34 Instance { mat4 model_matrix; uint
+ * mesh_idx; }, :102-131 fetch_hit_info / fetch_triangle through instance.mesh_idx, :150-160 transform_vertex) with the per-frame
+ * acceleration-structure update of main.cpp:74 (build_tlas).
+ *
+ * MI355X layout: ONE 8-wide BVH in world space.  Every instance owns a private copy of its mesh's subtree (the topology is built once per
+ * mesh in object space; 288 GB of HBM pay for the copies) under a top level over the instance roots, so every trace kernel keeps the
+ * single-level walk of hr_scene_create — no ray transform at an instance boundary, no second stack.  hr_scene_update_instances moves
+ * instances on the GPU: world-space vertices = model_matrix * (x, y, z, 1) rounded per operation (((m0 x + m1 y) + m2 z) + m3), then
+ * every node box is refitted bottom-up from the triangles (one launch, children before parents by arrival counters), all on `stream`.
+ * A triangle is hit iff the watertight test accepts its world-space vertices, so the answer of a query is the one a flattened
+ * hr_scene_create over the same world-space vertices gives (any-hit: a function of the geometry; closest hit: smallest t, ties to the
+ * smallest triangle index = instance order, then mesh order).  Hit shading interpolates the OBJECT-space vertex attributes and then
+ * applies the instance's matrix: position = model_matrix * p, normal / tangent = normalize(mat3(model_matrix) * normalize(n)) — the
+ * operation order of interpolated_vertex + transform_vertex.  Hit records name the global triangle index: triangles of instance i
+ * follow those of instance i - 1, in mesh order. */
+typedef struct
+{
+    const float*    positions;    /* [n_tris][3][3] OBJECT-space vertex positions                                  */
+    const float*    normals;      /* [n_tris][3][3] or NULL (geometric)                                            */
+    const uint32_t* tri_material; /* [n_tris] or NULL: index into hr_instanced_scene_desc.materials                */
+    const float*    uvs;          /* [n_tris][3][2] or NULL                                                        */
+    const float*    tangents;     /* [n_tris][3][3] or NULL                                                        */
+    int32_t         n_tris;
+} hr_mesh_desc;
+
+typedef struct
+{
+    float    model_matrix[16];    /* column-major mat4, object -> world (Instance::model_matrix)                   */
+    uint32_t mesh_idx;            /* Instance::mesh_idx                                                            */
+    uint32_t mesh_id;             /* the value g_buffer.frag:109 writes to GB3.z for this instance's pixels        */
+} hr_instance;
+
+typedef struct
+{
+    const hr_mesh_desc* meshes;
+    int32_t             n_meshes;
+    const hr_instance*  instances;
+    int32_t             n_instances;
+    const float*        materials;          /* as hr_scene_desc */
+    int32_t             n_materials;
+    const int32_t*      material_textures;  /* as hr_scene_desc (NULL: untextured) */
+    const hr_texture*   textures;
+    int32_t             n_textures;
+} hr_instanced_scene_desc;
+
+/* Builds the per-mesh topologies on the host, lays out one subtree per instance + the top level, uploads, and runs the first update with
+ * the instances' matrices.  Errors as hr_scene_create; HR_ERR_INVALID_ARG also for mesh_idx >= n_meshes or a non-finite matrix. */
+hr_status hr_scene_create_instanced(hr_ctx* ctx, const hr_instanced_scene_desc* desc, hr_scene** out);
+/* model_matrices: HOST [n_instances][16] column-major (copied before the call returns).  Enqueues on `stream`: matrix upload, vertex
+ * transform, bottom-up refit; no host synchronisation.  Passes rendered on the same stream afterwards see the new geometry; per-scene
+ * caches of the passes (AO entry-node table) notice the change.  HR_ERR_INVALID_ARG for a scene from hr_scene_create. */
+hr_status hr_scene_update_instances(hr_scene* scene, const float* model_matrices, void* stream);
+int32_t   hr_scene_instance_count(const hr_scene* scene);   /* 0 for a scene from hr_scene_create */
+/* Introspection (tests, tools): copies the device BVH to the host after synchronising the device — hr_scene_info.node_bytes of 80-byte nodes
+ * and .tri_bytes of 48-byte triangle references (layouts: csrc/bvh.h).  Either pointer may be NULL. */
+hr_status hr_scene_read_bvh(const hr_scene* scene, void* nodes_out, void* tris_out);
 hr_status hr_scene_destroy(hr_scene* scene);
 
 /* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).

@@ -33,6 +33,48 @@ void orc_scene_set_textures(void* scene, const float* uvs, const float* tangents
         s->textures[i].rgba.assign(tex_rgba[i], tex_rgba[i] + (size_t)tex_w[i] * tex_h[i] * 4);
     }
 }
+void orc_instances_flatten(int n_instances, const float* matrices, const uint32_t* first_tri, const uint32_t* mesh_tri_base, const uint32_t* n_tris,
+                           const float* mesh_positions, const float* mesh_normals, float* out_positions, float* out_normals)
+{
+    for (int i = 0; i < n_instances; i++)
+    {
+        const float* m = matrices + (size_t)i * 16;
+        for (uint32_t t = 0; t < n_tris[i]; t++)
+            for (int v = 0; v < 3; v++)
+            {
+                const float* p = mesh_positions + ((size_t)mesh_tri_base[i] + t) * 9 + v * 3;
+                float*       o = out_positions + ((size_t)first_tri[i] + t) * 9 + v * 3;
+                for (int r = 0; r < 3; r++) o[r] = ((m[r] * p[0] + m[4 + r] * p[1]) + m[8 + r] * p[2]) + m[12 + r] * 1.0f;
+                if (mesh_normals && out_normals)
+                {
+                    const float* n = mesh_normals + ((size_t)mesh_tri_base[i] + t) * 9 + v * 3;
+                    float*       q = out_normals + ((size_t)first_tri[i] + t) * 9 + v * 3;
+                    for (int r = 0; r < 3; r++) q[r] = (m[r] * n[0] + m[4 + r] * n[1]) + m[8 + r] * n[2];
+                }
+            }
+    }
+}
+void orc_scene_set_instances(void* scene, int n_instances, const float* matrices, const uint32_t* first_tri, const uint32_t* mesh_tri_base, const uint32_t* mesh_id,
+                             const uint32_t* n_tris, int n_mesh_tris, const float* mesh_positions, const float* mesh_normals, const uint32_t* mesh_material,
+                             const float* mesh_uvs, const float* mesh_tangents)
+{
+    Scene* s = (Scene*)scene;
+    s->instances.resize((size_t)n_instances);
+    s->tri_instance.assign(s->tris.size(), 0u);
+    for (int i = 0; i < n_instances; i++)
+    {
+        Scene::Instance& r = s->instances[(size_t)i];
+        for (int k = 0; k < 16; k++) r.m[k] = matrices[(size_t)i * 16 + k];
+        r.first_tri = first_tri[i]; r.mesh_tri_base = mesh_tri_base[i]; r.mesh_id = mesh_id[i]; r.n_tris = n_tris[i];
+        for (uint32_t t = 0; t < r.n_tris; t++) s->tri_instance[(size_t)r.first_tri + t] = (uint32_t)i;
+    }
+    const size_t n = (size_t)n_mesh_tris;
+    s->mesh_positions.assign(mesh_positions, mesh_positions + n * 9);
+    if (mesh_normals) s->mesh_normals.assign(mesh_normals, mesh_normals + n * 9);
+    if (mesh_material) s->mesh_material.assign(mesh_material, mesh_material + n);
+    if (mesh_uvs) s->mesh_uvs.assign(mesh_uvs, mesh_uvs + n * 6);
+    if (mesh_tangents) s->mesh_tangents.assign(mesh_tangents, mesh_tangents + n * 9);
+}
 void orc_scene_destroy(void* scene) { delete (Scene*)scene; }
 int  orc_scene_num_nodes(const void* scene) { return (int)((const Scene*)scene)->nodes.size(); }
 

@@ -14,6 +14,17 @@ extern "C" {
 void*    orc_scene_create(const float* verts, int n_tris, const float* normals, const uint32_t* tri_material, const uint32_t* tri_mesh_id, const float* materials, int n_materials);
 void     orc_scene_set_textures(void* scene, const float* uvs, const float* tangents, const int32_t* mat_tex, int n_materials, int n_tex,
                                 const uint8_t* const* tex_rgba, const int32_t* tex_w, const int32_t* tex_h);
+// Instanced scenes (scene_descriptor_set.glsl:30-34, :150-160; main.cpp:74 rebuilds the TLAS every frame).
+// orc_instances_flatten: world vertices = model_matrix * vec4(p, 1), rows summed left to right ((m0 x + m1 y) + m2 z) + m3 (transform_vertex :155);
+// world vertex normals (G-buffer synthesis only) = mat3(model_matrix) * n, not normalised.  Instance i's triangles follow instance i - 1's.
+// matrices [I][16] column-major; first_tri / mesh_tri_base / n_tris [I]; mesh_* concatenated per-mesh arrays; out_* [sum n_tris][3][3].
+void     orc_instances_flatten(int n_instances, const float* matrices, const uint32_t* first_tri, const uint32_t* mesh_tri_base, const uint32_t* n_tris,
+                               const float* mesh_positions, const float* mesh_normals, float* out_positions, float* out_normals);
+// after orc_scene_create over the flattened vertices: the hit shading interpolates the object-space attributes, then applies the matrix
+// (interpolated_vertex + transform_vertex).  mesh_normals / mesh_material / mesh_uvs / mesh_tangents nullable.
+void     orc_scene_set_instances(void* scene, int n_instances, const float* matrices, const uint32_t* first_tri, const uint32_t* mesh_tri_base, const uint32_t* mesh_id,
+                                 const uint32_t* n_tris, int n_mesh_tris, const float* mesh_positions, const float* mesh_normals, const uint32_t* mesh_material,
+                                 const float* mesh_uvs, const float* mesh_tangents);
 void     orc_scene_destroy(void* scene);
 int      orc_scene_num_nodes(const void* scene);
 // rays: [n][8] = origin xyz, t_max, dir xyz, t_min.  out: [n] uint8 (1 = occluded).

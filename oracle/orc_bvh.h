@@ -113,6 +113,15 @@ struct Scene
     struct Texture { std::vector<uint8_t> rgba; int w, h; };
     std::vector<Texture>  textures;      // RGBA8 UNORM
 
+    // instanced scenes (scene_descriptor_set.glsl:30-34 Instance, :150-160 transform_vertex): `tris` / `tri_normals` are then the WORLD-space
+    // vertices / mat3(model) * n that orc_instances_flatten produced (intersection, G-buffer synthesis), and the hit shading (orc_shading.h
+    // surface_at) interpolates the OBJECT-space per-mesh attributes below before it applies the instance's matrix
+    struct Instance { float m[16]; uint32_t first_tri, mesh_tri_base, mesh_id, n_tris; };
+    std::vector<Instance> instances;
+    std::vector<uint32_t> tri_instance;                                       // [n] global triangle -> instance
+    std::vector<float>    mesh_positions, mesh_normals, mesh_uvs, mesh_tangents;
+    std::vector<uint32_t> mesh_material;
+
     void build(const float* verts, int n_tris);
     bool any_hit(vec3 o, vec3 d, float t_min, float t_max) const;
     bool any_hit_brute(vec3 o, vec3 d, float t_min, float t_max) const;

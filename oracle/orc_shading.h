@@ -288,22 +288,43 @@ static inline float comp4(vec4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y :
 // (scene_descriptor_set.glsl:133-220).  Quirk kept: every hit shader calls fetch_normal(material, tangent, TANGENT, normal, uv)
 // (reflections_ray_trace.rchit:134, gi_ray_trace.rchit:112, ground_truth_path_trace.rchit:131), so the TBN matrix of a
 // normal-mapped material is (T, T, N).
+// mat3(model_matrix) * v and model_matrix * vec4(p, 1), rows summed left to right (transform_vertex, scene_descriptor_set.glsl:150-160)
+static inline vec3 inst_mul3(const float* m, vec3 v)
+{
+    return v3((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z, (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+static inline vec3 inst_point(const float* m, vec3 p)
+{
+    return v3(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12] * 1.0f, ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13] * 1.0f, ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f);
+}
 static inline SurfaceHit surface_at(const Scene& s, const Hit& h)
 {
     SurfaceHit o;
-    const Tri& t  = s.tris[h.prim];
-    float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-    o.P = (t.v0 * b0 + t.v1 * b1) + t.v2 * b2;
-    vec3 n;
-    if (!s.tri_normals.empty())
+    // instanced scene: interpolate the mesh's object-space attributes, then transform_vertex with the instance's matrix
+    const Scene::Instance* ir = s.tri_instance.empty() ? nullptr : &s.instances[s.tri_instance[(size_t)h.prim]];
+    const size_t q = ir ? (size_t)ir->mesh_tri_base + ((uint32_t)h.prim - ir->first_tri) : (size_t)h.prim;
+    vec3 pv0, pv1, pv2;
+    if (ir)
     {
-        const float* q = &s.tri_normals[(size_t)h.prim * 9];
-        n = (v3(q[0], q[1], q[2]) * b0 + v3(q[3], q[4], q[5]) * b1) + v3(q[6], q[7], q[8]) * b2;
+        const float* p = &s.mesh_positions[q * 9];
+        pv0 = v3(p[0], p[1], p[2]); pv1 = v3(p[3], p[4], p[5]); pv2 = v3(p[6], p[7], p[8]);
+    }
+    else { const Tri& t = s.tris[h.prim]; pv0 = t.v0; pv1 = t.v1; pv2 = t.v2; }
+    float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+    o.P = (pv0 * b0 + pv1 * b1) + pv2 * b2;
+    if (ir) o.P = inst_point(ir->m, o.P);
+    const std::vector<float>& normals = ir ? s.mesh_normals : s.tri_normals;
+    vec3 n;
+    if (!normals.empty())
+    {
+        const float* qn = &normals[q * 9];
+        n = (v3(qn[0], qn[1], qn[2]) * b0 + v3(qn[3], qn[4], qn[5]) * b1) + v3(qn[6], qn[7], qn[8]) * b2;
     }
     else
-        n = cross(t.v1 - t.v0, t.v2 - t.v0);
-    o.N = normalize(normalize(n)); // interpolated_vertex normalises, transform_vertex normalises again
-    uint32_t mat = s.tri_material.empty() ? 0u : s.tri_material[h.prim];
+        n = cross(pv1 - pv0, pv2 - pv0);
+    o.N = ir ? normalize(inst_mul3(ir->m, normalize(n))) : normalize(normalize(n)); // interpolated_vertex normalises, transform_vertex normalises again
+    const std::vector<uint32_t>& tmat = ir ? s.mesh_material : s.tri_material;
+    uint32_t mat = tmat.empty() ? 0u : tmat[q];
     if (!s.materials.empty())
     {
         const float* m = &s.materials[(size_t)mat * 8];
@@ -314,11 +335,12 @@ static inline SurfaceHit surface_at(const Scene& s, const Hit& h)
     {
         const int32_t* mt = &s.mat_tex[(size_t)mat * 6];
         float tu = 0.0f, tv = 0.0f;
-        if (!s.tri_uvs.empty())
+        const std::vector<float>& uvs = ir ? s.mesh_uvs : s.tri_uvs;
+        if (!uvs.empty())
         {
-            const float* q = &s.tri_uvs[(size_t)h.prim * 6];
-            tu = (q[0] * b0 + q[2] * b1) + q[4] * b2;
-            tv = (q[1] * b0 + q[3] * b1) + q[5] * b2;
+            const float* qu = &uvs[q * 6];
+            tu = (qu[0] * b0 + qu[2] * b1) + qu[4] * b2;
+            tv = (qu[1] * b0 + qu[3] * b1) + qu[5] * b2;
         }
         if (mt[0] >= 0) { vec4 c = sample_texture(s.textures[mt[0]], tu, tv); o.albedo = v3(c.x, c.y, c.z); }
         if (mt[2] >= 0) o.roughness = fmax2(comp4(sample_texture(s.textures[mt[2]], tu, tv), mt[4]), 0.1f);
@@ -326,12 +348,13 @@ static inline SurfaceHit surface_at(const Scene& s, const Hit& h)
         if (mt[1] >= 0)
         {
             vec3 tg = v3(1.0f, 0.0f, 0.0f);
-            if (!s.tri_tangents.empty())
+            const std::vector<float>& tans = ir ? s.mesh_tangents : s.tri_tangents;
+            if (!tans.empty())
             {
-                const float* q = &s.tri_tangents[(size_t)h.prim * 9];
-                tg = (v3(q[0], q[1], q[2]) * b0 + v3(q[3], q[4], q[5]) * b1) + v3(q[6], q[7], q[8]) * b2;
+                const float* qt = &tans[q * 9];
+                tg = (v3(qt[0], qt[1], qt[2]) * b0 + v3(qt[3], qt[4], qt[5]) * b1) + v3(qt[6], qt[7], qt[8]) * b2;
             }
-            tg = normalize(normalize(tg));                       // interpolated_vertex, then transform_vertex
+            tg = ir ? normalize(inst_mul3(ir->m, normalize(tg))) : normalize(normalize(tg));   // interpolated_vertex, then transform_vertex
             const vec3 T = normalize(tg), Nn = normalize(o.N);   // get_normal_from_map: TBN = (T, T, N) (quirk above)
             vec4 c  = sample_texture(s.textures[mt[1]], tu, tv);
             vec3 tn = normalize(v3(c.x, c.y, c.z) * 2.0f - v3(1.0f, 1.0f, 1.0f));

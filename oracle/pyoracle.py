@@ -199,6 +199,46 @@ class Scene:
         return dict(gb1=gb1, gb2=gb2, gb3=gb3, depth=depth)
 
 
+class InstancedScene(Scene):
+    """Oracle mirror of an instanced scene (scene_descriptor_set.glsl:30-34, :150-160; main.cpp:74): the BVH2 is built over the WORLD-space
+    vertices orc_instances_flatten produces (model_matrix * vec4(p, 1), rows summed left to right), the hit shading interpolates the
+    object-space attributes and then applies the matrix.  update(matrices) = the per-frame TLAS rebuild: a fresh oracle scene."""
+
+    def __init__(self, isd, matrices=None):
+        self.isd = isd
+        self._arr = isd.mesh_arrays()
+        self._layout = isd.layout()
+        self._build(isd.matrices() if matrices is None else np.ascontiguousarray(np.asarray(matrices, np.float32).reshape(-1, 16)))
+
+    def flatten(self, mats):
+        """(world positions, world normals) [N][3][3] by the oracle's C arithmetic"""
+        first, mbase, mid, n = self._layout
+        N = int(n.sum())
+        pos, nor = np.zeros((N, 3, 3), np.float32), np.zeros((N, 3, 3), np.float32)
+        lib().orc_instances_flatten(C.c_int(len(n)), _p(mats, c_f32p), _p(first, c_u32p), _p(mbase, c_u32p), _p(n, c_u32p), _p(self._arr["positions"], c_f32p),
+                                    _p(self._arr["normals"], c_f32p), _p(pos, c_f32p), _p(nor, c_f32p))
+        return pos, nor
+
+    def _build(self, mats):
+        import dataclasses
+        self.matrices = mats
+        first, mbase, mid, n = self._layout
+        pos, nor = self.flatten(mats)
+        flat = self.isd.flatten(mats)    # numpy restatement: material / mesh-id / texture arrays; its vertices must equal the C ones
+        assert np.array_equal(flat.verts.view(np.uint32), pos.view(np.uint32)) and np.array_equal(flat.normals.view(np.uint32), nor.view(np.uint32)), "numpy and C flatten disagree"
+        Scene.__init__(self, dataclasses.replace(flat, verts=pos, normals=nor))
+        a = self._arr
+        lib().orc_scene_set_instances(self.h, C.c_int(len(n)), _p(mats, c_f32p), _p(first, c_u32p), _p(mbase, c_u32p), _p(mid, c_u32p), _p(n, c_u32p),
+                                      C.c_int(len(a["positions"])), _p(a["positions"], c_f32p), _p(a["normals"], c_f32p), _p(a["material"], c_u32p),
+                                      _p(a["uvs"], c_f32p), _p(a["tangents"], c_f32p))
+
+    def update(self, matrices):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+        self._build(np.ascontiguousarray(np.asarray(matrices, np.float32).reshape(-1, 16)))
+
+
 # ---------------------------------------------------------------------------------- shadows
 
 def shadows_ray_trace(scene: Scene, ubo, depth, gb2, sobol, sr, bias=0.5, num_frames=0):

@@ -440,6 +440,71 @@ class RefScene:
         pipe.set_all("u_TopLevelAS", np.uint64(oscene.h.value))
         pipe.lib.ref_set_any_hit(C.cast(oracle.lib().orc_any_hit_one, C.c_void_p))
         pipe.lib.ref_set_closest_hit(C.cast(oracle.lib().orc_closest_hit_one, C.c_void_p))
+        if hasattr(pipe.lib, "ref_set_instance_map"):
+            pipe.lib.ref_set_instance_map(None, None)     # one instance
+        pipe._keep["scene"] = self
+
+
+class RefInstancedScene:
+    """The reference's scene descriptor set for a synth.InstancedSceneData: Instances.data[i] = { model_matrix, mesh_idx }, one vertex / index /
+    submesh buffer per MESH (object space), one BLAS geometry per mesh triangle — fetch_hit_info / fetch_triangle / transform_vertex
+    (scene_descriptor_set.glsl:102-160) then run as the reference wrote them.  The ray queries are answered by the oracle's BVH over the
+    flattened world-space vertices; the shim maps the hit triangle to (instance, geometry) (refshim/runtime_rt.inc)."""
+
+    def __init__(self, isd, matrices=None):
+        mats = isd.matrices() if matrices is None else np.ascontiguousarray(np.asarray(matrices, np.float32).reshape(-1, 16))
+        self.vertices, self.indices, self.submesh = [], [], []
+        for me in isd.meshes:
+            n = me.n_tris
+            v = np.zeros((n * 3, 5, 4), np.float32)
+            v[:, 0, :3], v[:, 0, 3] = np.asarray(me.verts, np.float32).reshape(-1, 3), 1.0
+            v[:, 2, :3] = np.asarray(me.normals, np.float32).reshape(-1, 3)
+            v[:, 3, 0], v[:, 4, 1] = 1.0, 1.0
+            if me.uvs is not None:
+                v[:, 1, :2] = np.asarray(me.uvs, np.float32).reshape(-1, 2)
+            if me.tangents is not None:
+                v[:, 3, :3] = np.asarray(me.tangents, np.float32).reshape(-1, 3)
+                v[:, 4, :3] = np.asarray(me.tangents, np.float32).reshape(-1, 3)
+            self.vertices.append(np.ascontiguousarray(v))
+            self.indices.append(np.arange(n * 3, dtype=np.uint32))
+            self.submesh.append(np.ascontiguousarray(np.stack([np.arange(n, dtype=np.uint32), np.asarray(me.tri_material, np.uint32)], 1)))
+        mt = np.asarray(isd.materials, np.float32)
+        m = np.zeros((len(mt), 20), np.float32)
+        mi = m.view(np.int32)
+        mi[:, 0:8] = -1
+        m[:, 8:11], m[:, 11] = mt[:, 0:3], 1.0
+        m[:, 12:15] = mt[:, 5:8]
+        m[:, 16], m[:, 17] = mt[:, 4], mt[:, 3]
+        self.textures = []
+        if isd.material_textures is not None:
+            mtx = np.asarray(isd.material_textures, np.int32)
+            mi[:, 0:4] = mtx[:, 0:4]
+            mi[:, 6], mi[:, 7] = mtx[:, 4], mtx[:, 5]
+            self.textures = [pyref.Tex(np.ascontiguousarray(t, np.uint8), "rgba8", linear=True, repeat=True) for t in isd.textures]
+            self.texture_table = np.array([t.ptr for t in self.textures], np.uint64)
+        self.materials = np.ascontiguousarray(m)
+        inst = np.zeros((len(isd.instances), 17), np.float32)
+        inst[:, :16] = mats
+        inst.view(np.uint32)[:, 16] = [k for _, k, _ in isd.instances]
+        self.instances = np.ascontiguousarray(inst)
+        first, _, _, n = isd.layout()
+        self.first_tri = np.ascontiguousarray(first, np.uint32)
+        self.tri_instance = np.ascontiguousarray(np.repeat(np.arange(len(n), dtype=np.uint32), n))
+
+    def bind(self, pipe, oscene):
+        pipe.set_all("Materials.data", np.uint64(self.materials.ctypes.data))
+        pipe.set_all("Instances.data", np.uint64(self.instances.ctypes.data))
+        for k in range(len(self.vertices)):
+            pipe.set_at_all("Vertices", np.uint64(self.vertices[k].ctypes.data), 8 * k)
+            pipe.set_at_all("Indices", np.uint64(self.indices[k].ctypes.data), 8 * k)
+            pipe.set_at_all("SubmeshInfo", np.uint64(self.submesh[k].ctypes.data), 8 * k)
+        if self.textures:
+            pipe.set_all("s_Textures", np.uint64(self.texture_table.ctypes.data))
+        pipe.set_all("u_TopLevelAS", np.uint64(oscene.h.value))
+        pipe.lib.ref_set_any_hit(C.cast(oracle.lib().orc_any_hit_one, C.c_void_p))
+        pipe.lib.ref_set_closest_hit(C.cast(oracle.lib().orc_closest_hit_one, C.c_void_p))
+        if hasattr(pipe.lib, "ref_set_instance_map"):   # ray-tracing pipelines; a ray QUERY (shadows / AO) never asks which instance it hit
+            pipe.lib.ref_set_instance_map(C.c_void_p(self.tri_instance.ctypes.data), C.c_void_p(self.first_tri.ctypes.data))
         pipe._keep["scene"] = self
 
 
