@@ -49,45 +49,9 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-NODE_BYTES, TRI_BYTES = 80, 48
-# stage name of a pass profiler -> EXACT kernel instance (normalised rocprofv3 name: no "void", namespaces or argument list), so that
-# every a-trous step / template instance carries its own counters (a substring match gave steps 1..8 step 1's traffic)
-def kernel_of(pass_, stage, exact):
-    step = {"atrous_0": 1, "atrous_1": 2, "atrous_2": 4, "atrous_3": 8}
-    if pass_ == "shadows":
-        if stage == "ray_trace": return "k_shadows_trace<false>"
-        if stage == "temporal_accumulation": return "k_shadows_temporal" if exact else "kf_shadows_temporal<1>"   # <1>: reprojection from the pass's geometry records
-        if stage == "atrous_01": return "kf_shadows_atrous01<16, true>"
-        if stage in step:
-            if exact: return "k_shadows_atrous<1, true>"       # one instance serves the four iterations in the parity mode
-            return ("kf_shadows_atrous_lds<%d, true>" if step[stage] <= 2 else "kf_shadows_atrous<%d, true>") % step[stage]
-    if pass_ == "ao":
-        if stage == "ray_trace": return "k_ao_trace<false>"
-        if stage == "temporal_accumulation": return "k_ao_temporal<true>" if exact else "kf_ao_temporal<true, 2>"
-        if stage == "blur_xy": return "kf_ao_blur_xy<4, 16>"
-        if stage in ("blur_x", "blur_y"): return "k_ao_blur<4>" if exact else "kf_ao_blur<4>"   # two launches of one instance: the counters average X and Y
-    if pass_ == "ddgi":
-        return {"ray_trace": "k_ddgi_trace<false>", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
-                "sample_probe_grid": "k_ddgi_sample" if exact else "kf_ddgi_sample"}.get(stage)
-    if pass_ == "reflections":
-        if stage == "ray_trace": return "k_refl_trace<false, false>" if exact else "k_refl_trace<false, true>"   # <., FAST>: tolerance-mode irradiance gathers
-        if stage == "temporal_accumulation": return "k_refl_temporal" if exact else "kf_refl_temporal<1>"
-        if stage == "atrous_01": return "kf_refl_atrous01<16, true>"
-        if stage in step: return "k_refl_atrous<1>" if exact else "kf_refl_atrous<%d, true>" % step[stage]
-        if stage == "upsample": return "k_upsample<4>" if exact else "kf_upsample<4>"
-    return None
-
-
-def norm_kernel(name):
-    n = re.sub(r"^void\s+", "", name.strip())
-    n = n.replace("(anonymous namespace)::", "").replace("hr::", "")
-    return n.split("(")[0].strip()
-
-
-N_SIMD = 1024            # 256 CUs x 4 SIMDs
-N_XCD = 8                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-
+import bench_report
+from bench_report import (HBM_PEAK_GBS, NODE_BYTES, TRI_BYTES, LINE_LIMIT, DETAIL_FILE, kernel_of, norm_kernel, load_profile, classify, compact_line,
+                          binding_frac, pass_roofline, kernel_entries)
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -107,85 +71,6 @@ def parse():
     return ap.parse_args()
 
 
-def load_profile(suffix=""):
-    """latest profiles/r*/ directory of this build that holds the counters for this frame size (suffix "" = 1080p, "_4k" = 3840x2160;
-    tools/profile_round.sh): per-kernel PMC traffic, raw SQ counters and rocprofv3's average duration, keyed by the EXACT normalised
-    kernel name.  PMC cannot be sampled from inside this process: the files are committed with the build, and every number taken
-    from them is marked stale when the kernel's live HIP-event time is more than 10 % off the profiled duration.
-      traffic     = 2 * FETCH_SIZE + WRITE_SIZE   FETCH_SIZE tallies every L2 -> fabric read request at 64 B; a streaming read's requests
-                                                  are 128 B (profiles/r3_calib: streams read back exactly 1/2 of their bytes, writes 1/1)
-      traffic_lo  = FETCH_SIZE + WRITE_SIZE       a sparse gather's requests are 64 B (r3_calib: 4 B gathers, one per line, tally 64 B per
-                                                  lane; two lanes on the two halves of a line tally 64 B per pair): BVH-walking kernels lie
-                                                  between the two
-      valu_issue_frac  = 4 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   share of the SIMD cycles a VALU instruction issues in
-      lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)             active lanes per issued VALU instruction
-    (the derived VALUBusy of this rocprofv3 falls back to gfx94x formulas and exceeds 100 %: not used)"""
-    prof = {"dir": None, "traffic": {}, "traffic_lo": {}, "sq": {}, "avg_us": {}, "suffix": suffix}
-    try:
-        pd = os.path.join(ROOT, "profiles")
-        dirs = sorted(d for d in os.listdir(pd) if os.path.exists(os.path.join(pd, d, f"pmc_summary{suffix}.json")))
-        if not dirs:
-            return prof
-        d = os.path.join(pd, dirs[-1])
-        prof["dir"] = "profiles/" + dirs[-1]
-        for k, v in json.load(open(os.path.join(d, f"pmc_summary{suffix}.json"))).items():
-            if "FETCH_SIZE_KB_avg_per_launch" in v and "WRITE_SIZE_KB_avg_per_launch" in v:
-                f_, w_ = v["FETCH_SIZE_KB_avg_per_launch"] * 1024, v["WRITE_SIZE_KB_avg_per_launch"] * 1024
-                prof["traffic"][norm_kernel(k)] = int(2 * f_ + w_)
-                prof["traffic_lo"][norm_kernel(k)] = int(f_ + w_)
-        sq = os.path.join(d, f"sq_counters{suffix}.json")
-        if os.path.exists(sq):
-            prof["sq"] = {norm_kernel(k): v for k, v in json.load(open(sq)).items()}
-        import csv
-        for fn in (f"kernel_stats{suffix}.csv", f"frame_kernel_stats{suffix}.csv"):   # the frame file wins: same command as the counters
-            fp = os.path.join(d, fn)
-            if os.path.exists(fp):
-                for row in csv.DictReader(open(fp)):
-                    prof["avg_us"][norm_kernel(row["Name"])] = float(row["AverageNs"]) / 1e3
-    except Exception as e:
-        prof["error"] = repr(e)[:200]
-    return prof
-
-
-def classify(prof, kernel, ms, alg_bytes, gather=False):
-    """-> dict(frac, traffic, dram_frac, valu_issue_frac, lane_utilisation, valu_frac, bound, ...) for ONE kernel instance (exact name).
-    bound: `valu` if VALU instructions issue in > 70 % of the SIMD cycles, `hbm` if the counter traffic moves at > 50 % of peak, else
-    `latency` (dependent fetches / too little in flight).  valu_frac = issue share x lane utilisation = the part of the VALU roof that does
-    useful work; it is the operative roofline figure of a `valu` kernel (an HBM fraction says little about it)."""
-    out = {"kernel": kernel, "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 and alg_bytes else None}
-    tr, sq, avg = prof["traffic"].get(kernel), prof["sq"].get(kernel), prof["avg_us"].get(kernel)
-    state = None
-    if avg is not None and ms > 0:
-        out["profile_avg_us"] = round(avg, 2)
-        state = "fresh" if abs(ms * 1e3 - avg) <= 0.10 * avg + 3.0 else "stale"   # + 3 us: the HIP-event pair includes the launch gap
-        out["profile_state"] = state
-    if tr is not None:
-        out["traffic"] = tr
-        out["dram_frac"] = round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None
-        if gather:
-            out["traffic_lo"] = prof["traffic_lo"].get(kernel)
-    if sq and sq.get("SQ_INSTS_VALU") and sq.get("GRBM_GUI_ACTIVE"):
-        raw = 4.0 * sq["SQ_INSTS_VALU"] / (N_SIMD * sq["GRBM_GUI_ACTIVE"] / N_XCD)
-        # the 4-cycles-per-wave64-instruction model over-counts kernels with long EXEC-masked stretches (a fully masked VALU instruction
-        # retires faster): raw values of 1.0-1.4 were measured on the trace and probe-update kernels; they mean "saturated"
-        out["valu_issue_frac"] = round(min(raw, 1.0), 3)
-        if raw > 1.0:
-            out["valu_issue_raw"] = round(raw, 3)
-    if sq and sq.get("SQ_ACTIVE_INST_VALU"):
-        out["lane_utilisation"] = round(sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 3)
-    if "valu_issue_frac" in out and "lane_utilisation" in out:
-        out["valu_frac"] = round(out["valu_issue_frac"] * out["lane_utilisation"], 3)
-    if "valu_issue_frac" not in out and tr is None:
-        out["bound"] = None
-    elif out.get("valu_issue_frac", 0.0) > 0.70:
-        out["bound"] = "valu"
-    elif (out.get("dram_frac") or 0.0) > 0.5:
-        out["bound"] = "hbm"
-    else:
-        out["bound"] = "latency"
-    return out
-
-
 # ---- one JSON line, whatever happens (VERDICT r3 #4: first multi-GPU contact must not be able to end without a parseable line) -------------
 PROGRESS = {"stage": "start", "rank": 0, "world": 1}     # where this rank is (the watchdog prints it)
 PARTIAL = {}                                             # rank 0: the line as far as it is known
@@ -194,110 +79,6 @@ _printed = threading.Event()
 
 def stage(name):
     PROGRESS["stage"] = name
-
-
-LINE_LIMIT = 7000        # bytes: the driver keeps an ~8 KB tail of stdout; round 4's 23 KB line was not parsed (BENCH_r04.parsed = null)
-DETAIL_FILE = "bench_detail.json"
-
-
-def _pick(d, keys):
-    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
-
-
-def _short(s_, n=160):
-    return s_ if not isinstance(s_, str) or len(s_) <= n else s_[:n - 1] + "…"
-
-
-_PASS_KEYS = ("ms", "frac", "dram_frac", "valu_frac", "bound")
-
-
-def _pass_summary(entry, roof):
-    """{ms, frac, dram_frac, valu_frac, bound} of one pass from its pass_roofline() aggregate (+ wall-clock ms / Mrays/s when known)"""
-    out = {}
-    if isinstance(entry, dict):
-        if entry.get("ms_per_frame") is not None:
-            out["wall_ms"] = entry["ms_per_frame"]
-        if entry.get("Mrays_per_s") is not None:
-            out["Mrays_per_s"] = entry["Mrays_per_s"]
-    if isinstance(roof, dict):
-        out.update(ms=roof.get("ms"), frac=roof.get("frac"), dram_frac=roof.get("dram_frac"), valu_frac=roof.get("valu_frac"), bound=roof.get("binding"))
-    return {k: v for k, v in out.items() if v is not None}
-
-
-def compact_line(full):
-    """the ONE stdout line: the contract's fields + config + roofline + cpu_baseline + a compact per-pass summary, < LINE_LIMIT bytes.  Everything
-    else (per-kernel blocks, notes, timed-region arrays) lives in bench_detail.json / on stderr.  Pure function of the full record (CPU-tested:
-    tests/test_bench_robustness.py::test_line_is_compact)."""
-    c = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data"))
-    c["vs_baseline"] = full.get("vs_baseline")
-    if "ms_per_step" not in c:
-        c["ms_per_step"] = None
-    cfg = full.get("config") or {}
-    c["config"] = {k: _short(v, 200) for k, v in cfg.items()}
-    for k in ("error", "requested_gpus", "passes_error"):
-        if full.get(k) is not None:
-            c[k] = _short(full[k], 400)
-    c.update(_pick(full, ("timed_repeats", "timed_total_ms", "denoised_frames_per_s", "trace_only_Mrays_per_s")))
-    r = full.get("roofline")
-    if isinstance(r, dict):
-        c["roofline"] = _pick(r, ("kernel", "kernel_name", "bound", "achieved", "peak", "unit", "frac", "traffic", "dram_frac", "valu_issue_frac", "lane_utilisation",
-                                  "valu_frac", "binding_frac", "frac_is_requested_bytes", "frac_full_walk", "algorithmic_bytes", "live_event_us", "profile_avg_us",
-                                  "profile_state", "counters"))
-        c["roofline"].setdefault("traffic", None)
-    st = full.get("stages")
-    if isinstance(st, dict):
-        c["stages"] = {n: _pick(v, _PASS_KEYS) for n, v in st.items() if isinstance(v, dict)}
-    for k in ("exact_mode", "tolerance_mode"):
-        if isinstance(full.get(k), dict):
-            c[k] = _pick(full[k], ("ms_per_step", "value"))
-    ps = full.get("passes")
-    if isinstance(ps, dict):
-        summ = {"1080p": {}, "4k": {}}
-        for n in ("shadows", "ao", "reflections", "ddgi"):
-            if isinstance(ps.get(n), dict):
-                summ["1080p"][n] = _pass_summary(ps[n], ps[n].get("roofline"))
-        h4 = ps.get("hybrid_4k_one_gpu") or {}
-        for n, roof in (h4.get("roofline") or {}).items():
-            summ["4k"][n] = _pass_summary(None, roof)
-        def frame(hb):
-            return {"serial": hb.get("ms_per_frame"), "streams": (hb.get("concurrent_streams") or {}).get("ms_per_frame"), "graph": (hb.get("hip_graph") or {}).get("ms_per_frame"),
-                    "Mrays_per_s": hb.get("Mrays_per_s")} if hb else None
-        summ["hybrid_frame_ms"] = {"1080p": frame(ps.get("hybrid_1080p")), "4k": frame(h4)}
-        if isinstance(ps.get("reflections_full_res"), dict):
-            summ["reflections_full_res"] = _pick(ps["reflections_full_res"], ("ms_per_frame", "Mrays_per_s"))
-        if isinstance(ps.get("hard_tier"), dict):
-            summ["hard_tier"] = _pick(ps["hard_tier"], ("ms_per_frame", "Mrays_per_s", "trace_only_Mrays_per_s", "nodes_per_ray", "tris_per_ray"))
-        summ["keys"] = "per pass: ms = sum of its kernels' HIP-event times, frac = algorithmic bytes / ms / 8 TB/s, dram_frac = counter traffic, valu_frac = issue x lanes, bound = of its longest kernel"
-        c["passes"] = summ
-    h = full.get("hybrid_4k")
-    if isinstance(h, dict):
-        c["hybrid_4k"] = _pick(h, ("n_gpus", "ms_per_frame", "frames_per_s", "Mrays_per_s", "bands", "scaling", "forked_streams"))
-        cm = h.get("comm_us_per_frame")
-        if isinstance(cm, dict):
-            c["hybrid_4k"]["comm_us_per_frame"] = {k: v for k, v in cm.items() if k != "note"}
-    cm = full.get("comm")
-    if isinstance(cm, dict):
-        c["comm"] = {k: _short(v, 300) for k, v in cm.items() if k != "note"}
-    cb = full.get("cpu_baseline")
-    if isinstance(cb, dict):
-        b = _pick(cb, ("value", "unit", "cores", "kind", "error"))
-        if cb.get("sample"):
-            b["sample"] = _short(cb["sample"], 260)
-        for k, keys in (("trace_replay", ("value", "rays_per_batch", "batches", "seconds", "nodes_per_ray_bvh2")),
-                        ("trace_replay_same_tree", ("value", "unit", "cores", "nodes_per_ray", "tris_per_ray", "masks_equal", "error")),
-                        ("denoise_ms", ("temporal", "atrous_x4")), ("whole_frames", ("frames_per_s", "Mrays_per_s")),
-                        ("reference_shaders", ("value", "unit", "cores", "bit_identical_to_port", "error"))):
-            if isinstance(cb.get(k), dict):
-                b[k] = _pick(cb[k], keys)
-        c["cpu_baseline"] = b
-    c["detail"] = DETAIL_FILE
-    # belt and braces: should the line still be too long (a future field, a long error), drop the optional blocks, least important first
-    for k in ("stages", "exact_mode", "tolerance_mode", "passes", "hybrid_4k", "comm"):
-        if len(json.dumps(c)) < LINE_LIMIT:
-            break
-        c.pop(k, None)
-        c["dropped"] = c.get("dropped", []) + [k]
-    return c
 
 
 _LINE_FD = None   # isolate_stdout(): the descriptor the ONE line goes to
@@ -393,34 +174,6 @@ def start_watchdog(args, rank, world):
     t.daemon = True
     t.start()
     return t
-
-
-def binding_frac(entry):
-    """the fraction of the roof that `bound` names (VERDICT r3 #5c: so that `frac` of a VALU-bound kernel is not read as "x % of HBM")"""
-    b = entry.get("bound")
-    if b == "valu":
-        return entry.get("valu_frac")
-    if b == "hbm":
-        return entry.get("dram_frac")
-    c = [v for v in (entry.get("valu_frac"), entry.get("dram_frac")) if v is not None]
-    return max(c) if c else None
-
-
-def pass_roofline(kernels):
-    """aggregate of one pass's kernels (the unit north_star's "each pass at >= 40 % of the HBM roofline" is stated in): algorithmic bytes and time
-    summed over its kernels; `binding` = the bound of the kernel the pass spends most of its time in, `valu_frac` time-weighted"""
-    ks = [k for k in kernels.values() if k.get("ms")]
-    ms = sum(k["ms"] for k in ks)
-    if not ks or ms <= 0:
-        return None
-    b = sum(k.get("alg_bytes") or 0 for k in ks)
-    top = max(ks, key=lambda k: k["ms"])
-    vf = [(k["ms"], k["valu_frac"]) for k in ks if k.get("valu_frac") is not None]
-    df = [(k["ms"], k["dram_frac"]) for k in ks if k.get("dram_frac") is not None]
-    return {"alg_bytes": int(b), "ms": round(ms, 4), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "binding": top.get("bound"),
-            "valu_frac": round(sum(m * v for m, v in vf) / sum(m for m, _ in vf), 3) if vf else None,
-            "dram_frac": round(sum(m * v for m, v in df) / sum(m for m, _ in df), 3) if df else None,
-            "kernels_missing_bytes": [n for n, k in kernels.items() if k.get("ms") and not k.get("alg_bytes")]}
 
 
 def main():
@@ -573,7 +326,7 @@ def run(args, torch, dist, rank, world, local_rank):
         if world > 1:
             dist.barrier()
 
-    def timed_run(tiled, steps, warmup, min_total_s=1.0):
+    def timed_run(tiled, steps, warmup, min_total_s=5.0):
         def step(k):
             fi = cycle[k % len(cycle)]
             fi.num_frames = k
@@ -613,11 +366,11 @@ def run(args, torch, dist, rank, world, local_rank):
                 el = float(t.item())
             return el
         # A region of K steps of a ~0.2 ms frame lasts a few ms: too short for a driver that samples GPU activity every few seconds, and one
-        # host hiccup is a large share of it.  The region is therefore repeated until >= 1 s has been timed in total (round 5; round 4: 50 ms —
-        # the driver's activity sampler still saw an idle GPU in all 3 samples of the 14 s run) — same K steps each, same brackets — and the
+        # host hiccup is a large share of it.  The region is therefore repeated until >= 5 s have been timed in total (round 6; round 5: 1 s —
+        # the driver's activity sampler, five samples over the 22 s run, still saw an idle GPU in every one) — same K steps each, same brackets — and the
         # MEDIAN region is reported (`timed_repeats`, VERDICT r3 #5d); one region if K steps already take that long.
         els = [region(warmup)]
-        n_rep = 1 if min_total_s <= 0 else int(min(500, max(1, math.ceil(min_total_s / max(els[0], 1e-6)))))
+        n_rep = 1 if min_total_s <= 0 else int(min(2500, max(1, math.ceil(min_total_s / max(els[0], 1e-6)))))
         if world > 1:   # every rank repeats the same number of times
             t = torch.tensor([n_rep], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -711,11 +464,7 @@ def run(args, torch, dist, rank, world, local_rank):
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         ex = torch.tensor([tiled.time_exchange(20)], dtype=torch.float64, device="cuda")
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
-        comm_info = {"backend": dist.get_backend(), "ranks_seen": int(seen.item()), "band_bounds": bounds, "history_rows_exchanged": tiled.history_rows,
-                     "exchange_us_per_frame": round(float(ex.item()), 1),
-                     "exchange_bytes_per_boundary": int(tiled.history_rows * W * (4 + 8)),
-                     "note": "one grouped ncclSend/ncclRecv pair per neighbour and frame (feedback image 4 B/px + moments 8 B/px of the 40 rows next to each band boundary), "
-                             "posted after the a-trous chain and waited for before the NEXT frame's temporal kernel; exchange_us_per_frame is its stand-alone cost"}
+        comm_info = bench_report.comm_block(dist.get_backend(), seen.item(), bounds, tiled.history_rows, ex.item(), W)
     dom = max(stages.items(), key=lambda kv: kv[1]["ms"])
     out = {
         "metric": "shadow Mrays/s over the fully denoised frame (1 spp trace + SVGF temporal + 4x a-trous)",
@@ -732,7 +481,7 @@ def run(args, torch, dist, rank, world, local_rank):
                    "nodes_per_ray_full_walk": round(walk_nodes_per_ray, 2), "tris_per_ray_full_walk": round(walk_tris_per_ray, 2)},
         "timed_repeats": timing["timed_repeats"], "timed_region_ms": timing["timed_region_ms"], "timed_total_ms": timing["timed_total_ms"],
         "timing_note": "ms_per_step = MEDIAN over `timed_repeats` timed regions of exactly `steps` steps each (barrier + synchronize on both sides of every region; "
-                       "repeated until >= 1 s is timed in total)",
+                       "repeated until >= 5 s are timed in total)",
         "denoised_frames_per_s": round(args.steps / elapsed, 2),                  # frames of W x H (the whole tiled frame)
         "denoised_1080p_equiv_per_s": round(W * H / (args.width * args.height) * args.steps / elapsed, 2),
         "trace_only_Mrays_per_s": round(rays_per_frame / (stages["ray_trace"]["ms"] * 1e-3) / 1e6, 2) if "ray_trace" in stages else None,
@@ -743,6 +492,8 @@ def run(args, torch, dist, rank, world, local_rank):
                      # a trace kernel's algorithmic bytes are REQUESTED bytes: every lane's 80 B node / 48 B triangle fetch, most of them L1 / L2 hits
                      # (the tree is ~17 MB) — `frac` is SURVEY 8d's figure, not an HBM share; dram_frac is (VERDICT r4 #1b)
                      "frac_is_requested_bytes": dom[0] == "ray_trace",
+                     "frac_kind": "requested_bytes" if dom[0] == "ray_trace" else "hbm_algorithmic",
+                     "l2_frac": (round(dom[1]["bytes"] / (dom[1]["ms"] * 1e-3) / 1e9 / bench_report.L2_PEAK_GBS, 4) if dom[0] == "ray_trace" and dom[1]["ms"] > 0 else None),
                      "frac_full_walk": (round(walk_bytes / (dom[1]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dom[0] == "ray_trace" and dom[1]["ms"] > 0 else None),
                      "binding_note": "fraction of the roof NAMED IN `bound`: valu -> valu_frac (issue share x lane utilisation), hbm -> dram_frac "
                                      "(counter traffic / time / 8 TB/s), latency -> the larger of the two; `frac` (contract) stays algorithmic bytes / time / 8 TB/s",
@@ -885,34 +636,6 @@ def passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact):
                    "event time is > 10 % off the profiled duration; the ray-trace kernels' algorithmic bytes come from their instrumented builds (hr_*_trace_stats: "
                    "node steps x 80 B + triangle tests x 48 B + the per-pixel inputs / outputs); `binding_frac` = the fraction of the roof named in `bound`")
     return res
-
-
-def kernel_entries(prof, pass_, stage_times, exact, trace=None):
-    """{stage: {ms, kernel, alg_bytes, frac, traffic, dram_frac, valu_issue_frac, lane_utilisation, valu_frac, bound, binding_frac, profile_state}} for one
-    pass.  trace: HybridFrame.trace_bytes()[pass] — the ray-trace kernel's algorithmic bytes from its instrumented build (nodes x 80 B + triangles x 48 B)"""
-    out = {}
-    for s, (ms, b) in stage_times.items():
-        k = kernel_of(pass_, s, exact)
-        e = {"ms": round(ms, 4)}
-        if s == "ray_trace":
-            b = trace["bytes"] if trace else 0
-            if trace:
-                e.update(rays=trace["rays"], nodes_per_ray=trace["nodes_per_ray"], tris_per_ray=trace["tris_per_ray"])
-        if b:
-            e["alg_bytes"] = int(b)
-        if k:
-            c = classify(prof, k, ms, b, gather=(s == "ray_trace"))
-            e.update({kk: vv for kk, vv in c.items() if vv is not None})
-            bf = binding_frac(c)
-            if bf is not None:
-                e["binding_frac"] = bf
-            if (e.get("frac") or 0) > 1.0:
-                e["frac_note"] = ("> 1: SURVEY 8d counts every lane's BVH node / triangle fetch (80 / 48 B each); they are L1 / L2 hits (the BVH is ~17 MB), "
-                                  "not HBM traffic — the kernel is VALU-bound: read binding_frac / dram_frac")
-        elif b and ms > 0:
-            e["frac"] = round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        out[s] = e
-    return out
 
 
 def hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact):

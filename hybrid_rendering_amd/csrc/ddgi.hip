@@ -511,6 +511,7 @@ hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, h
     HR_CHECK_ARG(ctx && out && grid && full_width > 0 && full_height > 0 && (int)scale >= 0 && (int)scale <= 2);
     const DDGIU& g = *grid;
     HR_CHECK_ARG(g.probe_counts[0] > 0 && g.probe_counts[1] > 0 && g.probe_counts[2] > 0 && g.rays_per_probe > 0);
+    HR_CHECK_ARG(g.probe_counts[0] <= 1024 && g.probe_counts[1] <= 1024 && g.probe_counts[2] <= 1024);   // a grid cell travels as 3 x 10 bits (shading.h sample_irradiance_net_coop)
     HR_CHECK_ARG(g.irradiance_probe_side_length >= 2 && g.irradiance_probe_side_length <= 16 && g.depth_probe_side_length >= 2 && g.depth_probe_side_length <= 16);
     // atlas sizing of ddgi.cpp:197-201
     HR_CHECK_ARG(g.irradiance_texture_width == (g.irradiance_probe_side_length + 2) * g.probe_counts[0] * g.probe_counts[1] + 2);

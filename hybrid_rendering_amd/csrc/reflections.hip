@@ -12,7 +12,6 @@
 #include "upsample.h"
 #include "pass_args.h"
 #include "tile_order.h"
-#include "ddgi_sample_fast.h"
 
 using namespace hr;
 
@@ -107,15 +106,16 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 #ifndef REFL_TRACE_EU
 #define REFL_TRACE_EU 1   // minimum waves per SIMD the register allocator must leave room for: 1 / 6 / 7 -> 216 / 226 / 235 us
 #endif
-// STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false, .>.
-// FAST: the DDGI irradiance gathers of the hit shading and of the rough pixels through ddgi_sample_fast.h instead of shading.h's
-// correctly rounded restatement (a third of this kernel: 339 k rough pixels + 350 k hit points of the 1080p bench frame; 149 vs 185 us
-// at 1080p, 382 vs 488 us at 4K).  NOT what ships (round 6): the fast gather leaves ~0.02 % of the trace image's colours one fp16 ulp
-// off, and one frame later `m2 - m1^2` of the stored luminance moments turns that into 0.4-100 % of a small variance, which normalises
-// the a-trous luminance weights (docs/EXPERIMENTS.md R5.8, R6.1): six fuzzed sequences missed the 99.9 % population bound because of
-// it, none does with the parity gather.  Both modes therefore launch <., false>: the trace image is bit-exact in tolerance mode too.
-// The template parameter stays for the developer A/B switch HR_REFL_FAST_SHADING=1.
-template <bool STATS, bool FAST>
+// STATS: the instrumented build behind hr_reflections_trace_stats (see k_ddgi_trace); the product launches <false>.
+// The DDGI irradiance gathers (rough pixels: reflections_ray_trace.rgen:152 approximate_with_ddgi; hit points: .rchit:87-111 indirect_lighting)
+// run the PARITY arithmetic in both modes (round 6).  Round 4-5's tolerance mode sent them through ddgi_sample_fast.h (149 vs 185 us at
+// 1080p): ~0.02 % of the trace image's colours then sat one fp16 ulp off, and one frame later `m2 - m1^2` of the stored luminance
+// moments turned that into 0.4-100 % of a small variance, which normalises the a-trous luminance weights — six fuzzed sequences missed
+// the 99.9 % population bound because of it (docs/EXPERIMENTS.md R5.8, R6.1), none does with the parity gather.  What takes the edge off
+// its cost: a lane is a rough pixel or has a hit point, never both, so ONE gather site per wave serves both kinds (the rolled eight-probe
+// loop runs once per wave instead of once at each of two sites: 185 -> 172 us at 1080p, 488 -> 466 us at 4K; the fast gather was 149 / 382).
+// The trace image is bit-exact in tolerance mode too.
+template <bool STATS>
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)
 {
     __shared__ uint32_t s_stack[REFL_TRACE_WAVES][HR_STACK_ENTRIES * 64];
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
     bool  geom = false, trace = false;
     f3    color = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 1.0f), ray_origin = mk3(0.0f, 0.0f, 0.0f);
     float ray_length = -1.0f;
+    // the lane's DDGI gather, if any (kind 1: rough pixel, 2: hit point) and what its result is combined with
+    int gather = 0;
+    f3  gP = mk3(0.0f, 0.0f, 0.0f), gN = mk3(0.0f, 0.0f, 1.0f), gWo = mk3(0.0f, 0.0f, 1.0f);
+    f3  hLo = mk3(0.0f, 0.0f, 0.0f), hkD = hLo, hcd = hLo, hspec = hLo;
     if (x < a.w && y >= a.y0 && y < a.y1)
     {
         const float  dp = a.depth[o];
@@ -152,8 +156,7 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
             if (roughness < 0.05f) { dir = reflect3(neg3(Wo), N); trace = true; }
             else if (roughness > 0.75f && a.approximate_with_ddgi == 1)
             {
-                const f3 R = reflect3(neg3(Wo), N);
-                color      = scale3(FAST ? ddgi_fast::sample_irradiance<false>(a.d, P, R, Wo, a.irr, a.dep) : sample_irradiance(a.d, P, R, Wo, a.irr, a.dep), a.rough_ddgi_intensity);
+                gather = 1; gP = P; gN = reflect3(neg3(Wo), N); gWo = Wo;
             }
             else
             {
@@ -194,24 +197,33 @@ __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_t
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
             HR_DIV(tc.dv = &dvs;)
             CubeMap  none { nullptr, 0 };
-            f3 Lo = direct_lighting<STATS>(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
+            hLo = direct_lighting<STATS>(tc, a.light, hWo, s.N, s.P, F0, c_diffuse, s.roughness, one3(), false, 0.0f, 0.0f, none, rays);
             if (STATS) { st_n += tc.nn; st_t += tc.nt; }
             if (a.sample_gi == 1)
             {
                 const f3    R   = reflect3(neg3(hWo), s.N);
                 const float ndv = max2(dot3(s.N, hWo), 0.0f);
                 const f3    F   = fresnel_schlick_roughness(ndv, F0, s.roughness);
-                const f3    kD  = scale3(sub3(one3(), F), 1.0f - s.metallic);
+                hkD             = scale3(sub3(one3(), F), 1.0f - s.metallic);
                 const f3    pre = a.env.prefiltered_fetch(R, s.roughness * 4.0f);
                 float bx, by;
                 a.env.lut_fetch(ndv, s.roughness, bx, by);
-                const f3 specular = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), a.ibl_intensity);
-                const f3 diffuse  = mul3(scale3(c_diffuse, a.gi_intensity),
-                                         FAST ? ddgi_fast::sample_irradiance<false>(a.d, s.P, s.N, hWo, a.irr, a.dep) : sample_irradiance(a.d, s.P, s.N, hWo, a.irr, a.dep));
-                Lo = add3(Lo, add3(mul3(kD, diffuse), specular));
+                hspec = scale3(mul3(pre, add3(scale3(F, bx), mk3(by, by, by))), a.ibl_intensity);
+                hcd   = c_diffuse;
+                gather = 2; gP = s.P; gN = s.N; gWo = hWo;
             }
-            color      = Lo;
+            color      = hLo;
             ray_length = 0.001f + hit.t;
+        }
+    }
+    // ONE parity gather for the rough pixels and the hit points of the tile (shading.h; the traversal stack is idle here — the cooperative A/B form borrows it)
+    {
+        const f3 net = sample_irradiance_net_coop(gather != 0, a.d, gP, gN, gWo, a.irr, a.dep, reinterpret_cast<float*>(s_stack[wave]), lane);
+        if (gather == 1) color = scale3(irradiance_from_net(a.d, net), a.rough_ddgi_intensity);
+        else if (gather == 2)
+        {
+            const f3 diffuse = mul3(scale3(hcd, a.gi_intensity), irradiance_from_net(a.d, net));
+            color = add3(hLo, add3(mul3(hkD, diffuse), hspec));
         }
     }
     if (geom) a.out[o] = make_uint2(pack_h2(min2(color.x, 0.7f), min2(color.y, 0.7f)), pack_h2(min2(color.z, 0.7f), ray_length));
@@ -451,7 +463,6 @@ struct hr_reflections
     // when the caller hands back as in->prev the images it passed as in->cur (the reference's ping-pong, g_buffer.cpp:208-211) — so does
     // the next frame's reprojection (see hr_shadows).
     bool          geo_history = true;   // developer A/B switch HR_GEO_HISTORY=0 (read once at create)
-    bool          fast_shading = false; // developer A/B switch HR_REFL_FAST_SHADING=1 (read once at create): k_refl_trace<., FAST> in tolerance mode
     bool          geo_valid = false;
     bool          dbg_require_geo = false;   // HR_DEBUG_REQUIRE_GEO (tests)
     int           geo_parity = 0;
@@ -482,7 +493,6 @@ hr_status hr_reflections_create(hr_ctx* ctx, int32_t full_width, int32_t full_he
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_GEO_HISTORY")) p->geo_history = atoi(e) != 0;
     if (const char* e = getenv("HR_DEBUG_REQUIRE_GEO")) p->dbg_require_geo = atoi(e) != 0;   // test switch, see hr_shadows
-    if (const char* e = getenv("HR_REFL_FAST_SHADING")) p->fast_shading = atoi(e) != 0;
     if (const char* e = getenv("HR_TILE_ORDER")) p->tile_order.enabled = atoi(e) != 0;
     p->tile_order.tag = "reflections";
     p->w = full_width >> (int)scale; p->h = full_height >> (int)scale; p->y0 = 0; p->y1 = p->h;
@@ -593,13 +603,12 @@ hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, con
         // instrumented build of the same kernel (hr_reflections_trace_stats): counters + 8 .. 32
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 8, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 8);
-        hipLaunchKernelGGL((k_refl_trace<true, false>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+        hipLaunchKernelGGL((k_refl_trace<true>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, px * 28);
-    if (prm->exact || !p->fast_shading) hipLaunchKernelGGL((k_refl_trace<false, false>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
-    else hipLaunchKernelGGL((k_refl_trace<false, true>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
+    hipLaunchKernelGGL((k_refl_trace<false>), dim3(cdiv(a.tiles_x * a.tiles_y, REFL_TRACE_WAVES)), dim3(64 * REFL_TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     if (a.cost)

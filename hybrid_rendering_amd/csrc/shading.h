@@ -180,17 +180,27 @@ HR_DEV f3 probe_location(const DDGIU& d, int index)
 // (col, row) = the probe's cell in the atlas = (probe_index % per_row, probe_index / per_row) with per_row = (tw - 2) / (side + 2)
 // (gi_common.glsl:164-184).  The atlas is probe_counts.x * probe_counts.y cells wide by construction (ddgi.cpp:197-201, checked in
 // hr_ddgi_create), so for probe (cx, cy, cz) the cell is (cx + cy * nx, cz): the same integers without two per-lane divisions.
-HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, int tw, int th, int side, float& u, float& v)
+// ... in two halves: the offset of the direction inside a probe's cell (the same for every probe) and the cell's corner
+HR_DEV void texture_coord_in_cell(f3 dir, int tw, int th, int side, float& cx, float& cy)
 {
     float ox, oy;
     gi_oct_encode(normalize3(dir), ox, oy);
     const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;
+    cx = __fdiv_rn(zx * (float)side, (float)tw); cy = __fdiv_rn(zy * (float)side, (float)th);
+}
+HR_DEV void texture_coord_of_cell(float cx, float cy, int col, int row, int tw, int th, int side, float& u, float& v)
+{
     const float pwb = (float)side + 2.0f;
-    const float cx = __fdiv_rn(zx * (float)side, (float)tw), cy = __fdiv_rn(zy * (float)side, (float)th);
     const float tlx = (float)col * pwb + 2.0f;
     const float tly = (float)row * pwb + 2.0f;
     u = __fdiv_rn(tlx, (float)tw) + cx;
     v = __fdiv_rn(tly, (float)th) + cy;
+}
+HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, int tw, int th, int side, float& u, float& v)
+{
+    float cx, cy;
+    texture_coord_in_cell(dir, tw, th, side, cx, cy);
+    texture_coord_of_cell(cx, cy, col, row, tw, th, side, u, v);
 }
 HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
 {
@@ -229,72 +239,175 @@ HR_DEV void atlas_bilinear_rg(const AtlasRG& a, float u, float v, float& r0, flo
     r1 = mix1(mix1(h2f_hi(t00), h2f_hi(t10), fx), mix1(h2f_hi(t01), h2f_hi(t11), fx), fy);
 }
 
-// gi_common.glsl:188-316: the weighted sqrt-space mean `net` (NaN components replaced by 0.5), before the squaring and scaling of :317-320
-HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+// gi_common.glsl:188-316: the weighted sqrt-space mean `net` (NaN components replaced by 0.5), before the squaring and scaling of :317-320 —
+// split into the part that places the shading point in the grid (:190-203) and the body of the eight-probe loop (:207-296), so that the
+// loop can run per lane (sample_irradiance_net) or one probe per lane (sample_irradiance_net_coop) on the very same operations.
+struct IrrCell { int bx, by, bz; f3 alpha; float icx, icy; };   // + the offset of N's texel inside a probe's irradiance cell (the same for all eight probes)
+HR_DEV IrrCell irradiance_cell(const DDGIU& d, f3 P, f3 N)
 {
     const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]);
     const f3 g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
-    const int bx = clampi((int)__fdiv_rn(P.x - g0.x, gs.x), 0, d.probe_counts[0] - 1);
-    const int by = clampi((int)__fdiv_rn(P.y - g0.y, gs.y), 0, d.probe_counts[1] - 1);
-    const int bz = clampi((int)__fdiv_rn(P.z - g0.z, gs.z), 0, d.probe_counts[2] - 1);
-    const f3  base_pos = grid_coord_to_position(d, bx, by, bz);
-    f3    sum_irr = mk3(0.0f, 0.0f, 0.0f);
-    float sum_w   = 0.0f;
-    const f3 alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
-                         clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
-    // deliberately NOT unrolled: fully unrolled the eight probes' fetches overlap, but the kernels that inline this need
-    // 168-178 VGPRs (2-3 waves per SIMD) — DDGI trace 0.43 -> 0.69 ms, reflections trace 0.31 -> 0.47 ms, sample pass unchanged
-    for (int i = 0; i < 8; ++i)
+    IrrCell c;
+    c.bx = clampi((int)__fdiv_rn(P.x - g0.x, gs.x), 0, d.probe_counts[0] - 1);
+    c.by = clampi((int)__fdiv_rn(P.y - g0.y, gs.y), 0, d.probe_counts[1] - 1);
+    c.bz = clampi((int)__fdiv_rn(P.z - g0.z, gs.z), 0, d.probe_counts[2] - 1);
+    const f3 base_pos = grid_coord_to_position(d, c.bx, c.by, c.bz);
+    c.alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
+                  clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
+    texture_coord_in_cell(normalize3(N), d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, c.icx, c.icy);
+    return c;
+}
+struct IrrTerm { f3 s; float w; };   // sqrt(probe irradiance) * weight, weight
+HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth, const IrrCell& c, const int i)
+{
+    const int bx = c.bx, by = c.by, bz = c.bz;
+    const f3  alpha = c.alpha;
+    const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
+    const int cx = clampi(bx + ox, 0, d.probe_counts[0] - 1), cy = clampi(by + oy, 0, d.probe_counts[1] - 1), cz = clampi(bz + oz, 0, d.probe_counts[2] - 1);
+    const int col = cx + cy * d.probe_counts[0];   // probe cx + cy * nx + cz * nx * ny sits in atlas cell (col, cz)
+    const f3 probe_pos      = grid_coord_to_position(d, cx, cy, cz);
+    const f3 probe_to_point = add3(sub3(P, probe_pos), scale3(add3(N, scale3(Wo, 3.0f)), d.normal_bias));
+    const f3 dir            = normalize3(neg3(probe_to_point));
+    const f3 tri = mk3(mix1(1.0f - alpha.x, alpha.x, (float)ox), mix1(1.0f - alpha.y, alpha.y, (float)oy), mix1(1.0f - alpha.z, alpha.z, (float)oz));
+    float weight = 1.0f;
     {
-        const int ox = i & 1, oy = (i >> 1) & 1, oz = (i >> 2) & 1;
-        const int cx = clampi(bx + ox, 0, d.probe_counts[0] - 1), cy = clampi(by + oy, 0, d.probe_counts[1] - 1), cz = clampi(bz + oz, 0, d.probe_counts[2] - 1);
-        const int col = cx + cy * d.probe_counts[0];   // probe cx + cy * nx + cz * nx * ny sits in atlas cell (col, cz)
-        const f3 probe_pos      = grid_coord_to_position(d, cx, cy, cz);
-        const f3 probe_to_point = add3(sub3(P, probe_pos), scale3(add3(N, scale3(Wo, 3.0f)), d.normal_bias));
-        const f3 dir            = normalize3(neg3(probe_to_point));
-        const f3 tri = mk3(mix1(1.0f - alpha.x, alpha.x, (float)ox), mix1(1.0f - alpha.y, alpha.y, (float)oy), mix1(1.0f - alpha.z, alpha.z, (float)oz));
-        float weight = 1.0f;
-        {
-            const f3    tdp = normalize3(sub3(probe_pos, P));
-            const float t   = max2(0.0001f, (dot3(tdp, N) + 1.0f) * 0.5f);
-            weight          = weight * (t * t + 0.2f);
-        }
-        if (d.visibility_test == 1)
-        {
-            float u, v, mean, m2;
-            texture_coord_from_cell(neg3(dir), col, cz, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
-            const float dist = len3(probe_to_point);
-            atlas_bilinear_rg(depth, u, v, mean, m2);
-            const float variance = fabsf(mean * mean - m2);
-            const float dm  = max2(dist - mean, 0.0f);
-            float che = __fdiv_rn(variance, variance + dm * dm);
-            che       = max2(che * che * che, 0.0f);
-            weight    = weight * ((dist <= mean) ? 1.0f : che);
-        }
-        weight = max2(0.000001f, weight);
-        float u, v;
-        texture_coord_from_cell(normalize3(N), col, cz, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
-        f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
-        const float crush = 0.2f;
-        if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
-        weight    = weight * (tri.x * tri.y * tri.z);
-        probe_irr = mk3(hr_sqrt(probe_irr.x), hr_sqrt(probe_irr.y), hr_sqrt(probe_irr.z)); // sqrt-space blending (LINEAR_BLENDING undefined)
-        sum_irr   = add3(sum_irr, scale3(probe_irr, weight));
-        sum_w += weight;
+        const f3    tdp = normalize3(sub3(probe_pos, P));
+        const float t   = max2(0.0001f, (dot3(tdp, N) + 1.0f) * 0.5f);
+        weight          = weight * (t * t + 0.2f);
     }
+    if (d.visibility_test == 1)
+    {
+        float u, v, mean, m2;
+        texture_coord_from_cell(neg3(dir), col, cz, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
+        const float dist = len3(probe_to_point);
+        atlas_bilinear_rg(depth, u, v, mean, m2);
+        const float variance = fabsf(mean * mean - m2);
+        const float dm  = max2(dist - mean, 0.0f);
+        float che = __fdiv_rn(variance, variance + dm * dm);
+        che       = max2(che * che * che, 0.0f);
+        weight    = weight * ((dist <= mean) ? 1.0f : che);
+    }
+    weight = max2(0.000001f, weight);
+    float u, v;
+    texture_coord_of_cell(c.icx, c.icy, col, cz, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
+    f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
+    const float crush = 0.2f;
+    if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
+    weight    = weight * (tri.x * tri.y * tri.z);
+    probe_irr = mk3(hr_sqrt(probe_irr.x), hr_sqrt(probe_irr.y), hr_sqrt(probe_irr.z)); // sqrt-space blending (LINEAR_BLENDING undefined)
+    IrrTerm t;
+    t.s = scale3(probe_irr, weight);
+    t.w = weight;
+    return t;
+}
+HR_DEV f3 irradiance_net_from_sums(f3 sum_irr, float sum_w)
+{
     f3 net = div3s(sum_irr, sum_w);
     net.x = (net.x != net.x) ? 0.5f : net.x;
     net.y = (net.y != net.y) ? 0.5f : net.y;
     net.z = (net.z != net.z) ? 0.5f : net.z;
     return net;
 }
-// gi_common.glsl:188-320
-HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
 {
-    f3 net = sample_irradiance_net(d, P, N, Wo, irradiance, depth);
+    const IrrCell c = irradiance_cell(d, P, N);
+    f3    sum_irr = mk3(0.0f, 0.0f, 0.0f);
+    float sum_w   = 0.0f;
+    // deliberately NOT unrolled: fully unrolled the eight probes' fetches overlap, but the kernels that inline this need
+    // 168-178 VGPRs (2-3 waves per SIMD) — DDGI trace 0.43 -> 0.69 ms, reflections trace 0.31 -> 0.47 ms, sample pass unchanged
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i)
+    {
+        const IrrTerm t = irradiance_probe_term(d, P, N, Wo, irradiance, depth, c, i);
+        sum_irr = add3(sum_irr, t.s);
+        sum_w += t.w;
+    }
+    return irradiance_net_from_sums(sum_irr, sum_w);
+}
+// The same gather as ONE call per wave (round 6): every lane of the wave calls, `want` says which lanes have a shading point.  With
+// HR_IRR_COOP_MAX = 0 (shipping) those lanes run the per-lane loop above.  The WAVE-COOPERATIVE form behind it (developer A/B,
+// -DHR_IRR_COOP_MAX=k) computes the eight probe terms of a point on eight lanes at once — a wave with k points takes ceil(k / 8) turns
+// instead of eight; every term is the value irradiance_probe_term computes for that point and probe and the owner adds them in probe order,
+// so `net` is the per-lane loop's bit for bit (the GPU suite passes on it) — but it measured slower at every threshold, see below.
+// lds: kIrrCoopLdsFloats floats of the wave's own LDS that nothing else uses during the call (the traversal stack between two walks).
+constexpr int kIrrCoopIn = 16, kIrrCoopLdsFloats = 8 * kIrrCoopIn + 8 * 32;
+#ifndef HR_IRR_COOP_MAX
+#define HR_IRR_COOP_MAX 0    // points per wave up to which the shared form is used.  0 (shipping): never — measured on the reflections trace kernel at
+                             // 1080p / 4K (profiles/r6_c/ab_coop_threshold.txt): 0 -> 170-174 / 461-472 us, 24 -> 175 / 505, 40 -> 174 / 505, 56 -> 176 / 498,
+                             // 64 -> 179 / 519; DDGI probe trace 254 -> 266 with it.  Sharing never pays: waves with few points are rare (materials and
+                             // hit / miss regions are larger than an 8x8 tile), and every turn costs two LDS round trips behind wave barriers plus an owner-only
+                             // summation.  What DID pay is having ONE gather site per wave instead of two (reflections.hip): 185 -> 172 us, 488 -> 466 us.
+#endif
+constexpr int kIrrCoopMaxPoints = HR_IRR_COOP_MAX;
+static_assert(kIrrCoopLdsFloats <= HR_STACK_ENTRIES * 64, "the cooperative gather borrows the wave's traversal stack");
+HR_DEV f3 sample_irradiance_net_coop(bool want, const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth, float* lds, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    const int k = __popcll(m), rank = (int)lanes_below(m);
+    f3 net = mk3(0.0f, 0.0f, 0.0f);
+    if (k == 0) return net;
+    // A (nearly) full wave gains nothing from sharing — eight turns either way, and the shared form pays an LDS round trip per turn: per-lane loop
+    if (k > kIrrCoopMaxPoints)
+    {
+        if (want) net = sample_irradiance_net(d, P, N, Wo, irradiance, depth);
+        return net;
+    }
+    float* in = lds;                      // [8][kIrrCoopIn]  P, N, Wo, the point's IrrCell — of the eight points of this turn
+    float* tm = lds + 8 * kIrrCoopIn;     // [8][8][4]        their probe terms: s.xyz, w
+    IrrCell mc;
+    if (want) mc = irradiance_cell(d, P, N);   // once per point, by its owner
+    const int g = lane >> 3, i = lane & 7;
+    for (int b0 = 0; b0 < k; b0 += 8)   // wave-uniform
+    {
+        const bool mine = want && rank >= b0 && rank < b0 + 8;
+        if (mine)
+        {
+            float* q = in + (rank - b0) * kIrrCoopIn;
+            q[0] = P.x; q[1] = P.y; q[2] = P.z; q[3] = N.x; q[4] = N.y; q[5] = N.z; q[6] = Wo.x; q[7] = Wo.y; q[8] = Wo.z;
+            q[9] = __int_as_float(mc.bx | (mc.by << 10) | (mc.bz << 20)); q[10] = mc.alpha.x; q[11] = mc.alpha.y; q[12] = mc.alpha.z; q[13] = mc.icx; q[14] = mc.icy;
+        }
+        wave_fence();
+        if (b0 + g < k)
+        {
+            const float* q = in + g * kIrrCoopIn;
+            const f3 p = mk3(q[0], q[1], q[2]), n = mk3(q[3], q[4], q[5]), wo = mk3(q[6], q[7], q[8]);
+            IrrCell c;
+            const int pk = __float_as_int(q[9]);
+            c.bx = pk & 1023; c.by = (pk >> 10) & 1023; c.bz = (pk >> 20) & 1023;
+            c.alpha = mk3(q[10], q[11], q[12]); c.icx = q[13]; c.icy = q[14];
+            const IrrTerm t = irradiance_probe_term(d, p, n, wo, irradiance, depth, c, i);
+            float* o = tm + (g * 8 + i) * 4;
+            o[0] = t.s.x; o[1] = t.s.y; o[2] = t.s.z; o[3] = t.w;
+        }
+        wave_fence();
+        if (mine)
+        {
+            const float* o = tm + (rank - b0) * 32;
+            f3    sum_irr = mk3(0.0f, 0.0f, 0.0f);
+            float sum_w   = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+                sum_irr = add3(sum_irr, mk3(o[j * 4], o[j * 4 + 1], o[j * 4 + 2]));
+                sum_w += o[j * 4 + 3];
+            }
+            net = irradiance_net_from_sums(sum_irr, sum_w);
+        }
+        wave_fence();
+    }
+    return net;
+}
+// net^2 * energy_preservation * pi / 2 (gi_common.glsl:317-320)
+HR_DEV f3 irradiance_from_net(const DDGIU& d, f3 net)
+{
     net = mul3(net, net);
     net = scale3(net, d.energy_preservation);
     return scale3(net, 0.5f * HR_M_PI);
+}
+// gi_common.glsl:188-320
+HR_DEV f3 sample_irradiance(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
+{
+    return irradiance_from_net(d, sample_irradiance_net(d, P, N, Wo, irradiance, depth));
 }
 
 // ---- scene access at a hit -----------------------------------------------------------------------------

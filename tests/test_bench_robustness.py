@@ -128,3 +128,29 @@ def test_gpu_bench_line_as_the_driver_runs_it():
     assert set(d["passes"]["4k"]) == {"shadows", "ao", "reflections", "ddgi"}
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["value"] == d["value"] and "kernels" in detail["passes"]["ao"]
+
+
+def test_an_eight_gpu_line_keeps_the_fields_the_scale_record_needs():
+    """first contact with a real 8-GPU node must not be lost to formatting (r04's 1-GPU line was): a record shaped like the one
+    `bench.py --gpus 8` assembles — the round-4 full record + the `comm` block from bench_report.comm_block (the function bench.py itself calls)
+    + the strong-scaling `hybrid_4k` block — goes through compact_line(): n_gpus, comm.ranks_seen, comm.band_bounds, comm.exchange_us_per_frame,
+    hybrid_4k.comm_us_per_frame survive, the contract's fields are there, and the line stays under 7000 bytes"""
+    import bench, bench_report
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_n", "bench.json")))
+    bounds = [0, 520, 980, 1370, 1720, 2060, 2400, 2750, 3056]           # nine edges of eight cost-balanced bands of a 5432 x 3056 frame
+    full.update(n_gpus=8, requested_gpus=8, scaling="weak")
+    full["config"] = dict(full["config"], workload="5432x3056 procedural Sponza-like (277968 tris) ray-traced shadows 1spp + SVGF denoise, 8x the pixels of 1920x1080 (same view), "
+                                                   "row-tiled into 8 cost-balanced bands")
+    full["comm"] = bench_report.comm_block("nccl", 8, bounds, 40, 37.4, 5432)
+    full.pop("passes", None)
+    full["hybrid_4k"] = {"workload": "ONE 3840x2160 hybrid frame row-tiled over the GPUs", "n_gpus": 8, "ms_per_frame": 0.61, "frames_per_s": 1639.3, "Mrays_per_s": 9100.0,
+                         "bands": [[0, 270], [270, 540], [540, 810], [810, 1080], [1080, 1350], [1350, 1620], [1620, 1890], [1890, 2160]], "scaling": "strong", "forked_streams": True,
+                         "comm_us_per_frame": {"history_exchange": 41.0, "ddgi_all_gather": 18.5, "note": "x" * 500}}
+    line = json.dumps(bench.compact_line(full))
+    assert len(line.encode()) < bench.LINE_LIMIT, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "dropped" not in d
+    assert d["comm"]["ranks_seen"] == 8 and d["comm"]["band_bounds"] == bounds and d["comm"]["exchange_us_per_frame"] == 37.4 and d["comm"]["backend"] == "nccl"
+    assert d["hybrid_4k"]["n_gpus"] == 8 and d["hybrid_4k"]["comm_us_per_frame"] == {"history_exchange": 41.0, "ddgi_all_gather": 18.5} and len(d["hybrid_4k"]["bands"]) == 8
