@@ -52,7 +52,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hr_api.h"), __file__]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hr_api.h"), os.path.join(HERE, "..", "include", "hr_api_stages.h"),
+                                                           os.path.join(HERE, "..", "include", "hr_api_post.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -73,7 +74,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = None) -> st
     obj_dir = os.path.join(HERE, "_obj", variant or "product")
     os.makedirs(obj_dir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"] + extra
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "hr_api.h"), __file__]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", h) for h in ("hr_api.h", "hr_api_stages.h", "hr_api_post.h")] + [__file__]
     hdr_t = max(os.path.getmtime(h) for h in headers)
     tag = hashlib.sha1(" ".join(cflags).encode()).hexdigest()[:10]
 

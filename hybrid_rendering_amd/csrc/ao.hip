@@ -776,13 +776,17 @@ hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params*
     p->last_denoise = prm->denoise != 0;
     if (!prm->denoise) return HR_OK;
     hr_status s;
+    HR_SCOPED_SAMPLE("Denoise");   // ray_traced_ao.cpp:909
     if ((s = hr_ao_temporal(p, in, prm, stream)) != HR_OK) return s;
-    bool fused = false;
-    if (!prm->exact && p->fuse && prm->blur_radius == 4 && (s = ao_blur_xy(p, in, prm, stream, &fused)) != HR_OK) return s;
-    if (!fused)
     {
-        if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
-        if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+        HR_SCOPED_SAMPLE("Bilateral Blur");   // ray_traced_ao.cpp:1034
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->blur_radius == 4 && (s = ao_blur_xy(p, in, prm, stream, &fused)) != HR_OK) return s;
+        if (!fused)
+        {
+            if ((s = hr_ao_blur(p, in, prm, 0, stream)) != HR_OK) return s;
+            if ((s = hr_ao_blur(p, in, prm, 1, stream)) != HR_OK) return s;
+        }
     }
     if (p->scale != 0 && (s = hr_ao_upsample(p, in, prm, stream)) != HR_OK) return s;
     return HR_OK;
@@ -791,6 +795,7 @@ hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params*
 // RayTracedAO::render (ray_traced_ao.cpp:98-112)
 hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* prm, void* stream)
 {
+    HR_SCOPED_SAMPLE("Ambient Occlusion");
     HR_CHECK_ARG(p && scene && in && prm);
     HR_HIP(hipSetDevice(p->ctx->device));
     p->prof.begin_frame();

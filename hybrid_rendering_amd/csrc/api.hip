@@ -1,5 +1,6 @@
 // C-ABI glue: context, scene (BVH build + upload), raw ray queries, G-buffer synthesis.
 #include "hr_internal.h"
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -12,6 +13,96 @@ namespace hr {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
 } // namespace hr
+
+// ------------------------------------------------------------------------------------------------
+// profiler ranges (hr_internal.h): roctx through dlopen — the library is only needed when somebody asks for markers
+#include <dlfcn.h>
+#include <cstdlib>
+#include <mutex>
+namespace hr {
+namespace {
+std::atomic<int> g_marker_mode { -1 };   // -1: not decided (HR_MARKERS), 0 off, 1 roctx, 2 in-process log
+int  (*g_roctx_push)(const char*) = nullptr;
+int  (*g_roctx_pop)() = nullptr;
+std::mutex               g_marker_mutex;
+std::vector<std::string> g_marker_log;   // mode 2: "+name" / "-" in call order, capped
+int marker_mode()
+{
+    int m = g_marker_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    const char* e = getenv("HR_MARKERS");
+    m = e ? atoi(e) : 0;
+    if (m < 0 || m > 2) m = 0;
+    g_marker_mode.store(m);
+    return m;
+}
+bool roctx_ready()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* lib : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" })
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))
+            {
+                g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                g_roctx_pop  = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (g_roctx_push && g_roctx_pop) return;
+            }
+        g_roctx_push = nullptr; g_roctx_pop = nullptr;
+    });
+    return g_roctx_push && g_roctx_pop;
+}
+} // namespace
+bool samples_on() { return marker_mode() != 0; }
+void sample_push(const char* name)
+{
+    const int m = marker_mode();
+    if (m == 1) { if (roctx_ready()) (void)g_roctx_push(name); }
+    else if (m == 2) { std::lock_guard<std::mutex> l(g_marker_mutex); if (g_marker_log.size() < 4096) g_marker_log.push_back(std::string("+") + name); }
+}
+void sample_pop()
+{
+    const int m = marker_mode();
+    if (m == 1) { if (roctx_ready()) (void)g_roctx_pop(); }
+    else if (m == 2) { std::lock_guard<std::mutex> l(g_marker_mutex); if (g_marker_log.size() < 4096) g_marker_log.push_back("-"); }
+}
+const char* sample_name_of_stage(const char* stage)
+{
+    static const struct { const char* stage; const char* label; } table[] = {
+        { "ray_trace", "Ray Trace" }, { "temporal_accumulation", "Temporal Accumulation" }, { "upsample", "Upsample" },
+        { "atrous_0", "Iteration 0" }, { "atrous_1", "Iteration 1" }, { "atrous_2", "Iteration 2" }, { "atrous_3", "Iteration 3" }, { "atrous_4", "Iteration 4" },
+        { "atrous_01", "Iteration 0 + Iteration 1" },   // the tolerance mode runs the first two iterations in one launch
+        { "blur_x", "Vertical" }, { "blur_y", "Horizontal" },   // the reference's labels: its "Vertical" pass blurs along (1, 0) (ray_traced_ao.cpp:1042,1066)
+        { "blur_xy", "Vertical + Horizontal" },
+        { "irradiance_probe_update", "Irradiance" }, { "depth_probe_update", "Depth" }, { "border_update", "Border Update" }, { "sample_probe_grid", "Sample Probe Grid" },
+        { "path_trace", "Ground Truth Path Trace" }, { "taa", "TAA" },
+    };
+    for (const auto& t : table)
+        if (std::strcmp(t.stage, stage) == 0) return t.label;
+    return stage;
+}
+} // namespace hr
+
+extern "C" hr_status hr_set_markers(int32_t mode)
+{
+    HR_CHECK_ARG(mode >= 0 && mode <= 2);
+    hr::g_marker_mode.store(mode);
+    std::lock_guard<std::mutex> l(hr::g_marker_mutex);
+    hr::g_marker_log.clear();
+    return HR_OK;
+}
+extern "C" int32_t hr_markers_log(char* out, int32_t capacity)
+{
+    std::lock_guard<std::mutex> l(hr::g_marker_mutex);
+    std::string s;
+    for (const std::string& e : hr::g_marker_log) { s += e; s += '\n'; }
+    if (out && capacity > 0)
+    {
+        const size_t n = std::min(s.size(), (size_t)capacity - 1);
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return (int32_t)s.size();
+}
 
 // ------------------------------------------------------------------------------------------------
 // raw ray queries

@@ -668,6 +668,7 @@ hr_status hr_ddgi_trace_stats(hr_ddgi* p, const hr_scene* scene, const hr_frame_
 
 hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
 {
+    HR_SCOPED_SAMPLE("Probe Update");   // ddgi.cpp:831
     HR_CHECK_ARG(p);
     hipStream_t st = (hipStream_t)stream_;
     p->last_stream = st;
@@ -727,6 +728,7 @@ hr_status hr_ddgi_end_frame(hr_ddgi* p)
 
 hr_status hr_ddgi_render(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* prm, void* stream)
 {
+    HR_SCOPED_SAMPLE("DDGI");
     HR_CHECK_ARG(p && scene && in && env && prm);
     HR_HIP(hipSetDevice(p->ctx->device));
     p->prof.begin_frame();

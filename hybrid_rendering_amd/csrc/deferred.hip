@@ -165,6 +165,7 @@ hr_status hr_deferred_render(hr_deferred* p, const hr_frame_inputs* in, const hr
                              const hr_image_view* ao, const hr_image_view* reflections, const hr_image_view* gi,
                              const hr_deferred_params* prm, void* stream)
 {
+    HR_SCOPED_SAMPLE("Deferred Shading");
     HR_CHECK_ARG(p && in && env && prm);
     const hr_gbuffer_level& g = in->cur_full.gb2 ? in->cur_full : in->cur;
     HR_CHECK_ARG(g.gb1 && g.gb2 && g.gb3 && g.depth && g.width == p->w && g.height == p->h);

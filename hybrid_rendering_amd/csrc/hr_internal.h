@@ -34,6 +34,24 @@ void set_last_error(const std::string& s);
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Profiler ranges under the REFERENCE's sample names (DW_SCOPED_SAMPLE: ray_traced_shadows.cpp:102,974,1043,1096,1147,1221, ray_traced_ao.cpp:100,
+// 865,985,1034,1042,1091, ray_traced_reflections.cpp:109,999,1089,1145,1188,1262, ddgi.cpp:91,769,831,864,906,945, ...), so that a
+// `rocprofv3 --marker-trace` of an integrated frame reads like the reference's profiler tree.  Off unless hr_set_markers() / HR_MARKERS asks:
+// 1 = roctx (librocprofiler-sdk-roctx.so, dlopen'ed on first use), 2 = an in-process log (tests).  api.hip.
+void        sample_push(const char* name);
+void        sample_pop();
+const char* sample_name_of_stage(const char* stage);   // StageProfiler stage -> the reference's label
+bool        samples_on();
+struct ScopedSample
+{
+    bool on;
+    explicit ScopedSample(const char* name) : on(samples_on()) { if (on) sample_push(name); }
+    ~ScopedSample() { if (on) sample_pop(); }
+    ScopedSample(const ScopedSample&) = delete;
+    ScopedSample& operator=(const ScopedSample&) = delete;
+};
+#define HR_SCOPED_SAMPLE(name) ::hr::ScopedSample hr_scoped_sample_(name)
+
 // is per-stage event profiling switched on for this pass? (frame.hip: timing events cannot be captured into a hipGraph)
 bool profiling_enabled(const hr_shadows* p);
 bool profiling_enabled(const hr_ao* p);
@@ -130,8 +148,10 @@ struct StageProfiler
         if (frame_open) frame++;
         frame_open = false;
     }
+    int  marker_depth = 0;           // ranges begin() opened and end() still has to close
     int begin(const char* name, hipStream_t s, uint64_t algorithmic_bytes)
     {
+        if (samples_on()) { sample_push(sample_name_of_stage(name)); marker_depth++; }
         if (!enabled) return -1;
         int i = find_or_add(name);
         if (i < 0) return -1;
@@ -156,6 +176,7 @@ struct StageProfiler
     }
     void end(int i, hipStream_t s)
     {
+        if (marker_depth > 0) { sample_pop(); marker_depth--; }
         if (i >= 0) (void)hipEventRecord(stages[i].ev1[stages[i].last_frame % kRing], s);
     }
     void collect(hr_stage_times* out)

@@ -772,11 +772,14 @@ hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, c
     if (!prm->denoise) return HR_OK;
     hr_status s;
     if ((s = hr_reflections_temporal(p, in, prm, stream)) != HR_OK) return s;
-    bool fused = false;
-    if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
-        (s = reflections_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
-    for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
-        if ((s = hr_reflections_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    {
+        HR_SCOPED_SAMPLE("A-Trous Filter");   // ray_traced_reflections.cpp:1145
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+            (s = reflections_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
+            if ((s = hr_reflections_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    }
     if (p->scale != 0 && (s = hr_reflections_upsample(p, in, prm, stream)) != HR_OK) return s;
     return HR_OK;
 }
@@ -784,6 +787,7 @@ hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, c
 hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
                                 const hr_reflections_params* prm, void* stream)
 {
+    HR_SCOPED_SAMPLE("Ray Traced Reflections");
     HR_CHECK_ARG(p && scene && in && env && ddgi && prm);
     HR_HIP(hipSetDevice(p->ctx->device));
     p->prof.begin_frame();

@@ -1024,17 +1024,21 @@ hr_status hr_shadows_denoise(hr_shadows* p, const hr_frame_inputs* in, const hr_
     if (!prm->denoise) return HR_OK;
     hr_status s;
     if ((s = hr_shadows_temporal(p, in, prm, stream)) != HR_OK) return s;
-    bool fused = false;
-    if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
-        (s = shadows_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
-    for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
-        if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    {
+        HR_SCOPED_SAMPLE("A-Trous Filter");   // ray_traced_shadows.cpp:1096
+        bool fused = false;
+        if (!prm->exact && p->fuse && prm->filter_iterations >= 2 && prm->filter_iterations <= 8 && prm->radius == 1 &&
+            (s = shadows_atrous01(p, in, prm, stream, &fused)) != HR_OK) return s;
+        for (int i = fused ? 2 : 0; i < prm->filter_iterations; i++)
+            if ((s = hr_shadows_atrous_iteration(p, in, prm, i, stream)) != HR_OK) return s;
+    }
     if (p->scale != 0 && (s = hr_shadows_upsample(p, in, prm, stream)) != HR_OK) return s;
     return HR_OK;
 }
 
 hr_status hr_shadows_render(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* prm, void* stream)
 {
+    HR_SCOPED_SAMPLE("Ray Traced Shadows");
     HR_CHECK_ARG(p && scene && in && prm);
     HR_HIP(hipSetDevice(p->ctx->device));
     p->prof.begin_frame();

@@ -18,6 +18,9 @@
  *   - calls on one handle must be externally serialised; work is asynchronous on the given stream.
  *   - "band" fields describe row tiling across GPUs: a pass instance owns rows [band_y0, band_y1) of
  *     a full_height-row frame and its images hold rows [alloc_y0, alloc_y1) (band + halo).
+ *   - the two arithmetic modes (`exact`) and what the tolerance mode promises: docs/TOLERANCE.md.
+ * This file is the reference's PUBLIC class surface; hr_api_stages.h (stage-level entry points, introspection, the frame object) and
+ * hr_api_post.h (deferred composite, ground truth, TAA) are included at the end.
  */
 #ifndef HR_API_H
 #define HR_API_H
@@ -44,14 +47,8 @@ enum
 const char* hr_status_string(hr_status s);
 const char* hr_last_error(void); /* thread-local detail of the last failure */
 const char* hr_version(void);
-/* Revision of this header's struct layouts and entry points.  The parameter structs are passed by pointer WITHOUT a size field, so a host
- * built against another revision must not call into this library: compare hr_api_revision() with HR_API_REVISION once at start-up
- * (hr::Context does).  Revision 3 = round 3: hr_*_denoise, hr_hybrid_frame, ticketed hr_comm, HR_ERR_TIMEOUT / HR_ERR_COMM. */
-/* revision 4 (round 4): + hr_bvh_selfcheck, hr_ddgi_trace_stats, hr_reflections_trace_stats; structs unchanged */
-/* revision 5 (round 5): + hr_shadows_trace_stats_timed, hr_shadows_launch_order, hr_ao_launch_order; structs unchanged; every hr_*_create
- * returns with its images zero-filled (it waits for the fills), so a first render() on any stream is ordered after them */
-/* revision 6 (round 6): + hr_scene_id, hr_ddgi_grid_from_extents, hr_ddgi_set_normal_bias, hr_scene_create_instanced,
- * hr_scene_update_instances; structs unchanged */
+/* Revision of the struct layouts and entry points.  The parameter structs are passed by pointer WITHOUT a size field, so a host built against
+ * another revision must not call in: compare hr_api_revision() with HR_API_REVISION once at start-up (hr::Context does).  History: docs/API_HISTORY.md. */
 #define HR_API_REVISION 6
 int32_t hr_api_revision(void);
 
@@ -181,21 +178,13 @@ hr_status hr_bvh_build_info(const float* positions, int32_t n_tris, hr_scene_inf
  * 0 for a correct tree: the builder references a triangle from several leaves (spatial splits) and the pieces must cover it. */
 hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t samples_per_triangle, int64_t* uncovered);
 
-/* ---- instanced scenes: dw::RayTracedScene as the reference holds it (scene_descriptor_set.glsl:30-34 Instance { mat4 model_matrix; uint
- * mesh_idx; }, :102-131 fetch_hit_info / fetch_triangle through instance.mesh_idx, :150-160 transform_vertex) with the per-frame
- * acceleration-structure update of main.cpp:74 (build_tlas).
- *
- * MI355X layout: ONE 8-wide BVH in world space.  Every instance owns a private copy of its mesh's subtree (the topology is built once per
- * mesh in object space; 288 GB of HBM pay for the copies) under a top level over the instance roots, so every trace kernel keeps the
- * single-level walk of hr_scene_create — no ray transform at an instance boundary, no second stack.  hr_scene_update_instances moves
- * instances on the GPU: world-space vertices = model_matrix * (x, y, z, 1) rounded per operation (((m0 x + m1 y) + m2 z) + m3), then
- * every node box is refitted bottom-up from the triangles (one launch, children before parents by arrival counters), all on `stream`.
- * A triangle is hit iff the watertight test accepts its world-space vertices, so the answer of a query is the one a flattened
- * hr_scene_create over the same world-space vertices gives (any-hit: a function of the geometry; closest hit: smallest t, ties to the
- * smallest triangle index = instance order, then mesh order).  Hit shading interpolates the OBJECT-space vertex attributes and then
- * applies the instance's matrix: position = model_matrix * p, normal / tangent = normalize(mat3(model_matrix) * normalize(n)) — the
- * operation order of interpolated_vertex + transform_vertex.  Hit records name the global triangle index: triangles of instance i
- * follow those of instance i - 1, in mesh order. */
+/* ---- instanced scenes (scene_descriptor_set.glsl:30-34 Instance { mat4 model_matrix; uint mesh_idx; }, :102-160; main.cpp:74 build_tlas) ----
+ * The reference's scene model — meshes + instances, the acceleration structure updated every frame — on ONE world-space 8-wide BVH: every
+ * instance owns a private copy of its mesh's subtree under a top level over the instance roots, so the trace kernels keep the single-level
+ * walk of hr_scene_create.  hr_scene_update_instances moves instances on the GPU (vertices = model_matrix * (p, 1), one rounding per
+ * operation; node boxes refitted level by level; only instances whose matrix changed are touched).  Answers equal those of a flattened
+ * hr_scene_create over the same world-space vertices; hit records name the global triangle index (instance order, then mesh order); hit
+ * shading interpolates the OBJECT-space attributes, then applies interpolated_vertex + transform_vertex's operations.  DESIGN.md section 2. */
 typedef struct
 {
     const float*    positions;    /* [n_tris][3][3] OBJECT-space vertex positions                                  */
@@ -234,9 +223,6 @@ hr_status hr_scene_create_instanced(hr_ctx* ctx, const hr_instanced_scene_desc* 
  * caches of the passes (AO entry-node table) notice the change.  HR_ERR_INVALID_ARG for a scene from hr_scene_create. */
 hr_status hr_scene_update_instances(hr_scene* scene, const float* model_matrices, void* stream);
 int32_t   hr_scene_instance_count(const hr_scene* scene);   /* 0 for a scene from hr_scene_create */
-/* Introspection (tests, tools): copies the device BVH to the host after synchronising the device — hr_scene_info.node_bytes of 80-byte nodes
- * and .tri_bytes of 48-byte triangle references (layouts: csrc/bvh.h).  Either pointer may be NULL. */
-hr_status hr_scene_read_bvh(const hr_scene* scene, void* nodes_out, void* tris_out);
 hr_status hr_scene_destroy(hr_scene* scene);
 
 /* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).
@@ -307,36 +293,11 @@ typedef struct
     int32_t radius;             /* ATrous::radius = 1                            */
     int32_t filter_iterations;  /* ATrous::filter_iterations = 4  (1..5)         */
     int32_t feedback_iteration; /* ATrous::feedback_iteration = 1                */
-    int32_t exact;              /* 1 (default): every fp32 operation individually, correctly rounded — stage images equal the oracle
-                                   and the reference's shaders BIT FOR BIT (the parity mode).  0: tolerance mode for production — the
-                                   denoise / resolve kernels use the hardware's rcp / rsq / sqrt / exp / log and fused multiply-adds
-                                   (2-4x faster);
-                                   every fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels, with relative L2 error <= 1e-3 over
-                                   those texels and <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) additionally count
-                                   |diff| <= 1e-4 as equal; tile classes agree on >= 99.5 % of the tiles.  HARD CAP per texel: outside the
-                                   neighbourhoods of tiles whose class differs, every texel is within 32 fp16 ulp or 2^-10 of the oracle.  Round 5:
-                                   no counted exceptions for the shadows, AO, DDGI-sample and reflections-trace images — where the reference's
-                                   formulas are discontinuous (a history tap's validity thresholds, reprojection.glsl:52-67; the DDGI gather's
-                                   trilinear zero on a probe plane and its NaN-driven Chebyshev term where the fp16 depth moments overflow,
-                                   gi_common.glsl:188-320) the tolerance-mode kernels detect the shading points at which their fast operands
-                                   cannot be trusted and take the decision with the parity arithmetic.  The reflections' DENOISED images (temporal,
-                                   a-trous, upsampled output) may exceed the cap on at most max(4, 2e-5 of the pixels) pixels per image (x 5 * 4^scale
-                                   in a scaled pass's upsampled output), each within 512 fp16 ulp or 2^-5: the reference's luminance edge-stopping
-                                   weight exp(-|dl| / (phi sqrt(1e-10 + var))) moves by e^0.6 per fp16 ulp of its input where var == 0, so a 1-ulp
-                                   difference in a stored a-trous intermediate re-weights a tap of the next iteration.  The 99.9 % population bound, end to end, is likewise a property of
-                                   the SEQUENCE for the reflections' a-trous and output images — var is m2 - m1^2 of two stored fp16 moments, so one
-                                   ulp of a stored moment moves a small variance by more than its size and re-weights every tap around it: where
-                                   var is tiny over a region (the first frames of a history), the 1-ulp colours the trace image's fast DDGI gathers are
-                                   allowed reach it through the next frame's moments: 5 of 1214 fuzzed sequences measure 99.86 - 99.89 % (all 1214
-                                   >= 99.8 %; the temporal kernel's own moment path keeps the parity arithmetic); stage by stage — the a-trous and upsample kernels against the oracle's
-                                   stage run on the SAME input image — the bound holds with no counted exception at all
-                                   (tests/test_gpu_tolerance.py compare16; fuzz logs: profiles/r5_*);
-                                   visibility masks, ray counts and traversal are identical in both modes.
-                                   Tolerance mode also reprojects from the pass's own copy of the previous frame's geometry (normal, mesh id,
-                                   linear z — written by its temporal kernel) instead of in->prev.gb2 / gb3 whenever in->prev.gb2 / gb3 are the
-                                   pointers the previous call received as in->cur.gb2 / gb3 (the reference's G-buffer ping-pong,
-                                   g_buffer.cpp:208-211): same values, 5 fewer gathers per pixel.  A caller that rewrites those images between
-                                   the two calls must call hr_*_reset_history (or pass other pointers). */
+    int32_t exact;              /* 1 (default): parity mode — every stage image equals the oracle and the reference's shaders bit for bit.
+                                   0: tolerance mode (production; what bench.py times): hardware rcp / rsq / sqrt / exp / log + FMAs in the
+                                   denoise kernels; masks, ray counts, DDGI atlases and the reflections' trace image stay bit-exact, every other
+                                   fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels.  THE CONTRACT, clause by clause with
+                                   the test behind each: docs/TOLERANCE.md. */
 } hr_shadows_params;
 
 void      hr_shadows_default_params(hr_shadows_params* p);
@@ -348,56 +309,6 @@ hr_status hr_shadows_output(hr_shadows* p, hr_output_kind kind, hr_image_view* v
 /* m_first_frame = true (ray_traced_shadows.cpp:938-968) */
 hr_status hr_shadows_reset_history(hr_shadows* p);
 hr_status hr_shadows_destroy(hr_shadows* p);
-/* Stage-level entry points (the private methods ray_trace / temporal_accumulation / a_trous_filter /
- * upsample, ray_traced_shadows.cpp:972-1255) so a multi-GPU driver can exchange halos between them.
- * Launch order: the trace kernels of the shadows, AO and reflections passes record how long each 8x8 tile's wave lived and launch
- * the next frame's tiles heaviest first (the sort runs inside the pass's tolerance-mode temporal launch, else at the start of the next
- * trace call).  Outputs do not depend on it.  Like the visibility mask — which the next trace call overwrites and the temporal stage
- * reads — this state asks for what a frame loop does anyway: a pass's next *_ray_trace call is stream-ordered after its last
- * *_temporal call. */
-hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
-/* everything of render() after the trace: temporal + a-trous chain (+ upsample); hr_shadows_ray_trace + hr_shadows_denoise == hr_shadows_render.
- * In tolerance mode this (like render) launches a-trous iterations 0 and 1 as ONE kernel; the per-iteration entry point below stays. */
-hr_status hr_shadows_denoise(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
-hr_status hr_shadows_temporal(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
-hr_status hr_shadows_atrous_iteration(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, int32_t iteration, void* stream);
-hr_status hr_shadows_upsample(hr_shadows* p, const hr_frame_inputs* in, const hr_shadows_params* params, void* stream);
-/* Views of intermediates for halo exchange / golden taps: 0 mask, 1 temporal out, 2/3 moments[0/1],
- * 4 prev (feedback) image, 5/6 à-trous ping/pong, 7 upsample, 8 tile classes (uint8 as R8 in an R32 view is not
- * representable: width/height are in tiles, format HR_FORMAT_R32_UINT is NOT implied — 1 byte per tile).
- * STALE IMAGES: what render() / hr_shadows_denoise launch in tolerance mode (radius 1) fuses a-trous iterations 0 and 1, so the image
- * iteration 0 would have written (6) holds an older frame — read the pass's result through hr_shadows_output, or run the iterations one by
- * one (hr_shadows_atrous_iteration) when every intermediate is wanted. */
-hr_status hr_shadows_image(hr_shadows* p, int32_t which, hr_image_view* view);
-/* Row bands: did a history tap of the frames rendered since the last call fall on an image row this GPU does not hold (per-frame
- * motion beyond hr_band.history_halo)?  Such taps read as disoccluded: the band stays a valid image but stops being identical to the
- * single-GPU one; widen history_halo when this fires.  Synchronises the pass's stream; clears the flag. */
-hr_status hr_shadows_history_apron_exceeded(hr_shadows* p, int32_t* exceeded);
-hr_status hr_shadows_set_profiling(hr_shadows* p, int32_t enable);
-hr_status hr_shadows_get_stage_times(hr_shadows* p, hr_stage_times* out); /* synchronises the recorded events */
-/* rays fired by the last ray_trace (lit, non-sky pixels); synchronises the stream it ran on */
-hr_status hr_shadows_ray_count(hr_shadows* p, uint64_t* rays);
-/* the same per 8x8 tile: out = host array [tiles_y][tiles_x] (nullable: only the extent is returned) — the cost signal
- * the multi-GPU driver balances its row bands with (tiling.balanced_bounds) */
-hr_status hr_shadows_tile_ray_counts(hr_shadows* p, uint16_t* out, int32_t* tiles_x, int32_t* tiles_y);
-/* Runs the instrumented build of the trace kernel on the same inputs (same masks are produced) and
- * returns out3 = { rays fired, BVH nodes visited, triangles tested } — the terms of the trace pass's
- * algorithmic-bytes figure.  Synchronises the stream. */
-hr_status hr_shadows_trace_stats(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
-/* hr_shadows_trace_stats counts the full WALK: it bypasses the occluder cache (the triangle that shadowed a pixel last frame is tested before
- * the walk), whose contents depend on the previous frames.  This variant leaves the cache ON: the counts are those of the kernel a render()
- * of `in` launches in the pass's present state (bench.py divides THESE by the timed kernel's duration).  It advances the cache exactly as
- * that trace would; masks and every other output are the same either way. */
-/* The launch order of the trace kernel as its NEXT launch will read it (csrc/tile_order.h: launch slot -> 8x8 tile, last frame's heaviest tiles
- * first; the identity list from creation until the first sort has run).  out = host array of *n_tiles words (nullable: only the count is
- * returned; 0 when the launch order is switched off).  Always a permutation of 0 .. n_tiles - 1.  Synchronises the stream of the last render.
- * Introspection for tests and tools (tests/test_gpu_tile_order.py: a hipGraph captured on the FIRST frame replays with the order too). */
-hr_status hr_shadows_launch_order(hr_shadows* p, uint32_t* out, int32_t* n_tiles);
-hr_status hr_shadows_trace_stats_timed(hr_shadows* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_shadows_params* params, uint64_t* out3, void* stream);
-/* After hr_shadows_trace_stats: sum over waves of the slowest lane's (node + triangle) steps.  SIMD lane utilisation of
- * the traversal loop = (nodes + triangles) / (64 * wave_max_steps). */
-hr_status hr_shadows_trace_divergence(hr_shadows* p, uint64_t* wave_max_steps);
-
 /* ---- RayTracedAO (src/ray_traced_ao.h) ------------------------------------------------------------ */
 typedef struct hr_ao hr_ao;
 
@@ -422,25 +333,6 @@ hr_status hr_ao_render(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* i
 hr_status hr_ao_output(hr_ao* p, hr_output_kind kind, hr_image_view* view);
 hr_status hr_ao_reset_history(hr_ao* p);
 hr_status hr_ao_destroy(hr_ao* p);
-/* stage-level entry points: ray_trace (:863-903), temporal_accumulation (:983-1028),
- * bilateral_blur pass 0 = direction (1,0), pass 1 = (0,1) (:1032-1137), upsample (:918-955) */
-hr_status hr_ao_ray_trace(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
-/* temporal + blur X + blur Y (+ upsample); in tolerance mode (radius 4) the two blur passes are ONE kernel and IMG 5 (blur X) is not written */
-hr_status hr_ao_denoise(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
-hr_status hr_ao_temporal(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
-hr_status hr_ao_blur(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, int32_t pass, void* stream);
-hr_status hr_ao_upsample(hr_ao* p, const hr_frame_inputs* in, const hr_ao_params* params, void* stream);
-/* 0 mask planes, 1/2 AO[0/1], 3/4 history length[0/1], 5/6 blur[0/1], 7 upsample, 8 tile classes (1 byte per tile).
- * STALE IMAGE: in tolerance mode (blur radius 4) render() / hr_ao_denoise blur X and Y in one kernel and image 5 (blur X) is not written. */
-hr_status hr_ao_image(hr_ao* p, int32_t which, hr_image_view* view);
-hr_status hr_ao_history_apron_exceeded(hr_ao* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
-hr_status hr_ao_set_profiling(hr_ao* p, int32_t enable);
-hr_status hr_ao_get_stage_times(hr_ao* p, hr_stage_times* out);
-hr_status hr_ao_ray_count(hr_ao* p, uint64_t* rays);
-hr_status hr_ao_trace_stats(hr_ao* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_ao_params* params, uint64_t* out3, void* stream);
-/* as hr_shadows_launch_order */
-hr_status hr_ao_launch_order(hr_ao* p, uint32_t* out, int32_t* n_tiles);
-
 /* ---- environment inputs (replace CommonResources::current_skybox_ds / IBL images) ------------------- */
 /* Cubemaps are [6][size][size] RGBA16F, faces +X -X +Y -Y +Z -Z, fetched NEAREST.
  * prefiltered: `prefiltered_levels` mips of the specular-prefiltered environment, level l has size
@@ -498,33 +390,11 @@ hr_status hr_ddgi_render(hr_ddgi* p, const hr_scene* scene, const hr_frame_input
 hr_status hr_ddgi_output(hr_ddgi* p, hr_image_view* view);
 /* DDGI::current_read_ds (ddgi.cpp:135-138): irradiance + depth atlases written by the last render() */
 hr_status hr_ddgi_current_read(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
-/* Multi-GPU sharding (the reference is single-GPU): this instance traces and updates only the probes
- * of grid z-slabs [probe_z0, probe_z1) — their atlas rows [1 + z0*(side+2), 1 + z1*(side+2)) are contiguous
- * (ddgi.cpp:197-201) — and samples image rows [row_y0, row_y1) (row_y0 a multiple of 8).  The caller all-gathers the
- * slab rows of hr_ddgi_current_write() between hr_ddgi_probe_update and hr_ddgi_sample_probe_grid. */
-hr_status hr_ddgi_set_shard(hr_ddgi* p, int32_t probe_z0, int32_t probe_z1, int32_t row_y0, int32_t row_y1);
-hr_status hr_ddgi_current_write(hr_ddgi* p, hr_image_view* irradiance, hr_image_view* depth);
 /* DDGI::set_normal_bias (ddgi.h:29): read by the next render's uniform upload (ddgi.cpp:747); hr_ddgi_get_uniforms reads it back */
 hr_status hr_ddgi_set_normal_bias(hr_ddgi* p, float normal_bias);
 /* DDGI::restart_accumulation (ddgi.h:33) */
 hr_status hr_ddgi_restart_accumulation(hr_ddgi* p);
 hr_status hr_ddgi_destroy(hr_ddgi* p);
-/* stage-level entry points (ddgi.cpp:767-986); probe range [probe0, probe1) lets a multi-GPU driver
- * split G1-G4 by z-slab and all-gather the atlas rows */
-hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, void* stream);
-/* Instrumented ray trace (the counter build of the same kernel; same rays and results): out3 = rays traced (probe rays + the light / sky
- * rays of the hit points), BVH node steps, triangle tests — the BVH term of the trace pass's algorithmic bytes.  Synchronises. */
-hr_status hr_ddgi_trace_stats(hr_ddgi* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, const hr_ddgi_params* params, uint64_t* out3, void* stream);
-hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream);
-hr_status hr_ddgi_sample_probe_grid(hr_ddgi* p, const hr_frame_inputs* in, const hr_ddgi_params* params, void* stream);
-hr_status hr_ddgi_end_frame(hr_ddgi* p); /* m_first_frame = false; m_ping_pong = !m_ping_pong (ddgi.cpp:101-103) */
-/* 0 radiance, 1 direction+distance ([probes][rays] RGBA16F), 2/3 irradiance atlas[0/1], 4/5 depth atlas[0/1], 6 sample image */
-hr_status hr_ddgi_image(hr_ddgi* p, int32_t which, hr_image_view* view);
-hr_status hr_ddgi_get_uniforms(hr_ddgi* p, hr_ddgi_uniforms* out);
-hr_status hr_ddgi_set_profiling(hr_ddgi* p, int32_t enable);
-hr_status hr_ddgi_get_stage_times(hr_ddgi* p, hr_stage_times* out);
-hr_status hr_ddgi_ray_count(hr_ddgi* p, uint64_t* rays);
-
 /* ---- RayTracedReflections (src/ray_traced_reflections.h) ---------------------------------------------- */
 typedef struct hr_reflections hr_reflections;
 
@@ -564,158 +434,11 @@ hr_status hr_reflections_render(hr_reflections* p, const hr_scene* scene, const 
 hr_status hr_reflections_output(hr_reflections* p, hr_output_kind kind, hr_image_view* view);
 hr_status hr_reflections_reset_history(hr_reflections* p);
 hr_status hr_reflections_destroy(hr_reflections* p);
-/* stage-level entry points: ray_trace (:997-1057), temporal_accumulation (:1087-1139), a_trous_filter iteration (:1143-1256), upsample (:1260-1296) */
-hr_status hr_reflections_ray_trace(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
-                                   const hr_reflections_params* params, void* stream);
-/* Instrumented ray trace, as hr_ddgi_trace_stats: out3 = rays (reflection rays + light rays of the hit points), node steps, triangle tests. */
-hr_status hr_reflections_trace_stats(hr_reflections* p, const hr_scene* scene, const hr_frame_inputs* in, const hr_environment* env, hr_ddgi* ddgi,
-                                     const hr_reflections_params* params, uint64_t* out3, void* stream);
-/* temporal + a-trous chain (+ upsample); tolerance mode: iterations 0 and 1 as ONE kernel */
-hr_status hr_reflections_denoise(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
-hr_status hr_reflections_temporal(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
-hr_status hr_reflections_atrous_iteration(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, int32_t iteration, void* stream);
-hr_status hr_reflections_upsample(hr_reflections* p, const hr_frame_inputs* in, const hr_reflections_params* params, void* stream);
-/* 0 ray-trace output, 1/2 temporal colour[0/1], 3/4 moments[0/1], 5 prev (feedback) image, 6/7 a-trous ping/pong, 8 upsample, 9 tile classes.
- * STALE IMAGE: in tolerance mode (radius 1) render() / hr_reflections_denoise fuse a-trous iterations 0 and 1; the image iteration 0 would
- * have written (7) holds an older frame (see hr_shadows_image). */
-/* which = 10: the colour history the NEXT frame's temporal stage will read (feedback image with blur_as_input, else this frame's temporal
- * output) — the image a row-tiled host exchanges with its neighbours (hr_reflections_exchange_history does) */
-hr_status hr_reflections_image(hr_reflections* p, int32_t which, hr_image_view* view);
-hr_status hr_reflections_history_apron_exceeded(hr_reflections* p, int32_t* exceeded);   /* see hr_shadows_history_apron_exceeded */
-hr_status hr_reflections_set_profiling(hr_reflections* p, int32_t enable);
-hr_status hr_reflections_get_stage_times(hr_reflections* p, hr_stage_times* out);
-hr_status hr_reflections_ray_count(hr_reflections* p, uint64_t* rays);
-
-/* ---- the frame (src/main.cpp:80-83) ------------------------------------------------------------------------------- */
-/* The reference records shadows, AO, DDGI and reflections into ONE command buffer with per-resource barriers, so the GPU overlaps the
- * independent chains.  hr_hybrid_frame gives a HIP host the same: the four render() calls of a frame enqueued as the dependency graph
- * they form (shadows | AO | DDGI probe trace + updates -> reflections | DDGI per-pixel sample), every output bit-identical to the serial
- * order.  The passes are NOT owned; call order at the call site is the reference's, mode picks how the launches reach the GPU. */
-typedef struct hr_hybrid_frame hr_hybrid_frame;
-typedef enum
-{
-    HR_FRAME_SERIAL  = 0, /* one stream, the reference's order (= calling the four render() yourself) */
-    HR_FRAME_STREAMS = 1, /* fork / join over three internal streams + `stream` */
-    HR_FRAME_GRAPH   = 2  /* the forked frame captured into one hipGraph per frame; the instantiated graph is updated in place.
-                             Stage profiling (hr_*_set_profiling) must be off: timing events cannot be read back from a captured launch */
-} hr_frame_mode;
-typedef struct
-{
-    const hr_environment*        environment;          /* DDGI + reflections */
-    const hr_frame_inputs*       shadows_inputs;       /* each pass reads the G-buffer level of its own RayTraceScale */
-    const hr_shadows_params*     shadows_params;
-    const hr_frame_inputs*       ao_inputs;
-    const hr_ao_params*          ao_params;
-    const hr_frame_inputs*       ddgi_inputs;
-    const hr_ddgi_params*        ddgi_params;
-    const hr_frame_inputs*       reflections_inputs;
-    const hr_reflections_params* reflections_params;
-} hr_hybrid_frame_desc;
-/* any of the passes may be NULL (reflections need ddgi); they must outlive the frame object */
-hr_status hr_hybrid_frame_create(hr_ctx* ctx, hr_shadows* shadows, hr_ao* ao, hr_ddgi* ddgi, hr_reflections* reflections, hr_hybrid_frame** out);
-hr_status hr_hybrid_frame_render(hr_hybrid_frame* f, const hr_scene* scene, const hr_hybrid_frame_desc* desc, hr_frame_mode mode, void* stream);
-/* Fork / join for a host that enqueues the chains itself (hr::TiledHybridFrame: the row-tiled passes post their neighbour exchanges from
- * inside render()).  fork: side_streams[0..2] (owned by the frame object) wait for everything enqueued on `stream` so far; join: `stream`
- * waits for everything enqueued on them since. */
-hr_status hr_hybrid_frame_fork(hr_hybrid_frame* f, void* stream, void** side_streams);
-hr_status hr_hybrid_frame_join(hr_hybrid_frame* f, void* stream);
-/* HR_FRAME_GRAPH bookkeeping: graphs instantiated (1 in steady state) and in-place updates (one per later frame) */
-hr_status hr_hybrid_frame_graph_stats(hr_hybrid_frame* f, int32_t* instantiations, int32_t* updates);
-hr_status hr_hybrid_frame_destroy(hr_hybrid_frame* f);
-
-/* ---- DeferredShading composite (src/deferred_shading.h; SURVEY.md §8f "next" row 1) ------------------- */
-/* The consumer of the four passes: shaders/deferred.frag:177-205 as a per-pixel kernel.  Inputs are full-resolution views
- * (the passes' OUTPUT_UPSAMPLE outputs).  Like the reference every pixel is shaded; render_skybox then covers the sky texels. */
-typedef struct hr_deferred hr_deferred;
-
-typedef struct
-{
-    int32_t use_ray_traced_shadows;     /* Shading::use_ray_traced_shadows = true     */
-    int32_t use_ray_traced_ao;          /* true                                        */
-    int32_t use_ray_traced_reflections; /* true                                        */
-    int32_t use_ddgi;                   /* true                                        */
-    float   irradiance_sh9[9][4];       /* s_IrradianceSH (9x1 texels, rgb used) — dw::CubemapSHProjection output */
-    int32_t draw_skybox;                /* 1 (default): render_skybox (deferred_shading.cpp:734-789) — texels the G-buffer left at
-                                           depth 1 take hr_environment.sky along the ray through the pixel centre; 0: shading only */
-} hr_deferred_params;
-
-void      hr_deferred_default_params(hr_deferred_params* p);
-hr_status hr_deferred_create(hr_ctx* ctx, int32_t width, int32_t height, hr_deferred** out);
-/* DeferredShading::render(cmd_buf, ao, shadows, reflections, ddgi) -> render_shading (deferred_shading.cpp:715-723):
- * shadow / ao: R16F or RG16F view (channel 0 is read); reflections / gi: RGBA16F; any of them may be NULL when its flag is 0.
- * in->cur_full supplies GB1/GB2/GB3/depth; env supplies the prefiltered cubemap + BRDF LUT. */
-hr_status hr_deferred_render(hr_deferred* p, const hr_frame_inputs* in, const hr_environment* env, const hr_image_view* shadow,
-                             const hr_image_view* ao, const hr_image_view* reflections, const hr_image_view* gi,
-                             const hr_deferred_params* params, void* stream);
-/* DeferredShading::output_ds: RGBA16F HDR colour */
-hr_status hr_deferred_output(hr_deferred* p, hr_image_view* view);
-hr_status hr_deferred_destroy(hr_deferred* p);
-
-/* ---- GroundTruthPathTracer (src/ground_truth_path_tracer.h:7-44) — SURVEY.md §8f row 3 ---------------------- */
-typedef struct hr_ground_truth hr_ground_truth;
-typedef struct
-{
-    int32_t max_ray_bounces;      /* PathTrace::max_ray_bounces = 2 (ground_truth_path_tracer.h:30); only read when trace_indirect != 0 (< 32) */
-    float   roughness_multiplier; /* CommonResources::roughness_multiplier */
-    int32_t trace_indirect;       /* 0 (default) = the reference as shipped: the recursive traceRayEXT of rchit:95-105 is commented out.
-                                     1 = that call re-enabled (rchit:67-108 verbatim): a multi-bounce on-device reference */
-} hr_ground_truth_params;
-
-void      hr_ground_truth_default_params(hr_ground_truth_params* p);
-/* band: optional rows [band_y0, band_y1) of the image (pixels are independent: no halo, no exchange) */
-hr_status hr_ground_truth_create(hr_ctx* ctx, int32_t width, int32_t height, const hr_band* band, hr_ground_truth** out);
-/* GroundTruthPathTracer::render (ground_truth_path_tracer.cpp:44-111): one jittered primary sample per pixel, direct
- * light + sky light at the first hit, running mean over the frames since restart_accumulation(). */
-hr_status hr_ground_truth_render(hr_ground_truth* p, const hr_scene* scene, const hr_ubo* ubo, const hr_environment* env,
-                                 const hr_ground_truth_params* params, void* stream);
-/* GroundTruthPathTracer::output_ds (:122-125): RGBA16F running mean */
-hr_status hr_ground_truth_output(hr_ground_truth* p, hr_image_view* view);
-hr_status hr_ground_truth_restart_accumulation(hr_ground_truth* p); /* ground_truth_path_tracer.h:18 */
-hr_status hr_ground_truth_ray_count(hr_ground_truth* p, uint64_t* rays);
-hr_status hr_ground_truth_set_profiling(hr_ground_truth* p, int32_t enable);
-hr_status hr_ground_truth_get_stage_times(hr_ground_truth* p, hr_stage_times* out);
-hr_status hr_ground_truth_destroy(hr_ground_truth* p);
-
-/* ---- TemporalAA (src/temporal_aa.h:17-62) — SURVEY.md §8f row 4 ------------------------------------------------ */
-typedef struct hr_taa hr_taa;
-typedef struct
-{
-    int32_t enabled;      /* m_enabled = true */
-    int32_t sharpen;      /* m_sharpen = true */
-    int32_t reset;        /* m_reset = true and never cleared upstream (temporal_aa.cpp:112,184): history re-seeded every frame; 0 = keep history */
-    float   feedback_min; /* 0.88 */
-    float   feedback_max; /* 0.97 */
-} hr_taa_params;
-
-void      hr_taa_default_params(hr_taa_params* p);
-hr_status hr_taa_create(hr_ctx* ctx, int32_t width, int32_t height, hr_taa** out);
-/* TemporalAA::update (temporal_aa.cpp:64-81): advances the Halton(2,3) jitter; writes (current.xy, prev.xy) — the value
- * the application puts into hr_ubo.current_prev_jitter and into its projection matrix (main.cpp:941-957).  Nullable out. */
-hr_status hr_taa_update(hr_taa* p, uint32_t num_frames, const hr_taa_params* params, float* current_prev_jitter);
-/* TemporalAA::render (:84-172): colour = the image being anti-aliased (DeferredShading::output_ds), g = full-resolution
- * G-buffer level (GB2.zw motion vectors, depth), ping_pong = CommonResources::ping_pong. */
-hr_status hr_taa_render(hr_taa* p, const hr_image_view* color, const hr_gbuffer_level* g, int32_t ping_pong, const hr_taa_params* params, void* stream);
-/* TemporalAA::output_ds (:196-199) */
-hr_status hr_taa_output(hr_taa* p, int32_t ping_pong, hr_image_view* view);
-hr_status hr_taa_set_profiling(hr_taa* p, int32_t enable);
-hr_status hr_taa_get_stage_times(hr_taa* p, hr_stage_times* out);
-hr_status hr_taa_destroy(hr_taa* p);
-
-/* ToneMap::render (src/tone_map.cpp:98-143, shaders/tone_map.frag:50-68): exposure, ACES film curve, pow(1/2.2) over an
- * RGBA16F colour image read through the bilinear sampler at the pixel centres; single_channel = 1 shows .rrr (the
- * shadows / AO visualisations, tone_map.cpp:131).  Stateless.  out_rgba32f (device [h][w][4] float, nullable) receives
- * FS_OUT_Color; out_rgba8 (device [h][w][4] uint8, nullable) its UNORM8 conversion floor(c * 255 + 0.5). */
-hr_status hr_tone_map(hr_ctx* ctx, const hr_image_view* color, int32_t single_channel, float exposure, float* out_rgba32f, uint8_t* out_rgba8,
-                      void* stream);
-
-/* ---- self test ------------------------------------------------------------------------------------ */
-/* Evaluates the device-side arithmetic of the numerical contract on arrays so tests can
- * compare it bit for bit with a CPU replay.  which: 0 sincos(x)->(s,c)  1 exp(x)  2 log(x)  3 pow(x,y)
- * 4 fp32->fp16 bits (as float of the uint16)  5 oct_decode(x,y)->(nx,ny,nz)  6 oct_encode(x,y,z)->(ex,ey).
- * in: device [n][3] floats, out: device [n][3] floats. */
-hr_status hr_selftest_math(int32_t which, int64_t n, const float* in, float* out, void* stream);
-
 #ifdef __cplusplus
 }
 #endif
+/* the rest of the ABI: stage-level entry points, introspection and the frame object (multi-GPU drivers, tests, tools) ... */
+#include "hr_api_stages.h"
+/* ... and the SURVEY 8(f) rows: deferred composite, ground-truth accumulator, TAA, tone map, self test */
+#include "hr_api_post.h"
 #endif /* HR_API_H */

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, "include", "hr_api.h")).read()
+    # hr_api.h includes hr_api_stages.h and hr_api_post.h: together they are the ABI
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("hr_api.h", "hr_api_stages.h", "hr_api_post.h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hr_[a-z0-9_]+)\s*\(", src)))
 
@@ -137,3 +138,14 @@ def test_ddgi_grid_from_extents_follows_initialize_probe_grid():
     assert L.hr_ddgi_grid_from_extents(f3, f3, C.c_float(0.0), C.c_int32(256), C.byref(api_gi.hr_ddgi_uniforms())) == 1   # HR_ERR_INVALID_ARG
     assert L.hr_ddgi_grid_from_extents(None, f3, C.c_float(1.0), C.c_int32(256), None) == 1
     assert L.hr_scene_id(None) == 0
+
+
+def test_the_public_header_stays_small_and_essay_free():
+    """an integrator must be able to find the enforceable rule.  hr_api.h = the reference's public class surface in <= 450 lines, no comment
+    block longer than 16 lines (the tolerance contract lives in docs/TOLERANCE.md, the revision history in docs/API_HISTORY.md)"""
+    for h, limit in (("hr_api.h", 450), ("hr_api_stages.h", 220), ("hr_api_post.h", 140)):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        assert txt.count("\n") <= limit, (h, txt.count("\n"))
+        for m in re.finditer(r"/\*.*?\*/", txt, flags=re.S):
+            assert m.group(0).count("\n") < 16 or m.start() == 0, (h, m.group(0)[:80])
+    assert "docs/TOLERANCE.md" in open(os.path.join(ROOT, "include", "hr_api.h")).read()

@@ -1,27 +1,10 @@
 """Tolerance mode (hr_*_params.exact = 0: hardware rcp / rsq / sqrt / exp / log, fused multiply-adds, re-associated sums —
-csrc/denoise_fast.hip) against the CPU oracle.
-
-Stated tolerance (north_star "AO / reflections / GI within a stated fp32 tolerance"):
-  * visibility masks, ray counts: BIT-EXACT (the trace kernels have one mode);
-  * every fp16 output image, EVERY channel: <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 error <= 1e-3 over those texels and
-    <= 1e-2 over ALL texels; variance channels (shadows .y, reflections .a) also count |diff| <= 1e-4 as equal, the temporal stages'
-    intermediate images |diff| <= 2e-4 (both are differences of nearly equal numbers: m2 - m1^2, E[x^2] - E[x]^2).  The remaining <= 0.1 % are discrete decisions flipped by an fp32 ulp (a reprojection validity threshold, a truncation
-    to a texel index, a tile whose only non-trivial pixel sits on the classification threshold) or 0/0 situations of the reference's
-    own arithmetic (a DDGI pixel all of whose probe weights were crushed to the 1e-6 floor); their energy is bounded by the second
-    L2 figure, not ignored;
-  * HARD CAPS on every single texel: outside the neighbourhoods of flipped tiles <= 32 fp16 ulp OR |diff| <= 2^-10.  Round 5: NO counted
-    allowance any more for the shadows, AO and DDGI probe-grid-sample images and the reflections' trace image — the discrete decisions that
-    used to cost a handful of pixels per frame are now taken with the parity kernels' arithmetic wherever the fast operands cannot be
-    trusted with them (a history tap on a knife edge of the validity test, reprojection.glsl:52-67: Reproj::exact_bits in
-    csrc/denoise_fast.hip; a DDGI gather whose weights are ill-conditioned or NaN-driven, gi_common.glsl:262-320: the redo of
-    csrc/ddgi_sample_fast.h).  The reflections' DENOISED images keep one, tightly bounded (OUTLIER_* below): at most max(4, 2e-5 of the
-    pixels) pixels per image (x 5 * 4^scale for the upsampled output of a scaled pass), each within 512 fp16 ulp or 2^-5 of the oracle —
-    not "the channel's value range" of round 4 — because the reference's own luminance edge-stopping weight is ill-conditioned where the
-    variance estimate is 0 (see OUTLIER_PIXELS); texels inside a flipped-tile neighbourhood (a flipped tile is copied / cleared instead of
-    filtered) must stay within the value range of the reference image's channel;
-  * tile classes: equal on >= 99.5 % of the tiles;
-  * DDGI atlases are produced by the exact kernels in both modes (bit-exact); the per-pixel probe-grid sample obeys the image rule.
-The runs are several frames long with a moving camera, so the bound holds through the temporal feedback loops."""
+csrc/denoise_fast.hip) against the CPU oracle.  THE CONTRACT these runners enforce is stated once, clause by clause, in docs/TOLERANCE.md
+(north_star "AO / reflections / GI within a stated fp32 tolerance"): masks, ray counts, DDGI atlases and the reflections'
+trace image bit-exact; every other fp16 image <= 2 fp16 ulp on >= 99.9 % of the texels, relative L2 <= 1e-3 (<= 1e-2 over all texels), a hard
+cap of 32 ulp / 2^-10 per texel outside flipped-tile neighbourhoods, one bounded allowance for the reflections' denoised images, tile classes
+equal on >= 99.5 % of the tiles.  Every threshold below is a constant (tests/test_tolerance_rule.py).  The runs are several frames long with
+a moving camera, so the bound holds through the temporal feedback loops."""
 import numpy as np
 import pytest
 
