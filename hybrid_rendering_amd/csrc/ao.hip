@@ -162,6 +162,9 @@ __global__ __launch_bounds__(64 * AO_TRACE_WAVES, AO_TRACE_EU) void k_ao_trace(A
         }
         if (!looked_up) entry = entry_node_for_box(a.nodes, mk3(ro.x - r, ro.y - r, ro.z - r), mk3(ro.x + r, ro.y + r, ro.z + r));
     }
+#if AO_SEQ && !defined(HR_DEV_PATHS)
+#error "-DAO_SEQ=N is an A/B path: build with -DHR_DEV_PATHS"
+#endif
 #if AO_SEQ
     if (!STATS)
     {

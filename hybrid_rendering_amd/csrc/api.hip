@@ -320,7 +320,11 @@ const char* hr_status_string(hr_status s)
     }
 }
 const char* hr_last_error(void) { return g_last_error.c_str(); }
-const char* hr_version(void) { return "hybrid_rendering_amd 0.3 (gfx950)"; }
+#ifdef HR_DEV_PATHS
+const char* hr_version(void) { return "hybrid_rendering_amd 0.4 (gfx950) +dev"; }   // built with the A/B paths that lost (HR_CFLAGS=-DHR_DEV_PATHS)
+#else
+const char* hr_version(void) { return "hybrid_rendering_amd 0.4 (gfx950)"; }
+#endif
 int32_t hr_api_revision(void) { return HR_API_REVISION; }
 
 hr_status hr_ctx_create(int device_ordinal, hr_ctx** out)

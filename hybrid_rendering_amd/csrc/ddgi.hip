@@ -6,7 +6,9 @@
 #include "hr_internal.h"
 #include "shading.h"
 #include "pass_args.h"
+#ifdef HR_DEV_PATHS
 #include "trace_queue.h"
+#endif
 
 using namespace hr;
 
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
             const float r2x = next_float(rng), r2y = next_float(rng);
             TraceCtx tc { a.nodes, a.tris, s_stack[wave], lane };
             HR_DIV(tc.dv = &dvs;)
+#if DDGI_SEQ && !defined(HR_DEV_PATHS)
+#error "-DDDGI_SEQ=1 is an A/B path: build with -DHR_DEV_PATHS"
+#endif
 #if DDGI_SEQ
             // the light ray and the sky ray of the hit point back to back per lane inside ONE wave loop (traverse.h trace_any_seq) instead of
             // two wave-level traversals; the visibilities enter direct_lighting's result exactly as in shading.h DirectSplit
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(64 * DDGI_TRACE_WAVES, DDGI_TRACE_EU) void k_ddgi_t
     }
 }
 
+#ifdef HR_DEV_PATHS   // A/B path that lost (>= 500 us against 333, docs/EXPERIMENTS.md 4.3); build with HR_CFLAGS=-DHR_DEV_PATHS, select with HR_DDGI_WAVEFRONT=1
 // ---- wavefront form of ray_trace() (trace_queue.h): gen -> closest-hit queue -> shade + secondary queue -> any-hit queue -> combine
 struct DDGIWaveArgs
 {
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(256) void k_ddgi_combine(DDGIWaveArgs w)
     if (p2.w & 2u) L = add3(L, I);
     a.radiance[(size_t)probe * R + ray] = make_uint2(pack_h2(L.x, L.y), pack_h2(L.z, 0.0f));
 }
+#endif // HR_DEV_PATHS
 
 // ------------------------------------------------------------------------------------------------
 struct DDGIUpdateArgs
@@ -534,11 +541,13 @@ hr_status hr_ddgi_create(hr_ctx* ctx, int32_t full_width, int32_t full_height, h
     A(sample, (size_t)p->w * p->h * 8)
     A(counters, 64)
     A(ray_slots, ((nr + 255) / 256) * 4 * 4)
+#ifdef HR_DEV_PATHS
     if (const char* e = getenv("HR_DDGI_WAVEFRONT")) p->wavefront = atoi(e) != 0;   // developer A/B switch, read once
     if (p->wavefront)
     {
         A(wf_rays, nr * sizeof(RayRec)) A(wf_hits, nr * 16) A(wf_sec_rays, 2 * nr * sizeof(RayRec)) A(wf_occluded, 2 * nr) A(wf_part, nr * 48)
     }
+#endif
 #undef A
     for (int i = 0; i < 2; i++) { HR_HIP(hipMemset(p->irr[i].p, 0, ib)); HR_HIP(hipMemset(p->dep[i].p, 0, db)); }
     HR_HIP(hipMemset(p->counters.p, 0, 64));
@@ -620,6 +629,7 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
         return HR_OK;
     }
     int ev = p->prof.begin("ray_trace", st, (uint64_t)n * 16);
+#ifdef HR_DEV_PATHS
     if (p->wavefront)
     {
         // queue words (counters + 32): word 1 = length of the secondary queue (appended by k_ddgi_shade, read by the any-hit queue kernel)
@@ -641,6 +651,7 @@ hr_status hr_ddgi_ray_trace(hr_ddgi* p, const hr_scene* scene, const hr_frame_in
         hipLaunchKernelGGL(k_ddgi_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w);
     }
     else
+#endif
     {
         const int tb = 64 * DDGI_TRACE_WAVES;
         hipLaunchKernelGGL(k_ddgi_trace<false>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, st, a);

@@ -315,7 +315,10 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
     float sum_w   = 0.0f;
     // deliberately NOT unrolled: fully unrolled the eight probes' fetches overlap, but the kernels that inline this need
     // 168-178 VGPRs (2-3 waves per SIMD) — DDGI trace 0.43 -> 0.69 ms, reflections trace 0.31 -> 0.47 ms, sample pass unchanged
-#pragma unroll 1
+#ifndef HR_IRR_UNROLL
+#define HR_IRR_UNROLL 1   // round 6, partial unrolling re-measured (profiles/r6_d/ab_exact_gather_unroll.txt): 2 -> reflections trace 174 / 481 us (1: 172 / 467),
+#endif                    // DDGI trace 262 / 260 (1: 262 / 259); 4 -> 183 / 530 and 275 / 282.  The rolled loop stays.
+#pragma unroll HR_IRR_UNROLL
     for (int i = 0; i < 8; ++i)
     {
         const IrrTerm t = irradiance_probe_term(d, P, N, Wo, irradiance, depth, c, i);
@@ -651,6 +654,7 @@ HR_DEV f3 direct_lighting(TraceCtx& tc, const hr_light& light, f3 Wo, f3 N, f3 P
     return Lo;
 }
 
+#ifdef HR_DEV_PATHS   // only the A/B paths that lost use it (ddgi.hip wavefront kernels, -DDDGI_SEQ)
 // direct_lighting split for the wavefront path (trace_queue.h): everything but the two visibility rays.  With occlusion o1 / o2 of
 // the light ray and the sky ray known, direct_lighting's result is, operation for operation,
 //     Lo = (ray1 && o1) ? 0 : P1;   if (sky && !o2) Lo = Lo + P2;
@@ -690,6 +694,7 @@ HR_DEV DirectSplit direct_lighting_split(const hr_light& light, f3 Wo, f3 N, f3 
     }
     return s;
 }
+#endif // HR_DEV_PATHS
 
 } // namespace hr
 

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(64 * TRACE_WAVES, SHADOWS_TRACE_EU) void k_shadows_
     }
 }
 
+#ifdef HR_DEV_PATHS   // A/B path that lost (13 % slower, docs/EXPERIMENTS.md 4.2); build with HR_CFLAGS=-DHR_DEV_PATHS, select with HR_TRACE_KERNEL=queue
 // ------------------------------------------------------------------------------------------------
 // Persistent-wave variant (HR_TRACE_KERNEL=queue; NOT the default — measured 13% slower on the bench scene although it
 // raises the SIMD lane utilisation of the traversal loop from 0.50 to 0.83-0.89: mixing rays of several tiles and
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void k_shadows_trace_pw(TraceArgs a)
         }
     }
 }
+#endif // HR_DEV_PATHS
 
 // ------------------------------------------------------------------------------------------------
 
@@ -592,7 +594,9 @@ hr_status hr_shadows_create(hr_ctx* ctx, int32_t full_width, int32_t full_height
     HR_HIP(hipSetDevice(ctx->device));
     hr_shadows* p = new hr_shadows();
     p->ctx = ctx; p->full_w = full_width; p->full_h = full_height; p->scale = (int)scale;
+#ifdef HR_DEV_PATHS
     { const char* e = getenv("HR_TRACE_KERNEL"); p->persistent_waves = (e && std::string(e) == "queue"); }
+#endif
     if (const char* e = getenv("HR_DEBUG_ONLY_TILE")) sscanf(e, "%d,%d", &p->dbg_only_tx, &p->dbg_only_ty);
     if (const char* e = getenv("HR_FUSE")) p->fuse = atoi(e) != 0;
     if (const char* e = getenv("HR_SHADOW_CACHE")) p->occluder_cache = atoi(e) != 0;
@@ -778,8 +782,11 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         // instrumented build of the same kernel: counts node visits / triangle tests
         HR_HIP(hipMemsetAsync((char*)p->counters.p + 16, 0, 24, st));
         a.stats = (unsigned long long*)((char*)p->counters.p + 16);
+#ifdef HR_DEV_PATHS
         if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<true>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+        else
+#endif
+        hipLaunchKernelGGL(k_shadows_trace<true>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
         HR_HIP(hipGetLastError());
         return HR_OK;
     }
@@ -800,8 +807,11 @@ hr_status hr_shadows_ray_trace(hr_shadows* p, const hr_scene* scene, const hr_fr
         a.timeline = nullptr;
     }
     int ev = p->prof.begin("ray_trace", st, px * 12 + px / 8);
+#ifdef HR_DEV_PATHS
     if (p->persistent_waves) hipLaunchKernelGGL(k_shadows_trace_pw<false>, dim3(cdiv(n_tiles, PW_TILES)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
+    else
+#endif
+    hipLaunchKernelGGL(k_shadows_trace<false>, dim3(cdiv(n_slots, TRACE_WAVES)), dim3(64 * TRACE_WAVES), 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     if (a.cost && !p->persistent_waves && (s = p->tile_order.traced(n_tiles, st)) != HR_OK) return s;

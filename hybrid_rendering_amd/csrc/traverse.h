@@ -411,6 +411,7 @@ HR_DEV bool trace_any(const Node8* __restrict__ nodes, const TriGPU* __restrict_
 HR_DEV void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 HR_DEV uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
+#ifdef HR_DEV_PATHS   // A/B paths that lost (docs/EXPERIMENTS.md 4.3): -DAO_SEQ / -DDDGI_SEQ need -DHR_DEV_PATHS
 // ---- lane-sequential any-hit rays ---------------------------------------------------------------------------------------------
 // NB rays per lane (the sample rays of one AO pixel), walked back to back INSIDE one wave-level loop: a lane whose ray is done
 // (occluded, or its stack ran empty) switches to its next ray at once instead of idling until the slowest lane of the wave has
@@ -518,7 +519,9 @@ HR_DEV uint32_t trace_any_seq(bool active, int n_rays, const Node8* __restrict__
     }
     return occluded;
 }
+#endif // HR_DEV_PATHS
 
+#ifdef HR_DEV_PATHS   // the persistent-wave shadow trace (shadows.hip k_shadows_trace_pw) and the wavefront queue kernels (trace_queue.h)
 // ---- step-wise any-hit traversal (for persistent waves that refill idle lanes from a ray queue) ------------------
 struct AnyHitLane
 {
@@ -559,6 +562,7 @@ HR_DEV int anyhit_step(AnyHitLane& s, const Node8* __restrict__ nodes, const Tri
     }
     return ((s.cur & 0xffu) != 0u || s.st.sp > 0) ? 0 : 2;
 }
+#endif // HR_DEV_PATHS
 
 struct HitRec
 {

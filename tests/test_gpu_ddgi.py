@@ -70,12 +70,3 @@ def test_ddgi_intensities_not_one(oracle, hr, ctx):
     back end once fused it into v_fma_mixlo_f16 — one rounding of the exact product; found by tools/fuzz_gpu.py)"""
     _run(oracle, hr, ctx, "sponza_small", 139, 108, (3, 2, 3), 24, 2, params=dict(infinite_bounces=True, infinite_bounce_intensity=1.7469917, gi_intensity=0.9183527))
     _run(oracle, hr, ctx, "sponza_small", 171, 121, (3, 2, 3), 24, 2, params=dict(infinite_bounces=False, infinite_bounce_intensity=1.58, gi_intensity=1.4340005))
-
-
-def test_ddgi_wavefront_variant(oracle, hr, ctx, monkeypatch):
-    """HR_DDGI_WAVEFRONT=1 (developer A/B, csrc/trace_queue.h): ray generation -> persistent closest-hit queue -> dense hit shading
-    with a secondary ray queue -> persistent any-hit queue -> combine.  Same images, bit for bit, as the single-kernel path and the
-    oracle (it is not the default because it is slower: DESIGN.md §4)."""
-    monkeypatch.setenv("HR_DDGI_WAVEFRONT", "1")
-    _run(oracle, hr, ctx, "sponza_small", 160, 96, (6, 3, 5), 128, 3)
-    _run(oracle, hr, ctx, "sponza_small", 96, 64, (4, 3, 4), 96, 2, light_kind="point", params=dict(infinite_bounce_intensity=0.8, gi_intensity=2.0))
