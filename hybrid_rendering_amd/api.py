@@ -91,7 +91,7 @@ SCALE_FULL_RES, SCALE_HALF_RES, SCALE_QUARTER_RES = 0, 1, 2
 
 # every symbol include/hr_api.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info", "hr_scene_id", "hr_scene_create_instanced", "hr_scene_update_instances", "hr_scene_instance_count", "hr_scene_read_bvh", "hr_set_markers", "hr_markers_log",
+    "hr_status_string", "hr_last_error", "hr_version", "hr_api_revision", "hr_ctx_create", "hr_ctx_destroy", "hr_ctx_device", "hr_scene_create", "hr_scene_get_info", "hr_scene_id", "hr_scene_create_instanced", "hr_scene_update_instances", "hr_scene_instance_count", "hr_scene_rebuild_top_level", "hr_scene_top_level_rebuilds", "hr_scene_read_bvh", "hr_set_markers", "hr_markers_log",
     "hr_scene_destroy", "hr_trace_any_hit", "hr_trace_closest_hit", "hr_gbuffer_raycast", "hr_shadows_default_params", "hr_shadows_create",
     "hr_shadows_render", "hr_shadows_output", "hr_shadows_reset_history", "hr_shadows_destroy", "hr_shadows_ray_trace", "hr_shadows_denoise", "hr_shadows_temporal",
     "hr_shadows_atrous_iteration", "hr_shadows_upsample", "hr_shadows_image", "hr_shadows_history_apron_exceeded", "hr_shadows_set_profiling", "hr_shadows_get_stage_times",
@@ -279,6 +279,13 @@ class InstancedScene(Scene):
         _check(lib().hr_scene_create_instanced(ctx.h, C.byref(d), C.byref(self.h)), "hr_scene_create_instanced")
         self.info = hr_scene_info()
         self.refresh_info()
+
+    def rebuild_top_level(self, stream=None):
+        _check(lib().hr_scene_rebuild_top_level(self.h, _stream_ptr(stream)), "hr_scene_rebuild_top_level")
+
+    @property
+    def top_level_rebuilds(self) -> int:
+        return int(lib().hr_scene_top_level_rebuilds(self.h))
 
     def update(self, matrices, stream=None):
         """hr_scene_update_instances: matrices [n_instances][16] column-major (host); enqueued on ``stream`` (default: torch's current stream)"""

@@ -246,6 +246,23 @@ struct hr_scene
     uint64_t      geometry_epoch = 0;   // bumped by every update: with `uid` the key of geometry-dependent caches of the passes (AO entry table)
     hr::DevBuf    inst_records, tri_instance, mesh_positions, mesh_normals, mesh_uvs, mesh_tangents, mesh_material;
     hr::DevBuf    level_nodes, node_box, bounds_bits, leaf_cells, node_inst, inst_dirty_dev;
+    // the top level over the instance roots lives in the first `top_cap` node slots and can be RE-BUILT (host SAH over the instances' boxes, then
+    // the slots, the level lists and everything above the subtrees are uploaded again): what a fixed top level loses after long motion
+    int                   top_cap = 1;            // node slots reserved for top-level nodes + instance roots (2 x instances)
+    std::vector<hr::Node8> inst_root_node;        // per instance: its subtree's root (topology fields final), wherever the top level puts it
+    std::vector<float>    inst_root_cells;        // per instance: the 48 leaf-cell floats of that root
+    std::vector<int32_t>  node_inst_host, node_rel_depth;   // per node: owning instance (-1 top level) / depth below the instance root
+    std::vector<float>    inst_box;               // per instance: conservative world box (lo xyz, hi xyz) of the last update, host side
+    std::vector<int32_t>  top_parent, top_first_child;      // host mirror of the top level (slot -> parent slot / first child slot) for its quality check
+    std::vector<hr::Node8> top_nodes_host;        // upload staging, kept alive for the asynchronous copies
+    std::vector<uint32_t> level_nodes_host;
+    std::vector<int32_t>  inst_root_slot;
+    std::vector<float>    top_cells_host;
+    int           top_used = 1;
+    bool          auto_rebuild = true;            // HR_TOP_LEVEL_REBUILD=0 switches the automatic re-build off (developer A/B)
+    double        rebuild_ratio = 1.5;
+    double        top_area_at_build = 0.0;        // sum of the top-level nodes' half areas when it was built: the re-build trigger compares against it
+    int           top_rebuilds = 0;
     std::vector<uint32_t> inst_dirty;             // per instance: its matrix changed in the update being enqueued
     std::vector<int32_t>  level_offsets;          // level_nodes[level_offsets[d] .. level_offsets[d + 1]): the nodes of depth d
     std::vector<uint32_t> inst_mesh;              // per instance: mesh index

@@ -257,34 +257,236 @@ bool finite16(const float* m)
     return true;
 }
 
-// conservative world bounds of the instances (the eight corners of every mesh box through its matrix, in double, widened by an ulp-scale
-// margin) — what the box padding and the passes' grids are sized from without reading anything back
-void conservative_bounds(const hr_scene* s, float* lo, float* hi)
+// ---- the top level ------------------------------------------------------------------------------------------------------------------
+// Host side.  Inputs are the instances' conservative world boxes (mesh box corners through the matrix, in double); the result is a binary
+// SAH tree (full sweep along the three axes of the box centres) collapsed to 8-wide nodes by opening the child with the largest area first,
+// laid out breadth first in the first top_cap node slots: the children of a node — other top-level nodes and instance ROOTS alike, both are
+// "internal children" to the traversal — sit contiguously, sorted along the node's longest axis (the traversal's near-to-far hint).
+struct TopLevel
 {
-    double l[3] = { 1e300, 1e300, 1e300 }, h[3] = { -1e300, -1e300, -1e300 };
-    for (int i = 0; i < s->n_instances; i++)
+    std::vector<Node8>   nodes;       // top_cap slots; instance-root slots are filled in by place_roots()
+    std::vector<int32_t> inst;        // per slot: -1 = top-level node, else the instance whose root sits there
+    std::vector<int32_t> depth;       // per slot
+    std::vector<int32_t> root_slot;   // per instance
+    int                  used = 0, max_depth = 0;
+};
+struct BinNode { float lo[3], hi[3]; int left, right, inst; };
+
+inline double half_area(const float* lo, const float* hi)
+{
+    const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+
+int build_binary(std::vector<BinNode>& t, std::vector<int>& items, int begin, int end, const float* boxes, int depth)
+{
+    BinNode n;
+    for (int a = 0; a < 3; a++) { n.lo[a] = INFINITY; n.hi[a] = -INFINITY; }
+    for (int k = begin; k < end; k++)
+        for (int a = 0; a < 3; a++) { n.lo[a] = std::min(n.lo[a], boxes[(size_t)items[(size_t)k] * 6 + a]); n.hi[a] = std::max(n.hi[a], boxes[(size_t)items[(size_t)k] * 6 + 3 + a]); }
+    n.left = n.right = -1; n.inst = -1;
+    const int id = (int)t.size();
+    t.push_back(n);
+    const int cnt = end - begin;
+    if (cnt == 1) { t[(size_t)id].inst = items[(size_t)begin]; return id; }
+    int    best_axis = -1, best_split = begin + cnt / 2;
+    double best_cost = 1e300;
+    std::vector<int>    sorted(items.begin() + begin, items.begin() + end), best_sorted;
+    std::vector<double> right_area((size_t)cnt);
+    if (depth < 40)   // beyond that: median splits (the traversal stack bounds the depth)
+        for (int a = 0; a < 3; a++)
+        {
+            std::stable_sort(sorted.begin(), sorted.end(), [&](int x, int y) {
+                return (double)boxes[(size_t)x * 6 + a] + boxes[(size_t)x * 6 + 3 + a] < (double)boxes[(size_t)y * 6 + a] + boxes[(size_t)y * 6 + 3 + a]; });
+            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int k = cnt - 1; k > 0; k--)
+            {
+                for (int b = 0; b < 3; b++) { lo[b] = std::min(lo[b], boxes[(size_t)sorted[(size_t)k] * 6 + b]); hi[b] = std::max(hi[b], boxes[(size_t)sorted[(size_t)k] * 6 + 3 + b]); }
+                right_area[(size_t)k] = half_area(lo, hi);
+            }
+            for (int b = 0; b < 3; b++) { lo[b] = INFINITY; hi[b] = -INFINITY; }
+            for (int k = 1; k < cnt; k++)
+            {
+                for (int b = 0; b < 3; b++) { lo[b] = std::min(lo[b], boxes[(size_t)sorted[(size_t)k - 1] * 6 + b]); hi[b] = std::max(hi[b], boxes[(size_t)sorted[(size_t)k - 1] * 6 + 3 + b]); }
+                const double c = half_area(lo, hi) * k + right_area[(size_t)k] * (cnt - k);
+                if (c < best_cost) { best_cost = c; best_axis = a; best_split = begin + k; best_sorted = sorted; }
+            }
+        }
+    if (best_axis >= 0) std::copy(best_sorted.begin(), best_sorted.end(), items.begin() + begin);
+    const int l = build_binary(t, items, begin, best_split, boxes, depth + 1);
+    const int r = build_binary(t, items, best_split, end, boxes, depth + 1);
+    t[(size_t)id].left = l; t[(size_t)id].right = r;
+    return id;
+}
+
+// per instance: conservative world box (host); also the scene's conservative bounds (grid_lo / grid_hi)
+void instance_boxes(hr_scene* s)
+{
+    const int I = s->n_instances;
+    s->inst_box.assign((size_t)I * 6, 0.0f);
+    double L[3] = { 1e300, 1e300, 1e300 }, H[3] = { -1e300, -1e300, -1e300 };
+    for (int i = 0; i < I; i++)
     {
         const float* m  = s->inst_host[(size_t)i].m;
         const float* mb = &s->mesh_bounds[(size_t)s->inst_mesh[(size_t)i] * 6];
-        if (!(mb[0] <= mb[3])) continue;   // empty mesh
-        for (int c = 0; c < 8; c++)
-        {
-            const double x = mb[(c & 1) ? 3 : 0], y = mb[(c & 2) ? 4 : 1], z = mb[(c & 4) ? 5 : 2];
-            for (int k = 0; k < 3; k++)
+        double l[3] = { 1e300, 1e300, 1e300 }, h[3] = { -1e300, -1e300, -1e300 };
+        if (mb[0] <= mb[3])
+            for (int c = 0; c < 8; c++)
             {
-                const double v = (double)m[k] * x + (double)m[4 + k] * y + (double)m[8 + k] * z + (double)m[12 + k];
-                const double e = 1e-6 * (std::fabs((double)m[k] * x) + std::fabs((double)m[4 + k] * y) + std::fabs((double)m[8 + k] * z) + std::fabs((double)m[12 + k]));
-                l[k] = std::min(l[k], v - e); h[k] = std::max(h[k], v + e);
+                const double x = mb[(c & 1) ? 3 : 0], y = mb[(c & 2) ? 4 : 1], z = mb[(c & 4) ? 5 : 2];
+                for (int k = 0; k < 3; k++)
+                {
+                    const double v = (double)m[k] * x + (double)m[4 + k] * y + (double)m[8 + k] * z + (double)m[12 + k];
+                    const double e = 1e-6 * (std::fabs((double)m[k] * x) + std::fabs((double)m[4 + k] * y) + std::fabs((double)m[8 + k] * z) + std::fabs((double)m[12 + k]));
+                    l[k] = std::min(l[k], v - e); h[k] = std::max(h[k], v + e);
+                }
             }
+        else
+            for (int k = 0; k < 3; k++) { l[k] = h[k] = (double)m[12 + k]; }   // empty mesh: a point at the instance's origin
+        for (int k = 0; k < 3; k++)
+        {
+            float lo = (float)l[k], hi = (float)h[k];
+            if ((double)lo > l[k]) lo = std::nextafter(lo, -INFINITY);
+            if ((double)hi < h[k]) hi = std::nextafter(hi, INFINITY);
+            s->inst_box[(size_t)i * 6 + k] = lo; s->inst_box[(size_t)i * 6 + 3 + k] = hi;
+            if (mb[0] <= mb[3]) { L[k] = std::min(L[k], (double)lo); H[k] = std::max(H[k], (double)hi); }
         }
     }
     for (int k = 0; k < 3; k++)
     {
-        if (!(l[k] <= h[k])) { l[k] = 0.0; h[k] = 0.0; }
-        lo[k] = (float)l[k]; hi[k] = (float)h[k];
-        if ((double)lo[k] > l[k]) lo[k] = std::nextafter(lo[k], -INFINITY);
-        if ((double)hi[k] < h[k]) hi[k] = std::nextafter(hi[k], INFINITY);
+        if (!(L[k] <= H[k])) { L[k] = 0.0; H[k] = 0.0; }
+        s->grid_lo[k] = (float)L[k]; s->grid_hi[k] = (float)H[k];
     }
+}
+
+void build_top_level(const hr_scene* s, TopLevel& tl)
+{
+    const int I = s->n_instances;
+    tl.nodes.assign((size_t)s->top_cap, Node8());
+    std::memset(tl.nodes.data(), 0, tl.nodes.size() * sizeof(Node8));
+    tl.inst.assign((size_t)s->top_cap, -1);
+    tl.depth.assign((size_t)s->top_cap, 0);
+    tl.root_slot.assign((size_t)I, 0);
+    tl.used = 1; tl.max_depth = 0;
+    if (I == 1) { tl.inst[0] = 0; return; }
+    std::vector<BinNode> bin;
+    bin.reserve((size_t)I * 2);
+    std::vector<int> items((size_t)I);
+    for (int i = 0; i < I; i++) items[(size_t)i] = i;
+    const int root = build_binary(bin, items, 0, I, s->inst_box.data(), 0);
+    struct Q { int bin, slot, depth; };
+    std::vector<Q> queue { { root, 0, 0 } };
+    for (size_t qi = 0; qi < queue.size(); qi++)
+    {
+        const Q q = queue[qi];
+        // open the child of largest area until eight children stand (instance leaves cannot be opened)
+        int kids[8], nk = 2;
+        kids[0] = bin[(size_t)q.bin].left; kids[1] = bin[(size_t)q.bin].right;
+        while (nk < 8)
+        {
+            int    best = -1;
+            double ba = -1.0;
+            for (int c = 0; c < nk; c++)
+                if (bin[(size_t)kids[c]].inst < 0)
+                {
+                    const double ar = half_area(bin[(size_t)kids[c]].lo, bin[(size_t)kids[c]].hi);
+                    if (ar > ba) { ba = ar; best = c; }
+                }
+            if (best < 0) break;
+            const int k = kids[best];
+            kids[best] = bin[(size_t)k].left; kids[nk++] = bin[(size_t)k].right;
+        }
+        // sorted along the longest axis of the node's box: the traversal walks them near to far / far to near by the ray's sign (bvh.h)
+        const BinNode& me = bin[(size_t)q.bin];
+        int ax = 0;
+        if (me.hi[1] - me.lo[1] > me.hi[ax] - me.lo[ax]) ax = 1;
+        if (me.hi[2] - me.lo[2] > me.hi[ax] - me.lo[ax]) ax = 2;
+        std::stable_sort(kids, kids + nk, [&](int x, int y) { return (double)bin[(size_t)x].lo[ax] + bin[(size_t)x].hi[ax] < (double)bin[(size_t)y].lo[ax] + bin[(size_t)y].hi[ax]; });
+        Node8& n = tl.nodes[(size_t)q.slot];
+        n.ex = n.ey = n.ez = 1;
+        n.counts = (uint8_t)(nk | (nk << 4));
+        n.child_base = (uint32_t)tl.used;
+        n.tri_base = 0;
+        for (int c = 0; c < nk; c++) n.meta[c] = (uint8_t)(0x10 | (c == 0 ? ax : 0));
+        tl.inst[(size_t)q.slot] = -1; tl.depth[(size_t)q.slot] = q.depth;
+        for (int c = 0; c < nk; c++)
+        {
+            const int slot = tl.used++;
+            tl.depth[(size_t)slot] = q.depth + 1;
+            tl.max_depth = std::max(tl.max_depth, q.depth + 1);
+            if (bin[(size_t)kids[c]].inst >= 0) { tl.inst[(size_t)slot] = bin[(size_t)kids[c]].inst; tl.root_slot[(size_t)bin[(size_t)kids[c]].inst] = slot; }
+            else queue.push_back({ kids[c], slot, q.depth + 1 });
+        }
+    }
+}
+
+// half-area sum of the top-level nodes with the instances' CURRENT boxes (host refit of the top region): what a re-build is judged by
+double top_level_area(const hr_scene* s, const TopLevel* fresh = nullptr)
+{
+    const std::vector<Node8>&   nodes = fresh ? fresh->nodes : s->top_nodes_host;
+    const std::vector<int32_t>& inst  = fresh ? fresh->inst : s->node_inst_host;
+    const int used = fresh ? fresh->used : s->top_used;
+    if (s->n_instances <= 1) return 0.0;
+    std::vector<float> box((size_t)used * 6);
+    double sum = 0.0;
+    for (int slot = used - 1; slot >= 0; slot--)   // children sit behind their parent
+    {
+        float* b = &box[(size_t)slot * 6];
+        if (inst[(size_t)slot] >= 0) { std::memcpy(b, &s->inst_box[(size_t)inst[(size_t)slot] * 6], 24); continue; }
+        const Node8& n = nodes[(size_t)slot];
+        for (int a = 0; a < 3; a++) { b[a] = INFINITY; b[3 + a] = -INFINITY; }
+        for (int c = 0; c < (n.counts >> 4); c++)
+            for (int a = 0; a < 3; a++) { b[a] = std::min(b[a], box[((size_t)n.child_base + c) * 6 + a]); b[3 + a] = std::max(b[3 + a], box[((size_t)n.child_base + c) * 6 + 3 + a]); }
+        sum += half_area(b, b + 3);
+    }
+    return sum;
+}
+
+// writes the top level into the scene's host mirrors: node slots (top-level nodes + instance roots), owner / cell arrays, level lists
+void adopt_top_level(hr_scene* s, const TopLevel& tl)
+{
+    const int I = s->n_instances;
+    const size_t n_nodes = s->node_inst_host.size();
+    s->top_nodes_host = tl.nodes;
+    s->top_used = tl.used;
+    s->inst_root_slot = tl.root_slot;
+    s->top_cells_host.assign((size_t)s->top_cap * 48, 0.0f);
+    for (int slot = 0; slot < s->top_cap; slot++) s->node_inst_host[(size_t)slot] = -1;
+    for (int i = 0; i < I; i++)
+    {
+        const int slot = tl.root_slot[(size_t)i];
+        s->top_nodes_host[(size_t)slot] = s->inst_root_node[(size_t)i];
+        s->node_inst_host[(size_t)slot] = i;
+        std::memcpy(&s->top_cells_host[(size_t)slot * 48], &s->inst_root_cells[(size_t)i * 48], 48 * sizeof(float));
+    }
+    // unused slots of the region: childless nodes nobody points at (the refit skips them: depth -1)
+    int max_depth = 0;
+    std::vector<int32_t> depth(n_nodes, -1);
+    for (int slot = 0; slot < tl.used; slot++) depth[(size_t)slot] = tl.depth[(size_t)slot];
+    for (size_t j = (size_t)s->top_cap; j < n_nodes; j++)
+    {
+        const int i = s->node_inst_host[j];
+        depth[j] = tl.depth[(size_t)tl.root_slot[(size_t)i]] + s->node_rel_depth[j];
+    }
+    for (size_t j = 0; j < n_nodes; j++) max_depth = std::max(max_depth, depth[j]);
+    s->info.max_depth = max_depth;
+    s->level_offsets.assign((size_t)max_depth + 2, 0);
+    for (size_t j = 0; j < n_nodes; j++) if (depth[j] >= 0) s->level_offsets[(size_t)depth[j] + 1]++;
+    for (size_t dd = 0; dd + 1 < s->level_offsets.size(); dd++) s->level_offsets[dd + 1] += s->level_offsets[dd];
+    s->level_nodes_host.assign(n_nodes, 0u);
+    std::vector<int32_t> cur(s->level_offsets.begin(), s->level_offsets.end() - 1);
+    for (size_t j = 0; j < n_nodes; j++) if (depth[j] >= 0) s->level_nodes_host[(size_t)cur[(size_t)depth[j]]++] = (uint32_t)j;
+    s->top_area_at_build = top_level_area(s);
+}
+
+// the top region + the level lists to the device, ordered on `st`
+hr_status upload_top_level(hr_scene* s, hipStream_t st)
+{
+    HR_HIP(hipMemcpyAsync(s->nodes.p, s->top_nodes_host.data(), (size_t)s->top_cap * sizeof(Node8), hipMemcpyHostToDevice, st));
+    HR_HIP(hipMemcpyAsync(s->node_inst.p, s->node_inst_host.data(), (size_t)s->top_cap * 4, hipMemcpyHostToDevice, st));
+    HR_HIP(hipMemcpyAsync(s->leaf_cells.p, s->top_cells_host.data(), (size_t)s->top_cap * 48 * 4, hipMemcpyHostToDevice, st));
+    HR_HIP(hipMemcpyAsync(s->level_nodes.p, s->level_nodes_host.data(), s->level_nodes_host.size() * 4, hipMemcpyHostToDevice, st));
+    return HR_OK;
 }
 
 hr_status update_impl(hr_scene* s, const float* matrices, hipStream_t st, bool all_dirty)
@@ -309,7 +511,7 @@ hr_status update_impl(hr_scene* s, const float* matrices, hipStream_t st, bool a
     // the records are small (80 B per instance); the copies are ordered on `st` and read the scene's own host arrays, which live until the next update
     HR_HIP(hipMemcpyAsync(s->inst_records.p, s->inst_host.data(), (size_t)m * sizeof(InstanceRec), hipMemcpyHostToDevice, st));
     HR_HIP(hipMemcpyAsync(s->inst_dirty_dev.p, s->inst_dirty.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-    conservative_bounds(s, s->grid_lo, s->grid_hi);
+    instance_boxes(s);
     {
         const double dx = (double)s->grid_hi[0] - s->grid_lo[0], dy = (double)s->grid_hi[1] - s->grid_lo[1], dz = (double)s->grid_hi[2] - s->grid_lo[2];
         float pad = (float)(3e-5 * std::sqrt(dx * dx + dy * dy + dz * dz));   // bvh_build.cpp: well above the fp32 error of the triangle test
@@ -317,6 +519,25 @@ hr_status update_impl(hr_scene* s, const float* matrices, hipStream_t st, bool a
         // subtrees that stand keep the pad they were refitted with; the refitted ones never get a smaller one (250x the fp32 epsilon of the
         // scene's diagonal: a scene that doubles in size still leaves the standing boxes a margin of two orders of magnitude)
         if (all_dirty || pad > s->info.box_pad) s->info.box_pad = pad;
+    }
+    // The top level is re-built when the instances have moved far enough for its boxes to overlap: the half-area sum of its nodes over the
+    // instances' current boxes against the sum when it was built (host arithmetic over `instances` boxes; the reference re-builds its TLAS
+    // every frame, main.cpp:74).  A re-build re-places the instance roots, so every level is refitted once.
+    if (!all_dirty && m > 1 && s->auto_rebuild && top_level_area(s) > s->rebuild_ratio * s->top_area_at_build)
+    {
+        TopLevel tl;
+        build_top_level(s, tl);
+        if (top_level_area(s, &tl) < 0.9 * top_level_area(s))   // only if the fresh one IS better (instances that merely spread out gain nothing)
+        {
+            adopt_top_level(s, tl);
+            const hr_status us = upload_top_level(s, st);
+            if (us != HR_OK) return us;
+            s->top_rebuilds++;
+            all_dirty = true;
+            for (int i = 0; i < m; i++) s->inst_dirty[(size_t)i] = 1u;
+            HR_HIP(hipMemcpyAsync(s->inst_dirty_dev.p, s->inst_dirty.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+        }
+        else s->top_area_at_build = top_level_area(s);   // the spread is the new normal
     }
     const uint32_t* dirty = (const uint32_t*)s->inst_dirty_dev.p;
     hipLaunchKernelGGL(k_instances_reset_bounds, dim3(cdiv(m, 256)), dim3(256), 0, st, (uint32_t*)s->bounds_bits.p, dirty, m);
@@ -399,7 +620,7 @@ hr_status create_impl(hr_ctx* ctx, const hr_instanced_scene_desc* d, hr_scene** 
             for (int c = 0; c < (b.nodes[j].counts & 15); c++) dep[(size_t)b.nodes[j].child_base + c] = dep[j] + 1;
     }
 
-    // ---- top level: instances in Morton order of their (initial) world box centres, grouped by eight, level by level --------------------
+    // ---- layout: [ top region: top-level nodes + instance roots, top_cap slots | instance 0's other nodes | instance 1's ... ] ------------------
     s->n_instances = I;
     s->inst_mesh.resize((size_t)I);
     s->inst_host.resize((size_t)I);
@@ -414,95 +635,43 @@ hr_status create_impl(hr_ctx* ctx, const hr_instanced_scene_desc* d, hr_scene** 
         total_tris += (uint64_t)d->meshes[k].n_tris; total_refs += blas[k].tris.size(); total_sub_nodes += blas[k].nodes.size() - 1;
     }
     if (total_tris >= (1ull << 31) || total_refs >= (1ull << 26)) { set_last_error("hr_scene_create_instanced: more than 2^26 triangle references"); return HR_ERR_UNSUPPORTED; }
-    conservative_bounds(s, s->grid_lo, s->grid_hi);
-    std::vector<int> order((size_t)I);
-    for (int i = 0; i < I; i++) order[(size_t)i] = i;
-    if (I > 1)
-    {
-        std::vector<uint64_t> code((size_t)I);
-        for (int i = 0; i < I; i++)
-        {
-            const float* m  = s->inst_host[(size_t)i].m;
-            const float* mb = &s->mesh_bounds[(size_t)s->inst_mesh[(size_t)i] * 6];
-            const double c[3] = { 0.5 * ((double)mb[0] + mb[3]), 0.5 * ((double)mb[1] + mb[4]), 0.5 * ((double)mb[2] + mb[5]) };
-            uint64_t key = 0;
-            uint32_t q[3];
-            for (int a = 0; a < 3; a++)
-            {
-                const double w   = (double)m[a] * c[0] + (double)m[4 + a] * c[1] + (double)m[8 + a] * c[2] + (double)m[12 + a];
-                const double ext = (double)s->grid_hi[a] - s->grid_lo[a];
-                double       u   = ext > 0.0 ? (w - s->grid_lo[a]) / ext : 0.0;
-                u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
-                q[a] = (uint32_t)(u * 1048575.0);
-            }
-            for (int b = 19; b >= 0; b--)
-                for (int a = 0; a < 3; a++) key = (key << 1) | ((q[a] >> b) & 1u);
-            code[(size_t)i] = key;
-        }
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return code[(size_t)x] < code[(size_t)y]; });
-    }
-    // level sizes from the bottom (groups of eight instance roots) to a single root
-    std::vector<int> tl_sizes;   // bottom first
-    if (I > 1)
-    {
-        int n = I;
-        do { n = (n + 7) / 8; tl_sizes.push_back(n); } while (n > 1);
-    }
-    const int tl_levels = (int)tl_sizes.size();
-    int n_top = 0;
-    for (int v : tl_sizes) n_top += v;
-    const uint64_t n_nodes64 = (uint64_t)n_top + (uint64_t)I + total_sub_nodes;
+    s->top_cap = I > 1 ? 2 * I : 1;   // at most I - 1 top-level nodes over I roots
+    const uint64_t n_nodes64 = (uint64_t)s->top_cap + total_sub_nodes;
     if (n_nodes64 >= (1ull << 23)) { set_last_error("hr_scene_create_instanced: more than 2^23 BVH nodes"); return HR_ERR_UNSUPPORTED; }
     const size_t n_nodes = (size_t)n_nodes64;
     std::vector<Node8>  nodes(n_nodes);
-    std::vector<int>    depth(n_nodes, 0);
-    std::vector<float>   cells(n_nodes * 48, 0.0f);     // object-space cell of every leaf slot
-    std::vector<int32_t> node_inst(n_nodes, -1);
+    std::vector<float>  cells(n_nodes * 48, 0.0f);     // object-space cell of every leaf slot
     std::vector<TriGPU> tris((size_t)total_refs);
     std::memset(nodes.data(), 0, n_nodes * sizeof(Node8));
-    // top-level nodes, top-down: level L (0 = root) starts at tl_start[L]; its node g has the children [8 g, 8 g + 8) of the level below
-    std::vector<int> tl_start((size_t)tl_levels + 1, 0);
-    for (int L = 0; L < tl_levels; L++) tl_start[(size_t)L + 1] = tl_start[(size_t)L] + tl_sizes[(size_t)(tl_levels - 1 - L)];
-    const int roots_at = n_top;   // the instance roots, in `order`
-    for (int L = 0; L < tl_levels; L++)
-    {
-        const int count = tl_sizes[(size_t)(tl_levels - 1 - L)];
-        const int below = L + 1 < tl_levels ? tl_sizes[(size_t)(tl_levels - 2 - L)] : I;
-        const int below_at = L + 1 < tl_levels ? tl_start[(size_t)L + 1] : roots_at;
-        for (int g = 0; g < count; g++)
-        {
-            Node8& n = nodes[(size_t)tl_start[(size_t)L] + g];
-            const int nk = std::min(8, below - 8 * g);
-            n.ex = n.ey = n.ez = 1;
-            n.counts = (uint8_t)(nk | (nk << 4));
-            n.child_base = (uint32_t)(below_at + 8 * g);
-            n.tri_base = 0;
-            for (int c = 0; c < nk; c++) n.meta[c] = 0x10;   // slot 0's low bits: the axis the children are sorted along (0: the order is Morton, not sorted — only a hint)
-            depth[(size_t)tl_start[(size_t)L] + g] = L;
-        }
-    }
-    // instance subtrees
-    size_t node_at = (size_t)roots_at + (size_t)I, ref_at = 0;
-    int    max_depth = 0;
+    s->node_inst_host.assign(n_nodes, -1);
+    s->node_rel_depth.assign(n_nodes, 0);
+    s->inst_root_node.resize((size_t)I);
+    s->inst_root_cells.assign((size_t)I * 48, 0.0f);
+    size_t node_at = (size_t)s->top_cap, ref_at = 0;
+    int    max_rel = 0;
     std::vector<uint32_t> tri_instance((size_t)total_tris);
-    for (int oi = 0; oi < I; oi++)
+    for (int i = 0; i < I; i++)
     {
-        const int       i = order[(size_t)oi];
         const uint32_t  k = s->inst_mesh[(size_t)i];
         const BuiltBVH& b = blas[k];
-        const size_t    root = I > 1 ? (size_t)roots_at + (size_t)oi : 0;
-        const size_t    base = node_at;   // mesh node j >= 1 -> base + j - 1
+        const size_t    base = node_at;   // mesh node j >= 1 -> base + j - 1; the root (j = 0) goes wherever the top level puts it
         for (size_t j = 0; j < b.nodes.size(); j++)
         {
             Node8 n = b.nodes[j];
             if (n.counts & 15) n.child_base = (uint32_t)(base + n.child_base - 1);
             n.tri_base += (uint32_t)ref_at;
-            const size_t at = j == 0 ? root : base + j - 1;
+            if (j == 0)
+            {
+                s->inst_root_node[(size_t)i] = n;
+                std::memcpy(&s->inst_root_cells[(size_t)i * 48], &b.child_boxes[0], 48 * sizeof(float));
+                continue;
+            }
+            const size_t at = base + j - 1;
             nodes[at] = n;
-            node_inst[at] = i;
+            s->node_inst_host[at] = i;
+            s->node_rel_depth[at] = blas_depth[k][j];
             std::memcpy(&cells[at * 48], &b.child_boxes[j * 48], 48 * sizeof(float));
-            depth[at] = tl_levels + blas_depth[k][j];
-            max_depth = std::max(max_depth, depth[at]);
+            max_rel = std::max(max_rel, blas_depth[k][j]);
         }
         const InstanceRec& r = s->inst_host[(size_t)i];
         for (size_t t = 0; t < b.tris.size(); t++)
@@ -514,16 +683,19 @@ hr_status create_impl(hr_ctx* ctx, const hr_instanced_scene_desc* d, hr_scene** 
         for (uint32_t t = 0; t < r.n_tris; t++) tri_instance[(size_t)r.first_tri + t] = (uint32_t)i;
         node_at += b.nodes.size() - 1; ref_at += b.tris.size();
     }
-    if (max_depth + 1 >= kMaxTraversalDepth) { set_last_error("hr_scene_create_instanced: BVH depth exceeds the traversal stack"); return HR_ERR_UNSUPPORTED; }
-    // nodes by depth
-    s->level_offsets.assign((size_t)max_depth + 2, 0);
-    for (size_t j = 0; j < n_nodes; j++) s->level_offsets[(size_t)depth[j] + 1]++;
-    for (size_t dd = 0; dd + 1 < s->level_offsets.size(); dd++) s->level_offsets[dd + 1] += s->level_offsets[dd];
-    std::vector<uint32_t> level_nodes(n_nodes);
+    // ---- the top level over the instances' initial boxes ---------------------------------------------------------------------------------
+    instance_boxes(s);
     {
-        std::vector<int32_t> cur(s->level_offsets.begin(), s->level_offsets.end() - 1);
-        for (size_t j = 0; j < n_nodes; j++) level_nodes[(size_t)cur[(size_t)depth[j]]++] = (uint32_t)j;
+        TopLevel tl;
+        build_top_level(s, tl);
+        if (tl.max_depth + max_rel + 1 >= kMaxTraversalDepth) { set_last_error("hr_scene_create_instanced: BVH depth exceeds the traversal stack"); return HR_ERR_UNSUPPORTED; }
+        adopt_top_level(s, tl);
     }
+    std::memcpy(nodes.data(), s->top_nodes_host.data(), (size_t)s->top_cap * sizeof(Node8));
+    std::memcpy(cells.data(), s->top_cells_host.data(), (size_t)s->top_cap * 48 * sizeof(float));
+    const std::vector<int32_t>&  node_inst = s->node_inst_host;
+    const std::vector<uint32_t>& level_nodes = s->level_nodes_host;
+    const int max_depth = s->info.max_depth;
 
     // ---- attributes --------------------------------------------------------------------------------------------------------------------
     const size_t MT = mesh_tri_base[(size_t)M], N = (size_t)total_tris;
@@ -594,9 +766,10 @@ hr_status create_impl(hr_ctx* ctx, const hr_instanced_scene_desc* d, hr_scene** 
 #undef UP
     s->n_materials = d->materials ? d->n_materials : 0;
     { static std::atomic<uint64_t> next_uid { 1ull << 40 }; s->uid = next_uid.fetch_add(1); }   // disjoint from hr_scene_create's counter
+    if (const char* e = getenv("HR_TOP_LEVEL_REBUILD")) s->auto_rebuild = atoi(e) != 0;
     s->info.n_tris     = (int32_t)N;
     s->info.n_nodes    = (int32_t)n_nodes;
-    s->info.max_depth  = max_depth;
+    (void)max_depth;   // set by adopt_top_level
     s->info.node_bytes = n_nodes * sizeof(Node8);
     s->info.tri_bytes  = tris.size() * sizeof(TriGPU);
     // first update: the instances' own matrices, then wait (creation is synchronous like hr_scene_create)
@@ -663,5 +836,24 @@ hr_status hr_scene_update_instances(hr_scene* scene, const float* model_matrices
 }
 
 int32_t hr_scene_instance_count(const hr_scene* scene) { return scene ? scene->n_instances : 0; }
+
+hr_status hr_scene_rebuild_top_level(hr_scene* scene, void* stream)
+{
+    HR_CHECK_ARG(scene);
+    if (scene->n_instances <= 0) { set_last_error("hr_scene_rebuild_top_level: not an instanced scene"); return HR_ERR_INVALID_ARG; }
+    if (scene->n_instances == 1) return HR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HR_HIP(hipSetDevice(scene->ctx->device));
+    TopLevel tl;
+    build_top_level(scene, tl);
+    adopt_top_level(scene, tl);
+    const hr_status us = upload_top_level(scene, st);
+    if (us != HR_OK) return us;
+    scene->top_rebuilds++;
+    std::vector<float> mats((size_t)scene->n_instances * 16);
+    for (int i = 0; i < scene->n_instances; i++) std::memcpy(&mats[(size_t)i * 16], scene->inst_host[(size_t)i].m, 64);
+    return update_impl(scene, mats.data(), st, true);   // every level once: the instance roots moved to other slots
+}
+int32_t hr_scene_top_level_rebuilds(const hr_scene* scene) { return scene ? scene->top_rebuilds : 0; }
 
 } // extern "C"

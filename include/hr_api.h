@@ -182,7 +182,7 @@ hr_status hr_bvh_selfcheck(const float* positions, int32_t n_tris, int32_t sampl
  * The reference's scene model — meshes + instances, the acceleration structure updated every frame — on ONE world-space 8-wide BVH: every
  * instance owns a private copy of its mesh's subtree under a top level over the instance roots, so the trace kernels keep the single-level
  * walk of hr_scene_create.  hr_scene_update_instances moves instances on the GPU (vertices = model_matrix * (p, 1), one rounding per
- * operation; node boxes refitted level by level; only instances whose matrix changed are touched).  Answers equal those of a flattened
+ * operation; node boxes refitted level by level; only instances whose matrix changed are touched; the top level re-built when it degrades).  Answers equal those of a flattened
  * hr_scene_create over the same world-space vertices; hit records name the global triangle index (instance order, then mesh order); hit
  * shading interpolates the OBJECT-space attributes, then applies interpolated_vertex + transform_vertex's operations.  DESIGN.md section 2. */
 typedef struct
@@ -223,6 +223,11 @@ hr_status hr_scene_create_instanced(hr_ctx* ctx, const hr_instanced_scene_desc* 
  * caches of the passes (AO entry-node table) notice the change.  HR_ERR_INVALID_ARG for a scene from hr_scene_create. */
 hr_status hr_scene_update_instances(hr_scene* scene, const float* model_matrices, void* stream);
 int32_t   hr_scene_instance_count(const hr_scene* scene);   /* 0 for a scene from hr_scene_create */
+/* The top level over the instance roots (host SAH over the instances' boxes, 8-wide) is re-built by hr_scene_update_instances on its own when the
+ * instances have moved far enough for its boxes to overlap (half-area sum > 1.5x the sum at the last build, and a fresh one at least 10 % better);
+ * this forces one (re-places the roots, refits every level once) / counts them.  Answers never depend on it. */
+hr_status hr_scene_rebuild_top_level(hr_scene* scene, void* stream);
+int32_t   hr_scene_top_level_rebuilds(const hr_scene* scene);
 hr_status hr_scene_destroy(hr_scene* scene);
 
 /* Raw ray queries against the scene (replace rayQueryEXT / traceRayEXT; used by tests and tools).

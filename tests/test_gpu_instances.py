@@ -35,9 +35,11 @@ def test_queries_after_every_update_equal_the_flattened_scene_and_the_oracle(ora
     g = hr.InstancedScene(ctx, isd)
     rays = _rays(40000, seed)
     rd = torch.from_numpy(rays).cuda()
-    for f in (0, 1, 2, 7):
+    for f in (0, 1, 2, 7, 90, 91):   # frame 90: the movers have crossed the room — the top level is re-built on its own when that pays
         mats = _mats(isd, n_boxes, seed, f)
         g.update(mats)
+        if f == 91:
+            g.rebuild_top_level()   # and on demand: the instance roots change slots, every level is refitted
         flat_sd = isd.flatten(mats)
         gf = hr.Scene(ctx, flat_sd)
         occ, (tuv, prim) = g.any_hit(rd).cpu().numpy(), [t.cpu().numpy() for t in g.closest_hit(rd)]
@@ -53,6 +55,7 @@ def test_queries_after_every_update_equal_the_flattened_scene_and_the_oracle(ora
         assert list(info.bounds_lo) == list(finfo.bounds_lo) and list(info.bounds_hi) == list(finfo.bounds_hi), "exact bounds after the update"
         gf.close()
         assert 0.05 < occ.mean() < 0.999
+    assert g.top_level_rebuilds >= (1 if n_boxes > 1 else 0)
     g.close()
 
 

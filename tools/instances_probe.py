@@ -47,7 +47,8 @@ def main():
     torch.cuda.synchronize()
     upd_ms = (time.perf_counter() - t0) / len(mats) * 1e3
     info = g.refresh_info()
-    res = dict(tris=info.n_tris, nodes=info.n_nodes, depth=info.max_depth, instances=a.movers + 1, create_s=round(t_create, 2), update_ms=round(upd_ms, 4))
+    res = dict(tris=info.n_tris, nodes=info.n_nodes, depth=info.max_depth, instances=a.movers + 1, create_s=round(t_create, 2), update_ms=round(upd_ms, 4),
+               top_level_rebuilds=g.top_level_rebuilds, auto_rebuild=os.environ.get("HR_TOP_LEVEL_REBUILD", "1"))
     # quality of the refitted tree after `frames` updates
     light = synth.sponza_light()
     cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(2)]
