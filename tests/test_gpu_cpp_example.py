@@ -64,3 +64,11 @@ def test_cpp_tiled_frame_example_runs(hr):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "every band row equals the un-tiled render" in out.stdout, out.stdout
     assert out.stdout.count("(forked)") == 2 and out.stdout.count("shadows ==  ao ==  ddgi ==  reflections ==") == 2, out.stdout
+
+
+def test_cpp_instanced_scene_example_runs(hr):
+    """examples/instanced_scene.cpp: hr::Scene(ctx, hr_instanced_scene_desc) + update_instances() every frame in the place of build_tlas (main.cpp:74);
+    the masks of four frames with a moving instance equal those of hr_scene_create over the same world-space triangles"""
+    out = _run_example("instanced_scene")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "4 of 4 masks equal the flattened scene's" in out.stdout, out.stdout

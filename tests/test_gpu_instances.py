@@ -187,3 +187,39 @@ def test_update_rejects_flat_scenes_and_bad_matrices(hr, ctx):
     assert hr.lib().hr_scene_update_instances(g.h, bad.ctypes.data_as(C.POINTER(C.c_float)), None) == 1
     g.update(isd.matrices())      # still usable
     flat.close(); g.close()
+
+
+def test_degenerate_instances_against_the_flattened_scene(hr, ctx):
+    """an empty mesh, an instance squashed to a plane (scale 0 along one axis), one collapsed to a point, one far away, one mirrored (negative
+    scale), mixed with ordinary ones: queries equal those of hr_scene_create over the same world vertices, before and after an update"""
+    import dataclasses
+    import torch
+    base = synth.instanced_cornell(4, seed=8)
+    empty = dataclasses.replace(base.meshes[2], verts=np.zeros((0, 3, 3), np.float32), normals=np.zeros((0, 3, 3), np.float32), tri_material=np.zeros(0, np.uint32),
+                                tri_mesh_id=np.zeros(0, np.uint32))
+    meshes = list(base.meshes) + [empty]
+    inst = list(base.instances)
+    inst += [(synth.model_matrix((50, 50, 50)), 3, 30),                                   # the empty mesh
+             (synth.model_matrix((30, 20, 60), (0, 1, 0), 0.4, (20, 0.0, 20)), 1, 31),    # squashed to a plane
+             (synth.model_matrix((70, 20, 30), (1, 0, 0), 0.0, 0.0), 2, 32),              # a point
+             (synth.model_matrix((4000, 3000, -2500), (1, 1, 0), 1.1, 15.0), 1, 33),      # far away
+             (synth.model_matrix((60, 30, 40), (0, 0, 1), 0.7, (-12, 9, 14)), 2, 34)]     # mirrored
+    isd = synth.InstancedSceneData(meshes=meshes, instances=inst, materials=base.materials)
+    g = hr.InstancedScene(ctx, isd)
+    rays = _rays(30000, 12)
+    rays[:3000, :3] = np.array([3900, 2950, -2450], np.float32) + np.random.RandomState(1).uniform(-60, 60, (3000, 3)).astype(np.float32)   # around the far one
+    rd = torch.from_numpy(rays).cuda()
+    mats = isd.matrices()
+    for step in range(3):
+        if step:
+            mats = mats.copy()
+            mats[1:5, 12:15] += np.float32(3.5 * step)      # move the ordinary ones
+            mats[8, 12:15] += np.float32(-500.0 * step)     # and the far one
+            g.update(mats)
+        gf = hr.Scene(ctx, isd.flatten(mats))
+        occ, (tuv, prim) = g.any_hit(rd).cpu().numpy(), [t.cpu().numpy() for t in g.closest_hit(rd)]
+        occ_f, (tuv_f, prim_f) = gf.any_hit(rd).cpu().numpy(), [t.cpu().numpy() for t in gf.closest_hit(rd)]
+        assert np.array_equal(occ, occ_f) and np.array_equal(prim, prim_f) and np.array_equal(tuv.view(np.uint32), tuv_f.view(np.uint32)), f"step {step}"
+        assert (prim >= 0).mean() > 0.5
+        gf.close()
+    g.close()

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r6_p; mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests/test_gpu_cpp_example.py -x -q 2>&1 | tail -25 | tee $OUT/pytest_cpp.txt
+examples/_build/instanced_scene
