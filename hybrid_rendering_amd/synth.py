@@ -110,7 +110,7 @@ def model_matrix(translate=(0.0, 0.0, 0.0), axis=(0.0, 1.0, 0.0), angle=0.0, sca
     return np.ascontiguousarray(M.T.reshape(16), np.float32)   # column-major
 
 
-def instanced_cornell(n_boxes: int = 5, seed: int = 3, frame: int = 0) -> InstancedSceneData:
+def instanced_cornell(n_boxes: int = 5, seed: int = 3, frame: int = 0, textured: bool = False) -> InstancedSceneData:
     """The Cornell room as ONE mesh (identity instance) + a unit-cube mesh and a small pyramid mesh instanced `n_boxes` times with
     rotations, non-uniform scales and translations; `frame` moves every second instance (a per-frame TLAS update, main.cpp:74)."""
     room = _Builder()
@@ -126,6 +126,11 @@ def instanced_cornell(n_boxes: int = 5, seed: int = 3, frame: int = 0) -> Instan
     apex, b0, b1, b2, b3 = (0, 1, 0), (-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5)
     pyr.add(np.array([[b0, apex, b1], [b1, apex, b2], [b2, apex, b3], [b3, apex, b0], [b0, b1, b2], [b0, b2, b3]], np.float32), None, 3)
     meshes = [room.finish(mats, "room"), cube.finish(mats, "cube"), pyr.finish(mats, "pyramid")]
+    if textured:
+        # per-mesh (object-space) texture coordinates and tangents; the textures and the material -> texture table are the scene's
+        meshes = [with_textures(m) for m in meshes]
+        return InstancedSceneData(meshes=meshes, instances=instanced_cornell_instances(n_boxes, seed, frame), materials=mats, name="instanced_cornell_textured",
+                                  material_textures=meshes[0].material_textures, textures=meshes[0].textures)
     return InstancedSceneData(meshes=meshes, instances=instanced_cornell_instances(n_boxes, seed, frame), materials=mats, name="instanced_cornell")
 
 

@@ -223,3 +223,58 @@ def test_degenerate_instances_against_the_flattened_scene(hr, ctx):
         assert (prim >= 0).mean() > 0.5
         gf.close()
     g.close()
+
+
+def test_textured_instances(oracle, hr, ctx):
+    """textured materials on instanced meshes: per-MESH texture coordinates and tangents (object space), the normal map's TBN built from the tangent
+    that transform_vertex rotated (scene_descriptor_set.glsl:150-160, :168-220) — DDGI radiance, reflections trace image and the ground-truth
+    accumulator against the oracle's instanced scene (which tests/test_instances.py pins to the reference's own hit shaders), two moving frames"""
+    import torch
+    from hybrid_rendering_amd import api_gi, api_reflections, api_post
+    from oracle import pyoracle_ddgi as od, pyoracle_reflections as orf, pyoracle_post as opost
+    n_boxes, seed, W, H = 7, 6, 128, 96
+    isd = synth.instanced_cornell(n_boxes, seed=seed, textured=True)
+    g, osc = hr.InstancedScene(ctx, isd), oracle.InstancedScene(isd)
+    sob, sr = synth.blue_noise_tables()
+    sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
+    lo, hi = isd.flatten().bounds()
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=(3, 3, 3), rays_per_probe=64, normal_bias=1.0)
+    sky = synth_env.sky_cubemap(16)
+    pre, lut = synth_env.prefiltered_chain(sky, 5), synth_env.brdf_lut(16)
+    env_np = dict(sky=sky, prefiltered=pre, pre_size=16, pre_levels=5, lut=lut)
+    f16 = lambda a: torch.from_numpy(a).cuda().view(torch.float16)
+    env = api_gi.environment(f16(sky), f16(pre), 16, 5, f16(lut))
+    gd, odd = api_gi.DDGI(ctx, W, H, ddgi), od.DDGIPass(ddgi)
+    gr, orr = api_reflections.RayTracedReflections(ctx, W, H, 0), orf.ReflectionsPass(W, H)
+    gt, ogt = api_post.GroundTruthPathTracer(ctx, W, H), opost.GroundTruthPass(W, H)
+    cams = helpers.cameras("cornell", W / H, 3, 1.0)
+    light = helpers.light_for("cornell", "soft")
+    rng = np.random.RandomState(4)
+    prev = None
+    for f in range(2):
+        mats = synth.InstancedSceneData(isd.meshes, synth.instanced_cornell_instances(n_boxes, seed=seed, frame=f), isd.materials).matrices()
+        g.update(mats)
+        osc.update(mats)
+        ubo = synth.make_ubo(cams[f], cams[f - 1] if f else None, light)
+        cur = osc.gbuffer(ubo, W, H)
+        ch = cur["gb3"][..., 0]
+        ch[ch == np.float16(0.8).view(np.uint16)] = np.float16(0.03).view(np.uint16)
+        cur_d = helpers.to_cuda(cur)
+        fi = hr.frame_inputs(cur_d, helpers.to_cuda(prev if prev is not None else cur), ubo, f, f & 1, sob_d, sr_d)
+        orient = synth_env.random_orientation(rng)
+        gd.render(g, fi, env, orient)
+        odd.render(osc, ubo, cur, sky, orient, f)
+        torch.cuda.synchronize()
+        assert np.array_equal(helpers.bits16(gd.image(gd.IMG_RADIANCE)), odd.stages["radiance"]), f"frame {f}: DDGI radiance"
+        irr, dep = odd.current_read()
+        gr.render(g, fi, env, gd)
+        orr.render(osc, ubo, ddgi, cur, prev if prev is not None else cur, sob, sr, f, env_np, irr, dep, ping_pong=bool(f & 1))
+        torch.cuda.synchronize()
+        assert np.array_equal(helpers.bits16(gr.image(gr.IMG_TRACE)), orr.stages["trace"]), f"frame {f}: reflections trace image"
+        gt.render(g, ubo, env)
+        ref = ogt.render(osc, ubo, sky)
+        torch.cuda.synchronize()
+        assert np.array_equal(helpers.bits16(gt.output()), ref), f"frame {f}: ground-truth accumulator"
+        prev = cur
+    for p in (gd, gr, gt, g):
+        p.close()

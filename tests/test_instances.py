@@ -94,13 +94,13 @@ def test_moving_instances_change_the_answers_and_match_a_fresh_flat_scene(oracle
 
 
 @pytest.mark.skipif(not pyref.available(), reason="neither /root/reference nor a prebuilt oracle/_ref")
-@pytest.mark.parametrize("approx", [1, 0])
-def test_instanced_hit_shading_against_the_reference_hit_shaders(oracle, approx):
+@pytest.mark.parametrize("approx,textured", [(1, False), (0, False), (1, True)])
+def test_instanced_hit_shading_against_the_reference_hit_shaders(oracle, approx, textured):
     """THE PIN for instances: reflections_ray_trace.{rgen,rchit,rmiss} and gi_ray_trace.{rgen,rchit,rmiss} — the reference's own fetch_hit_info /
     fetch_triangle / interpolated_vertex / transform_vertex (scene_descriptor_set.glsl:102-160) over 10 instances of 3 meshes with rotations and
-    non-uniform scales, two of them moving between the frames — against the oracle's instanced surface_at, bit for bit."""
+    non-uniform scales, two of them moving between the frames — against the oracle's instanced surface_at, bit for bit; once with textured materials."""
     from oracle import ref_harness as rh, pyoracle_ddgi as od, pyoracle_reflections as orf
-    isd = synth.instanced_cornell(9, seed=5)
+    isd = synth.instanced_cornell(9, seed=5, textured=textured)   # textured: fetch_albedo / fetch_normal / ... through per-mesh uvs and tangents (TBN = (T, T, N))
     osc = oracle.InstancedScene(isd)
     W, H = 56, 40
     lo, hi = isd.flatten().bounds()
