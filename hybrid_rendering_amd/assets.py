@@ -206,8 +206,8 @@ def _quat_to_mat(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
 
 
-def load_gltf(path: str, scale: float = 1.0) -> SceneData:
-    """glTF 2.0 (.gltf with external / base64 buffers, or .glb) -> SceneData: the scene's node hierarchy is flattened to world
+def load_gltf(path: str, scale: float = 1.0, instanced: bool = False):
+    """instanced=True: see load_gltf_instanced.  glTF 2.0 (.gltf with external / base64 buffers, or .glb) -> SceneData: the scene's node hierarchy is flattened to world
     space (matrix or TRS nodes), every TRIANGLES primitive contributes its (indexed) triangles, NORMAL is transformed by the
     inverse transpose (missing: geometric normal), materials come from pbrMetallicRoughness (baseColorFactor, metallicFactor,
     roughnessFactor) + emissiveFactor.  One mesh id per (node, primitive).  The reference loads meshes/*.gltf through assimp
@@ -294,6 +294,7 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
 
     verts, norms, tmat, tmesh, uvs, tans = [], [], [], [], [], []
     mesh_id = [0]
+    node_instances = []   # instanced: (column-major world matrix, glTF mesh index) per node that carries a mesh
 
     def visit(ni, parent):
         node = doc["nodes"][ni]
@@ -304,6 +305,14 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
             local[:3, :3] = _quat_to_mat(node.get("rotation", [0, 0, 0, 1])) @ np.diag(node.get("scale", [1, 1, 1]))
             local[:3, 3] = node.get("translation", [0, 0, 0])
         M = parent @ local
+        if instanced:
+            if "mesh" in node:
+                Ms = M.copy()
+                Ms[:3, :] *= scale          # world = scale * (M * p)
+                node_instances.append((np.ascontiguousarray(Ms.T.reshape(16), np.float32), int(node["mesh"])))
+            for c in node.get("children", []):
+                visit(c, M)
+            return
         if "mesh" in node:
             nm = np.linalg.inv(M[:3, :3]).T
             for prim in doc["meshes"][node["mesh"]]["primitives"]:
@@ -341,6 +350,50 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
     scenes = doc.get("scenes") or [{"nodes": list(range(len(doc.get("nodes", []))))}]
     for root in scenes[doc.get("scene", 0)]["nodes"]:
         visit(root, np.eye(4))
+    if instanced:
+        from .synth import InstancedSceneData
+        # one mesh per glTF mesh (all its TRIANGLES primitives, OBJECT space): scene_descriptor_set.glsl's per-mesh vertex / index / submesh buffers
+        used = sorted({k for _, k in node_instances})
+        if not used:
+            raise ValueError(f"{path}: no node carries a mesh")
+        meshes, slot = [], {}
+        for k in used:
+            mv, mn, mm, mu, mt_ = [], [], [], [], []
+            for prim in doc["meshes"][k]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue
+                pos = accessor(prim["attributes"]["POSITION"]).astype(np.float32)
+                idx = accessor(prim["indices"]).reshape(-1).astype(np.int64) if "indices" in prim else np.arange(len(pos))
+                idx = idx[: len(idx) // 3 * 3].reshape(-1, 3)
+                tri = pos[idx]
+                if "NORMAL" in prim["attributes"]:
+                    tn = accessor(prim["attributes"]["NORMAL"]).astype(np.float32)[idx]
+                else:
+                    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+                    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+                    tn = np.repeat(fn[:, None, :], 3, axis=1).astype(np.float32)
+                mu.append(accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32)[idx] if "TEXCOORD_0" in prim["attributes"] else np.zeros((len(tri), 3, 2), np.float32))
+                if "TANGENT" in prim["attributes"]:
+                    mt_.append(accessor(prim["attributes"]["TANGENT"]).astype(np.float32)[:, :3][idx])
+                else:
+                    tg = np.zeros_like(tn)
+                    tg[..., 0] = 1.0
+                    mt_.append(tg)
+                mv.append(tri); mn.append(tn)
+                mm.append(np.full(len(tri), prim.get("material", default_mat), np.uint32))
+            if not mv:
+                continue
+            slot[k] = len(meshes)
+            meshes.append(SceneData(verts=np.ascontiguousarray(np.concatenate(mv), np.float32), normals=np.ascontiguousarray(np.concatenate(mn), np.float32),
+                                    tri_material=np.concatenate(mm), tri_mesh_id=np.zeros(sum(len(v) for v in mv), np.uint32), materials=np.asarray(mats, np.float32),
+                                    name=doc["meshes"][k].get("name", f"mesh{k}"),
+                                    uvs=np.ascontiguousarray(np.concatenate(mu), np.float32) if textures else None,
+                                    tangents=np.ascontiguousarray(np.concatenate(mt_), np.float32) if textures else None))
+        inst = [(m, slot[k], i + 1) for i, (m, k) in enumerate(node_instances) if k in slot]
+        if not inst:
+            raise ValueError(f"{path}: no triangle primitives")
+        return InstancedSceneData(meshes=meshes, instances=inst, materials=np.asarray(mats, np.float32), name=os.path.basename(path),
+                                  material_textures=np.asarray(mat_tex, np.int32) if textures else None, textures=textures if textures else None)
     if not verts:
         raise ValueError(f"{path}: no triangle primitives")
     sd = SceneData(verts=np.ascontiguousarray(np.concatenate(verts), np.float32), normals=np.ascontiguousarray(np.concatenate(norms), np.float32),
@@ -352,3 +405,12 @@ def load_gltf(path: str, scale: float = 1.0) -> SceneData:
         sd.material_textures = np.asarray(mat_tex, np.int32)
         sd.textures = textures
     return sd
+
+
+def load_gltf_instanced(path: str, scale: float = 1.0):
+    """glTF 2.0 -> synth.InstancedSceneData, the layout the reference's scene has on the GPU (scene_descriptor_set.glsl:5-34): one mesh per glTF
+    mesh in OBJECT space (positions, normals, texture coordinates, tangents, per-triangle material), one instance { model_matrix, mesh_idx } per
+    node that carries a mesh (world matrix of the node hierarchy, times `scale`; mesh id = 1 + the node's order of appearance).  A mesh referenced
+    by several nodes is stored once.  hr.InstancedScene(ctx, it) builds it; its flatten() gives the world-space triangles load_gltf() returns
+    (up to the rounding of the pinned fp32 transform; normals through mat3(model), as transform_vertex does, not the inverse transpose)."""
+    return load_gltf(path, scale, instanced=True)

@@ -252,3 +252,32 @@ def test_gltf_textures_reach_the_hit_shading(tmp_path, oracle):
         outs.append(oracle.f16(gt.render(oracle.Scene(s), ubo, sky))[12:20, 12:20, :3].mean((0, 1)))
     assert outs[0][0] > 4 * outs[0][2] and outs[0][0] > 4 * outs[0][1]            # red albedo texture
     assert not np.allclose(outs[0], outs[1])                                        # factor (0.2, 0.4, 0.6) without the textures
+
+
+def test_gltf_instanced_loader_keeps_meshes_and_instances(tmp_path, oracle):
+    """load_gltf_instanced: the reference's scene layout (scene_descriptor_set.glsl:5-34) — meshes in object space, stored once however many nodes
+    reference them, one instance { model_matrix, mesh_idx } per node; its flatten() is the world-space scene load_gltf() returns, and the oracle
+    answers ray queries on both alike"""
+    import json
+    doc, blob = _gltf_doc(tmp_path, embed=True)
+    doc["nodes"].append({"mesh": 0, "translation": [0, 0, 3], "rotation": [0.38268343, 0, 0, 0.92387953]})   # the quad a second time, tilted 45 deg about x
+    doc["nodes"][0]["children"].append(3)
+    path = tmp_path / "inst.gltf"
+    path.write_text(json.dumps(doc))
+    isd = assets.load_gltf_instanced(str(path), scale=2.0)
+    assert [m.n_tris for m in isd.meshes] == [2, 1] and [(k, i) for _, k, i in isd.instances] == [(0, 1), (1, 2), (0, 3)]
+    assert np.allclose(isd.meshes[0].verts[0], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])                      # object space, untouched
+    flat, world = isd.flatten(), assets.load_gltf(str(path), scale=2.0)
+    assert flat.n_tris == world.n_tris == 5
+    order = [0, 1, 2, 3, 4]            # same traversal order of the node hierarchy
+    assert np.allclose(flat.verts[order], world.verts, atol=1e-4) and list(flat.tri_material) == list(world.tri_material)
+    fn = flat.normals / np.linalg.norm(flat.normals, axis=-1, keepdims=True)
+    assert np.allclose(fn, world.normals, atol=1e-5)                                                   # rigid + uniform scale: mat3(model) n and the inverse transpose agree
+    oi, of = oracle.InstancedScene(isd), oracle.Scene(world)
+    rng = np.random.RandomState(2)
+    rays = np.zeros((500, 8), np.float32)
+    lo, hi = world.bounds()
+    rays[:, :3] = rng.uniform(lo - 1, hi + 1, (500, 3)); rays[:, 2] = 30.0
+    rays[:, 4:7] = [0, 0, -1]; rays[:, 3] = 100.0; rays[:, 7] = 0.001
+    hit_i, hit_f = oi.any_hit(rays), of.any_hit(rays)
+    assert hit_i.sum() > 5 and (hit_i != hit_f).mean() < 0.01          # (the two transforms round differently: a ray on an edge may differ)
