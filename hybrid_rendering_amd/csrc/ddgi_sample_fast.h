@@ -1,5 +1,6 @@
-// Tolerance-mode restatement of sample_irradiance (gi_common.glsl:188-320) — shared by the per-pixel probe-grid sample
-// (kf_ddgi_sample, denoise_fast.hip) and by the reflections' hit shading in tolerance mode (k_refl_trace<.., FAST>, reflections.hip):
+// Tolerance-mode restatement of sample_irradiance (gi_common.glsl:188-320) — used by the per-pixel probe-grid sample (kf_ddgi_sample,
+// denoise_fast.hip).  (Rounds 4-5 also used it for the reflections' hit shading in tolerance mode; round 6 returned those gathers to the
+// parity arithmetic — one fp16 ulp in the trace image's colours did not survive the next frame's variance, docs/EXPERIMENTS.md R6.1.)
 // hardware rcp / rsq / sqrt, contracted FMAs, re-associated sums; the ill-conditioned sub-expressions (atlas coordinates, bilinear
 // weights of the depth moments, the Chebyshev variance) keep the reference's operation order (fast_math.h *_rn helpers).
 // Hoisted out of the 8-probe loop: the octahedral texel offset of the surface normal (identical for every probe), the bias vector,
