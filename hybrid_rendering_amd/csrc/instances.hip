@@ -13,7 +13,8 @@
 //   k_instances_transform   one thread per triangle: world vertices = model_matrix * (p, 1) (the hit records, the G-buffer synthesiser and
 //                           the references read them), world vertex normals for the G-buffer synthesiser, per-instance bounds by atomic min / max
 //   k_instances_gather      one thread per triangle reference: the 36 vertex bytes of its TriGPU
-//   k_instances_refit       one launch per tree level, deepest first: a thread per node recomputes the boxes of its eight children (internal
+//   k_instances_refit[_top] one launch per WIDE tree level, deepest first, then one single-workgroup launch for all the narrow levels near the root
+//                           (a barrier between levels): a thread per node recomputes the boxes of its eight children (internal
 //                           children: the box their own thread stored one launch earlier; leaves: the bounds of their triangles CUT to the
 //                           leaf's cell — the builder splits references spatially (SBVH), so a leaf of a mesh with long triangles bounds
 //                           only the pieces inside its object-space cell: the cell goes through the instance's matrix (centre + |M| extent,
@@ -67,11 +68,8 @@ __device__ uint8_t exponent_for_dev(float extent)
 __device__ float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
 __device__ float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
 
-__global__ __launch_bounds__(64) void k_instances_refit(RefitArgs a)
+__device__ void refit_node(const RefitArgs& a, const uint32_t ni)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.count) return;
-    const uint32_t ni = a.list[i];
     const int      in = a.node_inst[ni];
     if (in >= 0 && !a.dirty[in]) return;   // the instance did not move: its subtree stands
     Node8 n = a.nodes[ni];
@@ -146,6 +144,25 @@ __global__ __launch_bounds__(64) void k_instances_refit(RefitArgs a)
             n.qlo[k][c] = ql; n.qhi[k][c] = qh;
         }
     a.nodes[ni] = n;
+}
+
+__global__ __launch_bounds__(64) void k_instances_refit(RefitArgs a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < a.count) refit_node(a, a.list[i]);
+}
+
+// The levels near the root hold a handful of nodes each: ONE workgroup walks them all, deepest first, a barrier between levels (the nodes a level
+// reads were written by this workgroup: __syncthreads orders them) — a dozen launches of a few microseconds each become one.
+struct RefitTopArgs { RefitArgs r; const uint32_t* lists; int offs[kMaxTraversalDepth + 2]; int d_top; };
+__global__ __launch_bounds__(256) void k_instances_refit_top(RefitTopArgs t)
+{
+    for (int d = t.d_top; d >= 0; d--)
+    {
+        for (int i = t.offs[d] + (int)threadIdx.x; i < t.offs[d + 1]; i += 256) refit_node(t.r, t.lists[i]);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // ordered-integer image of a float: unsigned comparison == float comparison
@@ -555,11 +572,22 @@ hr_status update_impl(hr_scene* s, const float* matrices, hipStream_t st, bool a
     RefitArgs r;
     r.nodes = (Node8*)s->nodes.p; r.tris = (const TriGPU*)s->tris.p; r.node_box = (float*)s->node_box.p; r.pad = s->info.box_pad;
     r.cells = (const float*)s->leaf_cells.p; r.node_inst = (const int32_t*)s->node_inst.p; r.inst = (const InstanceRec*)s->inst_records.p; r.dirty = dirty;
-    for (int d = (int)s->level_offsets.size() - 2; d >= 0; d--)
+    // levels 0 .. d_top (each no larger than a few hundred nodes) in one launch, the wide levels below them one launch each
+    const int n_levels = (int)s->level_offsets.size() - 1;
+    int d_top = -1;
+    while (d_top + 1 < n_levels && d_top + 1 <= kMaxTraversalDepth && s->level_offsets[(size_t)d_top + 2] - s->level_offsets[(size_t)d_top + 1] <= 512) d_top++;
+    for (int d = n_levels - 1; d > d_top; d--)
     {
         r.list = (const uint32_t*)s->level_nodes.p + s->level_offsets[(size_t)d];
         r.count = s->level_offsets[(size_t)d + 1] - s->level_offsets[(size_t)d];
         if (r.count > 0) hipLaunchKernelGGL(k_instances_refit, dim3(cdiv(r.count, 64)), dim3(64), 0, st, r);
+    }
+    if (d_top >= 0)
+    {
+        RefitTopArgs t;
+        t.r = r; t.lists = (const uint32_t*)s->level_nodes.p; t.d_top = d_top;
+        for (int d = 0; d <= d_top + 1; d++) t.offs[d] = s->level_offsets[(size_t)d];
+        hipLaunchKernelGGL(k_instances_refit_top, dim3(1), dim3(256), 0, st, t);
     }
     HR_HIP(hipGetLastError());
     s->geometry_epoch++;
