@@ -41,6 +41,11 @@ class RayTracedReflections(_Pass):
         _check(lib().hr_reflections_render(self.h, scene.h, C.byref(inputs), C.byref(env), ddgi.h, C.byref(self.params), _stream_ptr(stream)),
                "hr_reflections_render")
 
+    def atrous_iteration(self, inputs, i, stream=None):
+        """one iteration of a_trous_filter (ray_traced_reflections.cpp:1143-1256) on the pass's current images: iteration 0 reads the temporal colour image,
+        iteration i > 0 the a-trous image iteration i - 1 wrote (IMG_ATROUS1 for even i - 1, IMG_ATROUS0 for odd); writes the other one"""
+        _check(lib().hr_reflections_atrous_iteration(self.h, C.byref(inputs), C.byref(self.params), C.c_int32(i), _stream_ptr(stream)), "hr_reflections_atrous_iteration")
+
     def trace_stats(self, scene, inputs, env, ddgi, stream=None):
         """(rays, BVH node steps, triangle tests) of the ray-trace stage from the instrumented kernel (reflection rays + light rays)."""
         out = (C.c_uint64 * 3)()

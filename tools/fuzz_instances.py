@@ -49,8 +49,10 @@ sob, sr = synth.blue_noise_tables()
 sob_d, sr_d = torch.from_numpy(sob).cuda(), torch.from_numpy(sr).cuda()
 for trial in range(n):
     meshes = [room, cube, pyr, sphere(int(rng.randint(3, 9)))]
+    materials = base.materials
     if rng.rand() < 0.25:
         meshes.append(synth.sponza_like(0.1 + 0.1 * rng.rand()))
+        materials = meshes[-1].materials       # 11 materials: the other meshes' indices (0..4) stay valid
     I = int(rng.choice([2, 5, 9, 17, 64, 130, 400]))
     inst = [(synth.model_matrix(), 0, 1)]
     for i in range(I - 1):
@@ -59,7 +61,7 @@ for trial in range(n):
         if k == 4:
             m = synth.model_matrix(rng.uniform(-50, 50, 3), (0, 1, 0), rng.uniform(0, 6.28), rng.uniform(0.05, 0.15))
         inst.append((m, k, 2 + i))
-    isd = synth.InstancedSceneData(meshes=meshes, instances=inst, materials=base.materials)
+    isd = synth.InstancedSceneData(meshes=meshes, instances=inst, materials=materials)
     msg = []
     try:
         g = hr.InstancedScene(ctx, isd)
