@@ -534,6 +534,10 @@ def run(args, torch, dist, rank, world, local_rank):
             if world == 1:
                 out["passes"] = passes_block(torch, hr, HybridFrame, ctx, scene, sd, prof, exact)
                 out["passes"]["hard_tier"] = hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact)
+                try:
+                    out["passes"]["instanced"] = instanced_block(torch, hr, synth, ctx, sd, sob_d, sr_d, exact)
+                except Exception as e:   # a new block must not cost the line
+                    out["passes"]["instanced"] = {"error": repr(e)[:200]}
             else:
                 hf = HybridFrame(ctx, scene, sd, 3840, 2160, rank, world, exact=exact)
                 first_cut = list(hf.bounds)
@@ -676,6 +680,59 @@ def hard_tier_block(torch, hr, synth, ctx, sob_d, sr_d, exact):
            "tris_per_ray": round(nt / max(r, 1), 2), "trace_only_Mrays_per_s": round(rays / acc.get("ray_trace", 1e9) / 1e3, 1),
            "stage_ms": {k: round(v, 4) for k, v in acc.items()}}
     p.close(); scene.close()
+    return out
+
+
+def instanced_block(torch, hr, synth, ctx, sd, sob_d, sr_d, exact, movers=200, frames=30):
+    """the reference's scene model (meshes + instances, the acceleration structure updated every frame: main.cpp:74): the bench building as one identity
+    instance + `movers` cubes / pyramids flying through it — what hr_scene_update_instances costs per frame and what the headline pass costs on the updated
+    tree against hr_scene_create over the same world vertices (masks equal)"""
+    W, H = 1920, 1080
+    small = synth.instanced_cornell(2)
+    cube, pyr = small.meshes[1], small.meshes[2]
+    lo, hi = sd.bounds()
+    rng = np.random.RandomState(1)
+    base = [(rng.uniform(lo + 0.15 * (hi - lo), hi - 0.15 * (hi - lo)), rng.uniform(-1, 1, 3), rng.uniform(0, 6.28), rng.uniform(6, 30, 3), rng.uniform(-2, 2, 3)) for _ in range(movers)]
+
+    def instances(f):
+        return [(synth.model_matrix(), 0, 1)] + [(synth.model_matrix(p + v * f, ax, ang + 0.05 * f, sc), 1 + (i & 1), 2 + i) for i, (p, ax, ang, sc, v) in enumerate(base)]
+    isd = synth.InstancedSceneData(meshes=[sd, cube, pyr], instances=instances(0), materials=sd.materials)
+    g = hr.InstancedScene(ctx, isd)
+    mats = [synth.InstancedSceneData(isd.meshes, instances(f), isd.materials).matrices() for f in range(frames + 1)]
+    for m in mats[:3]:
+        g.update(m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for m in mats:
+        g.update(m)
+    torch.cuda.synchronize()
+    upd_ms = (time.perf_counter() - t0) / len(mats) * 1e3
+    flat = hr.Scene(ctx, isd.flatten(mats[-1]))
+    cams = [synth.sponza_camera(W / H, frame=f, dolly=0.5) for f in range(2)]
+    ubo = synth.make_ubo(cams[1], cams[0], synth.sponza_light())
+    gb = flat.gbuffer(ubo, W, H)
+    fi = hr.frame_inputs(gb, gb, ubo, 0, 0, sob_d, sr_d)
+    ms, masks = {}, {}
+    for tag, sc in (("updated", g), ("rebuilt", flat)):
+        p = hr.RayTracedShadows(ctx, W, H)
+        p.params.exact = exact
+        for k in range(6):
+            fi.num_frames = k
+            p.render(sc, fi)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(6, 46):
+            fi.num_frames = k
+            p.render(sc, fi)
+        torch.cuda.synchronize()
+        ms[tag] = (time.perf_counter() - t0) / 40 * 1e3
+        masks[tag] = p.image(p.IMG_MASK).clone()
+        p.close()
+    info = g.refresh_info()
+    out = {"workload": f"bench building + {movers} moving instances ({info.n_tris} tris, {info.n_nodes} nodes), {frames} frames of motion, shadows 1 spp + SVGF at 1920x1080",
+           "instances": movers + 1, "update_ms_per_frame": round(upd_ms, 4), "top_level_rebuilds": g.top_level_rebuilds,
+           "ms_per_frame_updated_tree": round(ms["updated"], 4), "ms_per_frame_rebuilt_tree": round(ms["rebuilt"], 4), "masks_equal": bool(torch.equal(masks["updated"], masks["rebuilt"]))}
+    g.close(); flat.close()
     return out
 
 

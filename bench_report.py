@@ -208,6 +208,8 @@ def compact_line(full):
         summ["hybrid_frame_ms"] = {"1080p": frame(ps.get("hybrid_1080p")), "4k": frame(h4)}
         if isinstance(ps.get("reflections_full_res"), dict):
             summ["reflections_full_res"] = _pick(ps["reflections_full_res"], ("ms_per_frame", "Mrays_per_s"))
+        if isinstance(ps.get("instanced"), dict):
+            summ["instanced"] = _pick(ps["instanced"], ("instances", "update_ms_per_frame", "top_level_rebuilds", "ms_per_frame_updated_tree", "ms_per_frame_rebuilt_tree", "masks_equal", "error"))
         if isinstance(ps.get("hard_tier"), dict):
             summ["hard_tier"] = _pick(ps["hard_tier"], ("ms_per_frame", "Mrays_per_s", "trace_only_Mrays_per_s", "nodes_per_ray", "tris_per_ray"))
         summ["keys"] = ("per pass: ms = sum of its kernels' HIP-event times; frac = SURVEY 8d bytes / ms / 8 TB/s with frac_kind hbm = compulsory HBM bytes, req = REQUESTED bytes of a "
