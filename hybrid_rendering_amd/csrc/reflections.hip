@@ -113,7 +113,8 @@ extern "C" int hr_debug_divergence_refl(uint64_t* out, int reset)
 // moments turned that into 0.4-100 % of a small variance, which normalises the a-trous luminance weights — six fuzzed sequences missed
 // the 99.9 % population bound because of it (docs/EXPERIMENTS.md R5.8, R6.1), none does with the parity gather.  What takes the edge off
 // its cost: a lane is a rough pixel or has a hit point, never both, so ONE gather site per wave serves both kinds (the rolled eight-probe
-// loop runs once per wave instead of once at each of two sites: 185 -> 172 us at 1080p, 488 -> 466 us at 4K; the fast gather was 149 / 382).
+// loop runs once per wave instead of once at each of two sites: 185 -> 172 us at 1080p, 488 -> 466 us at 4K; prepared denominators for the
+// atlas coordinates, shading.h IrrDiv: -> 165 / 454; the fast gather was 149 / 382).
 // The trace image is bit-exact in tolerance mode too.
 template <bool STATS>
 __global__ __launch_bounds__(64 * REFL_TRACE_WAVES, REFL_TRACE_EU) void k_refl_trace(ReflTraceArgs a)

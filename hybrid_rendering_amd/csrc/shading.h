@@ -180,27 +180,33 @@ HR_DEV f3 probe_location(const DDGIU& d, int index)
 // (col, row) = the probe's cell in the atlas = (probe_index % per_row, probe_index / per_row) with per_row = (tw - 2) / (side + 2)
 // (gi_common.glsl:164-184).  The atlas is probe_counts.x * probe_counts.y cells wide by construction (ddgi.cpp:197-201, checked in
 // hr_ddgi_create), so for probe (cx, cy, cz) the cell is (cx + cy * nx, cz): the same integers without two per-lane divisions.
-// ... in two halves: the offset of the direction inside a probe's cell (the same for every probe) and the cell's corner
-HR_DEV void texture_coord_in_cell(f3 dir, int tw, int th, int side, float& cx, float& cy)
+// ... in two halves: the offset of the direction inside a probe's cell (the same for every probe) and the cell's corner.  The four
+// divisions are by the atlas extents: with the denominator half of the correctly rounded sequence done once (DivBy, device_math.h — the very
+// FMAs the compiler's expansion of `/` performs, bit-identical results) a quotient costs five FMAs instead of ~eleven instructions.
+HR_DEV void texture_coord_in_cell(f3 dir, const DivBy& Dw, const DivBy& Dh, int side, float& cx, float& cy)
 {
     float ox, oy;
     gi_oct_encode(normalize3(dir), ox, oy);
     const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;
-    cx = __fdiv_rn(zx * (float)side, (float)tw); cy = __fdiv_rn(zy * (float)side, (float)th);
+    cx = div_by(zx * (float)side, Dw); cy = div_by(zy * (float)side, Dh);
 }
-HR_DEV void texture_coord_of_cell(float cx, float cy, int col, int row, int tw, int th, int side, float& u, float& v)
+HR_DEV void texture_coord_of_cell(float cx, float cy, int col, int row, const DivBy& Dw, const DivBy& Dh, int side, float& u, float& v)
 {
     const float pwb = (float)side + 2.0f;
     const float tlx = (float)col * pwb + 2.0f;
     const float tly = (float)row * pwb + 2.0f;
-    u = __fdiv_rn(tlx, (float)tw) + cx;
-    v = __fdiv_rn(tly, (float)th) + cy;
+    u = div_by(tlx, Dw) + cx;
+    v = div_by(tly, Dh) + cy;
+}
+HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, const DivBy& Dw, const DivBy& Dh, int side, float& u, float& v)
+{
+    float cx, cy;
+    texture_coord_in_cell(dir, Dw, Dh, side, cx, cy);
+    texture_coord_of_cell(cx, cy, col, row, Dw, Dh, side, u, v);
 }
 HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, int tw, int th, int side, float& u, float& v)
 {
-    float cx, cy;
-    texture_coord_in_cell(dir, tw, th, side, cx, cy);
-    texture_coord_of_cell(cx, cy, col, row, tw, th, side, u, v);
+    texture_coord_from_cell(dir, col, row, div_prepare((float)tw), div_prepare((float)th), side, u, v);
 }
 HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
 {
@@ -243,7 +249,15 @@ HR_DEV void atlas_bilinear_rg(const AtlasRG& a, float u, float v, float& r0, flo
 // split into the part that places the shading point in the grid (:190-203) and the body of the eight-probe loop (:207-296), so that the
 // loop can run per lane (sample_irradiance_net) or one probe per lane (sample_irradiance_net_coop) on the very same operations.
 struct IrrCell { int bx, by, bz; f3 alpha; float icx, icy; };   // + the offset of N's texel inside a probe's irradiance cell (the same for all eight probes)
-HR_DEV IrrCell irradiance_cell(const DDGIU& d, f3 P, f3 N)
+struct IrrDiv { DivBy iw, ih, dw, dh; };                          // the four atlas extents as prepared denominators
+HR_DEV IrrDiv irradiance_div(const DDGIU& d)
+{
+    IrrDiv D;
+    D.iw = div_prepare((float)d.irradiance_texture_width); D.ih = div_prepare((float)d.irradiance_texture_height);
+    D.dw = div_prepare((float)d.depth_texture_width); D.dh = div_prepare((float)d.depth_texture_height);
+    return D;
+}
+HR_DEV IrrCell irradiance_cell(const DDGIU& d, const IrrDiv& D, f3 P, f3 N)
 {
     const f3 gs = mk3(d.grid_step[0], d.grid_step[1], d.grid_step[2]);
     const f3 g0 = mk3(d.grid_start_position[0], d.grid_start_position[1], d.grid_start_position[2]);
@@ -254,11 +268,11 @@ HR_DEV IrrCell irradiance_cell(const DDGIU& d, f3 P, f3 N)
     const f3 base_pos = grid_coord_to_position(d, c.bx, c.by, c.bz);
     c.alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
                   clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
-    texture_coord_in_cell(normalize3(N), d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, c.icx, c.icy);
+    texture_coord_in_cell(normalize3(N), D.iw, D.ih, d.irradiance_probe_side_length, c.icx, c.icy);
     return c;
 }
 struct IrrTerm { f3 s; float w; };   // sqrt(probe irradiance) * weight, weight
-HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth, const IrrCell& c, const int i)
+HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, const IrrDiv& D, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth, const IrrCell& c, const int i)
 {
     const int bx = c.bx, by = c.by, bz = c.bz;
     const f3  alpha = c.alpha;
@@ -278,7 +292,7 @@ HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, f3 P, f3 N, f3 Wo, const At
     if (d.visibility_test == 1)
     {
         float u, v, mean, m2;
-        texture_coord_from_cell(neg3(dir), col, cz, d.depth_texture_width, d.depth_texture_height, d.depth_probe_side_length, u, v);
+        texture_coord_from_cell(neg3(dir), col, cz, D.dw, D.dh, d.depth_probe_side_length, u, v);
         const float dist = len3(probe_to_point);
         atlas_bilinear_rg(depth, u, v, mean, m2);
         const float variance = fabsf(mean * mean - m2);
@@ -289,7 +303,7 @@ HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, f3 P, f3 N, f3 Wo, const At
     }
     weight = max2(0.000001f, weight);
     float u, v;
-    texture_coord_of_cell(c.icx, c.icy, col, cz, d.irradiance_texture_width, d.irradiance_texture_height, d.irradiance_probe_side_length, u, v);
+    texture_coord_of_cell(c.icx, c.icy, col, cz, D.iw, D.ih, d.irradiance_probe_side_length, u, v);
     f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
     const float crush = 0.2f;
     if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
@@ -310,7 +324,8 @@ HR_DEV f3 irradiance_net_from_sums(f3 sum_irr, float sum_w)
 }
 HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRGBA& irradiance, const AtlasRG& depth)
 {
-    const IrrCell c = irradiance_cell(d, P, N);
+    const IrrDiv  D = irradiance_div(d);
+    const IrrCell c = irradiance_cell(d, D, P, N);
     f3    sum_irr = mk3(0.0f, 0.0f, 0.0f);
     float sum_w   = 0.0f;
     // deliberately NOT unrolled: fully unrolled the eight probes' fetches overlap, but the kernels that inline this need
@@ -321,7 +336,7 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
 #pragma unroll HR_IRR_UNROLL
     for (int i = 0; i < 8; ++i)
     {
-        const IrrTerm t = irradiance_probe_term(d, P, N, Wo, irradiance, depth, c, i);
+        const IrrTerm t = irradiance_probe_term(d, D, P, N, Wo, irradiance, depth, c, i);
         sum_irr = add3(sum_irr, t.s);
         sum_w += t.w;
     }
@@ -357,8 +372,9 @@ HR_DEV f3 sample_irradiance_net_coop(bool want, const DDGIU& d, f3 P, f3 N, f3 W
     }
     float* in = lds;                      // [8][kIrrCoopIn]  P, N, Wo, the point's IrrCell — of the eight points of this turn
     float* tm = lds + 8 * kIrrCoopIn;     // [8][8][4]        their probe terms: s.xyz, w
+    const IrrDiv D = irradiance_div(d);
     IrrCell mc;
-    if (want) mc = irradiance_cell(d, P, N);   // once per point, by its owner
+    if (want) mc = irradiance_cell(d, D, P, N);   // once per point, by its owner
     const int g = lane >> 3, i = lane & 7;
     for (int b0 = 0; b0 < k; b0 += 8)   // wave-uniform
     {
@@ -378,7 +394,7 @@ HR_DEV f3 sample_irradiance_net_coop(bool want, const DDGIU& d, f3 P, f3 N, f3 W
             const int pk = __float_as_int(q[9]);
             c.bx = pk & 1023; c.by = (pk >> 10) & 1023; c.bz = (pk >> 20) & 1023;
             c.alpha = mk3(q[10], q[11], q[12]); c.icx = q[13]; c.icy = q[14];
-            const IrrTerm t = irradiance_probe_term(d, p, n, wo, irradiance, depth, c, i);
+            const IrrTerm t = irradiance_probe_term(d, D, p, n, wo, irradiance, depth, c, i);
             float* o = tm + (g * 8 + i) * 4;
             o[0] = t.s.x; o[1] = t.s.y; o[2] = t.s.z; o[3] = t.w;
         }
