@@ -29,7 +29,7 @@ def kernel_of(pass_, stage, exact):
         if stage == "blur_xy": return "kf_ao_blur_xy<4, 16>"
         if stage in ("blur_x", "blur_y"): return "k_ao_blur<4>" if exact else "kf_ao_blur<4>"   # two launches of one instance: the counters average X and Y
     if pass_ == "ddgi":
-        return {"ray_trace": "k_ddgi_trace<false>", "irradiance_probe_update": "k_ddgi_probe_update<false, false>", "depth_probe_update": "k_ddgi_probe_update<true, true>",
+        return {"ray_trace": "k_ddgi_trace<false>", "probe_update": "k_ddgi_probe_update<true>",
                 "sample_probe_grid": "k_ddgi_sample" if exact else "kf_ddgi_sample"}.get(stage)
     if pass_ == "reflections":
         if stage == "ray_trace": return "k_refl_trace<false>"   # one instance: the parity gather in both modes (round 6)

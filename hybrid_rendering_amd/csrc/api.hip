@@ -73,7 +73,8 @@ const char* sample_name_of_stage(const char* stage)
         { "atrous_01", "Iteration 0 + Iteration 1" },   // the tolerance mode runs the first two iterations in one launch
         { "blur_x", "Vertical" }, { "blur_y", "Horizontal" },   // the reference's labels: its "Vertical" pass blurs along (1, 0) (ray_traced_ao.cpp:1042,1066)
         { "blur_xy", "Vertical + Horizontal" },
-        { "irradiance_probe_update", "Irradiance" }, { "depth_probe_update", "Depth" }, { "border_update", "Border Update" }, { "sample_probe_grid", "Sample Probe Grid" },
+        { "probe_update", "Irradiance + Depth + Border Update" },   // one launch for the three (ddgi.hip k_ddgi_probe_update)
+        { "sample_probe_grid", "Sample Probe Grid" },
         { "path_trace", "Ground Truth Path Trace" }, { "taa", "TAA" },
     };
     for (const auto& t : table)

@@ -1,7 +1,7 @@
 // DDGI on MI355X — HIP replacement for src/ddgi.{h,cpp} and src/shaders/gi/*.
 //   ray_trace()         ddgi.cpp:767-825, gi_ray_trace.{rgen:78-100, rchit:95-128, rmiss:24-27} -> k_ddgi_trace
-//   probe_update()      :829-900, gi_probe_update.glsl:136-184 (irradiance + depth variants)     -> k_ddgi_probe_update<DEPTH>
-//   border_update()     :904-939, gi_border_update.glsl:151-175                                  -> k_ddgi_border<DEPTH>
+//   probe_update()      :829-900, gi_probe_update.glsl:136-184 (irradiance + depth variants)     -> k_ddgi_probe_update (one launch for
+//   border_update()     :904-939, gi_border_update.glsl:151-175                                     both atlases and their borders)
 //   sample_probe_grid() :943-986, gi_sample_probe_grid.comp:75-99                                -> k_ddgi_sample
 #include "hr_internal.h"
 #include "shading.h"
@@ -320,28 +320,54 @@ struct DDGIUpdateArgs
     DDGIU        d;
     const uint2* radiance;
     const uint2* dirdist;
-    const void*  prev_atlas;
-    void*        out_atlas;
+    const uint2*    prev_irr;
+    uint2*          out_irr;
+    const uint32_t* prev_dep;
+    uint32_t*       out_dep;
     int          first_frame;
     int          gy0;   // first probe z-slab of this launch
 };
 
-// one workgroup per probe (gx = x + y*cx, gy = z), one thread per interior texel; the probe's rays are
-// staged through LDS in batches (gi_probe_update.glsl:73-84) — the accumulation order over rays is the
-// reference's (r = 0..rays_per_probe-1), so the fp32 sums are reproducible.
-// SHARP50: depth_sharpness == 50 (ddgi.h default) as a compile-time fact — the per-ray loop then has no run-time branch on it
-// and unrolls (four rays' LDS reads in flight together); SHARP50 = false is the generic exponent.
-template <bool DEPTH, bool SHARP50>
+// An interior texel and the border texels that mirror it (gi_border_update.glsl:35-143, the copy table by formula, inverted: which
+// border texels read THIS interior texel).  (sx, sy) in 1..S inside the probe's (S + 2)^2 cell whose corner is (cx, cy): an edge texel has
+// one copy on the opposite half of the facing border, a corner texel two of those plus the diagonally opposite corner.
+template <typename T>
+HR_DEV void store_texel_and_borders(T* atlas, int tw, int cx, int cy, int S, int sx, int sy, T v)
+{
+    auto put = [&](int dx, int dy) { atlas[(size_t)(cy + dy) * tw + cx + dx] = v; };
+    put(sx, sy);
+    if (sy == 1) put(S - sx + 1, 0);
+    if (sy == S) put(S - sx + 1, S + 1);
+    if (sx == 1) put(0, S - sy + 1);
+    if (sx == S) put(S + 1, S - sy + 1);
+    if ((sx == 1 || sx == S) && (sy == 1 || sy == S)) put(sx == S ? 0 : S + 1, sy == S ? 0 : S + 1);
+}
+
+// probe_update() + border_update() of one frame in ONE launch (ddgi.cpp:829-939; gi_probe_update.glsl:136-184 in its irradiance and depth
+// variants, gi_border_update.glsl:151-175).  One workgroup per probe (gx = x + y*cx, gy = z): the first depth_side^2 threads own the depth
+// texels, the threads from the next wave boundary on the irradiance texels — with the default 16 / 8 sides four depth waves and one irradiance
+// wave, which take about the same time (the irradiance texel does less per ray but reads two LDS vectors).  The probe's rays are staged through
+// LDS once for both (gi_probe_update.glsl:73-84), with what is the same for every texel done at the staging: the fp16 decode, the ray's clamped
+// distance and radiance * 0.95.  Every texel accumulates over the rays in the reference's order (r = 0 .. rays_per_probe - 1): the fp32 sums are
+// the reference's bit for bit.  A ray a texel does not take (weight below 1e-8) enters as weight 0 — x + y * 0 == x for the finite distances /
+// radiances the trace kernel writes — so the loop has ONE select per ray and no branch.  Each thread then writes its texel AND the border texels
+// that mirror it: no border launches, no second pass over the atlas.
+// Round 6, 16x8x16 probes x 256 rays: irradiance 34.1 + depth 67.3 + borders 2 x 5.0 us in four launches -> see DESIGN.md §5.
+// SHARP50: depth_sharpness == 50 (ddgi.h default) as a compile-time fact: the multiplications det_powi performs for n = 50, written out.
+template <bool SHARP50>
 __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
 {
     constexpr int CACHE = 256;
-    __shared__ float4 s_dd[CACHE];
-    __shared__ float4 s_rad[DEPTH ? 1 : CACHE];
-    const int side = DEPTH ? a.d.depth_probe_side_length : a.d.irradiance_probe_side_length;
-    const int tw   = DEPTH ? a.d.depth_texture_width : a.d.irradiance_texture_width;
+    __shared__ float4 s_dd[CACHE];    // direction, clamped distance
+    __shared__ float4 s_rad[CACHE];   // radiance * 0.95
+    const int sd = a.d.depth_probe_side_length, si = a.d.irradiance_probe_side_length;
+    const int irr_base = (sd * sd + 63) & ~63;
+    const bool depth_wave = (int)threadIdx.x < irr_base;   // wave-uniform
+    const int  side = depth_wave ? sd : si;
+    const int  k    = depth_wave ? (int)threadIdx.x : (int)threadIdx.x - irr_base;
+    const bool live = k < side * side;
     const int gx = blockIdx.x, gy = blockIdx.y + a.gy0;
-    const int lx = threadIdx.x % side, ly = threadIdx.x / side;
-    const int x = gx * (side + 2) + 2 + lx, y = gy * (side + 2) + 2 + ly;
+    const int lx = k % side, ly = k / side;
     const int probe = gx + (a.d.probe_counts[0] * a.d.probe_counts[1]) * gy; // == probe_id(current_coord, ...)
     const int R = a.d.rays_per_probe;
     const float ncx = ((float)lx + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f, ncy = ((float)ly + 0.5f) * __fdiv_rn(2.0f, (float)side) - 1.0f;
@@ -354,89 +380,66 @@ __global__ void k_ddgi_probe_update(DDGIUpdateArgs a)
         for (int i = threadIdx.x; i < num; i += blockDim.x)
         {
             const uint2 q = a.dirdist[(size_t)probe * R + offset + i];
-            s_dd[i] = make_float4(h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), h2f_hi(q.y));
-            if (!DEPTH)
-            {
-                const uint2 c = a.radiance[(size_t)probe * R + offset + i];
-                s_rad[i] = make_float4(h2f_lo(c.x), h2f_hi(c.x), h2f_lo(c.y), 0.0f);
-            }
+            float dist = min2(a.d.max_distance, h2f_hi(q.y) - 0.01f);
+            if (dist == -1.0f) dist = a.d.max_distance;
+            s_dd[i] = make_float4(h2f_lo(q.x), h2f_hi(q.x), h2f_lo(q.y), dist);
+            const uint2 c = a.radiance[(size_t)probe * R + offset + i];
+            s_rad[i] = make_float4(h2f_lo(c.x) * 0.95f, h2f_hi(c.x) * 0.95f, h2f_lo(c.y) * 0.95f, 0.0f);
         }
         __syncthreads();
-        // one ray of the probe (gi_probe_update.glsl:150-181); the accumulation order over rays is the reference's
-        auto one_ray = [&](int r) {
-            const float4 dd = s_dd[r];
-            const float  dp = max2(0.0f, dot3(texel_dir, mk3(dd.x, dd.y, dd.z)));
-            if (DEPTH)
-            {
-                float dist = min2(a.d.max_distance, dd.w - 0.01f);
-                if (dist == -1.0f) dist = a.d.max_distance;
+        if (!live) continue;
+        // one ray of the probe (gi_probe_update.glsl:150-181)
+        if (depth_wave)
+        {
+            auto one_ray = [&](int r) {
+                const float4 dd = s_dd[r];
+                const float  dp = __builtin_fmaxf(0.0f, dot3(texel_dir, mk3(dd.x, dd.y, dd.z)));   // the sum is never NaN: one v_max
                 float w;
-                // depth_sharpness = 50: the multiplications det_powi performs for n = 50, written out
                 if (SHARP50) { const float b2 = dp * dp, b4 = b2 * b2, b8 = b4 * b4, b16 = b8 * b8, b32 = b16 * b16; w = ((1.0f * b2) * b16) * b32; }
                 else w = det_pow_auto(dp, a.d.depth_sharpness);
-                const bool on = w >= 0.00000001f;
-                r0 = on ? r0 + dist * w : r0; r1 = on ? r1 + (dist * dist) * w : r1; total_w = on ? total_w + w : total_w;
-            }
-            else
-            {
-                if (dp >= 0.00000001f)   // half of the rays face away from a texel: the branch (measured) beats selects here
-                {
-                    const float4 c = s_rad[r];
-                    r0 += (c.x * 0.95f) * dp; r1 += (c.y * 0.95f) * dp; r2 += (c.z * 0.95f) * dp;
-                    total_w += dp;
-                }
-            }
-        };
-        int r = 0;
-        if (DEPTH)   // four rays per round: their LDS reads are in flight together (93 -> 70 us with the branch-free body; the irradiance loop is faster rolled)
+                w = w >= 0.00000001f ? w : 0.0f;
+                r0 += dd.w * w; r1 += (dd.w * dd.w) * w; total_w += w;
+            };
+            int r = 0;
+            for (; r + 4 <= num; r += 4) { one_ray(r); one_ray(r + 1); one_ray(r + 2); one_ray(r + 3); }   // four rays' LDS reads in flight together
+            for (; r < num; r++) one_ray(r);
+        }
+        else
+        {
+            auto one_ray = [&](int r) {
+                const float4 dd = s_dd[r], c = s_rad[r];
+                float dp = __builtin_fmaxf(0.0f, dot3(texel_dir, mk3(dd.x, dd.y, dd.z)));
+                dp = dp >= 0.00000001f ? dp : 0.0f;
+                r0 += c.x * dp; r1 += c.y * dp; r2 += c.z * dp; total_w += dp;
+            };
+            int r = 0;
             for (; r + 4 <= num; r += 4) { one_ray(r); one_ray(r + 1); one_ray(r + 2); one_ray(r + 3); }
-        for (; r < num; r++) one_ray(r);
+            for (; r < num; r++) one_ray(r);
+        }
     }
+    if (!live) return;
     if (total_w > 0.00000001f) { r0 = __fdiv_rn(r0, total_w); r1 = __fdiv_rn(r1, total_w); r2 = __fdiv_rn(r2, total_w); }
-    const size_t o = (size_t)y * tw + x;
-    if (DEPTH)
+    const int cx = gx * (side + 2) + 1, cy = gy * (side + 2) + 1;   // the corner of the probe's cell, border included
+    if (depth_wave)
     {
+        const int tw = a.d.depth_texture_width;
         if (a.first_frame == 0)
         {
-            const uint32_t pv = ((const uint32_t*)a.prev_atlas)[o];
+            const uint32_t pv = a.prev_dep[(size_t)(cy + ly + 1) * tw + cx + lx + 1];
             r0 = mix1(r0, h2f_lo(pv), a.d.hysteresis); r1 = mix1(r1, h2f_hi(pv), a.d.hysteresis);
         }
-        ((uint32_t*)a.out_atlas)[o] = pack_h2(r0, r1);
+        store_texel_and_borders<uint32_t>(a.out_dep, tw, cx, cy, side, lx + 1, ly + 1, pack_h2(r0, r1));
     }
     else
     {
+        const int tw = a.d.irradiance_texture_width;
         if (a.first_frame == 0)
         {
-            const uint2 pv = ((const uint2*)a.prev_atlas)[o];
+            const uint2 pv = a.prev_irr[(size_t)(cy + ly + 1) * tw + cx + lx + 1];
             r0 = mix1(r0, h2f_lo(pv.x), a.d.hysteresis); r1 = mix1(r1, h2f_hi(pv.x), a.d.hysteresis); r2 = mix1(r2, h2f_lo(pv.y), a.d.hysteresis);
         }
-        ((uint2*)a.out_atlas)[o] = make_uint2(pack_h2(r0, r1), pack_h2(r2, 1.0f));
+        store_texel_and_borders<uint2>(a.out_irr, tw, cx, cy, side, lx + 1, ly + 1, make_uint2(pack_h2(r0, r1), pack_h2(r2, 1.0f)));
     }
-}
-
-// border texels = octahedral wrap copies of interior texels (table of gi_border_update.glsl:35-143 by formula)
-template <bool DEPTH>
-__global__ void k_ddgi_border(DDGIU d, void* atlas, int gy0)
-{
-    const int S  = DEPTH ? d.depth_probe_side_length : d.irradiance_probe_side_length;
-    const int tw = DEPTH ? d.depth_texture_width : d.irradiance_texture_width;
-    const int cx = blockIdx.x * (S + 2) + 1, cy = (blockIdx.y + gy0) * (S + 2) + 1;
-    const int i = threadIdx.x;
-    if (i >= 4 * S + 4) return;
-    int sx, sy, dx, dy;
-    if (i < S) { sx = S - i; sy = 1; dx = i + 1; dy = 0; }
-    else if (i < 2 * S) { const int k = i - S; sx = S - k; sy = S; dx = k + 1; dy = S + 1; }
-    else if (i < 3 * S) { const int k = i - 2 * S; sx = 1; sy = S - k; dx = 0; dy = k + 1; }
-    else if (i < 4 * S) { const int k = i - 3 * S; sx = S; sy = S - k; dx = S + 1; dy = k + 1; }
-    else
-    {
-        const int k = i - 4 * S;
-        sx = (k == 0 || k == 2) ? S : 1; sy = (k == 0 || k == 1) ? S : 1;
-        dx = (k == 0 || k == 2) ? 0 : S + 1; dy = (k == 0 || k == 1) ? 0 : S + 1;
-    }
-    const size_t so = (size_t)(cy + sy) * tw + cx + sx, dst_o = (size_t)(cy + dy) * tw + cx + dx;
-    if (DEPTH) ((uint32_t*)atlas)[dst_o] = ((const uint32_t*)atlas)[so];
-    else ((uint2*)atlas)[dst_o] = ((const uint2*)atlas)[so];
 }
 
 
@@ -688,20 +691,14 @@ hr_status hr_ddgi_probe_update(hr_ddgi* p, void* stream_)
     const uint64_t nr = (uint64_t)grid.x * grid.y * p->d.rays_per_probe;
     DDGIUpdateArgs a;
     a.d = p->d; a.radiance = (const uint2*)p->radiance.p; a.dirdist = (const uint2*)p->dirdist.p; a.first_frame = p->first_frame ? 1 : 0; a.gy0 = p->z0;
-    a.prev_atlas = p->irr[rd].p; a.out_atlas = p->irr[wr].p;
-    int ev = p->prof.begin("irradiance_probe_update", st, nr * 16 + 2 * p->irr[0].bytes);
-    hipLaunchKernelGGL((k_ddgi_probe_update<false, false>), grid, dim3(p->d.irradiance_probe_side_length * p->d.irradiance_probe_side_length), 0, st, a);
-    p->prof.end(ev, st);
-    a.prev_atlas = p->dep[rd].p; a.out_atlas = p->dep[wr].p;
-    ev = p->prof.begin("depth_probe_update", st, nr * 8 + 2 * p->dep[0].bytes);
-    if (p->d.depth_sharpness == 50.0f) hipLaunchKernelGGL((k_ddgi_probe_update<true, true>), grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
-    else hipLaunchKernelGGL((k_ddgi_probe_update<true, false>), grid, dim3(p->d.depth_probe_side_length * p->d.depth_probe_side_length), 0, st, a);
-    p->prof.end(ev, st);
-    // algorithmic bytes: every border texel is read from an interior texel and written once (4 side + 4 texels per probe and atlas)
-    ev = p->prof.begin("border_update", st, (uint64_t)grid.x * grid.y * 2ull * ((4ull * p->d.irradiance_probe_side_length + 4) * 8 + (4ull * p->d.depth_probe_side_length + 4) * 4));
-    // one thread per border texel: 4 * side + 4 (hr_ddgi_create bounds the sides), rounded up to whole waves
-    hipLaunchKernelGGL(k_ddgi_border<false>, grid, dim3(cdiv(4 * p->d.irradiance_probe_side_length + 4, 64) * 64), 0, st, p->d, p->irr[wr].p, p->z0);
-    hipLaunchKernelGGL(k_ddgi_border<true>, grid, dim3(cdiv(4 * p->d.depth_probe_side_length + 4, 64) * 64), 0, st, p->d, p->dep[wr].p, p->z0);
+    a.prev_irr = (const uint2*)p->irr[rd].p; a.out_irr = (uint2*)p->irr[wr].p;
+    a.prev_dep = (const uint32_t*)p->dep[rd].p; a.out_dep = (uint32_t*)p->dep[wr].p;
+    // algorithmic bytes: both ray images once, each atlas read (history) and written (interior + borders) once
+    const int ev = p->prof.begin("probe_update", st, nr * 16 + 2 * (p->irr[0].bytes + p->dep[0].bytes));
+    const int sd2 = p->d.depth_probe_side_length * p->d.depth_probe_side_length, si2 = p->d.irradiance_probe_side_length * p->d.irradiance_probe_side_length;
+    const dim3 block(cdiv(sd2, 64) * 64 + cdiv(si2, 64) * 64);   // <= 512: hr_ddgi_create bounds the sides by 16
+    if (p->d.depth_sharpness == 50.0f) hipLaunchKernelGGL(k_ddgi_probe_update<true>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_ddgi_probe_update<false>, grid, block, 0, st, a);
     p->prof.end(ev, st);
     HR_HIP(hipGetLastError());
     return HR_OK;

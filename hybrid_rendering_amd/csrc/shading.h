@@ -333,7 +333,8 @@ HR_DEV f3 sample_irradiance_net(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasRG
 #ifndef HR_IRR_UNROLL
 #define HR_IRR_UNROLL 1   // round 6, partial unrolling re-measured (profiles/r6_d/ab_exact_gather_unroll.txt): 2 -> reflections trace 174 / 481 us (1: 172 / 467),
 #endif                    // DDGI trace 262 / 260 (1: 262 / 259); 4 -> 183 / 530 and 275 / 282.  The rolled loop stays.
-#pragma unroll HR_IRR_UNROLL
+    constexpr int kIrrUnroll = HR_IRR_UNROLL;   // a constant, not the macro, in the pragma: -save-temps (tools/isa_stats.py) re-parses preprocessed text
+#pragma unroll kIrrUnroll
     for (int i = 0; i < 8; ++i)
     {
         const IrrTerm t = irradiance_probe_term(d, D, P, N, Wo, irradiance, depth, c, i);

@@ -15,7 +15,7 @@ extern "C" {
 
 /* ---- profiler ranges --------------------------------------------------------------------------------------------- */
 /* Profiler ranges under the reference's DW_SCOPED_SAMPLE names ("Ray Traced Shadows" > "Ray Trace", "Temporal Accumulation", "Iteration 0" ...;
- * "Ambient Occlusion", "Ray Traced Reflections", "DDGI" > "Irradiance" / "Depth" / "Border Update" / "Sample Probe Grid", ...) around every pass and
+ * "Ambient Occlusion", "Ray Traced Reflections", "DDGI" > "Probe Update" / "Sample Probe Grid", ...; stages fused into one launch carry the joined names) around every pass and
  * stage, on the calling host thread.  mode 0: off (default; HR_MARKERS=1|2 in the environment sets the initial mode), 1: roctx — shows up in
  * `rocprofv3 --marker-trace` (librocprofiler-sdk-roctx.so is dlopen'ed on first use; silently nothing when it is absent), 2: an in-process log
  * that hr_markers_log() returns as "+name" / "-" lines (tests).  Process-wide. */
