@@ -9,14 +9,14 @@ from hybrid_rendering_amd import synth, synth_env
 pytestmark = pytest.mark.gpu
 
 
-def _run(oracle, hr, ctx, name, w, h, counts, rays, n_frames, light_kind="default", params=None):
+def _run(oracle, hr, ctx, name, w, h, counts, rays, n_frames, light_kind="default", params=None, **grid):
     import torch
     from hybrid_rendering_amd import api_gi
     from oracle import pyoracle_ddgi as od
     sd = helpers.scene_data(name)
     osc, gsc = oracle.Scene(sd), hr.Scene(ctx, sd)
     lo, hi = sd.bounds()
-    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=counts, rays_per_probe=rays, normal_bias=1.0 if name == "cornell" else 0.1)
+    ddgi = synth_env.ddgi_uniforms(lo, hi, probe_counts=counts, rays_per_probe=rays, normal_bias=1.0 if name == "cornell" else 0.1, **grid)
     sky = synth_env.sky_cubemap(16)
     sky_d = torch.from_numpy(sky).cuda().view(torch.float16)
     env = api_gi.environment(sky_d)
@@ -55,6 +55,15 @@ def _run(oracle, hr, ctx, name, w, h, counts, rays, n_frames, light_kind="defaul
 
 def test_ddgi_cornell(oracle, hr, ctx):
     _run(oracle, hr, ctx, "cornell", 96, 96, (4, 4, 4), 64, 3)
+
+
+def test_ddgi_odd_probe_sides_and_ray_counts(oracle, hr, ctx):
+    """The one-launch probe update (ddgi.hip k_ddgi_probe_update) away from the 16 / 8 / 256 / sharpness-50 preset: sides whose texel counts are not
+    whole waves (100 depth + 36 irradiance threads), the smallest sides (2 x 2: every texel is a corner with three border mirrors), a ray count that
+    is neither a multiple of four nor of the 256-ray LDS batch, and the generic depth exponent."""
+    _run(oracle, hr, ctx, "cornell", 64, 64, (3, 4, 3), 90, 2, irradiance_oct_size=6, depth_oct_size=10, depth_sharpness=37.0)
+    _run(oracle, hr, ctx, "cornell", 64, 64, (3, 3, 4), 322, 2, irradiance_oct_size=2, depth_oct_size=2)
+    _run(oracle, hr, ctx, "cornell", 64, 64, (4, 3, 3), 70, 2, irradiance_oct_size=16, depth_oct_size=16, depth_sharpness=3.5)
 
 
 def test_ddgi_sponza_small(oracle, hr, ctx):
