@@ -362,6 +362,15 @@ def test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, name, W, H, scal
 # The six fuzzed sequences (of 1784 in round 5, tools/fuzz_tolerance.py) that missed the 99.9 % population bound on a reflections image behind
 # the a-trous filter (docs/EXPERIMENTS.md R5.8: 99.83-99.89 %) while the trace kernel's DDGI gathers ran the fast arithmetic; (seed, trial) name
 # the draws of helpers.fuzz_configs.  Same runner, same rule, nothing relaxed.
+def test_long_sequences_do_not_drift(oracle, hr, ctx):
+    """The rule holds per frame over 100-frame sequences: the tolerance mode's history (feedback image, moments, history length) is re-read every frame, so an
+    error that accumulated through the temporal feedback would show up as a growing share of texels beyond 2 ulp.  (The per-stage comparisons are against the
+    oracle's stage images of the SAME frame, each computed from the oracle's own history.)"""
+    test_shadows_tolerance(oracle, hr, ctx, "sponza_small", 256, 144, 1.0, "default", None, n_frames=100)
+    test_ao_tolerance(oracle, hr, ctx, "sponza_small", 256, 144, 1, 2, None, n_frames=100)
+    test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, "sponza_small", 224, 128, 1, 1.0, None, n_frames=100)
+
+
 FUZZ_SEQUENCES = [(31337, 206), (555, 66), (8088, 21), (8088, 61), (8088, 84), (8088, 159)]
 
 
