@@ -139,6 +139,17 @@ HR_DEV float div_by(float n, const DivBy& D)
     }
     return __fdiv_rn(n, D.d);
 }
+// div_by without its range tests: the CALLER guarantees D.fast and n == 0 or 1e-12 <= |n| <= 3e5 (a NaN comes back a NaN either way)
+HR_DEV float div_by_inrange(float n, const DivBy& D)
+{
+    const float q0 = n * D.r1;
+    const float e1 = hr_fma(-D.d, q0, n);
+    const float q1 = hr_fma(e1, D.r1, q0);
+    const float e2 = hr_fma(-D.d, q1, n);
+    return hr_fma(e2, D.r1, q1);
+}
+// ... behind a flag the caller established once for all its numerators (wave-uniform where the denominator is): no per-quotient range branches
+HR_DEV float div_by_if(bool inrange, float n, const DivBy& D) { return inrange ? div_by_inrange(n, D) : __fdiv_rn(n, D.d); }
 
 HR_DEV float det_log(float x)
 {

@@ -109,15 +109,7 @@ HR_DEV float var_rn(float m2, float m1) { return m2 - m1 * m1; }
 // shading.h): u = tl / tw + (z * side) / tw, x = u * tw - 0.5.  The two divisions are correctly rounded through the shared
 // denominators Dw / Dh.  Needed for the DEPTH atlas only: its Chebyshev term |mean^2 - m2| cancels three digits (fp16 moments),
 // so 1e-5 texels of disagreement in the bilinear fractions show up as 1e-2 in a probe's weight.
-// div_by (device_math.h) without its range tests: the caller guarantees 1e-6 <= d <= 1e6 and n == 0 or 1e-12 <= |n| <= 3e5
-HR_DEV float div_by_inrange(float n, const DivBy& D)
-{
-    const float q0 = n * D.r1;
-    const float e1 = __builtin_fmaf(-D.d, q0, n);
-    const float q1 = __builtin_fmaf(e1, D.r1, q0);
-    const float e2 = __builtin_fmaf(-D.d, q1, n);
-    return __builtin_fmaf(e2, D.r1, q1);
-}
+using hr::div_by_inrange;   // device_math.h: div_by without its range tests — the callers here guarantee 1e-6 <= d <= 1e6 and n == 0 or 1e-12 <= |n| <= 3e5
 HR_DEV void atlas_coord_rn(float ox, float oy, int col, int row, int side, float tw, float th, const DivBy& Dw, const DivBy& Dh, float& x, float& y)
 {
     const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;

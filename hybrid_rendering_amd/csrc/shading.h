@@ -183,30 +183,37 @@ HR_DEV f3 probe_location(const DDGIU& d, int index)
 // ... in two halves: the offset of the direction inside a probe's cell (the same for every probe) and the cell's corner.  The four
 // divisions are by the atlas extents: with the denominator half of the correctly rounded sequence done once (DivBy, device_math.h — the very
 // FMAs the compiler's expansion of `/` performs, bit-identical results) a quotient costs five FMAs instead of ~eleven instructions.
-HR_DEV void texture_coord_in_cell(f3 dir, const DivBy& Dw, const DivBy& Dh, int side, float& cx, float& cy)
+// inrange (the caller's, once per gather — wave-uniform, the atlas extents are): both denominators are `fast` and at most 3e5.  All four
+// numerators then lie in div_by's fast range by construction — a cell corner is 2 .. the atlas extent, an in-cell offset z * side is 0 or at
+// least 2^-25 * side (z = (o + 1) / 2 with |o| <= 1 + an ulp) — and the quotients need no per-lane range branches (div_by_if): reflections trace
+// 165 -> 164 / 454 -> 444 us, exact DDGI sample 180 -> 173 / 672 -> 646 us (1080p / 4K, profiles/r6_h/passbench_inrange_gather.txt).  Instantiating the
+// whole probe loop for both values of the flag (no uniform branches left in it) measured no better: 162 / 447 and 180 / 677.
+HR_DEV bool atlas_div_inrange(const DivBy& Dw, const DivBy& Dh) { return Dw.fast && Dh.fast && Dw.d <= 3e5f && Dh.d <= 3e5f; }
+HR_DEV void texture_coord_in_cell(f3 dir, const DivBy& Dw, const DivBy& Dh, bool inrange, int side, float& cx, float& cy)
 {
     float ox, oy;
     gi_oct_encode(normalize3(dir), ox, oy);
     const float zx = (ox + 1.0f) * 0.5f, zy = (oy + 1.0f) * 0.5f;
-    cx = div_by(zx * (float)side, Dw); cy = div_by(zy * (float)side, Dh);
+    cx = div_by_if(inrange, zx * (float)side, Dw); cy = div_by_if(inrange, zy * (float)side, Dh);
 }
-HR_DEV void texture_coord_of_cell(float cx, float cy, int col, int row, const DivBy& Dw, const DivBy& Dh, int side, float& u, float& v)
+HR_DEV void texture_coord_of_cell(float cx, float cy, int col, int row, const DivBy& Dw, const DivBy& Dh, bool inrange, int side, float& u, float& v)
 {
     const float pwb = (float)side + 2.0f;
     const float tlx = (float)col * pwb + 2.0f;
     const float tly = (float)row * pwb + 2.0f;
-    u = div_by(tlx, Dw) + cx;
-    v = div_by(tly, Dh) + cy;
+    u = div_by_if(inrange, tlx, Dw) + cx;
+    v = div_by_if(inrange, tly, Dh) + cy;
 }
-HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, const DivBy& Dw, const DivBy& Dh, int side, float& u, float& v)
+HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, const DivBy& Dw, const DivBy& Dh, bool inrange, int side, float& u, float& v)
 {
     float cx, cy;
-    texture_coord_in_cell(dir, Dw, Dh, side, cx, cy);
-    texture_coord_of_cell(cx, cy, col, row, Dw, Dh, side, u, v);
+    texture_coord_in_cell(dir, Dw, Dh, inrange, side, cx, cy);
+    texture_coord_of_cell(cx, cy, col, row, Dw, Dh, inrange, side, u, v);
 }
 HR_DEV void texture_coord_from_cell(f3 dir, int col, int row, int tw, int th, int side, float& u, float& v)
 {
-    texture_coord_from_cell(dir, col, row, div_prepare((float)tw), div_prepare((float)th), side, u, v);
+    const DivBy Dw = div_prepare((float)tw), Dh = div_prepare((float)th);
+    texture_coord_from_cell(dir, col, row, Dw, Dh, atlas_div_inrange(Dw, Dh), side, u, v);
 }
 HR_DEV void texture_coord_from_direction(f3 dir, int probe_index, int tw, int th, int side, float& u, float& v)
 {
@@ -249,12 +256,13 @@ HR_DEV void atlas_bilinear_rg(const AtlasRG& a, float u, float v, float& r0, flo
 // split into the part that places the shading point in the grid (:190-203) and the body of the eight-probe loop (:207-296), so that the
 // loop can run per lane (sample_irradiance_net) or one probe per lane (sample_irradiance_net_coop) on the very same operations.
 struct IrrCell { int bx, by, bz; f3 alpha; float icx, icy; };   // + the offset of N's texel inside a probe's irradiance cell (the same for all eight probes)
-struct IrrDiv { DivBy iw, ih, dw, dh; };                          // the four atlas extents as prepared denominators
+struct IrrDiv { DivBy iw, ih, dw, dh; bool irr_in, dep_in; };     // the four atlas extents as prepared denominators (+ atlas_div_inrange of each pair)
 HR_DEV IrrDiv irradiance_div(const DDGIU& d)
 {
     IrrDiv D;
     D.iw = div_prepare((float)d.irradiance_texture_width); D.ih = div_prepare((float)d.irradiance_texture_height);
     D.dw = div_prepare((float)d.depth_texture_width); D.dh = div_prepare((float)d.depth_texture_height);
+    D.irr_in = atlas_div_inrange(D.iw, D.ih); D.dep_in = atlas_div_inrange(D.dw, D.dh);
     return D;
 }
 HR_DEV IrrCell irradiance_cell(const DDGIU& d, const IrrDiv& D, f3 P, f3 N)
@@ -268,7 +276,7 @@ HR_DEV IrrCell irradiance_cell(const DDGIU& d, const IrrDiv& D, f3 P, f3 N)
     const f3 base_pos = grid_coord_to_position(d, c.bx, c.by, c.bz);
     c.alpha = mk3(clamp1(__fdiv_rn(P.x - base_pos.x, gs.x), 0.0f, 1.0f), clamp1(__fdiv_rn(P.y - base_pos.y, gs.y), 0.0f, 1.0f),
                   clamp1(__fdiv_rn(P.z - base_pos.z, gs.z), 0.0f, 1.0f));
-    texture_coord_in_cell(normalize3(N), D.iw, D.ih, d.irradiance_probe_side_length, c.icx, c.icy);
+    texture_coord_in_cell(normalize3(N), D.iw, D.ih, D.irr_in, d.irradiance_probe_side_length, c.icx, c.icy);
     return c;
 }
 struct IrrTerm { f3 s; float w; };   // sqrt(probe irradiance) * weight, weight
@@ -292,7 +300,7 @@ HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, const IrrDiv& D, f3 P, f3 N
     if (d.visibility_test == 1)
     {
         float u, v, mean, m2;
-        texture_coord_from_cell(neg3(dir), col, cz, D.dw, D.dh, d.depth_probe_side_length, u, v);
+        texture_coord_from_cell(neg3(dir), col, cz, D.dw, D.dh, D.dep_in, d.depth_probe_side_length, u, v);
         const float dist = len3(probe_to_point);
         atlas_bilinear_rg(depth, u, v, mean, m2);
         const float variance = fabsf(mean * mean - m2);
@@ -303,7 +311,7 @@ HR_DEV IrrTerm irradiance_probe_term(const DDGIU& d, const IrrDiv& D, f3 P, f3 N
     }
     weight = max2(0.000001f, weight);
     float u, v;
-    texture_coord_of_cell(c.icx, c.icy, col, cz, D.iw, D.ih, d.irradiance_probe_side_length, u, v);
+    texture_coord_of_cell(c.icx, c.icy, col, cz, D.iw, D.ih, D.irr_in, d.irradiance_probe_side_length, u, v);
     f3 probe_irr = atlas_bilinear_rgb(irradiance, u, v);
     const float crush = 0.2f;
     if (weight < crush) weight = weight * (weight * weight * (1.0f / (crush * crush)));
