@@ -301,7 +301,7 @@ typedef struct
     int32_t exact;              /* 1 (default): parity mode — every stage image equals the oracle and the reference's shaders bit for bit.
                                    0: tolerance mode (production; what bench.py times): hardware rcp / rsq / sqrt / exp / log + FMAs in the
                                    denoise kernels; masks, ray counts, DDGI atlases and the reflections' trace image stay bit-exact, every other
-                                   fp16 image is within 2 fp16 ulp of the oracle on >= 99.9 % of its texels.  THE CONTRACT, clause by clause with
+                                   fp16 image is within 2 fp16 ulp (or 2^-20) of the oracle on >= 99.9 % of its texels.  THE CONTRACT, clause by clause with
                                    the test behind each: docs/TOLERANCE.md. */
 } hr_shadows_params;
 

@@ -65,6 +65,19 @@ def test_many_small_errors_fail_the_share_or_the_l2_bound():
         T.compare16(got, _bits(ref), "eight ulp everywhere")
 
 
+def test_absolute_floor_binds_only_below_a_thousandth():
+    """OUTPUT_FLOOR = 2^-20: a patch five ulp apart at 1e-4 (3e-7) counts as equal, the same patch five ulp apart at 4e-3 (2e-5) does not"""
+    def patch(v):
+        ref = np.ones((32, 32), np.float16)
+        ref[8:16, 8:16] = v
+        got = _bits(ref).copy()
+        got[8:16, 8:16] = (got[8:16, 8:16].astype(np.int32) + 5).astype(np.uint16)
+        return got, _bits(ref)
+    T.compare16(*patch(1.0e-4), "five ulp at 1e-4")
+    with pytest.raises(AssertionError):
+        T.compare16(*patch(4.0e-3), "five ulp at 4e-3")
+
+
 def test_thresholds_are_constants():
     """every threshold of the tolerance rule is a constant of tests/test_gpu_tolerance.py: no environment variable can loosen it (round 5 had
     HR_TEST_* overrides for strict fuzz campaigns); the one switch left prints a report"""
@@ -72,7 +85,7 @@ def test_thresholds_are_constants():
     src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_tolerance.py")).read()
     assert re.findall(r"environ[^\n]*?(HR_TEST_\w+)", src) == ["HR_TEST_TOLERANCE_REPORT"]
     assert not [k for k in os.environ if k.startswith("HR_TEST_") and k != "HR_TEST_TOLERANCE_REPORT"]
-    assert (T.CAP_ULPS, T.CAP_ABS, T.INTERMEDIATE_FLOOR, T.VARIANCE_FLOOR) == (32, 2.0 ** -10, 2e-4, 1e-4)
+    assert (T.CAP_ULPS, T.CAP_ABS, T.INTERMEDIATE_FLOOR, T.VARIANCE_FLOOR, T.OUTPUT_FLOOR) == (32, 2.0 ** -10, 2e-4, 1e-4, 2.0 ** -20)
     assert (T.OUTLIER_PIXELS, T.DDGI_OUTLIERS, T.REFL_OUTLIERS, T.OUTLIER_ULPS, T.OUTLIER_ABS) == (0.0, 0.0, 2e-5, 512, 2.0 ** -5)
 
 
