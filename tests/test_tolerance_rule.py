@@ -86,7 +86,7 @@ def test_thresholds_are_constants():
     assert re.findall(r"environ[^\n]*?(HR_TEST_\w+)", src) == ["HR_TEST_TOLERANCE_REPORT"]
     assert not [k for k in os.environ if k.startswith("HR_TEST_") and k != "HR_TEST_TOLERANCE_REPORT"]
     assert (T.CAP_ULPS, T.CAP_ABS, T.INTERMEDIATE_FLOOR, T.VARIANCE_FLOOR, T.OUTPUT_FLOOR) == (32, 2.0 ** -10, 2e-4, 1e-4, 2.0 ** -20)
-    assert (T.OUTLIER_PIXELS, T.DDGI_OUTLIERS, T.REFL_OUTLIERS, T.OUTLIER_ULPS, T.OUTLIER_ABS) == (0.0, 0.0, 2e-5, 512, 2.0 ** -5)
+    assert (T.OUTLIER_PIXELS, T.DDGI_OUTLIERS, T.REFL_OUTLIERS, T.ATROUS_OUTLIERS, T.OUTLIER_ULPS, T.OUTLIER_ABS) == (0.0, 0.0, 2e-5, 2e-5, 512, 2.0 ** -5)
 
 
 def test_fuzz_sequences_name_the_recorded_draws():
