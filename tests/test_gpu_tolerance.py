@@ -289,7 +289,16 @@ def test_ao_tolerance(oracle, hr, ctx, name, W, H, scale, spp, params, n_frames=
         compare16(helpers.bits16(gp.image(gp.IMG_BLUR1)), st["blur1"], f"frame {f} blurred AO", exclude=ex)
         out = helpers.bits16(gp.output(hr.OUTPUT_UPSAMPLE))
         ref = st["output"] if st["output"].ndim == 2 else st["output"][..., 0]
+        # stage-wise (late round 6, as for the a-trous chains): the blur launch(es) and the upsample against the ORACLE's stages run on the very images the GPU launches read
+        tiles_np = np.ascontiguousarray(gp.image(gp.IMG_TILES).cpu().numpy().astype(st["tiles"].dtype))
+        t_g = np.ascontiguousarray(helpers.bits16(gp.image(gp.IMG_AO1 if f & 1 else gp.IMG_AO0)).reshape(st["temporal"].shape))
+        b_g = np.ascontiguousarray(helpers.bits16(gp.image(gp.IMG_BLUR1)).reshape(st["blur1"].shape))
+        zb = np.asarray(zbp, np.float32)
+        b_ref = oracle.ao_blur(oracle.ao_blur(t_g, cur["depth"], cur["gb2"], tiles_np, zb, (1, 0), op.p["blur_radius"]), cur["depth"], cur["gb2"], tiles_np, zb, (0, 1), op.p["blur_radius"])
+        compare16(b_g, b_ref, f"frame {f} blur kernel(s) against the oracle's two blur passes over the same image")
         if scale:
+            up_ref = oracle.upsample(full, cur, b_g[..., None], channels=1, sky_value=1.0, power=op.p["power"])
+            compare16(out.reshape(ref.shape), up_ref if up_ref.ndim == 2 else up_ref[..., 0], f"frame {f} upsample kernel against the oracle's upsample of the same image")
             ex = upscale_mask(ex, scale, H, W)
         compare16(out, ref, f"frame {f} AO output", exclude=ex, outlier_scale=upsample_scale(scale))
     gp.close(); gsc.close()
