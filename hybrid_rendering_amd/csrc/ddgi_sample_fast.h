@@ -68,7 +68,12 @@ HR_DEV Bilin bilin_setup(float x, float y, int w, int h)   // x, y in texel unit
 //       regime in which the reference's own arithmetic is NaN-driven, and exactness is what can still be compared.
 //       (Measured and dropped: the same note wherever var < 2e-4 mean^2, "steep" — +19 % on the 1080p bench frame for no outlier it
 //       explained; every diagnosed outlier was (a) or an inf.)
-// A pixel that meets either is REDONE with the parity kernels' own gather (shading.h sample_irradiance_net on their operands: exact_inputs) —
+//   (c) the shading point ON a probe (late round 6; tools/fuzz_tolerance.py 6351 #150, frame 1: the corner of the Cornell room — the grid is fitted to the scene's
+//       bounds, so its corner probes sit on the bounding box's corners).  normalize(probe - P) is 0 * inf = NaN in the parity arithmetic, the NaN passes through
+//       max() into the probe's weight and the sums, and the shader's NaN replacement makes the pixel net = 0.5; here v_max_f32 drops the NaN and the pixel
+//       gets a finite, different value (532 fp16 ulp apart).  Test: |probe - P|^2 <= (1e-6 x (|P|_1 + |grid|_1))^2 — a hundred times the distance by which
+//       the two arithmetics' probe positions (fused against unfused g0 + step * c) can disagree about "on".
+// A pixel that meets any of them is REDONE with the parity kernels' own gather (shading.h sample_irradiance_net on their operands: exact_inputs) —
 // a handful of pixels per frame on the bench scene (0.005 % of the pixels have sum_w < 1e-3), so the hot loop carries only the tests.
 // exact_inputs(P, N, Wo): fills in the PARITY kernels' operands of this shading point (only called by the redo); a caller whose P, N, Wo
 // already are those values passes them back (SameInputs).
@@ -106,6 +111,7 @@ HR_DEV f3 sample_irradiance_pass(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasR
                              + fm::fmax_(__builtin_fabsf(g0.x), __builtin_fabsf(g0.x + gs.x * (float)(nx - 1))) + fm::fmax_(__builtin_fabsf(g0.y), __builtin_fabsf(g0.y + gs.y * (float)(ny - 1)))
                              + fm::fmax_(__builtin_fabsf(g0.z), __builtin_fabsf(g0.z + gs.z * (float)(nz - 1))));
     const bool wild_possible = !(d.max_distance * d.max_distance < 60000.0f);
+    const float near2 = G * G * 0.0625f;   // (c): (1e-6 x (|P|_1 + |grid|_1))^2 — G is 4e-6 x that sum
     bool  noted  = false;
     float max_nt = 0.0f;   // (a): the largest weight before its trilinear factor
     auto probe = [&](const int i) {
@@ -116,7 +122,9 @@ HR_DEV f3 sample_irradiance_pass(const DDGIU& d, f3 P, f3 N, f3 Wo, const AtlasR
         const f3  ptp = mk3(P.x - pp.x + nb.x, P.y - pp.y + nb.y, P.z - pp.z + nb.z);
         const f3  tri = mk3(ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z);
         f3 tdp = mk3(pp.x - P.x, pp.y - P.y, pp.z - P.z);
-        const float t = fm::fmax_(0.0001f, (fm::dot(tdp, N) * fm::rsq(fm::dot(tdp, tdp)) + 1.0f) * 0.5f);
+        const float tl2 = fm::dot(tdp, tdp);
+        noted = noted || !(tl2 > near2);   // (c): the shading point ON a probe (see above)
+        const float t = fm::fmax_(0.0001f, (fm::dot(tdp, N) * fm::rsq(tl2) + 1.0f) * 0.5f);
         float weight = t * t + 0.2f;
         if (d.visibility_test == 1)
         {

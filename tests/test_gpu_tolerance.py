@@ -436,6 +436,15 @@ def test_reflections_fuzz_sequences_that_missed_the_population_bound(oracle, hr,
     test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, c["name"], c["W"], c["H"], min(c["scale"], 1), c["dolly"], c["reflections"])
 
 
+def test_ddgi_sample_fuzz_sequence_with_a_pixel_on_a_probe(oracle, hr, ctx):
+    """tools/fuzz_tolerance.py 6351 #150 (Cornell room, 254 x 138): on frame 1 pixel (109, 86) shows the corner of the room, which IS a corner probe of the grid fitted
+    to the scene's bounds.  The reference's normalize(probe - P) is NaN there and its NaN replacement decides the pixel (net = 0.5); the fast gather's v_max dropped the
+    NaN (532 fp16 ulp apart) until ddgi_sample_fast.h learnt to hand such a shading point to the parity gather (case (c) of its redo)."""
+    c = helpers.fuzz_config(6351, 150)
+    assert (c["name"], c["W"], c["H"], c["scale"]) == ("cornell", 254, 138, 0)
+    test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, c["name"], c["W"], c["H"], min(c["scale"], 1), c["dolly"], c["reflections"])
+
+
 @pytest.mark.parametrize("tier", ["standard", "hard"])
 def test_1080p_bench_frame_tolerance(oracle, hr, ctx, tier):
     """the bench workload (BASELINE configs[1], 1920x1080, 278k triangles) in the mode bench.py times: 3 moving frames; and bench.py's
