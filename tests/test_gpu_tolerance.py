@@ -445,6 +445,18 @@ def test_ddgi_sample_fuzz_sequence_with_a_pixel_on_a_probe(oracle, hr, ctx):
     test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, c["name"], c["W"], c["H"], min(c["scale"], 1), c["dolly"], c["reflections"])
 
 
+@pytest.mark.xfail(strict=False, reason="KNOWN MISS, open at the end of round 6 (docs/EXPERIMENTS.md R6.14): one flipped history-tap decision of kf_refl_temporal, spread by five radius-2 "
+                                        "a-trous iterations on a 93 x 106 image: 5 pixels beyond the cap against an allowance of 4, 99.88 % of the texels within 2 ulp against 99.9 %")
+def test_reflections_fuzz_sequence_with_a_flipped_history_tap(oracle, hr, ctx):
+    """tools/fuzz_tolerance.py 6361 #385 (half-resolution reflections of a 187 x 212 frame, five a-trous iterations of radius 2, phi_normal 8): on frame 1 ONE pixel of the
+    moments image is 92 fp16 ulp from the oracle's — the reflections' temporal kernel still decides a history tap's validity with the fast arithmetic (the shadows and AO
+    temporal kernels re-run such pixels with the parity verdicts) — and the a-trous chain spreads it.  Every a-trous / upsample launch passes its stage-wise check.  The
+    fix (the cold second run in kf_refl_temporal) was not made in round 6: recorded as an expected failure rather than by loosening the rule."""
+    c = helpers.fuzz_config(6361, 385)
+    assert (c["name"], c["W"], c["H"], c["scale"]) == ("sponza_small", 187, 212, 1)
+    test_reflections_and_ddgi_sample_tolerance(oracle, hr, ctx, c["name"], c["W"], c["H"], min(c["scale"], 1), c["dolly"], c["reflections"])
+
+
 @pytest.mark.parametrize("tier", ["standard", "hard"])
 def test_1080p_bench_frame_tolerance(oracle, hr, ctx, tier):
     """the bench workload (BASELINE configs[1], 1920x1080, 278k triangles) in the mode bench.py times: 3 moving frames; and bench.py's
