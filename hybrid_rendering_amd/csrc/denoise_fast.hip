@@ -1236,12 +1236,37 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
 #if !FR_ALIAS
     const uint2 cq = s_col[ly + FR_R][lx + FR_R];
 #endif
+    // The pixel's program from the history taps on.  It runs once; a wave in which some history tap sat on a knife edge of the validity test (Reproj::tap_valid notes
+    // it) runs it a SECOND time — a cold copy, as in kf_shadows_temporal / kf_ao_temporal — in which the noted taps take the parity kernels' verdicts
+    // (Reproj::exact_bits), and stores again (late round 6: tools/fuzz_tolerance.py 6361 #385 had ONE such tap flip a pixel's moments by 92 fp16 ulp, and five a-trous
+    // iterations of radius 2 spread that beyond the chain's counted allowance; docs/EXPERIMENTS.md R6.14).  The separable sums are still in LDS for it.
+    bool flag = false;
+    auto pixel = [&](const bool redo) -> uint32_t {
     Reproj<8, true, true, GEO> rp;
     rp.M = a.vpi; rp.pgb2 = a.pgb2.p; rp.pgb3 = a.pgb3.p; rp.pdepth = a.pdepth.p; rp.hist = a.hist.p; rp.hist_moments = a.hist_moments.p; rp.hist_len = nullptr;
     rp.geo = a.geo_hist;
     rp.g = HistGeom { a.w, a.h, a.pgb2.y0, a.pgb2.y1 };
+    uint32_t ovr = 0u, known = 0u;
+    if (redo && live)
+    {
+        rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]), a.pvp, fm::hi(cq.y));
+        ReprojOut r0;
+        rp.template resolve<true>(r0);
+        if (rp.near13)
+        {
+            known = rp.near13;
+            ovr   = rp.exact_bits(known, x, y, d, cg2.x, cg2.y);
+            if ((((ovr ^ rp.valid13) & known) & 0xfu) != 0u)   // a bilinear verdict flipped: the 3x3 fallback may run where it did not (or the other way round)
+            {
+                const uint32_t rest = 0x1ff0u & ~known;
+                ovr |= rp.exact_bits(rest, x, y, d, cg2.x, cg2.y);
+                known |= rest;
+            }
+        }
+    }
     if (live) rp.issue(x, y, d, cg2.y, fm::lo(cg3.y), fm::hi(cg3.x), fm::oct_unit(cg2.x), mk3(a.cam[0], a.cam[1], a.cam[2]), a.pvp, fm::hi(cq.y));
-    if (a.apron_flag && live && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) atomicOr(a.apron_flag, 1u);   // rare
+    if (!redo && a.apron_flag && live && y >= a.band_y0 && y < a.band_y1 && rp.apron_miss) atomicOr(a.apron_flag, 1u);   // rare
+    rp.near13 = 0u;
     // vertical pass of the separable sums (LDS only) while the history taps are in flight
     float s1[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
 #pragma unroll 6   // in groups: fully unrolled, the 34 LDS reads are hoisted together and cost 100 VGPRs next to the 25 tap registers
@@ -1251,7 +1276,6 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
         const float2 hb = s_hb[ly + dy][lx];
         s1[0] += ha.x; s1[1] += ha.y; s1[2] += ha.z; s2[0] += ha.w; s2[1] += hb.x; s2[2] += hb.y;
     }
-    bool flag = false;
     if (have)
     {
         const float roughness = fm::lo(cg3.x);
@@ -1260,7 +1284,7 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
         {
             const f3  color = mk3(fm::lo(cq.x), fm::hi(cq.x), fm::lo(cq.y));
             ReprojOut r;
-            const bool success = rp.resolve(r);
+            const bool success = rp.template resolve<true>(r, ovr, known);
             hl = fm::fmin_(32.0f, success ? r.length + 1.0f : 1.0f);
             f3 history = mk3(r.col[0], r.col[1], r.col[2]);
             if (success)
@@ -1300,6 +1324,12 @@ __global__ __launch_bounds__(256, FR_EU) void kf_refl_temporal(ReflTemporalArgs 
         if (a.geo_out) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.geo_out) + o * 8u) = make_uint2(cg2.x, cg3.y);
         if (d != 1.0f && roughness >= 0.05f) flag = (a.approximate_with_ddgi == 1) ? (roughness <= 0.75f) : true;
     }
+    return live ? rp.near13 : 0u;
+    };
+    const uint32_t doubt = pixel(false);
+#if HR_TAP_REDO
+    if (__any(doubt != 0u)) pixel(true);   // rare: the cold copy
+#endif
     // tile classification per 8x8 tile (4 tiles per workgroup): :262-272
     if (flag) atomicOr(&s_flag[lx >> 3], 1);
     __syncthreads();
