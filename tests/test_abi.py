@@ -149,3 +149,25 @@ def test_the_public_header_stays_small_and_essay_free():
         for m in re.finditer(r"/\*.*?\*/", txt, flags=re.S):
             assert m.group(0).count("\n") < 16 or m.start() == 0, (h, m.group(0)[:80])
     assert "docs/TOLERANCE.md" in open(os.path.join(ROOT, "include", "hr_api.h")).read()
+
+
+def test_every_profiled_stage_has_a_reference_sample_label():
+    """hr_set_markers (api.hip sample_name_of_stage): every stage name a pass hands to its StageProfiler maps to a label of the reference's profiler tree
+    (DW_SCOPED_SAMPLE names) — a stage added or renamed without a label would show up in a roctx trace under its internal name"""
+    import glob, re
+    src = os.path.join(ROOT, "hybrid_rendering_amd", "csrc")
+    names = set()
+    for f in glob.glob(os.path.join(src, "*.hip")):
+        text = open(f).read()
+        names |= set(re.findall(r'prof\.begin\("([a-z_0-9]+)"', text))
+        for pair in re.findall(r'prof\.begin\([^"\n]*\? "([a-z_0-9]+)" : "([a-z_0-9]+)"', text):   # prof.begin(cond ? "a" : "b", ...)
+            names |= set(pair)
+        for m in re.finditer(r'names\[8\] = \{([^}]*)\}', text):
+            names |= set(re.findall(r'"([a-z_0-9]+)"', m.group(1)))
+    assert {"ray_trace", "temporal_accumulation", "probe_update", "blur_x", "atrous_3"} <= names, names
+    table = open(os.path.join(src, "api.hip")).read()
+    table = table[table.index("sample_name_of_stage"):]
+    table = table[:table.index("return stage;")]
+    labelled = set(re.findall(r'\{ "([a-z_0-9]+)", "', table))
+    generic = {"atrous_%d" % i for i in range(5, 8)}   # iterations beyond the reference's maximum keep their internal names
+    assert names - generic <= labelled, sorted(names - generic - labelled)
